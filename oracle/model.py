@@ -1,0 +1,773 @@
+"""ORACLE (test infrastructure, NOT product code) -- spec-level big-integer restatement of the
+hot path of dalek-cryptography/zkp and of the third-party arithmetic behind it.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (zkp_amd/, the C-ABI library) never does.
+
+What is restated, and from where:
+
+* ristretto255 group (field 2^255-19, decode/encode, Elligator map, Edwards add/double):
+  RFC 9496 section 4 -- this is what `curve25519-dalek = "2"` (reference Cargo.toml:27, NOT
+  vendored under /root/reference, newest 2.x = 2.1.3) implements behind
+  `CompressedRistretto::decompress` (reference src/toolbox/verifier.rs:90,164;
+  batch_verifier.rs:226) and `RistrettoPoint::compress` (src/toolbox/mod.rs:180,204).
+* multiscalar multiplication: the mathematical definition  enc(sum_i s_i * dec(P_i))  which is
+  what `multiscalar_mul` (prover.rs:94), `vartime_multiscalar_mul` (verifier.rs:97) and
+  `optional_multiscalar_mul` (verifier.rs:162, batch_verifier.rs:219) return; ristretto
+  encodings are canonical so the result bytes are algorithm independent.
+* scalars mod l: `Scalar::from_bytes_mod_order_wide` (mod.rs:226), `s*c+b` (prover.rs:108),
+  negation (verifier.rs:95,142), `Scalar::from(u128)` (verifier.rs:153, batch_verifier.rs:179).
+* Merlin transcripts (`merlin = "2"`, reference Cargo.toml:21, not vendored): STROBE-128 over
+  Keccak-f[1600] with Merlin's framing; TranscriptRng as used by prover.rs:78-89.
+* the toolbox itself: TranscriptProtocol (mod.rs:165-228), Prover (prover.rs:41-132),
+  Verifier (verifier.rs:47-173), BatchVerifier (batch_verifier.rs:67-235), Matrix (util.rs).
+
+PARITY PIN STATUS: the reference cannot be compiled here (no Rust toolchain, dependencies not
+vendored) and its own tests hold no golden bytes (every proof is randomised through
+thread_rng, prover.rs:82).  This model is pinned instead against (tests/test_oracle_model.py):
+RFC 9496 appendix A vectors (multiples of the generator, invalid encodings, hash-to-group),
+libsodium 1.0.18's independent ristretto255 (in this container only; fixtures committed under
+tests/golden/), Merlin's published known-answer test, and the deterministic public inputs of
+the reference's tests (tests/zkp.rs:34-37, tests/dleq_using_constraint_api.rs:42-46).
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+# --------------------------------------------------------------------------------------------
+# Field GF(2^255 - 19)                                                   RFC 9496 section 4.1
+# --------------------------------------------------------------------------------------------
+P = 2**255 - 19
+D = (-121665 * pow(121666, P - 2, P)) % P
+SQRT_M1 = pow(2, (P - 1) // 4, P)
+L = 2**252 + 27742317777372353535851937790883648493
+
+
+def _is_neg(x: int) -> bool:
+    return (x % P) & 1 == 1
+
+
+def _abs(x: int) -> int:
+    x %= P
+    return P - x if x & 1 else x
+
+
+def sqrt_ratio_m1(u: int, v: int) -> Tuple[bool, int]:
+    """RFC 9496 section 4.2 SQRT_RATIO_M1."""
+    u %= P
+    v %= P
+    v3 = v * v % P * v % P
+    v7 = v3 * v3 % P * v % P
+    r = u * v3 % P * pow(u * v7 % P, (P - 5) // 8, P) % P
+    check = v * r % P * r % P
+    correct = check == u
+    flipped = check == (-u) % P
+    flipped_i = check == (-u) * SQRT_M1 % P
+    if flipped or flipped_i:
+        r = r * SQRT_M1 % P
+    return (correct or flipped), _abs(r)
+
+
+def _const_sqrt(x: int) -> int:
+    ok, r = sqrt_ratio_m1(x, 1)
+    assert ok
+    return r
+
+
+INVSQRT_A_MINUS_D = sqrt_ratio_m1(1, (-1 - D) % P)[1]
+SQRT_AD_MINUS_ONE = P - _const_sqrt((-D - 1) % P)   # RFC 9496 lists the odd ("negative") root
+ONE_MINUS_D_SQ = (1 - D * D) % P
+D_MINUS_ONE_SQ = (D - 1) * (D - 1) % P
+
+# RFC 9496 section 4.1 lists these as decimals; the derived values must match.
+assert D == 37095705934669439343138083508754565189542113879843219016388785533085940283555
+assert SQRT_M1 == 19681161376707505956807079304988542015446066515923890162744021073123829784752
+assert INVSQRT_A_MINUS_D == 54469307008909316920995813868745141605393597292927456921205312896311721017578
+assert SQRT_AD_MINUS_ONE == 25063068953384623474111414158702152701244531502492656460079210482610430750235
+assert ONE_MINUS_D_SQ == 1159843021668779879193775521855586647937357759715417654439879720876111806838
+assert D_MINUS_ONE_SQ == 40440834346308536858101042469323190826248399146238708352240133220865137265952
+
+# --------------------------------------------------------------------------------------------
+# Edwards points in extended coordinates (X:Y:Z:T), a = -1
+# --------------------------------------------------------------------------------------------
+Point = Tuple[int, int, int, int]
+IDENTITY: Point = (0, 1, 1, 0)
+
+
+def pt_add(p: Point, q: Point) -> Point:
+    x1, y1, z1, t1 = p
+    x2, y2, z2, t2 = q
+    a = (y1 - x1) * (y2 - x2) % P
+    b = (y1 + x1) * (y2 + x2) % P
+    c = 2 * D * t1 % P * t2 % P
+    d = 2 * z1 * z2 % P
+    e, f, g, h = b - a, d - c, d + c, b + a
+    return (e * f % P, g * h % P, f * g % P, e * h % P)
+
+
+def pt_double(p: Point) -> Point:
+    return pt_add(p, p)
+
+
+def pt_neg(p: Point) -> Point:
+    x, y, z, t = p
+    return ((-x) % P, y, z, (-t) % P)
+
+
+def pt_mul(s: int, p: Point) -> Point:
+    acc = IDENTITY
+    for bit in bin(s)[2:] if s else "":
+        acc = pt_double(acc)
+        if bit == "1":
+            acc = pt_add(acc, p)
+    return acc
+
+
+# --------------------------------------------------------------------------------------------
+# ristretto255 decode / encode / equality / one-way map                 RFC 9496 section 4.3
+# --------------------------------------------------------------------------------------------
+def ristretto_decode(b: bytes) -> Optional[Point]:
+    """CompressedRistretto::decompress; None on any invalid encoding."""
+    if len(b) != 32:
+        return None
+    s = int.from_bytes(b, "little")
+    if s >= P or (s & 1):
+        return None
+    ss = s * s % P
+    u1 = (1 - ss) % P
+    u2 = (1 + ss) % P
+    u2_sqr = u2 * u2 % P
+    v = (-(D * u1 % P * u1) - u2_sqr) % P
+    ok, invsqrt = sqrt_ratio_m1(1, v * u2_sqr % P)
+    den_x = invsqrt * u2 % P
+    den_y = invsqrt * den_x % P * v % P
+    x = _abs(2 * s * den_x % P)
+    y = u1 * den_y % P
+    t = x * y % P
+    if (not ok) or _is_neg(t) or y == 0:
+        return None
+    return (x, y, 1, t)
+
+
+def ristretto_encode(p: Point) -> bytes:
+    """RistrettoPoint::compress."""
+    x0, y0, z0, t0 = p
+    u1 = (z0 + y0) * (z0 - y0) % P
+    u2 = x0 * y0 % P
+    _, invsqrt = sqrt_ratio_m1(1, u1 * u2 % P * u2 % P)
+    den1 = invsqrt * u1 % P
+    den2 = invsqrt * u2 % P
+    z_inv = den1 * den2 % P * t0 % P
+    ix0 = x0 * SQRT_M1 % P
+    iy0 = y0 * SQRT_M1 % P
+    enchanted_denominator = den1 * INVSQRT_A_MINUS_D % P
+    rotate = _is_neg(t0 * z_inv % P)
+    if rotate:
+        x, y, den_inv = iy0, ix0, enchanted_denominator
+    else:
+        x, y, den_inv = x0, y0, den2
+    if _is_neg(x * z_inv % P):
+        y = (-y) % P
+    s = _abs(den_inv * ((z0 - y) % P) % P)
+    return s.to_bytes(32, "little")
+
+
+def _elligator_map(t: int) -> Point:
+    r = SQRT_M1 * t % P * t % P
+    u = (r + 1) * ONE_MINUS_D_SQ % P
+    v = (-1 - r * D) % P * ((r + D) % P) % P
+    was_square, s = sqrt_ratio_m1(u, v)
+    s_prime = (-_abs(s * t % P)) % P
+    if not was_square:
+        s = s_prime
+    c = (P - 1) if was_square else r
+    n = (c * ((r - 1) % P) % P * D_MINUS_ONE_SQ - v) % P
+    w0 = 2 * s * v % P
+    w1 = n * SQRT_AD_MINUS_ONE % P
+    w2 = (1 - s * s) % P
+    w3 = (1 + s * s) % P
+    return (w0 * w3 % P, w2 * w1 % P, w1 * w3 % P, w0 * w2 % P)
+
+
+def ristretto_from_uniform_bytes(b: bytes) -> Point:
+    """RistrettoPoint::from_uniform_bytes (RFC 9496 section 4.3.4)."""
+    assert len(b) == 64
+    t1 = (int.from_bytes(b[:32], "little") & ((1 << 255) - 1)) % P
+    t2 = (int.from_bytes(b[32:], "little") & ((1 << 255) - 1)) % P
+    return pt_add(_elligator_map(t1), _elligator_map(t2))
+
+
+def ristretto_hash_from_bytes_sha512(msg: bytes) -> Point:
+    """RistrettoPoint::hash_from_bytes::<Sha512> as used by reference tests/zkp.rs:34."""
+    return ristretto_from_uniform_bytes(hashlib.sha512(msg).digest())
+
+
+BASEPOINT: Point = ristretto_decode(
+    bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76")
+)  # type: ignore[assignment]
+IDENTITY_ENC = bytes(32)
+
+
+# --------------------------------------------------------------------------------------------
+# Scalars mod l
+# --------------------------------------------------------------------------------------------
+def sc_from_bytes_mod_order_wide(b: bytes) -> int:
+    assert len(b) == 64
+    return int.from_bytes(b, "little") % L
+
+
+def sc_to_bytes(s: int) -> bytes:
+    return (s % L).to_bytes(32, "little")
+
+
+def sc_from_bytes(b: bytes) -> int:
+    return int.from_bytes(b, "little")
+
+
+# --------------------------------------------------------------------------------------------
+# Multiscalar multiplication: the definition all three dalek entry points compute
+# --------------------------------------------------------------------------------------------
+def msm_points(scalars: Sequence[int], points: Sequence[Point]) -> Point:
+    assert len(scalars) == len(points)
+    acc = IDENTITY
+    for s, p in zip(scalars, points):
+        acc = pt_add(acc, pt_mul(s % L, p))
+    return acc
+
+
+def msm_optional(scalars: Sequence[bytes], encodings: Sequence[bytes]) -> Optional[bytes]:
+    """optional_multiscalar_mul over decompress()ed encodings: None if any decode fails,
+    otherwise the canonical encoding of the sum (verifier.rs:162-166, batch_verifier.rs:219-228)."""
+    pts = []
+    for e in encodings:
+        p = ristretto_decode(e)
+        if p is None:
+            return None
+        pts.append(p)
+    return ristretto_encode(msm_points([sc_from_bytes(s) for s in scalars], pts))
+
+
+# --------------------------------------------------------------------------------------------
+# Keccak-f[1600], STROBE-128, Merlin                                        merlin 2.x
+# --------------------------------------------------------------------------------------------
+_RC = [
+    0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000,
+    0x000000000000808B, 0x0000000080000001, 0x8000000080008081, 0x8000000000008009,
+    0x000000000000008A, 0x0000000000000088, 0x0000000080008009, 0x000000008000000A,
+    0x000000008000808B, 0x800000000000008B, 0x8000000000008089, 0x8000000000008003,
+    0x8000000000008002, 0x8000000000000080, 0x000000000000800A, 0x800000008000000A,
+    0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008,
+]
+_ROT = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]
+_M64 = (1 << 64) - 1
+
+
+def keccak_f1600(state: bytearray) -> None:
+    a = [[int.from_bytes(state[8 * (x + 5 * y): 8 * (x + 5 * y) + 8], "little") for y in range(5)] for x in range(5)]
+    for rnd in range(24):
+        c = [a[x][0] ^ a[x][1] ^ a[x][2] ^ a[x][3] ^ a[x][4] for x in range(5)]
+        d = [c[(x - 1) % 5] ^ (((c[(x + 1) % 5] << 1) | (c[(x + 1) % 5] >> 63)) & _M64) for x in range(5)]
+        a = [[a[x][y] ^ d[x] for y in range(5)] for x in range(5)]
+        b = [[0] * 5 for _ in range(5)]
+        for x in range(5):
+            for y in range(5):
+                r = _ROT[x][y]
+                v = a[x][y]
+                b[y][(2 * x + 3 * y) % 5] = ((v << r) | (v >> (64 - r))) & _M64 if r else v
+        a = [[b[x][y] ^ ((~b[(x + 1) % 5][y]) & b[(x + 2) % 5][y]) & _M64 for y in range(5)] for x in range(5)]
+        a[0][0] ^= _RC[rnd]
+    for x in range(5):
+        for y in range(5):
+            state[8 * (x + 5 * y): 8 * (x + 5 * y) + 8] = (a[x][y] & _M64).to_bytes(8, "little")
+
+
+_STROBE_R = 166
+_FLAG_I, _FLAG_A, _FLAG_C, _FLAG_T, _FLAG_M, _FLAG_K = 1, 2, 4, 8, 16, 32
+
+keccak_f_count = 0  # instrumentation for DESIGN.md's host-cost table
+
+
+class Strobe128:
+    def __init__(self, protocol_label: bytes):
+        st = bytearray(200)
+        st[0:6] = bytes([1, _STROBE_R + 2, 1, 0, 1, 96])
+        st[6:18] = b"STROBEv1.0.2"
+        self.state = st
+        self._permute()
+        self.pos = 0
+        self.pos_begin = 0
+        self.cur_flags = 0
+        self.meta_ad(protocol_label, False)
+
+    def clone(self) -> "Strobe128":
+        c = object.__new__(Strobe128)
+        c.state = bytearray(self.state)
+        c.pos, c.pos_begin, c.cur_flags = self.pos, self.pos_begin, self.cur_flags
+        return c
+
+    def _permute(self) -> None:
+        global keccak_f_count
+        keccak_f_count += 1
+        keccak_f1600(self.state)
+
+    def _run_f(self) -> None:
+        self.state[self.pos] ^= self.pos_begin
+        self.state[self.pos + 1] ^= 0x04
+        self.state[_STROBE_R + 1] ^= 0x80
+        self._permute()
+        self.pos = 0
+        self.pos_begin = 0
+
+    def _absorb(self, data: bytes) -> None:
+        for byte in data:
+            self.state[self.pos] ^= byte
+            self.pos += 1
+            if self.pos == _STROBE_R:
+                self._run_f()
+
+    def _overwrite(self, data: bytes) -> None:
+        for byte in data:
+            self.state[self.pos] = byte
+            self.pos += 1
+            if self.pos == _STROBE_R:
+                self._run_f()
+
+    def _squeeze(self, n: int) -> bytes:
+        out = bytearray(n)
+        for i in range(n):
+            out[i] = self.state[self.pos]
+            self.state[self.pos] = 0
+            self.pos += 1
+            if self.pos == _STROBE_R:
+                self._run_f()
+        return bytes(out)
+
+    def _begin_op(self, flags: int, more: bool) -> None:
+        if more:
+            assert self.cur_flags == flags
+            return
+        assert flags & _FLAG_T == 0
+        old_begin = self.pos_begin
+        self.pos_begin = self.pos + 1
+        self.cur_flags = flags
+        self._absorb(bytes([old_begin, flags]))
+        if flags & (_FLAG_C | _FLAG_K) and self.pos != 0:
+            self._run_f()
+
+    def meta_ad(self, data: bytes, more: bool) -> None:
+        self._begin_op(_FLAG_M | _FLAG_A, more)
+        self._absorb(data)
+
+    def ad(self, data: bytes, more: bool) -> None:
+        self._begin_op(_FLAG_A, more)
+        self._absorb(data)
+
+    def prf(self, n: int, more: bool) -> bytes:
+        self._begin_op(_FLAG_I | _FLAG_A | _FLAG_C, more)
+        return self._squeeze(n)
+
+    def key(self, data: bytes, more: bool) -> None:
+        self._begin_op(_FLAG_A | _FLAG_C, more)
+        self._overwrite(data)
+
+
+def _u32le(n: int) -> bytes:
+    return n.to_bytes(4, "little")
+
+
+class Transcript:
+    """merlin::Transcript plus the zkp TranscriptProtocol extension (mod.rs:165-228)."""
+
+    def __init__(self, label: bytes):
+        self.strobe = Strobe128(b"Merlin v1.0")
+        self.append_message(b"dom-sep", label)
+
+    def clone(self) -> "Transcript":
+        c = object.__new__(Transcript)
+        c.strobe = self.strobe.clone()
+        return c
+
+    def append_message(self, label: bytes, message: bytes) -> None:
+        self.strobe.meta_ad(label, False)
+        self.strobe.meta_ad(_u32le(len(message)), True)
+        self.strobe.ad(message, False)
+
+    def challenge_bytes(self, label: bytes, n: int) -> bytes:
+        self.strobe.meta_ad(label, False)
+        self.strobe.meta_ad(_u32le(n), True)
+        return self.strobe.prf(n, False)
+
+    # -- TranscriptProtocol (mod.rs:165-228) -------------------------------------------------
+    def domain_sep(self, label: bytes) -> None:                      # mod.rs:166-169
+        self.append_message(b"dom-sep", b"schnorrzkp/1.0/ristretto255")
+        self.append_message(b"dom-sep", label)
+
+    def append_scalar_var(self, label: bytes) -> None:               # mod.rs:171-173
+        self.append_message(b"scvar", label)
+
+    def append_point_var(self, label: bytes, point: Point) -> bytes:  # mod.rs:175-184
+        enc = ristretto_encode(point)
+        self.append_message(b"ptvar", label)
+        self.append_message(b"val", enc)
+        return enc
+
+    def validate_and_append_point_var(self, label: bytes, enc: bytes) -> None:  # mod.rs:186-197
+        if enc == IDENTITY_ENC:
+            raise VerificationFailure()
+        self.append_message(b"ptvar", label)
+        self.append_message(b"val", enc)
+
+    def append_blinding_commitment(self, label: bytes, point: Point) -> bytes:  # mod.rs:199-208
+        enc = ristretto_encode(point)
+        self.append_message(b"blindcom", label)
+        self.append_message(b"val", enc)
+        return enc
+
+    def validate_and_append_blinding_commitment(self, label: bytes, enc: bytes) -> None:  # mod.rs:210-221
+        if enc == IDENTITY_ENC:
+            raise VerificationFailure()
+        self.append_message(b"blindcom", label)
+        self.append_message(b"val", enc)
+
+    def get_challenge(self, label: bytes) -> int:                     # mod.rs:223-227
+        return sc_from_bytes_mod_order_wide(self.challenge_bytes(label, 64))
+
+    # -- TranscriptRng (merlin 2.x), used by prover.rs:78-89 -----------------------------------
+    def build_rng(self) -> "TranscriptRngBuilder":
+        return TranscriptRngBuilder(self.strobe.clone())
+
+
+class TranscriptRngBuilder:
+    def __init__(self, strobe: Strobe128):
+        self.strobe = strobe
+
+    def rekey_with_witness_bytes(self, label: bytes, witness: bytes) -> "TranscriptRngBuilder":
+        self.strobe.meta_ad(label, False)
+        self.strobe.meta_ad(_u32le(len(witness)), True)
+        self.strobe.key(witness, False)
+        return self
+
+    def finalize(self, entropy32: bytes) -> "TranscriptRng":
+        """`finalize(&mut thread_rng())`: the 32 bytes the external RNG would have produced are
+        passed in explicitly so that whole proofs become deterministic and fixture-able."""
+        assert len(entropy32) == 32
+        self.strobe.meta_ad(b"rng", False)
+        self.strobe.key(entropy32, False)
+        return TranscriptRng(self.strobe)
+
+
+class TranscriptRng:
+    def __init__(self, strobe: Strobe128):
+        self.strobe = strobe
+
+    def fill_bytes(self, n: int) -> bytes:
+        self.strobe.meta_ad(_u32le(n), False)
+        return self.strobe.prf(n, False)
+
+    def random_scalar(self) -> int:
+        """Scalar::random(&mut rng) = from_bytes_mod_order_wide(64 rng bytes)."""
+        return sc_from_bytes_mod_order_wide(self.fill_bytes(64))
+
+
+# --------------------------------------------------------------------------------------------
+# errors.rs / proofs.rs
+# --------------------------------------------------------------------------------------------
+class ProofError(Exception):
+    pass
+
+
+class VerificationFailure(ProofError):      # errors.rs:6-7
+    pass
+
+
+class BatchSizeMismatch(ProofError):        # errors.rs:9-10
+    pass
+
+
+@dataclass
+class CompactProof:                         # proofs.rs:15-20
+    challenge: int
+    responses: List[int]
+
+
+@dataclass
+class BatchableProof:                       # proofs.rs:27-32
+    commitments: List[bytes]
+    responses: List[int]
+
+
+Constraint = Tuple[int, List[Tuple[int, int]]]
+
+
+# --------------------------------------------------------------------------------------------
+# Prover (prover.rs)
+# --------------------------------------------------------------------------------------------
+class Prover:
+    def __init__(self, proof_label: bytes, transcript: Transcript):   # prover.rs:41-50
+        transcript.domain_sep(proof_label)
+        self.transcript = transcript
+        self.scalars: List[int] = []
+        self.points: List[Point] = []
+        self.point_labels: List[bytes] = []
+        self.constraints: List[Constraint] = []
+
+    def allocate_scalar(self, label: bytes, assignment: int) -> int:  # prover.rs:53-57
+        self.transcript.append_scalar_var(label)
+        self.scalars.append(assignment % L)
+        return len(self.scalars) - 1
+
+    def allocate_point(self, label: bytes, assignment: Point) -> Tuple[int, bytes]:  # prover.rs:64-73
+        enc = self.transcript.append_point_var(label, assignment)
+        self.points.append(assignment)
+        self.point_labels.append(label)
+        return len(self.points) - 1, enc
+
+    def constrain(self, lhs: int, lc: List[Tuple[int, int]]) -> None:  # prover.rs:139-141
+        self.constraints.append((lhs, list(lc)))
+
+    def _prove_impl(self, entropy32: bytes):                            # prover.rs:76-112
+        rng_builder = self.transcript.build_rng()
+        for s in self.scalars:
+            rng_builder = rng_builder.rekey_with_witness_bytes(b"", sc_to_bytes(s))
+        rng = rng_builder.finalize(entropy32)
+        blindings = [rng.random_scalar() for _ in self.scalars]
+        commitments = []
+        for lhs, lc in self.constraints:
+            com = msm_points([blindings[sv] for sv, _ in lc], [self.points[pv] for _, pv in lc])
+            commitments.append(self.transcript.append_blinding_commitment(self.point_labels[lhs], com))
+        challenge = self.transcript.get_challenge(b"chal")
+        responses = [(s * challenge + b) % L for s, b in zip(self.scalars, blindings)]
+        return challenge, responses, commitments, blindings
+
+    def prove_compact(self, entropy32: bytes) -> CompactProof:        # prover.rs:115-122
+        c, r, _, _ = self._prove_impl(entropy32)
+        return CompactProof(c, r)
+
+    def prove_batchable(self, entropy32: bytes) -> BatchableProof:    # prover.rs:125-132
+        _, r, coms, _ = self._prove_impl(entropy32)
+        return BatchableProof(coms, r)
+
+
+# --------------------------------------------------------------------------------------------
+# Verifier (verifier.rs)
+# --------------------------------------------------------------------------------------------
+class Verifier:
+    def __init__(self, proof_label: bytes, transcript: Transcript):   # verifier.rs:47-56
+        transcript.domain_sep(proof_label)
+        self.transcript = transcript
+        self.num_scalars = 0
+        self.points: List[bytes] = []
+        self.point_labels: List[bytes] = []
+        self.constraints: List[Constraint] = []
+
+    def allocate_scalar(self, label: bytes) -> int:                   # verifier.rs:59-63
+        self.transcript.append_scalar_var(label)
+        self.num_scalars += 1
+        return self.num_scalars - 1
+
+    def allocate_point(self, label: bytes, assignment: bytes) -> int:  # verifier.rs:67-77
+        self.transcript.validate_and_append_point_var(label, assignment)
+        self.points.append(assignment)
+        self.point_labels.append(label)
+        return len(self.points) - 1
+
+    def constrain(self, lhs: int, lc: List[Tuple[int, int]]) -> None:
+        self.constraints.append((lhs, list(lc)))
+
+    def verify_compact(self, proof: CompactProof) -> None:            # verifier.rs:80-120
+        if len(proof.responses) != self.num_scalars:
+            raise VerificationFailure()
+        points = []
+        for enc in self.points:
+            p = ristretto_decode(enc)
+            if p is None:
+                raise VerificationFailure()
+            points.append(p)
+        minus_c = (-proof.challenge) % L
+        for lhs, lc in self.constraints:
+            com = msm_points(
+                [proof.responses[sv] for sv, _ in lc] + [minus_c],
+                [points[pv] for _, pv in lc] + [points[lhs]],
+            )
+            self.transcript.append_blinding_commitment(self.point_labels[lhs], com)
+        if self.transcript.get_challenge(b"chal") != proof.challenge % L:
+            raise VerificationFailure()
+
+    def verify_batchable(self, proof: BatchableProof, weights: Sequence[int]) -> None:  # verifier.rs:123-173
+        """`weights[i]` replaces `Scalar::from(thread_rng().gen::<u128>())` for constraint i."""
+        if len(proof.responses) != self.num_scalars:
+            raise VerificationFailure()
+        if len(proof.commitments) != len(self.constraints):
+            raise VerificationFailure()
+        for i, com in enumerate(proof.commitments):
+            lhs, _ = self.constraints[i]
+            self.transcript.validate_and_append_blinding_commitment(self.point_labels[lhs], com)
+        minus_c = (-self.transcript.get_challenge(b"chal")) % L
+        off = len(self.points)
+        coeffs = [0] * (len(self.points) + len(proof.commitments))
+        for i, (lhs, lc) in enumerate(self.constraints):
+            r = weights[i] % (1 << 128)
+            coeffs[off + i] = (coeffs[off + i] - r) % L
+            coeffs[lhs] = (coeffs[lhs] + r * minus_c) % L
+            for sv, pv in lc:
+                coeffs[pv] = (coeffs[pv] + r * proof.responses[sv]) % L
+        check = msm_optional([sc_to_bytes(c) for c in coeffs], list(self.points) + list(proof.commitments))
+        if check is None or check != IDENTITY_ENC:
+            raise VerificationFailure()
+
+
+# --------------------------------------------------------------------------------------------
+# BatchVerifier (batch_verifier.rs).  PointVar = ("S", idx) | ("I", idx)
+# --------------------------------------------------------------------------------------------
+class BatchVerifier:
+    def __init__(self, proof_label: bytes, batch_size: int, transcripts: List[Transcript]):  # :67-87
+        if len(transcripts) != batch_size:
+            raise BatchSizeMismatch()
+        for t in transcripts:
+            t.domain_sep(proof_label)
+        self.batch_size = batch_size
+        self.transcripts = transcripts
+        self.num_scalars = 0
+        self.static_points: List[bytes] = []
+        self.static_point_labels: List[bytes] = []
+        self.instance_points: List[List[bytes]] = []
+        self.instance_point_labels: List[bytes] = []
+        self.constraints: List[Tuple[Tuple[str, int], List[Tuple[int, Tuple[str, int]]]]] = []
+
+    def allocate_scalar(self, label: bytes) -> int:                   # :90-96
+        for t in self.transcripts:
+            t.append_scalar_var(label)
+        self.num_scalars += 1
+        return self.num_scalars - 1
+
+    def allocate_static_point(self, label: bytes, assignment: bytes):  # :100-112
+        for t in self.transcripts:
+            t.validate_and_append_point_var(label, assignment)
+        self.static_points.append(assignment)
+        self.static_point_labels.append(label)
+        return ("S", len(self.static_points) - 1)
+
+    def allocate_instance_point(self, label: bytes, assignments: List[bytes]):  # :115-134
+        if len(assignments) != self.batch_size:
+            raise BatchSizeMismatch()
+        for t, a in zip(self.transcripts, assignments):
+            t.validate_and_append_point_var(label, a)
+        self.instance_points.append(list(assignments))
+        self.instance_point_labels.append(label)
+        return ("I", len(self.instance_points) - 1)
+
+    def constrain(self, lhs, lc) -> None:
+        self.constraints.append((lhs, list(lc)))
+
+    def coefficient_build(self, proofs: List[BatchableProof], weights: Sequence[Sequence[int]]):
+        """batch_verifier.rs:137-217: everything before the MSM.  Returns (scalars, encodings)
+        exactly as they are chained into optional_multiscalar_mul at :219-228.
+        `weights[i][j]` replaces the u128 drawn for constraint i, proof j (:179)."""
+        if len(proofs) != self.batch_size:
+            raise BatchSizeMismatch()
+        for pr in proofs:
+            if len(pr.commitments) != len(self.constraints):
+                raise VerificationFailure()
+            if len(pr.responses) != self.num_scalars:
+                raise VerificationFailure()
+        for j in range(self.batch_size):
+            for i, com in enumerate(proofs[j].commitments):
+                kind, idx = self.constraints[i][0]
+                label = self.static_point_labels[idx] if kind == "S" else self.instance_point_labels[idx]
+                self.transcripts[j].validate_and_append_blinding_commitment(label, com)
+        minus_c = [(-t.get_challenge(b"chal")) % L for t in self.transcripts]
+        num_s, num_i, num_c = len(self.static_points), len(self.instance_points), len(self.constraints)
+        n = self.batch_size
+        static_coeffs = [0] * num_s
+        inst = [0] * ((num_i + num_c) * n)       # util.rs Matrix: entries[cols*r + c]
+        for i, (lhs, lc) in enumerate(self.constraints):
+            for j in range(n):
+                r = weights[i][j] % (1 << 128)
+                inst[n * (num_i + i) + j] = (inst[n * (num_i + i) + j] - r) % L
+                kind, idx = lhs
+                if kind == "S":
+                    static_coeffs[idx] = (static_coeffs[idx] + r * minus_c[j]) % L
+                else:
+                    inst[n * idx + j] = (inst[n * idx + j] + r * minus_c[j]) % L
+                for sv, (kind, idx) in lc:
+                    resp = proofs[j].responses[sv]
+                    if kind == "S":
+                        static_coeffs[idx] = (static_coeffs[idx] + r * resp) % L
+                    else:
+                        inst[n * idx + j] = (inst[n * idx + j] + r * resp) % L
+        rows = [list(r) for r in self.instance_points]
+        for i in range(num_c):
+            rows.append([pr.commitments[i] for pr in proofs])
+        flat = [e for row in rows for e in row]
+        return static_coeffs + inst, list(self.static_points) + flat
+
+    def verify_batchable(self, proofs: List[BatchableProof], weights: Sequence[Sequence[int]]) -> None:
+        scalars, encs = self.coefficient_build(proofs, weights)
+        check = msm_optional([sc_to_bytes(s) for s in scalars], encs)       # :219-228
+        if check is None or check != IDENTITY_ENC:                          # :230-234
+            raise VerificationFailure()
+
+
+# --------------------------------------------------------------------------------------------
+# Statement descriptors: what define_proof! fixes (macros.rs:124-138, 206-258, 280-311, 336-370)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Statement:
+    """name/label, secret names, instance point names, common point names, constraints as
+    (lhs point name, [(secret name, point name)]).  Allocation order = secrets, then instance
+    points, then common points, each in declaration order (macros.rs:215-242)."""
+    label: bytes
+    secrets: List[str]
+    instance: List[str]
+    common: List[str]
+    constraints: List[Tuple[str, List[Tuple[str, str]]]] = field(default_factory=list)
+
+    def build_prover(self, transcript: Transcript, scalars: dict, points: dict):
+        pr = Prover(self.label, transcript)
+        sv = {n: pr.allocate_scalar(n.encode(), scalars[n]) for n in self.secrets}
+        pv, enc = {}, {}
+        for n in self.instance + self.common:
+            pv[n], enc[n] = pr.allocate_point(n.encode(), points[n])
+        for lhs, lc in self.constraints:
+            pr.constrain(pv[lhs], [(sv[s], pv[p]) for s, p in lc])
+        return pr, enc
+
+    def build_verifier(self, transcript: Transcript, encs: dict) -> Verifier:
+        vr = Verifier(self.label, transcript)
+        sv = {n: vr.allocate_scalar(n.encode()) for n in self.secrets}
+        pv = {n: vr.allocate_point(n.encode(), encs[n]) for n in self.instance + self.common}
+        for lhs, lc in self.constraints:
+            vr.constrain(pv[lhs], [(sv[s], pv[p]) for s, p in lc])
+        return vr
+
+    def build_batch_verifier(self, transcripts: List[Transcript], inst_encs: dict, common_encs: dict) -> BatchVerifier:
+        bv = BatchVerifier(self.label, len(transcripts), transcripts)
+        sv = {n: bv.allocate_scalar(n.encode()) for n in self.secrets}
+        pv = {}
+        for n in self.instance:
+            pv[n] = bv.allocate_instance_point(n.encode(), inst_encs[n])
+        for n in self.common:
+            pv[n] = bv.allocate_static_point(n.encode(), common_encs[n])
+        for lhs, lc in self.constraints:
+            bv.constrain(pv[lhs], [(sv[s], pv[p]) for s, p in lc])
+        return bv
+
+
+def dleq_statement() -> Statement:
+    """define_proof! {dleq, "DLEQ proof", (x), (A, B, H), (G) : A = (x * G), B = (x * H)} benches/zkp.rs:49."""
+    return Statement(b"DLEQ proof", ["x"], ["A", "B", "H"], ["G"],
+                     [("A", [("x", "G")]), ("B", [("x", "H")])])
+
+
+def cmz_statement(n: int = 10) -> Statement:
+    """cred_show_10, benches/zkp.rs:27-46."""
+    ms = [f"m_{i}" for i in range(1, n + 1)]
+    zs = [f"z_{i}" for i in range(1, n + 1)]
+    cs = [f"C_{i}" for i in range(1, n + 1)]
+    xs = [f"X_{i}" for i in range(1, n + 1)]
+    cons = [(cs[i], [(ms[i], "P"), (zs[i], "A")]) for i in range(n)]
+    cons.append(("V", [(ms[i], xs[i]) for i in range(n)] + [("minus_z_Q", "Q")]))
+    return Statement(f"CMZ cred show n={n}".encode(), ms + zs + ["minus_z_Q"], cs + ["P", "Q", "V"],
+                     xs + ["A", "B"], cons)

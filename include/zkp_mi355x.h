@@ -1,0 +1,117 @@
+/* zkp_mi355x.h -- C ABI of the MI355X (gfx950) ristretto255 MSM / codec engine.
+ *
+ * This is the drop-in boundary for the hot path of dalek-cryptography/zkp.
+ * The reference has no FFI: the path sits behind three curve25519-dalek trait methods plus the
+ * point codec.  Each entry point below names the reference call site(s) it replaces; the Rust
+ * `-sys` binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   scalar  : 32 bytes, little-endian integer.  Any 256-bit value is accepted and is used as an
+ *             integer multiplier (so non-canonical scalars give the same group element dalek's
+ *             `Scalar` would after reduction mod l).
+ *   point   : 32 bytes, ristretto255 encoding (RFC 9496).  Decoding rejects exactly what
+ *             `CompressedRistretto::decompress` rejects (non-canonical, negative s, non-square,
+ *             negative t, y == 0).
+ *   buffers : caller owned, not retained after return.  `_dev` variants take DEVICE pointers
+ *             (hipMalloc / torch CUDA tensors), enqueue on the context's stream and do not
+ *             synchronise; plain variants take HOST pointers, copy in/out and synchronise.
+ *   return  : 0 = computed.  < 0 = infrastructure failure (see ZKP_ERR_*): NO output may be
+ *             trusted, callers must fail closed (reference analogue: ProofError::VerificationFailure,
+ *             src/errors.rs:6).  There is no CPU fallback inside this library.
+ *   threads : one context per host thread / per GPU; a context is not re-entrant.
+ */
+#ifndef ZKP_MI355X_H
+#define ZKP_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKP_OK 0
+#define ZKP_ERR_HIP (-1)        /* a HIP runtime call failed (zkp_last_error has the text)        */
+#define ZKP_ERR_ARG (-2)        /* NULL pointer / inconsistent sizes / index out of range         */
+#define ZKP_ERR_NO_DEVICE (-3)  /* no gfx950 device visible                                       */
+#define ZKP_ERR_OOM (-4)        /* device allocation failed                                       */
+
+/* flags for zkp_msm_many */
+#define ZKP_VARTIME 0  /* replaces RistrettoPoint::vartime_multiscalar_mul (verifier.rs:97)        */
+#define ZKP_CT 1       /* replaces RistrettoPoint::multiscalar_mul (prover.rs:94): the instruction */
+                       /* stream and every address are independent of the scalars                  */
+
+typedef struct zkp_ctx zkp_ctx;
+
+/* One context per GPU (one process per GPU in multi-GPU jobs).  device_id is the HIP ordinal. */
+int zkp_ctx_create(zkp_ctx** out, int device_id);
+void zkp_ctx_destroy(zkp_ctx* ctx);
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the
+ * context's own stream. */
+int zkp_ctx_set_stream(zkp_ctx* ctx, void* hip_stream);
+int zkp_ctx_synchronize(zkp_ctx* ctx);
+/* Text of the last error on this thread (never NULL). */
+const char* zkp_last_error(void);
+/* Library / build identification, e.g. "zkp-mi355x 0.1 gfx950". */
+const char* zkp_version(void);
+
+/* (1) Many small multiscalar multiplications in CSR form, fused with compression.
+ *     Replaces, for a whole batch of proofs at once:
+ *       prover.rs:94-97   RistrettoPoint::multiscalar_mul(..)            (flags = ZKP_CT)
+ *       verifier.rs:97-106 RistrettoPoint::vartime_multiscalar_mul(..)   (flags = ZKP_VARTIME)
+ *     and the `point.compress()` of toolbox/mod.rs:204 applied to each result.
+ *       out[i]    = encode( sum_{t in [off[i], off[i+1])} scalars[t] * decode(points[pidx[t]]) )
+ *       status[i] = 0 ok | 1 some referenced point failed to decode (Rust: decompress() == None;
+ *                   out[i] is then 32 zero bytes and must not be used)
+ *     off has n_msm+1 entries, off[0] = 0, non-decreasing; T = off[n_msm] terms. An empty range
+ *     yields the identity encoding (32 zero bytes), like an empty dalek MSM. */
+int zkp_msm_many(zkp_ctx* ctx, uint32_t n_msm, const uint32_t* off, const uint8_t* scalars /*[T][32]*/,
+                 const uint32_t* pidx /*[T]*/, const uint8_t* points /*[n_points][32]*/, uint32_t n_points,
+                 int flags, uint8_t* out /*[n_msm][32]*/, uint8_t* status /*[n_msm]*/);
+int zkp_msm_many_dev(zkp_ctx* ctx, uint32_t n_msm, const uint32_t* d_off, const uint8_t* d_scalars,
+                     const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms,
+                     int flags, uint8_t* d_out, uint8_t* d_status);
+
+/* (2) One large multiscalar multiplication with decode-or-None.
+ *     Replaces RistrettoPoint::optional_multiscalar_mul(scalars, points.map(decompress)) at
+ *       verifier.rs:162-166 and batch_verifier.rs:219-228 (the batch-verification random linear
+ *       combination of size num_s + (num_i + num_c) * N).
+ *     *status = 0: Some(P), out_point = encode(P) (callers test for 32 zero bytes = identity,
+ *                  verifier.rs:168 / batch_verifier.rs:230)
+ *             = 1: None (some point failed to decode); out_point is zeroed and meaningless. */
+int zkp_msm_optional(zkp_ctx* ctx, uint64_t n, const uint8_t* scalars /*[n][32]*/,
+                     const uint8_t* points /*[n][32]*/, uint8_t out_point[32], int* status);
+int zkp_msm_optional_dev(zkp_ctx* ctx, uint64_t n, const uint8_t* d_scalars, const uint8_t* d_points,
+                         uint8_t* d_out_point /*[32]*/, uint32_t* d_status /*[1]*/);
+
+/* (3) Stand-alone decode / validity check, batched.  Replaces the
+ *     `.map(|pt| pt.decompress()).collect::<Option<Vec<_>>>()` of verifier.rs:87-92.
+ *     status[i] = 0 valid | 1 decompress() would return None.  If xyzt != NULL it receives the
+ *     affine extended coordinates (X, Y, Z = 1, T) as 4 x 32-byte little-endian field elements. */
+int zkp_decode_check(zkp_ctx* ctx, uint64_t n, const uint8_t* points /*[n][32]*/, uint8_t* status /*[n]*/,
+                     uint8_t* xyzt /*[n][128] or NULL*/);
+
+/* (4) Stand-alone encode.  Replaces `point.compress()` of mod.rs:180 for provers that hold
+ *     uncompressed points (prover.rs:64-73).  Input: extended coordinates (X, Y, Z, T), each a
+ *     32-byte little-endian field element (need not be reduced below p, bit 255 ignored). */
+int zkp_encode_many(zkp_ctx* ctx, uint64_t n, const uint8_t* xyzt /*[n][128]*/, uint8_t* out /*[n][32]*/);
+
+/* Timing of the last *_dev / host call on this context, measured with HIP events on the stream the
+ * kernels were launched on.  kernel_ms[] is indexed by ZKP_K_*; returns the number of entries. */
+enum {
+  ZKP_K_DECODE = 0,      /* ristretto decode (+ affine-niels conversion, digit extraction)       */
+  ZKP_K_TERMS = 1,       /* per-term scalar multiplication (small-MSM path)                       */
+  ZKP_K_REDUCE = 2,      /* per-MSM sum of partials + compress                                    */
+  ZKP_K_SORT = 3,        /* Pippenger: histogram + scan + scatter                                 */
+  ZKP_K_BUCKET = 4,      /* Pippenger: bucket accumulation                                        */
+  ZKP_K_COMBINE = 5,     /* Pippenger: bucket reduction + window combination + compress           */
+  ZKP_K_COUNT = 6
+};
+int zkp_ctx_last_timing(zkp_ctx* ctx, float* kernel_ms /*[ZKP_K_COUNT]*/, float* total_ms);
+/* Enable (1) / disable (0) per-kernel event timing (off by default: events add launch gaps). */
+int zkp_ctx_set_profiling(zkp_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKP_MI355X_H */

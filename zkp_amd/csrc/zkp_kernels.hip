@@ -1,0 +1,833 @@
+// MI355X (gfx950) kernels and C ABI of the ristretto255 MSM engine (include/zkp_mi355x.h).
+//
+// Two execution paths, both integer-VALU bound (v_mad_u64_u32 chains, see fe25519.h):
+//
+//  (A) many small MSMs  (zkp_msm_many; reference prover.rs:94, verifier.rs:97)
+//        k_decode_affine   1 lane / distinct point      encodings -> (x, y, t), valid flag
+//        k_terms_r4        1 lane / (scalar, point) term fixed-schedule signed radix-4 scalar
+//                                                       multiplication, table {P, 2P} in VGPRs
+//        k_reduce_encode   1 lane / MSM                 sum of its partials + ristretto encode
+//
+//  (B) one large MSM    (zkp_msm_optional; reference verifier.rs:162, batch_verifier.rs:219)
+//        k_pip_prepare<C>  1 lane / term                decode -> affine niels, signed radix-2^C
+//                                                       digits, per-window histogram
+//        k_pip_scan        1 block / window             exclusive scan of bucket sizes
+//        k_pip_scatter     1 lane / (term, window)      counting-sort scatter of term indices
+//        k_pip_bucket_sum  1 lane / (window, bucket)    mixed additions of the bucket's points
+//        k_pip_reduce_lvl  1 lane / 8 inputs            radix-8 tree evaluation of sum_b b*S_b
+//        k_pip_combine     1 block                      Horner over windows + ristretto encode
+//
+// Point addition is commutative and the final encoding canonical, so the (non-deterministic)
+// order in which the atomics of k_pip_scatter fill a bucket cannot change a single output bit.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/zkp_mi355x.h"
+#include "dev_layout.h"
+
+using namespace zkp;
+
+// =============================================================================================
+// scalar recoding
+// =============================================================================================
+// e = s + K where K has the bit pattern `pattern` in every word: signed-digit recoding without a
+// sequential carry (digit_i = e_i - 2^(c-1)).  top receives the carry out of bit 255.
+__device__ __forceinline__ void sc_add_pattern(uint32_t e[8], uint32_t& top, const uint32_t s[8], uint32_t pattern) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (uint64_t)s[i] + pattern;
+    e[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  top = (uint32_t)c;
+}
+
+// w[j] for a run-time j without dynamic register indexing (which would go to scratch)
+__device__ __forceinline__ uint32_t sel8(const uint32_t w[8], int j) {
+  uint32_t r = w[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) r = (j == i) ? w[i] : r;
+  return r;
+}
+
+// =============================================================================================
+// (A) small-MSM path
+// =============================================================================================
+__global__ void __launch_bounds__(128, 2)
+k_decode_affine(uint32_t n, const uint8_t* __restrict__ enc, dev_affine* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_vec<2>(w, enc + 32 * (size_t)i);
+  ge_p3 p;
+  const uint32_t ok = ristretto_decode(p, w);
+  store_affine(out + i, p, ok);
+}
+
+// partial[t] = scalars[t] * points[pidx[t]].  Fixed schedule: 128 windows of (2 doublings, 1 unified
+// addition of a masked-selected table entry); no branch or address depends on the scalar, so the
+// same kernel serves ZKP_CT and ZKP_VARTIME.
+__global__ void __launch_bounds__(128, 2)
+k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx,
+           uint32_t n_points, const dev_affine* __restrict__ pts, dev_ext* __restrict__ partial) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  uint32_t s[8], e[8], top;
+  load_vec<2>(s, scalars + 32 * (size_t)t);
+  sc_add_pattern(e, top, s, 0xAAAAAAAAu);           // digits e_i - 2 in {-2,-1,0,1}
+  ge_p3 P, P2, acc;
+  const uint32_t pi = pidx[t];
+  load_affine(P, pts + (pi < n_points ? pi : 0u));   // out-of-range index: flagged by k_reduce_encode
+  ge_cached c1, c2;
+  ge_to_cached(c1, P);
+  ge_double<true>(P2, P);
+  ge_to_cached(c2, P2);
+  ge_identity(acc);
+  fe_cmov(acc.X, P.X, top);                          // carry out of bit 255: digit 128 in {0,1}
+  fe_cmov(acc.Y, P.Y, top);
+  fe_cmov(acc.T, P.T, top);
+#pragma unroll 1
+  for (int j = 7; j >= 0; --j) {
+    uint32_t cur = sel8(e, j);
+#pragma unroll 1
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t d = cur >> 30;
+      cur <<= 2;
+      ge_double<false>(acc, acc);
+      ge_double<true>(acc, acc);
+      const uint32_t neg = (uint32_t)(d < 2);
+      const uint32_t mag = neg ? 2u - d : d - 2u;
+      ge_cached sel;
+      ge_cached_identity(sel);
+      ge_cached_cmov(sel, c1, (uint32_t)(mag == 1));
+      ge_cached_cmov(sel, c2, (uint32_t)(mag == 2));
+      ge_cached_cneg(sel, neg);
+      ge_add_cached(acc, acc, sel);
+    }
+  }
+  store_ext(partial + t, acc);
+}
+
+template <typename STATUS_T>
+__global__ void __launch_bounds__(128, 2)
+k_reduce_encode(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pidx,
+                uint32_t n_points, const dev_affine* __restrict__ pts, const dev_ext* __restrict__ partial,
+                uint8_t* __restrict__ out, STATUS_T* __restrict__ status) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_msm) return;
+  const uint32_t b = off[i], e = off[i + 1];
+  ge_p3 acc;
+  ge_identity(acc);
+  uint32_t bad = 0;
+#pragma unroll 1
+  for (uint32_t t = b; t < e; ++t) {
+    ge_p3 q;
+    load_ext(q, partial + t);
+    ge_add_p3(acc, acc, q);
+    const uint32_t pi = pidx[t];
+    bad |= pi < n_points ? (pts[pi].valid ^ 1u) : 1u;
+  }
+  uint32_t w[8];
+  ristretto_encode(w, acc);
+  if (bad) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = 0;
+  }
+  store_vec<2>(out + 32 * (size_t)i, w);
+  status[i] = (STATUS_T)bad;
+}
+
+__global__ void k_iota_single_msm(uint32_t n, uint32_t* __restrict__ pidx, uint32_t* __restrict__ off) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pidx[i] = i;
+  if (i == 0) { off[0] = 0; off[1] = n; }
+}
+
+// =============================================================================================
+// (B) Pippenger path
+// =============================================================================================
+template <int C>
+struct pip_cfg {
+  static constexpr int W = (256 + C - 1) / C;        // windows carrying the -2^(C-1) offset
+  static constexpr int W1 = W + 1;                   // + the carry window (digit in {0,1}, no offset)
+  static constexpr uint32_t B = 1u << (C - 1);       // bucket indices 1..B; index 0 unused
+  static constexpr uint32_t B1 = B + 1;
+  // word j of K = sum_{w<W} 2^(C-1 + C w)
+  static constexpr uint32_t kword(int j) {
+    uint32_t r = 0;
+    for (int w = 0; w < W; ++w) {
+      const int bit = C - 1 + C * w;
+      if (bit / 32 == j) r |= 1u << (bit % 32);
+    }
+    return r;
+  }
+};
+
+template <int C>
+__global__ void __launch_bounds__(128, 2)
+k_pip_prepare(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
+              dev_niels* __restrict__ niels, uint32_t* __restrict__ digits, uint32_t* __restrict__ hist,
+              uint32_t* __restrict__ invalid) {
+  using cfg = pip_cfg<C>;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  {
+    uint32_t w[8];
+    load_vec<2>(w, points + 32 * (size_t)i);
+    ge_p3 p;
+    const uint32_t ok = ristretto_decode(p, w);
+    ge_niels q;
+    ge_affine_to_niels(q, p);
+    store_niels(niels + i, q, ok);
+    if (!ok) atomicOr(invalid, 1u);
+  }
+  uint32_t s[8], e[10];
+  load_vec<2>(s, scalars + 32 * (size_t)i);
+  {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      c += (uint64_t)(j < 8 ? s[j] : 0u) + cfg::kword(j);
+      e[j] = (uint32_t)c;
+      c >>= 32;
+    }
+    e[9] = 0;
+  }
+#pragma unroll
+  for (int w = 0; w < cfg::W1; ++w) {
+    const int pos = C * w, lo = pos >> 5, sh = pos & 31;
+    uint32_t v = e[lo] >> sh;
+    if (sh + C > 32) v |= e[lo + 1] << (32 - sh);
+    v &= (1u << C) - 1u;
+    uint32_t mag, neg;
+    if (w < cfg::W) {
+      neg = (uint32_t)(v < cfg::B);
+      mag = neg ? cfg::B - v : v - cfg::B;
+    } else {
+      neg = 0;
+      mag = v;
+    }
+    digits[(size_t)w * n + i] = mag | (neg << 31);
+    if (mag) atomicAdd(&hist[(size_t)w * cfg::B1 + mag], 1u);
+  }
+}
+
+// exclusive scan of hist[w][0..bins) -> start[w][.], cursor[w][.]   (one block per window)
+__global__ void __launch_bounds__(256)
+k_pip_scan(uint32_t bins, const uint32_t* __restrict__ hist, uint32_t* __restrict__ start, uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t part[256];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x;
+  const uint32_t chunk = (bins + 255) / 256;
+  const uint32_t lo = tid * chunk, hi = min(lo + chunk, bins);
+  const uint32_t* h = hist + (size_t)w * bins;
+  uint32_t sum = 0;
+  for (uint32_t b = lo; b < hi; ++b) sum += h[b];
+  part[tid] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    const uint32_t v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - sum;
+  for (uint32_t b = lo; b < hi; ++b) {
+    start[(size_t)w * bins + b] = run;
+    cursor[(size_t)w * bins + b] = run;
+    run += h[b];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_pip_scatter(uint32_t n, uint32_t bins, const uint32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
+              uint32_t* __restrict__ sorted) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t w = blockIdx.y;
+  if (i >= n) return;
+  const uint32_t key = digits[(size_t)w * n + i];
+  const uint32_t mag = key & 0x7fffffffu;
+  if (!mag) return;
+  const uint32_t slot = atomicAdd(&cursor[(size_t)w * bins + mag], 1u);
+  sorted[(size_t)w * n + slot] = i | (key & 0x80000000u);
+}
+
+__global__ void __launch_bounds__(128, 2)
+k_pip_bucket_sum(uint32_t n, uint32_t bins, uint32_t total, const uint32_t* __restrict__ start,
+                 const uint32_t* __restrict__ hist, const uint32_t* __restrict__ sorted,
+                 const dev_niels* __restrict__ niels, dev_ext* __restrict__ buckets) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const uint32_t w = g / bins, b = g - w * bins;
+  ge_p3 acc;
+  ge_identity(acc);
+  const uint32_t cnt = b ? hist[g] : 0u;
+  const uint32_t* lst = sorted + (size_t)w * n + start[g];
+#pragma unroll 1
+  for (uint32_t k = 0; k < cnt; ++k) {
+    const uint32_t idx = lst[k];
+    ge_niels q;
+    load_niels(q, niels + (idx & 0x7fffffffu));
+    ge_niels_cneg(q, idx >> 31);
+    ge_madd(acc, acc, q);
+  }
+  store_ext(buckets + g, acc);
+}
+
+// One level of the radix-8 evaluation of T = sum_g g * S_g  (g = 0 .. 8^L - 1).
+// Invariant before level l:  T = sum_j ( A_j + 8^l * j * R_j ),  A absent (= 0) at level 0.
+// A lane folds 8 consecutive inputs j = 8j' + i:   R' = sum_i R_i,  A' = sum_i A_i + 8^l * sum_i i R_i.
+__global__ void __launch_bounds__(128, 2)
+k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t out_stride, int level,
+                 const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
+                 dev_ext* __restrict__ A_out, dev_ext* __restrict__ R_out) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const uint32_t w = g / n_out, j = g - w * n_out;
+  const dev_ext* rin = R_in + (size_t)w * in_stride + 8 * (size_t)j;
+  ge_p3 run, U, q;
+  ge_identity(run);
+  ge_identity(U);
+#pragma unroll 1
+  for (int i = 7; i >= 1; --i) {
+    load_ext(q, rin + i);
+    ge_add_p3(run, run, q);
+    ge_add_p3(U, U, run);
+  }
+  load_ext(q, rin);
+  ge_add_p3(run, run, q);
+#pragma unroll 1
+  for (int k = 0; k < 3 * level; ++k) ge_double<true>(U, U);
+  if (level > 0) {
+    const dev_ext* ain = A_in + (size_t)w * in_stride + 8 * (size_t)j;
+#pragma unroll 1
+    for (int i = 0; i < 8; ++i) {
+      load_ext(q, ain + i);
+      ge_add_p3(U, U, q);
+    }
+  }
+  store_ext(A_out + (size_t)w * out_stride + j, U);
+  store_ext(R_out + (size_t)w * out_stride + j, run);
+}
+
+// T_w = A_final[w] + B * S_{w,B};  result = sum_w 2^(C w) T_w;  encode.
+__global__ void __launch_bounds__(64)
+k_pip_combine(int W1, int C, uint32_t bins, const dev_ext* __restrict__ A_final,
+              const dev_ext* __restrict__ buckets, const uint32_t* __restrict__ invalid,
+              uint8_t* __restrict__ out_point, uint32_t* __restrict__ status) {
+  __shared__ dev_ext T[40];
+  const int w = threadIdx.x;
+  if (w < W1) {
+    ge_p3 t, top;
+    load_ext(t, A_final + w);
+    load_ext(top, buckets + (size_t)w * bins + (bins - 1));
+#pragma unroll 1
+    for (int k = 0; k < C - 1; ++k) ge_double<true>(top, top);
+    ge_add_p3(t, t, top);
+    store_ext(&T[w], t);
+  }
+  __syncthreads();
+  if (w == 0) {
+    ge_p3 acc, t;
+    load_ext(acc, &T[W1 - 1]);
+#pragma unroll 1
+    for (int k = W1 - 2; k >= 0; --k) {
+#pragma unroll 1
+      for (int d = 0; d < C; ++d) ge_double<true>(acc, acc);
+      load_ext(t, &T[k]);
+      ge_add_p3(acc, acc, t);
+    }
+    uint32_t o[8];
+    ristretto_encode(o, acc);
+    const uint32_t bad = *invalid;
+    if (bad) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = 0;
+    }
+    store_vec<2>(out_point, o);
+    *status = bad ? 1u : 0u;
+  }
+}
+
+// =============================================================================================
+// stand-alone codec kernels
+// =============================================================================================
+__global__ void __launch_bounds__(128, 2)
+k_decode_check(uint32_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ status, uint8_t* __restrict__ xyzt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_vec<2>(w, enc + 32 * (size_t)i);
+  ge_p3 p;
+  const uint32_t ok = ristretto_decode(p, w);
+  status[i] = (uint8_t)(ok ^ 1u);
+  if (xyzt) {
+    uint32_t o[32];
+    fe_towords(o, p.X); fe_towords(o + 8, p.Y); fe_towords(o + 16, p.Z); fe_towords(o + 24, p.T);
+    store_vec<8>(xyzt + 128 * (size_t)i, o);
+  }
+}
+
+__global__ void __launch_bounds__(128, 2)
+k_encode_many(uint32_t n, const uint8_t* __restrict__ xyzt, uint8_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[32];
+  load_vec<8>(w, xyzt + 128 * (size_t)i);
+  ge_p3 p;
+  fe_fromwords(p.X, w); fe_fromwords(p.Y, w + 8); fe_fromwords(p.Z, w + 16); fe_fromwords(p.T, w + 24);
+  uint32_t o[8];
+  ristretto_encode(o, p);
+  store_vec<2>(out + 32 * (size_t)i, o);
+}
+
+// =============================================================================================
+// host side: context, workspace, C ABI
+// =============================================================================================
+static thread_local std::string g_last_error = "";
+
+static int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(e_ == hipErrorOutOfMemory ? ZKP_ERR_OOM : ZKP_ERR_HIP,                       \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+  } while (0)
+
+struct zkp_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  bool profiling = false;
+  hipEvent_t ev[ZKP_K_COUNT + 1] = {};
+  int ev_kind[ZKP_K_COUNT + 1] = {};
+  int n_ev = 0;
+  float kernel_ms[ZKP_K_COUNT] = {};
+  float total_ms = 0;
+};
+
+namespace {
+
+struct carve {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+int ensure_ws(zkp_ctx* c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return ZKP_OK;
+  if (c->ws) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+  }
+  const size_t want = bytes + bytes / 8;
+  HIP_TRY(hipMalloc(&c->ws, want));
+  c->ws_bytes = want;
+  return ZKP_OK;
+}
+
+void prof_begin(zkp_ctx* c) {
+  c->n_ev = 0;
+  if (c->profiling) { hipEventRecord(c->ev[0], c->stream); c->ev_kind[0] = -1; c->n_ev = 1; }
+}
+void prof_mark(zkp_ctx* c, int kind) {
+  if (c->profiling && c->n_ev <= ZKP_K_COUNT) {
+    hipEventRecord(c->ev[c->n_ev], c->stream);
+    c->ev_kind[c->n_ev] = kind;
+    c->n_ev++;
+  }
+}
+
+inline dim3 grid1(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint8_t* d_scalars,
+                   const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms,
+                   uint8_t* d_out, uint8_t* d_status8, uint32_t* d_status32, size_t ws_reserved) {
+  carve cv;
+  cv.off = ws_reserved;
+  const size_t o_pts = cv.take((size_t)n_points * sizeof(dev_affine));
+  const size_t o_part = cv.take((size_t)n_terms * sizeof(dev_ext));
+  // ensure_ws was done by the caller for ws_reserved + this much; recompute defensively
+  if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
+  char* base = static_cast<char*>(c->ws);
+  dev_affine* pts = reinterpret_cast<dev_affine*>(base + o_pts);
+  dev_ext* part = reinterpret_cast<dev_ext*>(base + o_part);
+  if (n_points) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 128), dim3(128), 0, c->stream, n_points, d_points, pts);
+  prof_mark(c, ZKP_K_DECODE);
+  if (n_terms) hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 128), dim3(128), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part);
+  prof_mark(c, ZKP_K_TERMS);
+  if (n_msm) {
+    if (d_status8)
+      hipLaunchKernelGGL(k_reduce_encode<uint8_t>, grid1(n_msm, 128), dim3(128), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status8);
+    else
+      hipLaunchKernelGGL(k_reduce_encode<uint32_t>, grid1(n_msm, 128), dim3(128), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status32);
+  }
+  prof_mark(c, ZKP_K_REDUCE);
+  HIP_TRY(hipGetLastError());
+  return ZKP_OK;
+}
+size_t terms_path_ws(uint32_t n_points, uint32_t n_terms) {
+  carve cv;
+  cv.take((size_t)n_points * sizeof(dev_affine));
+  cv.take((size_t)n_terms * sizeof(dev_ext));
+  return cv.off;
+}
+
+template <int C>
+size_t pip_ws(uint64_t n) {
+  using cfg = pip_cfg<C>;
+  carve cv;
+  cv.take(n * sizeof(dev_niels));
+  cv.take((size_t)cfg::W1 * n * 4);            // digits
+  cv.take((size_t)cfg::W1 * n * 4);            // sorted
+  cv.take((size_t)cfg::W1 * cfg::B1 * 4 * 3);  // hist, start, cursor
+  cv.take(256);                                // invalid flag
+  cv.take((size_t)cfg::W1 * cfg::B1 * sizeof(dev_ext));       // buckets
+  cv.take((size_t)cfg::W1 * (cfg::B / 7 + 8) * sizeof(dev_ext) * 2);  // reduction levels (A and R)
+  return cv.off;
+}
+
+template <int C>
+int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_points, uint8_t* d_out,
+            uint32_t* d_status, size_t ws_reserved) {
+  using cfg = pip_cfg<C>;
+  carve cv;
+  cv.off = ws_reserved;
+  char* base = static_cast<char*>(c->ws);
+  dev_niels* niels = reinterpret_cast<dev_niels*>(base + cv.take((size_t)n * sizeof(dev_niels)));
+  uint32_t* digits = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * n * 4));
+  uint32_t* sorted = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * n * 4));
+  const size_t nb = (size_t)cfg::W1 * cfg::B1;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(base + cv.take(nb * 4 * 3));
+  uint32_t* start = hist + nb;
+  uint32_t* cursor = start + nb;
+  uint32_t* invalid = reinterpret_cast<uint32_t*>(base + cv.take(256));
+  dev_ext* buckets = reinterpret_cast<dev_ext*>(base + cv.take(nb * sizeof(dev_ext)));
+  const size_t lvl_cap = (size_t)cfg::W1 * (cfg::B / 7 + 8);
+  dev_ext* lvlA = reinterpret_cast<dev_ext*>(base + cv.take(lvl_cap * sizeof(dev_ext) * 2));
+  dev_ext* lvlR = lvlA + lvl_cap;
+  if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
+
+  HIP_TRY(hipMemsetAsync(hist, 0, nb * 4, c->stream));
+  HIP_TRY(hipMemsetAsync(invalid, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_pip_prepare<C>, grid1(n, 128), dim3(128), 0, c->stream, n, d_scalars, d_points, niels, digits, hist, invalid);
+  prof_mark(c, ZKP_K_DECODE);
+  hipLaunchKernelGGL(k_pip_scan, dim3(cfg::W1), dim3(256), 0, c->stream, cfg::B1, hist, start, cursor);
+  hipLaunchKernelGGL(k_pip_scatter, dim3((n + 255) / 256, cfg::W1), dim3(256), 0, c->stream, n, cfg::B1, digits, cursor, sorted);
+  prof_mark(c, ZKP_K_SORT);
+  hipLaunchKernelGGL(k_pip_bucket_sum, grid1(nb, 128), dim3(128), 0, c->stream, n, cfg::B1, (uint32_t)nb, start, hist, sorted, niels, buckets);
+  prof_mark(c, ZKP_K_BUCKET);
+  // radix-8 tree over bucket indices 0 .. B-1 (bucket B is added in k_pip_combine)
+  const dev_ext* Ain = nullptr;
+  const dev_ext* Rin = buckets;
+  uint32_t in_stride = cfg::B1, n_in = cfg::B;
+  size_t lvl_off = 0;
+  int level = 0;
+  const dev_ext* Afinal = nullptr;
+  while (n_in > 1) {
+    const uint32_t n_out = n_in / 8;
+    dev_ext* Aout = lvlA + lvl_off;
+    dev_ext* Rout = lvlR + lvl_off;
+    const uint32_t total = cfg::W1 * n_out;
+    hipLaunchKernelGGL(k_pip_reduce_lvl, grid1(total, 128), dim3(128), 0, c->stream, n_out, total, in_stride, n_out, level, Ain, Rin, Aout, Rout);
+    Ain = Aout;
+    Rin = Rout;
+    in_stride = n_out;
+    n_in = n_out;
+    lvl_off += total;
+    Afinal = Aout;
+    ++level;
+  }
+  hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(64), 0, c->stream, cfg::W1, C, cfg::B1, Afinal, buckets, invalid, d_out, d_status);
+  prof_mark(c, ZKP_K_COMBINE);
+  HIP_TRY(hipGetLastError());
+  return ZKP_OK;
+}
+
+// window size by problem size (bucket work ~ n * 257/c madds, reduction work ~ 2^c * 257/c adds)
+int pick_c(uint64_t n) {
+  if (n < (1u << 12)) return 7;
+  if (n < (1u << 15)) return 10;
+  if (n < (1u << 21)) return 13;
+  return 16;
+}
+constexpr uint64_t kSmallOptional = 192;   // below this, zkp_msm_optional uses the per-term path
+
+}  // namespace
+
+extern "C" {
+
+const char* zkp_last_error(void) { return g_last_error.c_str(); }
+const char* zkp_version(void) { return "zkp-mi355x 0.1 gfx950 (9x29-bit limbs, v_mad_u64_u32)"; }
+
+int zkp_ctx_create(zkp_ctx** out, int device_id) {
+  if (!out) return fail(ZKP_ERR_ARG, "zkp_ctx_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(ZKP_ERR_NO_DEVICE, "no HIP device visible");
+  if (device_id < 0 || device_id >= count) return fail(ZKP_ERR_ARG, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(ZKP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  zkp_ctx* c = new zkp_ctx();
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(ZKP_ERR_HIP, "hipStreamCreate failed"); }
+  c->stream = c->own_stream;
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(ZKP_ERR_HIP, "hipEventCreate failed"); }
+  *out = c;
+  return ZKP_OK;
+}
+
+void zkp_ctx_destroy(zkp_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->ws) hipFree(c->ws);
+  for (auto& e : c->ev) if (e) hipEventDestroy(e);
+  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int zkp_ctx_set_stream(zkp_ctx* c, void* s) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+  return ZKP_OK;
+}
+int zkp_ctx_synchronize(zkp_ctx* c) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+}
+int zkp_ctx_set_profiling(zkp_ctx* c, int enabled) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  c->profiling = enabled != 0;
+  return ZKP_OK;
+}
+int zkp_ctx_last_timing(zkp_ctx* c, float* kernel_ms, float* total_ms) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  for (float& k : c->kernel_ms) k = 0;
+  c->total_ms = 0;
+  if (c->n_ev >= 2) {
+    HIP_TRY(hipEventSynchronize(c->ev[c->n_ev - 1]));
+    for (int i = 1; i < c->n_ev; ++i) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, c->ev[i - 1], c->ev[i]));
+      if (c->ev_kind[i] >= 0) c->kernel_ms[c->ev_kind[i]] += ms;
+    }
+    HIP_TRY(hipEventElapsedTime(&c->total_ms, c->ev[0], c->ev[c->n_ev - 1]));
+  }
+  if (kernel_ms) memcpy(kernel_ms, c->kernel_ms, sizeof(c->kernel_ms));
+  if (total_ms) *total_ms = c->total_ms;
+  return ZKP_K_COUNT;
+}
+
+int zkp_msm_many_dev(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint8_t* d_scalars,
+                     const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms,
+                     int flags, uint8_t* d_out, uint8_t* d_status) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (flags != ZKP_CT && flags != ZKP_VARTIME) return fail(ZKP_ERR_ARG, "flags must be ZKP_CT or ZKP_VARTIME");
+  if (n_msm == 0) return ZKP_OK;
+  if (!d_off || !d_out || !d_status) return fail(ZKP_ERR_ARG, "NULL device pointer");
+  if (n_terms && (!d_scalars || !d_pidx || !d_points || n_points == 0)) return fail(ZKP_ERR_ARG, "terms without scalars/points");
+  if (!aligned16(d_scalars) || !aligned16(d_points) || !aligned16(d_out)) return fail(ZKP_ERR_ARG, "device buffers must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(c->device));
+  const int rc = ensure_ws(c, terms_path_ws(n_points, n_terms));
+  if (rc) return rc;
+  prof_begin(c);
+  return msm_terms_path(c, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms, d_out, d_status, nullptr, 0);
+}
+
+int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t* scalars, const uint32_t* pidx,
+                 const uint8_t* points, uint32_t n_points, int flags, uint8_t* out, uint8_t* status) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (flags != ZKP_CT && flags != ZKP_VARTIME) return fail(ZKP_ERR_ARG, "flags must be ZKP_CT or ZKP_VARTIME");
+  if (n_msm == 0) return ZKP_OK;
+  if (!off || !out || !status) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (off[0] != 0) return fail(ZKP_ERR_ARG, "off[0] must be 0");
+  for (uint32_t i = 0; i < n_msm; ++i)
+    if (off[i + 1] < off[i]) return fail(ZKP_ERR_ARG, "off must be non-decreasing");
+  const uint32_t n_terms = off[n_msm];
+  if (n_terms && (!scalars || !pidx || !points || n_points == 0)) return fail(ZKP_ERR_ARG, "terms without scalars/points");
+  for (uint32_t t = 0; t < n_terms; ++t)
+    if (pidx[t] >= n_points) return fail(ZKP_ERR_ARG, "pidx out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  carve cv;
+  const size_t o_off = cv.take((size_t)(n_msm + 1) * 4);
+  const size_t o_sc = cv.take((size_t)n_terms * 32);
+  const size_t o_pidx = cv.take((size_t)n_terms * 4);
+  const size_t o_pts = cv.take((size_t)n_points * 32);
+  const size_t o_out = cv.take((size_t)n_msm * 32);
+  const size_t o_st = cv.take((size_t)n_msm);
+  const size_t reserved = cv.off;
+  int rc = ensure_ws(c, reserved + terms_path_ws(n_points, n_terms));
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  HIP_TRY(hipMemcpyAsync(base + o_off, off, (size_t)(n_msm + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  if (n_terms) {
+    HIP_TRY(hipMemcpyAsync(base + o_sc, scalars, (size_t)n_terms * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(base + o_pidx, pidx, (size_t)n_terms * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  if (n_points) HIP_TRY(hipMemcpyAsync(base + o_pts, points, (size_t)n_points * 32, hipMemcpyHostToDevice, c->stream));
+  prof_begin(c);
+  rc = msm_terms_path(c, n_msm, reinterpret_cast<uint32_t*>(base + o_off), reinterpret_cast<uint8_t*>(base + o_sc),
+                      reinterpret_cast<uint32_t*>(base + o_pidx), reinterpret_cast<uint8_t*>(base + o_pts), n_points,
+                      n_terms, reinterpret_cast<uint8_t*>(base + o_out), reinterpret_cast<uint8_t*>(base + o_st), nullptr, reserved);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, base + o_out, (size_t)n_msm * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(status, base + o_st, (size_t)n_msm, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+}
+
+static int msm_optional_impl(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, const uint8_t* d_points,
+                             uint8_t* d_out, uint32_t* d_status, size_t reserved) {
+  if (n <= kSmallOptional) {
+    carve cv;
+    cv.off = reserved;
+    const size_t o_pidx = cv.take((size_t)(n + 1) * 4);
+    const size_t o_off = cv.take(256);
+    const size_t inner = cv.off;
+    int rc = ensure_ws(c, inner + terms_path_ws((uint32_t)n, (uint32_t)n));
+    if (rc) return rc;
+    char* base = static_cast<char*>(c->ws);
+    uint32_t* pidx = reinterpret_cast<uint32_t*>(base + o_pidx);
+    uint32_t* off = reinterpret_cast<uint32_t*>(base + o_off);
+    hipLaunchKernelGGL(k_iota_single_msm, grid1(n + 1, 256), dim3(256), 0, c->stream, (uint32_t)n, pidx, off);
+    return msm_terms_path(c, 1, off, d_scalars, pidx, d_points, (uint32_t)n, (uint32_t)n, d_out, nullptr, d_status, inner);
+  }
+  if (n > 0x7fffffffull) return fail(ZKP_ERR_ARG, "n too large (max 2^31-1 terms per call)");
+  const int cbits = pick_c(n);
+  size_t need = 0;
+  switch (cbits) {
+    case 7: need = pip_ws<7>(n); break;
+    case 10: need = pip_ws<10>(n); break;
+    case 13: need = pip_ws<13>(n); break;
+    default: need = pip_ws<16>(n); break;
+  }
+  int rc = ensure_ws(c, reserved + need);
+  if (rc) return rc;
+  switch (cbits) {
+    case 7: return pip_run<7>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
+    case 10: return pip_run<10>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
+    case 13: return pip_run<13>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
+    default: return pip_run<16>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
+  }
+}
+
+int zkp_msm_optional_dev(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, const uint8_t* d_points,
+                         uint8_t* d_out_point, uint32_t* d_status) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (!d_out_point || !d_status) return fail(ZKP_ERR_ARG, "NULL output pointer");
+  if (n && (!d_scalars || !d_points)) return fail(ZKP_ERR_ARG, "NULL input pointer");
+  if (!aligned16(d_scalars) || !aligned16(d_points) || !aligned16(d_out_point)) return fail(ZKP_ERR_ARG, "device buffers must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(c->device));
+  prof_begin(c);
+  return msm_optional_impl(c, n, d_scalars, d_points, d_out_point, d_status, 0);
+}
+
+int zkp_msm_optional(zkp_ctx* c, uint64_t n, const uint8_t* scalars, const uint8_t* points, uint8_t out_point[32], int* status) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (!out_point || !status) return fail(ZKP_ERR_ARG, "NULL output pointer");
+  if (n && (!scalars || !points)) return fail(ZKP_ERR_ARG, "NULL input pointer");
+  HIP_TRY(hipSetDevice(c->device));
+  carve cv;
+  const size_t o_sc = cv.take((size_t)n * 32 + 32);
+  const size_t o_pts = cv.take((size_t)n * 32 + 32);
+  const size_t o_out = cv.take(32);
+  const size_t o_st = cv.take(4);
+  const size_t reserved = cv.off;
+  // size the workspace once, up front (inputs are copied before the kernels are enqueued)
+  size_t need = 0;
+  if (n <= kSmallOptional) {
+    need = 1024 + (n + 1) * 4 + terms_path_ws((uint32_t)n, (uint32_t)n);
+  } else {
+    switch (pick_c(n)) {
+      case 7: need = pip_ws<7>(n); break;
+      case 10: need = pip_ws<10>(n); break;
+      case 13: need = pip_ws<13>(n); break;
+      default: need = pip_ws<16>(n); break;
+    }
+  }
+  int rc = ensure_ws(c, reserved + need);
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(base + o_sc, scalars, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(base + o_pts, points, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+  }
+  prof_begin(c);
+  rc = msm_optional_impl(c, n, reinterpret_cast<uint8_t*>(base + o_sc), reinterpret_cast<uint8_t*>(base + o_pts),
+                         reinterpret_cast<uint8_t*>(base + o_out), reinterpret_cast<uint32_t*>(base + o_st), reserved);
+  if (rc) return rc;
+  uint32_t st = 1;
+  HIP_TRY(hipMemcpyAsync(out_point, static_cast<char*>(c->ws) + o_out, 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&st, static_cast<char*>(c->ws) + o_st, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *status = (int)st;
+  return ZKP_OK;
+}
+
+int zkp_decode_check(zkp_ctx* c, uint64_t n, const uint8_t* points, uint8_t* status, uint8_t* xyzt) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (n == 0) return ZKP_OK;
+  if (!points || !status) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (n > 0x7fffffffull) return fail(ZKP_ERR_ARG, "n too large");
+  HIP_TRY(hipSetDevice(c->device));
+  carve cv;
+  const size_t o_pts = cv.take((size_t)n * 32);
+  const size_t o_st = cv.take((size_t)n);
+  const size_t o_xyzt = cv.take(xyzt ? (size_t)n * 128 : 0);
+  const int rc = ensure_ws(c, cv.off);
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  HIP_TRY(hipMemcpyAsync(base + o_pts, points, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+  prof_begin(c);
+  hipLaunchKernelGGL(k_decode_check, grid1(n, 128), dim3(128), 0, c->stream, (uint32_t)n, reinterpret_cast<uint8_t*>(base + o_pts),
+                     reinterpret_cast<uint8_t*>(base + o_st), xyzt ? reinterpret_cast<uint8_t*>(base + o_xyzt) : nullptr);
+  prof_mark(c, ZKP_K_DECODE);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(status, base + o_st, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  if (xyzt) HIP_TRY(hipMemcpyAsync(xyzt, base + o_xyzt, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+}
+
+int zkp_encode_many(zkp_ctx* c, uint64_t n, const uint8_t* xyzt, uint8_t* out) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (n == 0) return ZKP_OK;
+  if (!xyzt || !out) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (n > 0x7fffffffull) return fail(ZKP_ERR_ARG, "n too large");
+  HIP_TRY(hipSetDevice(c->device));
+  carve cv;
+  const size_t o_in = cv.take((size_t)n * 128);
+  const size_t o_out = cv.take((size_t)n * 32);
+  const int rc = ensure_ws(c, cv.off);
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  HIP_TRY(hipMemcpyAsync(base + o_in, xyzt, (size_t)n * 128, hipMemcpyHostToDevice, c->stream));
+  prof_begin(c);
+  hipLaunchKernelGGL(k_encode_many, grid1(n, 128), dim3(128), 0, c->stream, (uint32_t)n, reinterpret_cast<uint8_t*>(base + o_in), reinterpret_cast<uint8_t*>(base + o_out));
+  prof_mark(c, ZKP_K_REDUCE);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, base + o_out, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+}
+
+}  // extern "C"

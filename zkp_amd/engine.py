@@ -1,0 +1,171 @@
+"""ctypes binding of the C-ABI library (include/zkp_mi355x.h -> zkp_amd/libzkp_mi355x.so).
+
+This is plumbing only: every function forwards to the HIP library and raises if the library or a
+GPU is missing -- there is no CPU fallback anywhere in the product path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkp_mi355x.so")
+
+ZKP_VARTIME = 0
+ZKP_CT = 1
+K_NAMES = ("decode", "terms", "reduce", "sort", "bucket", "combine")
+
+EXPORTS = (
+    "zkp_ctx_create", "zkp_ctx_destroy", "zkp_ctx_set_stream", "zkp_ctx_synchronize", "zkp_last_error",
+    "zkp_version", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
+    "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
+)
+
+
+class ZkpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZkpError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u8p, u32p, i32 = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int
+    lib.zkp_ctx_create.argtypes = [ctypes.POINTER(vp), i32]
+    lib.zkp_ctx_destroy.argtypes = [vp]
+    lib.zkp_ctx_destroy.restype = None
+    lib.zkp_ctx_set_stream.argtypes = [vp, vp]
+    lib.zkp_ctx_synchronize.argtypes = [vp]
+    lib.zkp_last_error.restype = ctypes.c_char_p
+    lib.zkp_version.restype = ctypes.c_char_p
+    lib.zkp_msm_many.argtypes = [vp, ctypes.c_uint32, u32p, u8p, u32p, u8p, ctypes.c_uint32, i32, u8p, u8p]
+    lib.zkp_msm_many_dev.argtypes = [vp, ctypes.c_uint32, u32p, u8p, u32p, u8p, ctypes.c_uint32, ctypes.c_uint32, i32, u8p, u8p]
+    lib.zkp_msm_optional.argtypes = [vp, ctypes.c_uint64, u8p, u8p, u8p, ctypes.POINTER(i32)]
+    lib.zkp_msm_optional_dev.argtypes = [vp, ctypes.c_uint64, u8p, u8p, u8p, u32p]
+    lib.zkp_decode_check.argtypes = [vp, ctypes.c_uint64, u8p, u8p, u8p]
+    lib.zkp_encode_many.argtypes = [vp, ctypes.c_uint64, u8p, u8p]
+    lib.zkp_ctx_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    lib.zkp_ctx_set_profiling.argtypes = [vp, i32]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise ZkpError(f"{what} failed with code {rc}: {load_library().zkp_last_error().decode()}")
+
+
+def _u8(a, shape_last: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2 or a.shape[1] != shape_last:
+        raise ValueError(f"expected uint8 array of shape [n][{shape_last}], got {a.shape}")
+    return a
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    """One context on one GPU (HIP device ordinal `device`)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self._lib.zkp_ctx_create(ctypes.byref(h), device), "zkp_ctx_create")
+        self._h = h
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.zkp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def version(self) -> str:
+        return self._lib.zkp_version().decode()
+
+    # ---- host-buffer entry points (numpy) ---------------------------------------------------
+    def msm_many(self, off: Sequence[int], scalars, pidx: Sequence[int], points, flags: int = ZKP_VARTIME
+                 ) -> Tuple[np.ndarray, np.ndarray]:
+        """CSR batch of small MSMs -> (out[n_msm][32], status[n_msm])."""
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n_msm = len(off) - 1
+        pidx = np.ascontiguousarray(pidx, dtype=np.uint32)
+        n_terms = int(off[-1]) if n_msm >= 0 and len(off) else 0
+        scalars = _u8(scalars, 32) if n_terms else np.zeros((0, 32), np.uint8)
+        points = _u8(points, 32) if len(points) else np.zeros((0, 32), np.uint8)
+        if len(scalars) != n_terms or len(pidx) != n_terms:
+            raise ValueError("scalars / pidx length must equal off[-1]")
+        out = np.zeros((max(n_msm, 0), 32), np.uint8)
+        status = np.zeros(max(n_msm, 0), np.uint8)
+        _check(self._lib.zkp_msm_many(self._h, n_msm, _ptr(off), _ptr(scalars), _ptr(pidx), _ptr(points),
+                                      len(points), flags, _ptr(out), _ptr(status)), "zkp_msm_many")
+        return out, status
+
+    def msm_optional(self, scalars, points) -> Optional[bytes]:
+        """optional_multiscalar_mul: encoding of sum s_i * decode(P_i), or None if a decode fails."""
+        scalars = _u8(scalars, 32) if len(scalars) else np.zeros((0, 32), np.uint8)
+        points = _u8(points, 32) if len(points) else np.zeros((0, 32), np.uint8)
+        if len(scalars) != len(points):
+            raise ValueError("scalars and points must have equal length")
+        out = np.zeros(32, np.uint8)
+        st = ctypes.c_int(1)
+        _check(self._lib.zkp_msm_optional(self._h, len(scalars), _ptr(scalars), _ptr(points), _ptr(out), ctypes.byref(st)),
+               "zkp_msm_optional")
+        return None if st.value else out.tobytes()
+
+    def decode_check(self, points, want_coords: bool = False):
+        points = _u8(points, 32) if len(points) else np.zeros((0, 32), np.uint8)
+        status = np.zeros(len(points), np.uint8)
+        xyzt = np.zeros((len(points), 128), np.uint8) if want_coords else None
+        _check(self._lib.zkp_decode_check(self._h, len(points), _ptr(points), _ptr(status), _ptr(xyzt)), "zkp_decode_check")
+        return (status, xyzt) if want_coords else status
+
+    def encode_many(self, xyzt) -> np.ndarray:
+        xyzt = _u8(xyzt, 128) if len(xyzt) else np.zeros((0, 128), np.uint8)
+        out = np.zeros((len(xyzt), 32), np.uint8)
+        _check(self._lib.zkp_encode_many(self._h, len(xyzt), _ptr(xyzt), _ptr(out)), "zkp_encode_many")
+        return out
+
+    # ---- device-buffer entry points (raw device pointers, e.g. torch tensor .data_ptr()) ----
+    def set_stream(self, hip_stream: int) -> None:
+        _check(self._lib.zkp_ctx_set_stream(self._h, ctypes.c_void_p(hip_stream)), "zkp_ctx_set_stream")
+
+    def synchronize(self) -> None:
+        _check(self._lib.zkp_ctx_synchronize(self._h), "zkp_ctx_synchronize")
+
+    def msm_many_dev(self, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms, flags, d_out, d_status) -> None:
+        _check(self._lib.zkp_msm_many_dev(self._h, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms,
+                                          flags, d_out, d_status), "zkp_msm_many_dev")
+
+    def msm_optional_dev(self, n, d_scalars, d_points, d_out, d_status) -> None:
+        _check(self._lib.zkp_msm_optional_dev(self._h, n, d_scalars, d_points, d_out, d_status), "zkp_msm_optional_dev")
+
+    def set_profiling(self, enabled: bool) -> None:
+        _check(self._lib.zkp_ctx_set_profiling(self._h, int(enabled)), "zkp_ctx_set_profiling")
+
+    def last_timing(self):
+        arr = (ctypes.c_float * len(K_NAMES))()
+        tot = ctypes.c_float()
+        rc = self._lib.zkp_ctx_last_timing(self._h, arr, ctypes.byref(tot))
+        if rc < 0:
+            _check(rc, "zkp_ctx_last_timing")
+        return {k: float(arr[i]) for i, k in enumerate(K_NAMES)}, float(tot.value)

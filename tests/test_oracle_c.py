@@ -1,0 +1,260 @@
+"""Pins the C oracle (oracle/c, liboracle.so) before anything trusts it: RFC 9496 vectors, Merlin's
+published known-answer test, the reference tests' deterministic public inputs, and agreement with the
+big-integer model (oracle/model.py) for every primitive, every dalek MSM algorithm and the whole
+toolbox flow (proof bytes, accept/reject decisions, batch-verification MSM inputs)."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cbind as C
+from oracle import model as M
+from tests.test_host_field import BAD_ENCODINGS, GENERATOR_MULTIPLES
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    C.build()
+
+
+def sc(x):
+    return (x % (1 << 256)).to_bytes(32, "little")
+
+
+def arr(rows, width=32):
+    return np.frombuffer(b"".join(rows), np.uint8).reshape(-1, width) if rows else np.zeros((0, width), np.uint8)
+
+
+def test_rfc9496_vectors():
+    st = C.decode_check(arr([bytes.fromhex(h) for h in BAD_ENCODINGS]))
+    assert st.all()
+    st = C.decode_check(arr([bytes.fromhex(h) for h in GENERATOR_MULTIPLES]))
+    assert not st.any()
+    # k * B through each MSM algorithm
+    B = bytes.fromhex(GENERATOR_MULTIPLES[1])
+    for k, h in enumerate(GENERATOR_MULTIPLES):
+        for algo in ("straus_ct", "straus_vartime"):
+            assert C.msm_algo(algo, arr([sc(k)]), arr([B])).hex() == h
+
+
+def test_codec_matches_model():
+    rng = random.Random(21)
+    cases = [bytes(rng.randrange(256) for _ in range(32)) for _ in range(400)] + [bytes(32)]
+    st, xyzt = C.decode_check(arr(cases), want_coords=True)
+    for i, c in enumerate(cases):
+        p = M.ristretto_decode(c)
+        assert st[i] == (0 if p is not None else 1)
+        if p is not None:
+            got = [int.from_bytes(xyzt[i, 32 * k:32 * k + 32].tobytes(), "little") for k in range(4)]
+            assert got == [p[0], p[1], 1, p[3]]
+    pts = [M.pt_mul(rng.randrange(M.L), M.BASEPOINT) for _ in range(30)] + [M.IDENTITY]
+    rows = []
+    for p in pts:
+        z = rng.randrange(1, M.P)
+        rows.append(b"".join((c * z % M.P).to_bytes(32, "little") for c in p))
+    out = C.encode_many(arr(rows, 128))
+    for i, p in enumerate(pts):
+        assert out[i].tobytes() == M.ristretto_encode(p)
+    for _ in range(50):
+        u = bytes(rng.randrange(256) for _ in range(64))
+        assert C.from_uniform_bytes(u) == M.ristretto_encode(M.ristretto_from_uniform_bytes(u))
+
+
+def test_reference_test_inputs():
+    """Deterministic public inputs of the reference's own tests."""
+    h1 = C.from_uniform_bytes(hashlib.sha512(b"A VRF input, for instance").digest())       # tests/zkp.rs:34
+    assert h1.hex() == "8062d869a1a967d6a60604a3ec8d0316cef712e094f4cb991de60a9f52555068"
+    B = bytes.fromhex(GENERATOR_MULTIPLES[1])
+    h2 = C.from_uniform_bytes(hashlib.sha512(B).digest())          # tests/dleq_using_constraint_api.rs:43
+    assert h2.hex() == "90ca11cd6c6227cb0abc39e2710c444ae6617ea81898e716353f3410d9656605"
+    x = 89327492234
+    assert C.msm_algo("straus_vartime", arr([sc(x)]), arr([B])).hex() == "241dacbe397b94c04f21eaa1f1df11878ae3b9833351d8cc957c9c7c13a36800"
+    assert C.msm_algo("straus_ct", arr([sc(x)]), arr([h2])).hex() == "9ea41491e551a36b01db7bcf332ec44633d747e0a9ef73b5da77be43bbe5687e"
+    xinv = pow(x, M.L - 2, M.L)                                                              # tests/zkp.rs:35
+    assert C.msm_algo("straus_ct", arr([sc(xinv)]), arr([B])).hex() == "7af0b00ee8b188c437ed7a2ec4b679bb062c81fdc561f8e33296a4802e738643"
+    assert C.msm_algo("straus_vartime", arr([sc(xinv)]), arr([h1])).hex() == "76f4e263598bc40ee74ebf628aeb3b9ff8c9d33c860df353eafdf6eeb977c742"
+
+
+def test_scalars():
+    rng = random.Random(22)
+    for _ in range(300):
+        w = bytes(rng.randrange(256) for _ in range(64))
+        assert C.sc_from_wide(w) == sc(int.from_bytes(w, "little") % M.L)
+        a, b, c = (rng.randrange(1 << 256) for _ in range(3))
+        assert C.sc_muladd(sc(a), sc(b), sc(c)) == sc((a * b + c) % M.L)
+        assert C.sc_neg(sc(a)) == sc((-a) % M.L)
+    assert C.sc_from_wide(b"\xff" * 64) == sc(((1 << 512) - 1) % M.L)
+    assert C.sc_neg(sc(0)) == sc(0) and C.sc_neg(sc(M.L)) == sc(0)
+
+
+def test_merlin_kat():
+    got = C.merlin_challenge(b"test protocol", [(b"some label", b"some data")], b"challenge", 32)
+    assert got.hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    # longer traffic incl. messages crossing the 166-byte STROBE rate, against the model
+    rng = random.Random(23)
+    appends = [(b"l%d" % i, bytes(rng.randrange(256) for _ in range(n))) for i, n in enumerate([0, 1, 165, 166, 167, 400, 32])]
+    t = M.Transcript(b"proto")
+    for l, m in appends:
+        t.append_message(l, m)
+    assert C.merlin_challenge(b"proto", appends, b"c", 200) == t.challenge_bytes(b"c", 200)
+
+
+@pytest.mark.parametrize("algo,n", [("straus_ct", 0), ("straus_ct", 1), ("straus_ct", 2), ("straus_ct", 11),
+                                    ("straus_vartime", 1), ("straus_vartime", 3), ("straus_vartime", 36), ("straus_vartime", 189),
+                                    ("pippenger", 190), ("pippenger", 499), ("pippenger", 500), ("pippenger", 799),
+                                    ("pippenger", 800), ("pippenger", 1500)])
+def test_msm_algorithms(algo, n):
+    """Each dalek algorithm (and each Pippenger window size w = 6, 7, 8) against the definition."""
+    rng = random.Random(100 + n)
+    logs = [rng.randrange(1, M.L) for _ in range(16)]
+    encs = [M.ristretto_encode(M.pt_mul(k, M.BASEPOINT)) for k in logs]
+    idx = [rng.randrange(16) for _ in range(n)]
+    scal = [rng.randrange(M.L) for _ in range(n)]
+    for k, v in enumerate([0, 1, M.L - 1, (1 << 252) - 1, 1 << 252]):
+        if k < n:
+            scal[k] = v
+    got = C.msm_algo(algo, arr([sc(s) for s in scal]), arr([encs[j] for j in idx]))
+    dlog = sum(s * logs[j] for s, j in zip(scal, idx)) % M.L
+    assert got == M.ristretto_encode(M.pt_mul(dlog, M.BASEPOINT))
+
+
+def test_msm_contracts_small():
+    rng = random.Random(31)
+    pts = [M.ristretto_from_uniform_bytes(bytes(rng.randrange(256) for _ in range(64))) for _ in range(4)]
+    encs = [M.ristretto_encode(p) for p in pts] + [bytes.fromhex(BAD_ENCODINGS[4])]
+    off, scal, pidx = [0, 0, 2, 5, 6], [], []
+    for _ in range(5):
+        scal.append(rng.randrange(1 << 256))
+        pidx.append(rng.randrange(4))
+    scal.append(7)
+    pidx.append(4)
+    for flags in (0, 1):
+        out, status = C.msm_many(off, arr([sc(s) for s in scal]), pidx, arr(encs), flags)
+        assert list(status) == [0, 0, 0, 1]
+        assert out[0].tobytes() == bytes(32) and out[3].tobytes() == bytes(32)
+        for m in (1, 2):
+            ts = range(off[m], off[m + 1])
+            assert out[m].tobytes() == M.ristretto_encode(M.msm_points([scal[t] for t in ts], [pts[pidx[t]] for t in ts]))
+    assert C.msm_optional(arr([sc(1)] * 2), arr([encs[0], encs[4]])) is None
+    assert C.msm_optional(arr([sc(s) for s in scal[:3]]), arr([encs[p] for p in pidx[:3]])) == \
+        M.msm_optional([sc(s) for s in scal[:3]], [encs[p] for p in pidx[:3]])
+
+
+# ---- toolbox flow: C oracle == model, byte for byte ---------------------------------------------
+def _dleq_instance(rng):
+    x = rng.randrange(1, M.L)
+    G = M.BASEPOINT
+    H = M.ristretto_from_uniform_bytes(bytes(rng.randrange(256) for _ in range(64)))
+    return {"x": x}, {"A": M.pt_mul(x, G), "B": M.pt_mul(x, H), "H": H, "G": G}
+
+
+def _cmz_instance(rng, n=10):
+    sec = {f"m_{i}": rng.randrange(M.L) for i in range(1, n + 1)}
+    sec.update({f"z_{i}": rng.randrange(M.L) for i in range(1, n + 1)})
+    sec["minus_z_Q"] = rng.randrange(M.L)
+    rp = lambda: M.pt_mul(rng.randrange(1, M.L), M.BASEPOINT)
+    pts = {f"X_{i}": rp() for i in range(1, n + 1)}
+    pts.update({"A": rp(), "B": rp(), "P": rp(), "Q": rp()})
+    for i in range(1, n + 1):
+        pts[f"C_{i}"] = M.pt_add(M.pt_mul(sec[f"m_{i}"], pts["P"]), M.pt_mul(sec[f"z_{i}"], pts["A"]))
+    pts["V"] = M.msm_points([sec[f"m_{i}"] for i in range(1, n + 1)] + [sec["minus_z_Q"]],
+                            [pts[f"X_{i}"] for i in range(1, n + 1)] + [pts["Q"]])
+    return sec, pts
+
+
+@pytest.mark.parametrize("which", ["dleq", "cmz"])
+def test_prove_matches_model_and_verifies(which):
+    rng = random.Random(41)
+    mst = M.dleq_statement() if which == "dleq" else M.cmz_statement(10)
+    sec, pts = _dleq_instance(rng) if which == "dleq" else _cmz_instance(rng)
+    cst = C.Statement.from_model(mst)
+    entropy = bytes(rng.randrange(256) for _ in range(32))
+    label = b"Benchmark"
+    pr, encs = mst.build_prover(M.Transcript(label), sec, pts)
+    mc, mresp, mcoms, mblind = pr._prove_impl(entropy)
+    enc_rows = [encs[n] for n in cst.points]
+    chal, resp, coms, blind = C.prove(cst, label, arr([sc(sec[n]) for n in cst.secrets]), arr(enc_rows), entropy)
+    assert chal.tobytes() == sc(mc)
+    assert [r.tobytes() for r in resp] == [sc(r) for r in mresp]
+    assert [c.tobytes() for c in coms] == mcoms
+    assert [b.tobytes() for b in blind] == [sc(b) for b in mblind]
+    # accept
+    assert C.verify_compact(cst, label, arr(enc_rows), chal, resp) == 0
+    w = arr([rng.randrange(1 << 128).to_bytes(16, "little") for _ in cst.constraints], 16)
+    assert C.verify_batchable(cst, label, arr(enc_rows), coms, resp, w) == 0
+    mst.build_verifier(M.Transcript(label), encs).verify_compact(M.CompactProof(mc, mresp))
+    # reject: wrong transcript label, tampered response, tampered commitment, swapped public point (tests/sig_and_vrf_example.rs pattern)
+    assert C.verify_compact(cst, b"Benchmarl", arr(enc_rows), chal, resp) == 1
+    bad = resp.copy()
+    bad[0, 0] ^= 1
+    assert C.verify_compact(cst, label, arr(enc_rows), chal, bad) == 1
+    assert C.verify_batchable(cst, label, arr(enc_rows), coms, bad, w) == 1
+    badc = coms.copy()
+    badc[0] = np.frombuffer(enc_rows[0], np.uint8)
+    assert C.verify_batchable(cst, label, arr(enc_rows), badc, resp, w) == 1
+    swapped = list(enc_rows)
+    swapped[0], swapped[1] = swapped[1], swapped[0]
+    assert C.verify_compact(cst, label, arr(swapped), chal, resp) == 1
+    # identity public point / identity commitment are rejected before any arithmetic (mod.rs:191,215)
+    ident = list(enc_rows)
+    ident[1] = bytes(32)
+    assert C.verify_compact(cst, label, arr(ident), chal, resp) == 1
+    zc = coms.copy()
+    zc[0] = 0
+    assert C.verify_batchable(cst, label, arr(enc_rows), zc, resp, w) == 1
+
+
+def test_batch_verify_matches_model():
+    rng = random.Random(43)
+    mst = M.dleq_statement()
+    cst = C.Statement.from_model(mst)
+    n, label = 5, b"DLEQBatchTest"
+    proofs, encs_all = [], []
+    for _ in range(n):
+        sec, pts = _dleq_instance(rng)
+        pts["H"] = pts["H"]
+        pr, encs = mst.build_prover(M.Transcript(label), sec, pts)
+        proofs.append(pr.prove_batchable(bytes(rng.randrange(256) for _ in range(32))))
+        encs_all.append(encs)
+    weights = [[rng.randrange(1 << 128) for _ in range(n)] for _ in mst.constraints]
+    inst = {k: [e[k] for e in encs_all] for k in mst.instance}
+    common = {k: encs_all[0][k] for k in mst.common}
+    bv = mst.build_batch_verifier([M.Transcript(label) for _ in range(n)], inst, common)
+    m_scalars, m_points = bv.coefficient_build(proofs, weights)
+    inst_rows = arr([e for k in mst.instance for e in inst[k]])
+    common_rows = arr([common[k] for k in mst.common])
+    coms = arr([c for p in proofs for c in p.commitments])
+    resp = arr([sc(r) for p in proofs for r in p.responses])
+    w16 = arr([w.to_bytes(16, "little") for row in weights for w in row], 16)
+    rc, ms, mp = C.batch_verify(cst, label, n, inst_rows, common_rows, coms, resp, w16, want_msm_inputs=True)
+    assert rc == 0
+    assert [r.tobytes() for r in ms] == [sc(s) for s in m_scalars]
+    assert [r.tobytes() for r in mp] == m_points
+    assert C.batch_verify(cst, label, n, inst_rows, common_rows, coms, resp, w16) == 0
+    # one bad proof poisons the batch (the reference has no such test; batch_verifier.rs:230-234)
+    bad = resp.copy()
+    bad[3, 5] ^= 0x10
+    assert C.batch_verify(cst, label, n, inst_rows, common_rows, coms, bad, w16) == 1
+
+
+def test_golden_fixtures():
+    """tests/golden/*.json were produced by tests/golden/make_fixtures.py from the big-integer model with
+    libsodium cross-checks in this container; the C oracle must reproduce them."""
+    path = os.path.join(GOLDEN, "ristretto_msm.json")
+    fx = json.load(open(path))
+    for case in fx["msm"]:
+        got = C.msm_optional(arr([bytes.fromhex(s) for s in case["scalars"]]), arr([bytes.fromhex(p) for p in case["points"]]))
+        assert (got.hex() if got is not None else None) == case["expect"]
+    for case in fx["proofs"]:
+        mst = M.dleq_statement() if case["statement"] == "dleq" else M.cmz_statement(10)
+        cst = C.Statement.from_model(mst)
+        chal, resp, coms, _ = C.prove(cst, bytes.fromhex(case["label"]), arr([bytes.fromhex(s) for s in case["secrets"]]),
+                                      arr([bytes.fromhex(p) for p in case["points"]]), bytes.fromhex(case["entropy"]))
+        assert chal.tobytes().hex() == case["challenge"]
+        assert [r.tobytes().hex() for r in resp] == case["responses"]
+        assert [c.tobytes().hex() for c in coms] == case["commitments"]

@@ -1,0 +1,49 @@
+"""Pins the big-integer model (oracle/model.py) against published vectors and the committed fixtures
+(tests/golden/, generated with libsodium cross-checks by tests/golden/make_fixtures.py)."""
+import json
+import os
+
+from oracle import model as M
+from tests.test_host_field import BAD_ENCODINGS, GENERATOR_MULTIPLES
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ristretto_msm.json")
+
+
+def test_rfc9496_and_merlin_vectors():
+    for k, h in enumerate(GENERATOR_MULTIPLES):
+        assert M.ristretto_encode(M.pt_mul(k, M.BASEPOINT)).hex() == h
+    for h in BAD_ENCODINGS:
+        assert M.ristretto_decode(bytes.fromhex(h)) is None
+    t = M.Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+
+def test_fixtures_roundtrip():
+    fx = json.load(open(GOLDEN))
+    for case in fx["msm"]:
+        got = M.msm_optional([bytes.fromhex(s) for s in case["scalars"]], [bytes.fromhex(p) for p in case["points"]])
+        assert (got.hex() if got is not None else None) == case["expect"]
+    for case in fx["decode"]:
+        assert (M.ristretto_decode(bytes.fromhex(case["enc"])) is not None) == case["valid"]
+    for case in fx["proofs"]:
+        st = M.dleq_statement() if case["statement"] == "dleq" else M.cmz_statement(10)
+        names = st.instance + st.common
+        encs = {n: bytes.fromhex(p) for n, p in zip(names, case["points"])}
+        proof = M.CompactProof(int.from_bytes(bytes.fromhex(case["challenge"]), "little"),
+                               [int.from_bytes(bytes.fromhex(r), "little") for r in case["responses"]])
+        st.build_verifier(M.Transcript(bytes.fromhex(case["label"])), encs).verify_compact(proof)
+
+
+def test_keccak_counts_match_survey():
+    """59 Keccak-f permutations per CMZ proof on the prover, 16 on the verifier."""
+    fx = json.load(open(GOLDEN))
+    case = [c for c in fx["proofs"] if c["statement"] == "cmz"][0]
+    st = M.cmz_statement(10)
+    names = st.instance + st.common
+    encs = {n: bytes.fromhex(p) for n, p in zip(names, case["points"])}
+    proof = M.BatchableProof([bytes.fromhex(c) for c in case["commitments"]],
+                             [int.from_bytes(bytes.fromhex(r), "little") for r in case["responses"]])
+    before = M.keccak_f_count
+    st.build_verifier(M.Transcript(bytes.fromhex(case["label"])), encs).verify_batchable(proof, [1] * 11)
+    assert M.keccak_f_count - before == 16

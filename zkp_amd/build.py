@@ -1,0 +1,67 @@
+"""Builds the in-tree native libraries (no JIT cache: the .so files travel with the repo snapshot).
+
+    python -m zkp_amd.build            # HIP library for gfx950 (+ host toolbox once present)
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HIP_LIB = os.path.join(HERE, "libzkp_mi355x.so")
+HOST_LIB = os.path.join(HERE, "libzkp_toolbox.so")
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _deps(*dirs, exts=(".h", ".hip", ".cpp", ".c")):
+    out = []
+    for d in dirs:
+        for root, _, files in os.walk(d):
+            out += [os.path.join(root, f) for f in files if f.endswith(exts)]
+    return out
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950: kernels + C ABI -> zkp_amd/libzkp_mi355x.so (cross-compiles without a GPU)."""
+    deps = _deps(CSRC, os.path.join(HERE, "..", "include"))
+    if force or _stale(HIP_LIB, deps):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+               os.path.join(CSRC, "zkp_kernels.hip"), "-o", HIP_LIB]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_host(force: bool = False, verbose: bool = False):
+    """g++: host-side toolbox (Merlin, Prover / Verifier / BatchVerifier over the C ABI) -> libzkp_toolbox.so"""
+    host_dir = os.path.join(CSRC, "host")
+    if not os.path.isdir(host_dir):
+        return None
+    srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp")]
+    if not srcs:
+        return None
+    deps = _deps(host_dir, os.path.join(HERE, "..", "include"))
+    if force or _stale(HOST_LIB, deps):
+        cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I", os.path.join(HERE, "..", "include")] + srcs + [
+            "-o", HOST_LIB, "-ldl"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    return build_hip(force, verbose), build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

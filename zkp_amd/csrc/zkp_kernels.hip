@@ -13,7 +13,8 @@
 //                                                       digits, per-window histogram
 //        k_pip_scan        1 block / window             exclusive scan of bucket sizes
 //        k_pip_scatter     1 lane / (term, window)      counting-sort scatter of term indices
-//        k_pip_bucket_sum  1 lane / (window, bucket)    mixed additions of the bucket's points
+//        k_pip_bucket_part 1 lane / <=L bucket entries  mixed additions (buckets split for load balance)
+//        k_pip_bucket_merge 1 lane / (window, bucket)   sum of the bucket's parts
 //        k_pip_reduce_lvl  1 lane / 8 inputs            radix-8 tree evaluation of sum_b b*S_b
 //        k_pip_combine     1 block                      Horner over windows + ristretto encode
 //
@@ -214,30 +215,52 @@ k_pip_prepare(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __
   }
 }
 
-// exclusive scan of hist[w][0..bins) -> start[w][.], cursor[w][.]   (one block per window)
+// Entries per part of a bucket with cnt entries: at least L, and about sqrt(cnt) for big buckets so that the
+// part sums (k_pip_bucket_part) and their merge (k_pip_bucket_merge) have equal sequential depth.
+__device__ __forceinline__ uint32_t part_len(uint32_t cnt, uint32_t L) {
+  const uint32_t r = (uint32_t)ceilf(sqrtf((float)cnt));
+  return r > L ? r : L;
+}
+__device__ __forceinline__ uint32_t part_count(uint32_t cnt, uint32_t L) {
+  const uint32_t pl = part_len(cnt, L);
+  return (cnt + pl - 1) / pl;
+}
+
+// exclusive scans over the buckets of one window (one block per window):
+//   start[w][b]  = sum_{b' < b} hist[w][b']            position of bucket b in the window's sorted list
+//   vstart[w][b] = sum_{b' < b} part_count(hist[w][b'])  first "virtual lane" of bucket b (bucket split into parts)
+//   vstart[w][bins] = total number of virtual lanes of the window
 __global__ void __launch_bounds__(256)
-k_pip_scan(uint32_t bins, const uint32_t* __restrict__ hist, uint32_t* __restrict__ start, uint32_t* __restrict__ cursor) {
+k_pip_scan(uint32_t bins, uint32_t L, const uint32_t* __restrict__ hist, uint32_t* __restrict__ start,
+           uint32_t* __restrict__ cursor, uint32_t* __restrict__ vstart) {
   __shared__ uint32_t part[256];
+  __shared__ uint32_t vpart[256];
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
   const uint32_t chunk = (bins + 255) / 256;
-  const uint32_t lo = tid * chunk, hi = min(lo + chunk, bins);
+  const uint32_t lo = min(tid * chunk, bins), hi = min(lo + chunk, bins);
   const uint32_t* h = hist + (size_t)w * bins;
-  uint32_t sum = 0;
-  for (uint32_t b = lo; b < hi; ++b) sum += h[b];
+  uint32_t sum = 0, vsum = 0;
+  for (uint32_t b = lo; b < hi; ++b) { sum += h[b]; vsum += part_count(h[b], L); }
   part[tid] = sum;
+  vpart[tid] = vsum;
   __syncthreads();
   for (uint32_t d = 1; d < 256; d <<= 1) {
     const uint32_t v = tid >= d ? part[tid - d] : 0;
+    const uint32_t vv = tid >= d ? vpart[tid - d] : 0;
     __syncthreads();
     part[tid] += v;
+    vpart[tid] += vv;
     __syncthreads();
   }
-  uint32_t run = part[tid] - sum;
+  uint32_t run = part[tid] - sum, vrun = vpart[tid] - vsum;
   for (uint32_t b = lo; b < hi; ++b) {
     start[(size_t)w * bins + b] = run;
     cursor[(size_t)w * bins + b] = run;
+    vstart[(size_t)w * (bins + 1) + b] = vrun;
     run += h[b];
+    vrun += part_count(h[b], L);
   }
+  if (tid == 255) vstart[(size_t)w * (bins + 1) + bins] = vpart[255];
 }
 
 __global__ void __launch_bounds__(256)
@@ -253,17 +276,31 @@ k_pip_scatter(uint32_t n, uint32_t bins, const uint32_t* __restrict__ digits, ui
   sorted[(size_t)w * n + slot] = i | (key & 0x80000000u);
 }
 
+// Bucket accumulation, load balanced: virtual lane v of window w sums one part (<= L entries) of one
+// bucket.  Buckets are split because digit distributions are NOT uniform in practice: canonical scalars
+// are < 2^253, so the top window only ever uses a few dozen buckets, each holding n/32 .. n/64 points.
 __global__ void __launch_bounds__(128, 2)
-k_pip_bucket_sum(uint32_t n, uint32_t bins, uint32_t total, const uint32_t* __restrict__ start,
-                 const uint32_t* __restrict__ hist, const uint32_t* __restrict__ sorted,
-                 const dev_niels* __restrict__ niels, dev_ext* __restrict__ buckets) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= total) return;
-  const uint32_t w = g / bins, b = g - w * bins;
+k_pip_bucket_part(uint32_t n, uint32_t bins, uint32_t L, uint32_t vmax, const uint32_t* __restrict__ start,
+                  const uint32_t* __restrict__ hist, const uint32_t* __restrict__ vstart,
+                  const uint32_t* __restrict__ sorted, const dev_niels* __restrict__ niels,
+                  dev_ext* __restrict__ parts) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t w = blockIdx.y;
+  const uint32_t* vs = vstart + (size_t)w * (bins + 1);
+  if (v >= vs[bins]) return;
+  // largest b with vs[b] <= v  (vs is non-decreasing; empty buckets repeat a value, so take the last one)
+  uint32_t lo = 0, hi = bins;                 // invariant: vs[lo] <= v < vs[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (vs[mid] <= v) lo = mid; else hi = mid;
+  }
+  const uint32_t b = lo, g = w * bins + b;
+  const uint32_t pl = part_len(hist[g], L);
+  const uint32_t first = (v - vs[b]) * pl;
+  const uint32_t cnt = min(pl, hist[g] - first);
+  const uint32_t* lst = sorted + (size_t)w * n + start[g] + first;
   ge_p3 acc;
   ge_identity(acc);
-  const uint32_t cnt = b ? hist[g] : 0u;
-  const uint32_t* lst = sorted + (size_t)w * n + start[g];
 #pragma unroll 1
   for (uint32_t k = 0; k < cnt; ++k) {
     const uint32_t idx = lst[k];
@@ -271,6 +308,30 @@ k_pip_bucket_sum(uint32_t n, uint32_t bins, uint32_t total, const uint32_t* __re
     load_niels(q, niels + (idx & 0x7fffffffu));
     ge_niels_cneg(q, idx >> 31);
     ge_madd(acc, acc, q);
+  }
+  store_ext(parts + (size_t)w * vmax + v, acc);
+}
+
+__global__ void __launch_bounds__(128, 2)
+k_pip_bucket_merge(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t* __restrict__ vstart,
+                   const dev_ext* __restrict__ parts, dev_ext* __restrict__ buckets) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const uint32_t w = g / bins, b = g - w * bins;
+  const uint32_t* vs = vstart + (size_t)w * (bins + 1);
+  const uint32_t v0 = vs[b], v1 = vs[b + 1];
+  const dev_ext* p = parts + (size_t)w * vmax;
+  ge_p3 acc;
+  if (v1 == v0) {
+    ge_identity(acc);
+  } else {
+    load_ext(acc, p + v0);
+#pragma unroll 1
+    for (uint32_t v = v0 + 1; v < v1; ++v) {
+      ge_p3 q;
+      load_ext(q, p + v);
+      ge_add_p3(acc, acc, q);
+    }
   }
   store_ext(buckets + g, acc);
 }
@@ -289,6 +350,12 @@ k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t ou
   ge_p3 run, U, q;
   ge_identity(run);
   ge_identity(U);
+  if (level == 0 && j == n_out - 1) {
+    // bucket index B = 8^L (digit -2^(C-1)) sits one past the tree's range: treat it as local index 8 of the
+    // last chunk, i.e. seed the running sums with it (it is then counted 8 times in U and once in R')
+    load_ext(run, rin + 8);
+    U = run;
+  }
 #pragma unroll 1
   for (int i = 7; i >= 1; --i) {
     load_ext(q, rin + i);
@@ -311,43 +378,30 @@ k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t ou
   store_ext(R_out + (size_t)w * out_stride + j, run);
 }
 
-// T_w = A_final[w] + B * S_{w,B};  result = sum_w 2^(C w) T_w;  encode.
+// result = sum_w 2^(C w) T_w  (Horner, one lane: 256 inherently sequential doublings);  encode.
 __global__ void __launch_bounds__(64)
-k_pip_combine(int W1, int C, uint32_t bins, const dev_ext* __restrict__ A_final,
-              const dev_ext* __restrict__ buckets, const uint32_t* __restrict__ invalid,
+k_pip_combine(int W1, int C, const dev_ext* __restrict__ T, const uint32_t* __restrict__ invalid,
               uint8_t* __restrict__ out_point, uint32_t* __restrict__ status) {
-  __shared__ dev_ext T[40];
-  const int w = threadIdx.x;
-  if (w < W1) {
-    ge_p3 t, top;
-    load_ext(t, A_final + w);
-    load_ext(top, buckets + (size_t)w * bins + (bins - 1));
+  if (threadIdx.x != 0) return;
+  ge_p3 acc, t;
+  load_ext(acc, T + (W1 - 1));
 #pragma unroll 1
-    for (int k = 0; k < C - 1; ++k) ge_double<true>(top, top);
-    ge_add_p3(t, t, top);
-    store_ext(&T[w], t);
+  for (int k = W1 - 2; k >= 0; --k) {
+#pragma unroll 1
+    for (int d = 0; d < C - 1; ++d) ge_double<false>(acc, acc);
+    ge_double<true>(acc, acc);
+    load_ext(t, T + k);
+    ge_add_p3(acc, acc, t);
   }
-  __syncthreads();
-  if (w == 0) {
-    ge_p3 acc, t;
-    load_ext(acc, &T[W1 - 1]);
-#pragma unroll 1
-    for (int k = W1 - 2; k >= 0; --k) {
-#pragma unroll 1
-      for (int d = 0; d < C; ++d) ge_double<true>(acc, acc);
-      load_ext(t, &T[k]);
-      ge_add_p3(acc, acc, t);
-    }
-    uint32_t o[8];
-    ristretto_encode(o, acc);
-    const uint32_t bad = *invalid;
-    if (bad) {
+  uint32_t o[8];
+  ristretto_encode(o, acc);
+  const uint32_t bad = *invalid;
+  if (bad) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = 0;
-    }
-    store_vec<2>(out_point, o);
-    *status = bad ? 1u : 0u;
+    for (int k = 0; k < 8; ++k) o[k] = 0;
   }
+  store_vec<2>(out_point, o);
+  *status = bad ? 1u : 0u;
 }
 
 // =============================================================================================
@@ -486,6 +540,11 @@ size_t terms_path_ws(uint32_t n_points, uint32_t n_terms) {
   return cv.off;
 }
 
+// entries per virtual lane of the bucket accumulation, and the resulting upper bound of lanes per window
+inline uint32_t pip_part_len(uint64_t n) { return n < (1u << 18) ? 16u : (n < (1u << 21) ? 32u : 64u); }
+template <int C>
+size_t pip_vmax(uint64_t n) { return (size_t)(n / pip_part_len(n)) + pip_cfg<C>::B1 + 1; }
+
 template <int C>
 size_t pip_ws(uint64_t n) {
   using cfg = pip_cfg<C>;
@@ -494,6 +553,8 @@ size_t pip_ws(uint64_t n) {
   cv.take((size_t)cfg::W1 * n * 4);            // digits
   cv.take((size_t)cfg::W1 * n * 4);            // sorted
   cv.take((size_t)cfg::W1 * cfg::B1 * 4 * 3);  // hist, start, cursor
+  cv.take((size_t)cfg::W1 * (cfg::B1 + 1) * 4);               // vstart
+  cv.take((size_t)cfg::W1 * pip_vmax<C>(n) * sizeof(dev_ext)); // bucket parts
   cv.take(256);                                // invalid flag
   cv.take((size_t)cfg::W1 * cfg::B1 * sizeof(dev_ext));       // buckets
   cv.take((size_t)cfg::W1 * (cfg::B / 7 + 8) * sizeof(dev_ext) * 2);  // reduction levels (A and R)
@@ -514,6 +575,10 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   uint32_t* hist = reinterpret_cast<uint32_t*>(base + cv.take(nb * 4 * 3));
   uint32_t* start = hist + nb;
   uint32_t* cursor = start + nb;
+  uint32_t* vstart = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * (cfg::B1 + 1) * 4));
+  const uint32_t L = pip_part_len(n);
+  const size_t vmax = pip_vmax<C>(n);
+  dev_ext* parts = reinterpret_cast<dev_ext*>(base + cv.take((size_t)cfg::W1 * vmax * sizeof(dev_ext)));
   uint32_t* invalid = reinterpret_cast<uint32_t*>(base + cv.take(256));
   dev_ext* buckets = reinterpret_cast<dev_ext*>(base + cv.take(nb * sizeof(dev_ext)));
   const size_t lvl_cap = (size_t)cfg::W1 * (cfg::B / 7 + 8);
@@ -525,10 +590,12 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   HIP_TRY(hipMemsetAsync(invalid, 0, 4, c->stream));
   hipLaunchKernelGGL(k_pip_prepare<C>, grid1(n, 128), dim3(128), 0, c->stream, n, d_scalars, d_points, niels, digits, hist, invalid);
   prof_mark(c, ZKP_K_DECODE);
-  hipLaunchKernelGGL(k_pip_scan, dim3(cfg::W1), dim3(256), 0, c->stream, cfg::B1, hist, start, cursor);
+  hipLaunchKernelGGL(k_pip_scan, dim3(cfg::W1), dim3(256), 0, c->stream, cfg::B1, L, hist, start, cursor, vstart);
   hipLaunchKernelGGL(k_pip_scatter, dim3((n + 255) / 256, cfg::W1), dim3(256), 0, c->stream, n, cfg::B1, digits, cursor, sorted);
   prof_mark(c, ZKP_K_SORT);
-  hipLaunchKernelGGL(k_pip_bucket_sum, grid1(nb, 128), dim3(128), 0, c->stream, n, cfg::B1, (uint32_t)nb, start, hist, sorted, niels, buckets);
+  hipLaunchKernelGGL(k_pip_bucket_part, dim3((unsigned)((vmax + 127) / 128), cfg::W1), dim3(128), 0, c->stream, n, cfg::B1, L, (uint32_t)vmax,
+                     start, hist, vstart, sorted, niels, parts);
+  hipLaunchKernelGGL(k_pip_bucket_merge, grid1(nb, 128), dim3(128), 0, c->stream, cfg::B1, (uint32_t)nb, (uint32_t)vmax, vstart, parts, buckets);
   prof_mark(c, ZKP_K_BUCKET);
   // radix-8 tree over bucket indices 0 .. B-1 (bucket B is added in k_pip_combine)
   const dev_ext* Ain = nullptr;
@@ -551,7 +618,7 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
     Afinal = Aout;
     ++level;
   }
-  hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(64), 0, c->stream, cfg::W1, C, cfg::B1, Afinal, buckets, invalid, d_out, d_status);
+  hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(64), 0, c->stream, cfg::W1, C, Afinal, invalid, d_out, d_status);
   prof_mark(c, ZKP_K_COMBINE);
   HIP_TRY(hipGetLastError());
   return ZKP_OK;

@@ -1,0 +1,121 @@
+/* zkp_toolbox.h -- C ABI of the HOST side of the MI355X zkp engine: Merlin transcripts and the
+ * Prover / Verifier / BatchVerifier flows of dalek-cryptography/zkp (src/toolbox/), batched so that the
+ * GPU is entered once per phase for a whole batch of proofs instead of once per 2-term MSM.
+ *
+ * Layering:  this library (libzkp_toolbox.so, C++/g++)  ->  zkp_mi355x.h (libzkp_mi355x.so, HIP).
+ * Everything that touches group arithmetic goes through the zkp_mi355x.h entry points; there is no CPU
+ * fallback.  Host work (STROBE/Keccak transcripts, scalar arithmetic mod l, coefficient build) runs on
+ * `n_threads` host threads (0 = all hardware threads).
+ *
+ * Reference mapping (what each call replaces, for N proofs of ONE statement at a time):
+ *   zkp_prove_batch            N x { macros.rs:206-258 build_prover ; prover.rs:76-112 prove_impl }
+ *   zkp_verify_compact_batch   N x { macros.rs:280-311 build_verifier ; verifier.rs:80-120 }
+ *   zkp_verify_batchable_each  N x { build_verifier ; verifier.rs:123-173 }
+ *   zkp_batch_verify           macros.rs:336-370 batch_verify ; batch_verifier.rs:67-235
+ * Return codes: 0 = done (per-proof verdicts in `results`); ZKP_TB_VERIFICATION_FAILURE /
+ * ZKP_TB_BATCH_SIZE_MISMATCH mirror src/errors.rs:4-11; negative = infrastructure failure (see
+ * zkp_mi355x.h) -- never treat a non-zero code as "verified".
+ */
+#ifndef ZKP_TOOLBOX_H
+#define ZKP_TOOLBOX_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "zkp_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKP_TB_OK 0
+#define ZKP_TB_VERIFICATION_FAILURE 1   /* ProofError::VerificationFailure (errors.rs:6)  */
+#define ZKP_TB_BATCH_SIZE_MISMATCH 2    /* ProofError::BatchSizeMismatch   (errors.rs:9)  */
+#define ZKP_TB_BAD_STATEMENT (-10)      /* malformed statement descriptor / NULL argument  */
+#define ZKP_TB_INVALID_POINT (-11)      /* prover was handed an encoding that does not decode */
+
+/* ---- Merlin transcripts (merlin::Transcript, re-exported by the reference at lib.rs:35) ----------- */
+#define ZKP_TRANSCRIPT_BYTES 208        /* opaque, plain-old-data: memcpy = Clone */
+void zkp_transcript_init(uint8_t t[ZKP_TRANSCRIPT_BYTES], const uint8_t* label, size_t label_len);
+void zkp_transcript_append_message(uint8_t t[ZKP_TRANSCRIPT_BYTES], const char* label, const uint8_t* msg, size_t len);
+void zkp_transcript_challenge_bytes(uint8_t t[ZKP_TRANSCRIPT_BYTES], const char* label, uint8_t* out, size_t len);
+
+/* ---- scalars mod l (curve25519_dalek::scalar::Scalar) -------------------------------------------- */
+void zkp_scalar_from_wide(uint8_t out[32], const uint8_t in[64]);   /* from_bytes_mod_order_wide */
+void zkp_scalar_muladd(uint8_t out[32], const uint8_t a[32], const uint8_t b[32], const uint8_t c[32]);   /* a*b + c */
+void zkp_scalar_neg(uint8_t out[32], const uint8_t a[32]);
+
+/* ---- statement descriptor: what define_proof! fixes (macros.rs:124-138, 159-170) ------------------ */
+typedef struct zkp_statement zkp_statement;
+zkp_statement* zkp_statement_new(const char* proof_label);
+void zkp_statement_free(zkp_statement* st);
+/* Variables are numbered in ALLOCATION order, which is part of the statement (it fixes the transcript).
+ * The macro allocates all secrets, then instance points, then common points (macros.rs:215-242). */
+int zkp_statement_add_secret(zkp_statement* st, const char* name);                 /* -> secret index  */
+int zkp_statement_add_point(zkp_statement* st, const char* name, int is_common);   /* -> point index   */
+/* lhs = sum_i secrets[i] * points[i]   (SchnorrCS::constrain, toolbox/mod.rs:86-98) */
+int zkp_statement_constrain(zkp_statement* st, uint32_t lhs_point, uint32_t n_terms, const uint32_t* secrets,
+                            const uint32_t* points);
+uint32_t zkp_statement_num_secrets(const zkp_statement* st);
+uint32_t zkp_statement_num_instance(const zkp_statement* st);
+uint32_t zkp_statement_num_common(const zkp_statement* st);
+uint32_t zkp_statement_num_constraints(const zkp_statement* st);
+
+/* Data layout shared by all batch calls (N = batch size, m = #secrets, ni / ns = #instance / #common
+ * points, nc = #constraints; "rank" = position among the points of the same kind, in allocation order):
+ *   transcripts   [N][ZKP_TRANSCRIPT_BYTES]  in/out: advanced exactly as the reference advances them
+ *   secrets       [N][m][32]
+ *   inst_points   [ni][N][32]   row = variable, column = proof (what allocate_instance_point receives,
+ *                               batch_verifier.rs:115-134; Matrix layout util.rs:21-37)
+ *   common_points [ns][32]
+ *   challenges    [N][32]   responses [N][m][32]   commitments [N][nc][32]
+ *   results       [N]       0 = Ok(()), 1 = Err(VerificationFailure)
+ */
+
+/* Prove N statements.  entropy = [N][32] bytes replacing the thread_rng contribution of prover.rs:82, or
+ * NULL to draw them from the OS.  Produces BOTH proof formats' fields: compact = (challenge, responses)
+ * (proofs.rs:15-20), batchable = (commitments, responses) (proofs.rs:27-32). */
+int zkp_prove_batch(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
+                    const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* entropy, int n_threads,
+                    uint8_t* challenges, uint8_t* responses, uint8_t* commitments);
+
+int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* transcripts,
+                             const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* challenges,
+                             const uint8_t* responses, int n_threads, uint8_t* results);
+
+/* weights16 = [N][nc][16] replacing the u128 draws of verifier.rs:153, or NULL for OS randomness */
+int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* transcripts,
+                              const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
+                              const uint8_t* responses, const uint8_t* weights16, int n_threads, uint8_t* results);
+
+/* One verdict for the whole batch (batch_verifier.rs:230-234): returns ZKP_TB_OK or
+ * ZKP_TB_VERIFICATION_FAILURE.  n_transcripts must equal N (else ZKP_TB_BATCH_SIZE_MISMATCH,
+ * batch_verifier.rs:72-74).  weights16 = [nc][N][16] replacing batch_verifier.rs:179, or NULL. */
+int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* transcripts,
+                     const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
+                     const uint8_t* responses, const uint8_t* weights16, int n_threads);
+
+/* ---- host-only halves, exposed so the host logic can be tested without a GPU ----------------------- */
+/* Everything of zkp_batch_verify up to (not including) the MSM: writes the exact operand sequence of
+ * batch_verifier.rs:219-228, ns + (ni + nc) * N scalars and encodings.  Returns 0 or the error the
+ * reference would have returned before the MSM. */
+int zkp_batch_verify_build(const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* transcripts,
+                           const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
+                           const uint8_t* responses, const uint8_t* weights16, int n_threads, uint8_t* msm_scalars,
+                           uint8_t* msm_points);
+/* Prover phase A (prover.rs:78-97 without the MSM): transcripts absorb the public points, blindings are
+ * derived; writes blindings [N][m][32] and the CSR multiscalar job for zkp_msm_many:
+ *   off [N*nc + 1], scalars [N*T][32], pidx [N*T] into the point table common_points || inst_points. */
+int zkp_prove_phase_a(const zkp_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
+                      const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* entropy, int n_threads,
+                      uint8_t* blindings, uint32_t* off, uint8_t* scalars, uint32_t* pidx);
+/* Prover phase B (prover.rs:98-109): absorb the commitments, derive challenges, compute responses. */
+int zkp_prove_phase_b(const zkp_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
+                      const uint8_t* blindings, const uint8_t* commitments, int n_threads, uint8_t* challenges,
+                      uint8_t* responses);
+/* total number of constraint terms T = sum |rhs| */
+uint32_t zkp_statement_num_terms(const zkp_statement* st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKP_TOOLBOX_H */

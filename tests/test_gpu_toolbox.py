@@ -1,0 +1,351 @@
+"""GPU tests of the whole drop-in path (Python binding -> C++ host toolbox -> C ABI -> HIP kernels), written
+after the reference's own integration tests:
+  tests/zkp.rs                          create_and_verify_compact / _batchable / create_batch_and_batch_verify
+  tests/dleq_using_constraint_api.rs    the same through Prover / Verifier / BatchVerifier
+  tests/sig_and_vrf_example.rs          accept / reject pattern, stateful transcript chaining
+plus what the reference lacks: byte-exact proofs against golden fixtures and the oracle (injected
+entropy), a bad proof inside a batch, malformed points, and the CMZ'13 workload at BASELINE sizes."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cbind as C
+from oracle import model as M
+from zkp_amd import toolbox as T
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ristretto_msm.json")
+BASEPOINT = bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zkp_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def sc(x):
+    return (x % M.L).to_bytes(32, "little")
+
+
+def mul(x: int, enc: bytes) -> bytes:
+    """test-input helper: x * P on the CPU (oracle)"""
+    return C.msm_algo("straus_vartime", np.frombuffer(sc(x), np.uint8).reshape(1, 32), np.frombuffer(enc, np.uint8).reshape(1, 32))
+
+
+def hash_to_point(msg: bytes) -> bytes:
+    return C.from_uniform_bytes(hashlib.sha512(msg).digest())       # RistrettoPoint::hash_from_bytes::<Sha512>
+
+
+# ---- tests/zkp.rs -----------------------------------------------------------------------------------------
+dleq = T.define_proof("dleq", b"DLEQ Example Proof", ["x"], ["A", "B", "H"], ["G"], [("A", [("x", "G")]), ("B", [("x", "H")])])
+
+
+def _dleq_assignments():
+    H = hash_to_point(b"A VRF input, for instance")
+    x = pow(89327492234, M.L - 2, M.L)                              # Scalar::from(89327492234u64).invert()
+    return x, {"A": mul(x, BASEPOINT), "B": mul(x, H), "G": BASEPOINT, "H": H}
+
+
+def test_create_and_verify_compact(eng):
+    x, points = _dleq_assignments()
+    transcript = T.Transcript(b"DLEQTest")
+    proof = dleq.prove_compact(eng, transcript, {"x": x}, points)
+    transcript = T.Transcript(b"DLEQTest")
+    dleq.verify_compact(eng, proof, transcript, points)             # is_ok()
+    assert len(proof.challenge) == 32 and len(proof.responses) == 1
+
+
+def test_create_and_verify_batchable(eng):
+    x, points = _dleq_assignments()
+    proof = dleq.prove_batchable(eng, T.Transcript(b"DLEQTest"), {"x": x}, points)
+    dleq.verify_batchable(eng, proof, T.Transcript(b"DLEQTest"), points)
+
+
+def test_create_batch_and_batch_verify(eng):
+    messages = [b"One message", b"Another message", b"A third message", b"A fourth message"]
+    proofs, pubkeys, vrf_outputs, Hs = [], [], [], []
+    for i, message in enumerate(messages):
+        H = hash_to_point(message)
+        x = 89327492234 * (i + 1)
+        A, B = mul(x, BASEPOINT), mul(x, H)
+        proofs.append(dleq.prove_batchable(eng, T.Transcript(b"DLEQTest"), {"x": x}, {"A": A, "B": B, "G": BASEPOINT, "H": H}))
+        pubkeys.append(A); vrf_outputs.append(B); Hs.append(H)
+    transcripts = [T.Transcript(b"DLEQTest") for _ in messages]
+    dleq.batch_verify(eng, proofs, transcripts, {"A": pubkeys, "B": vrf_outputs, "H": Hs}, {"G": BASEPOINT})
+    # (not in the reference) a single bad response poisons the batch
+    bad = [T.BatchableProof(list(p.commitments), list(p.responses)) for p in proofs]
+    bad[2].responses[0] = sc(int.from_bytes(bad[2].responses[0], "little") + 1)
+    with pytest.raises(T.VerificationFailure):
+        dleq.batch_verify(eng, bad, [T.Transcript(b"DLEQTest") for _ in messages], {"A": pubkeys, "B": vrf_outputs, "H": Hs}, {"G": BASEPOINT})
+    with pytest.raises(T.BatchSizeMismatch):
+        dleq.batch_verify(eng, proofs, transcripts[:3], {"A": pubkeys, "B": vrf_outputs, "H": Hs}, {"G": BASEPOINT})
+
+
+# ---- tests/dleq_using_constraint_api.rs -------------------------------------------------------------------
+def dleq_statement(cs, x, A, G, B, H):
+    cs.constrain(A, [(x, B)])
+    cs.constrain(G, [(x, H)])
+
+
+def _capi_points():
+    B = BASEPOINT
+    H = hash_to_point(B)
+    x = 89327492234
+    return x, mul(x, B), B, mul(x, H), H         # x, A, B, G, H  with A = x B, G = x H
+
+
+def test_create_and_verify_compact_dleq(eng):
+    x, A, B, G, H = _capi_points()
+    transcript = T.Transcript(b"DLEQTest")
+    prover = T.Prover(b"DLEQProof", transcript, eng)
+    var_x = prover.allocate_scalar(b"x", x)
+    var_B, _ = prover.allocate_point(b"B", B)
+    var_H, _ = prover.allocate_point(b"H", H)
+    var_A, cmpr_A = prover.allocate_point(b"A", A)
+    var_G, cmpr_G = prover.allocate_point(b"G", G)
+    dleq_statement(prover, var_x, var_A, var_G, var_B, var_H)
+    proof = prover.prove_compact()
+
+    transcript = T.Transcript(b"DLEQTest")
+    verifier = T.Verifier(b"DLEQProof", transcript, eng)
+    var_x = verifier.allocate_scalar(b"x")
+    var_B = verifier.allocate_point(b"B", B)
+    var_H = verifier.allocate_point(b"H", H)
+    var_A = verifier.allocate_point(b"A", cmpr_A)
+    var_G = verifier.allocate_point(b"G", cmpr_G)
+    dleq_statement(verifier, var_x, var_A, var_G, var_B, var_H)
+    verifier.verify_compact(proof)
+
+
+def test_create_and_verify_batchable_dleq(eng):
+    x, A, B, G, H = _capi_points()
+    prover = T.Prover(b"DLEQProof", T.Transcript(b"DLEQTest"), eng)
+    var_x = prover.allocate_scalar(b"x", x)
+    var_B, _ = prover.allocate_point(b"B", B)
+    var_H, _ = prover.allocate_point(b"H", H)
+    var_A, _ = prover.allocate_point(b"A", A)
+    var_G, _ = prover.allocate_point(b"G", G)
+    dleq_statement(prover, var_x, var_A, var_G, var_B, var_H)
+    proof = prover.prove_batchable()
+    verifier = T.Verifier(b"DLEQProof", T.Transcript(b"DLEQTest"), eng)
+    var_x = verifier.allocate_scalar(b"x")
+    var_B = verifier.allocate_point(b"B", B)
+    var_H = verifier.allocate_point(b"H", H)
+    var_A = verifier.allocate_point(b"A", A)
+    var_G = verifier.allocate_point(b"G", G)
+    dleq_statement(verifier, var_x, var_A, var_G, var_B, var_H)
+    verifier.verify_batchable(proof)
+    # identity public point is refused at allocation (mod.rs:191-193)
+    v2 = T.Verifier(b"DLEQProof", T.Transcript(b"DLEQTest"), eng)
+    with pytest.raises(T.VerificationFailure):
+        v2.allocate_point(b"B", bytes(32))
+
+
+def test_create_batch_and_batch_verify_dleq(eng):
+    B = BASEPOINT
+    H = hash_to_point(B)
+    batch_size = 16
+    proofs, cmpr_As, cmpr_Gs = [], [], []
+    for j in range(batch_size):
+        x = 89327492234 + j
+        A, G = mul(x, B), mul(x, H)
+        prover = T.Prover(b"DLEQProof", T.Transcript(b"DLEQBatchTest"), eng)
+        var_x = prover.allocate_scalar(b"x", x)
+        var_B, _ = prover.allocate_point(b"B", B)
+        var_H, _ = prover.allocate_point(b"H", H)
+        var_A, cmpr_A = prover.allocate_point(b"A", A)
+        var_G, cmpr_G = prover.allocate_point(b"G", G)
+        dleq_statement(prover, var_x, var_A, var_G, var_B, var_H)
+        proofs.append(prover.prove_batchable())
+        cmpr_As.append(cmpr_A); cmpr_Gs.append(cmpr_G)
+    transcripts = [T.Transcript(b"DLEQBatchTest") for _ in range(batch_size)]
+    verifier = T.BatchVerifier(b"DLEQProof", batch_size, transcripts, eng)
+    var_x = verifier.allocate_scalar(b"x")
+    var_B = verifier.allocate_static_point(b"B", B)
+    var_H = verifier.allocate_static_point(b"H", H)
+    var_A = verifier.allocate_instance_point(b"A", cmpr_As)
+    var_G = verifier.allocate_instance_point(b"G", cmpr_Gs)
+    dleq_statement(verifier, var_x, var_A, var_G, var_B, var_H)
+    verifier.verify_batchable(proofs)
+    with pytest.raises(T.BatchSizeMismatch):
+        T.BatchVerifier(b"DLEQProof", batch_size, transcripts[:-1], eng)
+
+
+# ---- tests/sig_and_vrf_example.rs ---------------------------------------------------------------------------
+sig_proof = T.define_proof("sig_proof", b"Sig", ["x"], ["A"], ["B"], [("A", [("x", "B")])])
+
+
+def sign(eng, sk: int, pk: bytes, message: bytes, transcript):
+    transcript.append_message(b"msg", message)
+    return sig_proof.prove_batchable(eng, transcript, {"x": sk}, {"A": pk, "B": BASEPOINT})
+
+
+def verify(eng, sig, message: bytes, pk: bytes, transcript):
+    transcript.append_message(b"msg", message)
+    sig_proof.verify_batchable(eng, sig, transcript, {"A": pk, "B": BASEPOINT})
+
+
+def test_create_and_verify_sig(eng):
+    rng = random.Random(3)
+    domain_sep, msg1, msg2 = b"My Sig Application", b"Test Message 1", b"Test Message 2"
+    sk1, sk2 = rng.randrange(1, M.L), rng.randrange(1, M.L)
+    pk1, pk2 = mul(sk1, BASEPOINT), mul(sk2, BASEPOINT)
+    sig1 = sign(eng, sk1, pk1, msg1, T.Transcript(domain_sep))
+    sig2 = sign(eng, sk2, pk2, msg2, T.Transcript(domain_sep))
+    verify(eng, sig1, msg1, pk1, T.Transcript(domain_sep))
+    verify(eng, sig2, msg2, pk2, T.Transcript(domain_sep))
+    for sig, msg, pk, dom in [(sig1, msg1, pk2, domain_sep), (sig2, msg2, pk1, domain_sep),       # wrong pubkey
+                              (sig1, msg2, pk1, domain_sep), (sig2, msg1, pk2, domain_sep),       # wrong message
+                              (sig1, msg1, pk1, b"Wrong"), (sig2, msg2, pk2, b"Wrong")]:          # wrong domain separator
+        with pytest.raises(T.VerificationFailure):
+            verify(eng, sig, msg, pk, T.Transcript(dom))
+
+
+def test_counterparty_signature_chain(eng):
+    rng = random.Random(4)
+    sk1, sk2 = rng.randrange(1, M.L), rng.randrange(1, M.L)
+    pk1, pk2 = mul(sk1, BASEPOINT), mul(sk2, BASEPOINT)
+    trans1, trans2 = T.Transcript(b"Counterparty Example"), T.Transcript(b"Counterparty Example")
+    msgs = [b"In this test, two counterparties exchange signatures.", b"However, the counterparties sign and verify messages",
+            b"using stateful transcript objects.", b"When party 1 signs, the party 1 transcript changes;",
+            b"when party 2 verifies, the party 2 transcript syncs.", b"In this way, the transcript states ratchet stateful signatures."]
+    for rnd in range(3):
+        s = sign(eng, sk1, pk1, msgs[2 * rnd], trans1)
+        verify(eng, s, msgs[2 * rnd], pk1, trans2)
+        s = sign(eng, sk2, pk2, msgs[2 * rnd + 1], trans2)
+        verify(eng, s, msgs[2 * rnd + 1], pk2, trans1)
+    assert (trans1.state == trans2.state).all()
+
+
+# ---- beyond the reference: byte-exact proofs ----------------------------------------------------------------
+def test_golden_proofs_byte_exact(eng):
+    """Injected entropy makes proofs deterministic: the GPU path must reproduce the committed fixtures."""
+    fx = json.load(open(GOLDEN))
+    for case in fx["proofs"]:
+        mod = T.dleq_module() if case["statement"] == "dleq" else T.cmz_module(10)
+        names = mod.instance + mod.common
+        points = {n: bytes.fromhex(p) for n, p in zip(names, case["points"])}
+        secrets = {n: bytes.fromhex(s) for n, s in zip(mod.secrets, case["secrets"])}
+        label = bytes.fromhex(case["label"])
+        proof = mod.prove_compact(eng, T.Transcript(label), secrets, points, entropy=bytes.fromhex(case["entropy"]))
+        assert proof.challenge.hex() == case["challenge"]
+        assert [r.hex() for r in proof.responses] == case["responses"]
+        bp = mod.prove_batchable(eng, T.Transcript(label), secrets, points, entropy=bytes.fromhex(case["entropy"]))
+        assert [c.hex() for c in bp.commitments] == case["commitments"]
+        mod.verify_compact(eng, proof, T.Transcript(label), points)
+        mod.verify_batchable(eng, bp, T.Transcript(label), points)
+    for case in fx["msm"]:
+        s = np.frombuffer(b"".join(bytes.fromhex(x) for x in case["scalars"]), np.uint8).reshape(-1, 32)
+        p = np.frombuffer(b"".join(bytes.fromhex(x) for x in case["points"]), np.uint8).reshape(-1, 32)
+        got = eng.msm_optional(s, p)
+        assert (got.hex() if got is not None else None) == case["expect"]
+    st = eng.decode_check(np.frombuffer(b"".join(bytes.fromhex(c["enc"]) for c in fx["decode"]), np.uint8).reshape(-1, 32))
+    assert [int(x) == 0 for x in st] == [c["valid"] for c in fx["decode"]]
+
+
+def _cmz_batch(n, seed):
+    """n valid CMZ'13 presentations sharing the issuer parameters; inputs made with the oracle's arithmetic."""
+    rng = np.random.default_rng(seed)
+    mod = T.cmz_module(10)
+
+    def rs(k):
+        s = rng.integers(0, 256, size=(k, 32), dtype=np.uint8)
+        s[:, 31] &= 0x0f
+        return s
+
+    base = np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32)
+    common_sc = rs(12)
+    common, _ = C.msm_many(np.arange(13, dtype=np.uint32), common_sc, np.zeros(12, np.uint32), base, 0)   # X_1..X_10, A, B
+    secrets = rs(n * 21).reshape(n, 21, 32)                        # m_1..m_10, z_1..z_10, minus_z_Q
+    pq, _ = C.msm_many(np.arange(2 * n + 1, dtype=np.uint32), rs(2 * n), np.zeros(2 * n, np.uint32), base, 0)
+    P, Q = pq[:n], pq[n:]
+    # C_i = m_i P + z_i A ; V = sum m_i X_i + minus_z_Q Q      (benches/zkp.rs:34-45)
+    table = np.concatenate([common, P, Q])
+    off, scal, pidx = [0], [], []
+    for j in range(n):
+        for i in range(10):
+            scal += [secrets[j, i], secrets[j, 10 + i]]
+            pidx += [12 + j, 10]
+            off.append(len(pidx))
+        for i in range(10):
+            scal.append(secrets[j, i]); pidx.append(i)
+        scal.append(secrets[j, 20]); pidx.append(12 + n + j)
+        off.append(len(pidx))
+    cv, st = C.msm_many(np.array(off, np.uint32), np.stack(scal), np.array(pidx, np.uint32), table, 0)
+    assert not st.any()
+    cv = cv.reshape(n, 11, 32)
+    inst = np.concatenate([cv[:, :10].transpose(1, 0, 2), P[None], Q[None], cv[:, 10][None]])      # C_1..C_10, P, Q, V
+    return mod, secrets, np.ascontiguousarray(inst), common
+
+
+@pytest.mark.parametrize("n", [64, 4096])
+def test_cmz_batch_prove_verify(eng, n):
+    """BASELINE configs[1] (n = 4096): prove -> verify_compact (every proof) -> batch_verify, and oracle parity."""
+    mod, secrets, inst, common = _cmz_batch(n, 11)
+    label = b"Benchmark"
+    rng = np.random.default_rng(12)
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ts = np.stack([T.Transcript(label).state] * n)
+    chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, common, entropy)
+    # the C oracle, run on a sample of the batch, must produce the same bytes
+    cst = C.Statement.from_model(M.cmz_statement(10))
+    for j in sorted(set([0, 1, n // 2, n - 1])):
+        pts = np.concatenate([inst[:, j], common])
+        ec, er, ek, _ = C.prove(cst, label, secrets[j], pts, entropy[j].tobytes())
+        assert chal[j].tobytes() == ec.tobytes() and (resp[j] == er).all() and (coms[j] == ek).all(), j
+    ts = np.stack([T.Transcript(label).state] * n)
+    res = T.verify_compact_batch(eng, mod.statement, ts, inst, common, chal, resp)
+    assert not res.any()
+    ts = np.stack([T.Transcript(label).state] * n)
+    res = T.verify_batchable_each(eng, mod.statement, ts, inst, common, coms, resp)
+    assert not res.any()
+    ts = np.stack([T.Transcript(label).state] * n)
+    T.batch_verify(eng, mod.statement, ts, inst, common, coms, resp)
+    # a bad proof inside the batch: batch fails, per-proof verification localises it
+    bad = resp.copy()
+    k = n // 3
+    bad[k, 7, 0] ^= 1
+    ts = np.stack([T.Transcript(label).state] * n)
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify(eng, mod.statement, ts, inst, common, coms, bad)
+    ts = np.stack([T.Transcript(label).state] * n)
+    res = T.verify_batchable_each(eng, mod.statement, ts, inst, common, coms, bad)
+    assert res[k] == 1 and res.sum() == 1
+    ts = np.stack([T.Transcript(label).state] * n)
+    res = T.verify_compact_batch(eng, mod.statement, ts, inst, common, chal, bad)
+    assert res[k] == 1 and res.sum() == 1
+    # a malformed instance point (does not decode): that proof fails, and the batch fails as a whole
+    badinst = inst.copy()
+    badinst[3, k] = np.frombuffer(bytes.fromhex("0100000000000000000000000000000000000000000000000000000000000000"), np.uint8)
+    ts = np.stack([T.Transcript(label).state] * n)
+    res = T.verify_compact_batch(eng, mod.statement, ts, badinst, common, chal, resp)
+    assert res[k] == 1 and res.sum() == 1
+    ts = np.stack([T.Transcript(label).state] * n)
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify(eng, mod.statement, ts, badinst, common, coms, resp)
+
+
+def test_unreferenced_point_must_still_decode(eng):
+    """CMZ's common point `B` is in no constraint, yet every verifier decompresses it (verifier.rs:87-92,
+    :162-166; batch_verifier.rs:224-226).  The prover only hashes its encoding, so a proof made over an
+    undecodable `B` has consistent transcripts and still must be rejected."""
+    mod, secrets, inst, common = _cmz_batch(4, 21)
+    label = b"Benchmark"
+    badc = common.copy()
+    badc[11] = np.frombuffer(bytes.fromhex("0100000000000000000000000000000000000000000000000000000000000000"), np.uint8)
+    ts = np.stack([T.Transcript(label).state] * 4)
+    chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, badc)
+    ts = np.stack([T.Transcript(label).state] * 4)
+    assert T.verify_compact_batch(eng, mod.statement, ts, inst, badc, chal, resp).all()
+    ts = np.stack([T.Transcript(label).state] * 4)
+    assert T.verify_batchable_each(eng, mod.statement, ts, inst, badc, coms, resp).all()
+    ts = np.stack([T.Transcript(label).state] * 4)
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify(eng, mod.statement, ts, inst, badc, coms, resp)

@@ -51,8 +51,8 @@ def build_host(force: bool = False, verbose: bool = False):
         return None
     deps = _deps(host_dir, os.path.join(HERE, "..", "include"))
     if force or _stale(HOST_LIB, deps):
-        cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I", os.path.join(HERE, "..", "include")] + srcs + [
-            "-o", HOST_LIB, "-ldl"]
+        cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall", "-I", os.path.join(HERE, "..", "include")] + srcs + [
+            "-o", HOST_LIB, "-L", HERE, "-lzkp_mi355x", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -1,0 +1,490 @@
+// Host side of the zkp toolbox on top of the MI355X engine: the Prover / Verifier / BatchVerifier flows
+// of the reference (src/toolbox/{prover,verifier,batch_verifier}.rs), restructured as
+//      phase A (host, all proofs, threaded)  ->  ONE GPU call  ->  phase B (host, all proofs, threaded)
+// because the reference's one-MSM-per-constraint call pattern (prover.rs:93-97, verifier.rs:96-106) would
+// be pure launch overhead on a GPU.  Transcript traffic is byte-identical to the reference's, so proofs
+// are interchangeable with proofs made by the Rust crate.  All group arithmetic goes through
+// include/zkp_mi355x.h; there is no CPU fallback here.
+#include <sys/random.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../../../include/zkp_toolbox.h"
+#include "merlin.hpp"
+#include "scalar.hpp"
+
+using zkp::host::Scalar;
+using zkp::host::Transcript;
+
+struct zkp_statement {
+  std::string label;
+  std::vector<std::string> secrets;
+  struct Point { std::string name; bool common; uint32_t rank; };
+  std::vector<Point> points;
+  uint32_t ni = 0, ns = 0;
+  struct Constraint { uint32_t lhs; std::vector<std::pair<uint32_t, uint32_t>> lc; };
+  std::vector<Constraint> cons;
+  uint32_t terms = 0;
+};
+
+namespace {
+
+constexpr size_t TB = ZKP_TRANSCRIPT_BYTES;
+
+template <typename F>
+void parallel_for(uint32_t n, int n_threads, F&& body) {
+  unsigned t = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
+  if (t == 0) t = 1;
+  t = std::min<unsigned>(t, (n + 63) / 64 ? (n + 63) / 64 : 1);      // at least ~64 proofs per thread
+  if (t <= 1) { body(0u, n); return; }
+  std::vector<std::thread> pool;
+  const uint32_t chunk = (n + t - 1) / t;
+  for (unsigned k = 0; k < t; ++k) {
+    const uint32_t lo = std::min<uint32_t>(n, k * chunk), hi = std::min<uint32_t>(n, lo + chunk);
+    if (lo < hi) pool.emplace_back([&body, lo, hi] { body(lo, hi); });
+  }
+  for (auto& th : pool) th.join();
+}
+
+void os_random(uint8_t* out, size_t len) {
+  size_t got = 0;
+  while (got < len) {
+    const ssize_t r = getrandom(out + got, len - got, 0);
+    if (r > 0) got += (size_t)r;
+  }
+}
+
+// encoding of point variable p for proof j
+inline const uint8_t* point_enc(const zkp_statement& st, uint32_t p, uint32_t j, uint32_t N, const uint8_t* inst,
+                                const uint8_t* common) {
+  const auto& pt = st.points[p];
+  return pt.common ? common + 32 * (size_t)pt.rank : inst + 32 * ((size_t)pt.rank * N + j);
+}
+// index of point variable p of proof j in the device point table  common || inst (row-major [ni][N])
+inline uint32_t table_index(const zkp_statement& st, uint32_t p, uint32_t j, uint32_t N) {
+  const auto& pt = st.points[p];
+  return pt.common ? pt.rank : st.ns + pt.rank * N + j;
+}
+
+bool all_transcripts_equal(const uint8_t* ts, uint32_t N) {
+  for (uint32_t j = 1; j < N; ++j)
+    if (std::memcmp(ts, ts + TB * (size_t)j, TB) != 0) return false;
+  return true;
+}
+
+// Prover::new + allocate_scalar for every secret (prover.rs:41-57) / the same on the verifier side.  When
+// all N incoming transcripts are equal (the usual case) this prefix is hashed once and cloned.
+void apply_prefix(const zkp_statement& st, uint32_t N, uint8_t* ts, int n_threads) {
+  auto prefix = [&](Transcript& t) {
+    t.domain_sep(st.label.c_str());
+    for (const auto& s : st.secrets) t.append_scalar_var(s.c_str());
+  };
+  if (N > 1 && all_transcripts_equal(ts, N)) {
+    Transcript t = Transcript::from_bytes(ts);
+    prefix(t);
+    for (uint32_t j = 0; j < N; ++j) t.to_bytes(ts + TB * (size_t)j);
+    return;
+  }
+  parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
+    for (uint32_t j = lo; j < hi; ++j) {
+      Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
+      prefix(t);
+      t.to_bytes(ts + TB * (size_t)j);
+    }
+  });
+}
+
+// point variables no constraint mentions (e.g. `B` of the CMZ statement, benches/zkp.rs:32): verify_compact
+// still insists that they decompress (verifier.rs:87-92)
+std::vector<uint32_t> unreferenced_points(const zkp_statement& st) {
+  std::vector<char> used(st.points.size(), 0);
+  for (const auto& c : st.cons) {
+    used[c.lhs] = 1;
+    for (const auto& t : c.lc) used[t.second] = 1;
+  }
+  std::vector<uint32_t> out;
+  for (uint32_t p = 0; p < st.points.size(); ++p)
+    if (!used[p]) out.push_back(p);
+  return out;
+}
+
+std::vector<uint8_t> point_table(const zkp_statement& st, uint32_t N, const uint8_t* inst, const uint8_t* common) {
+  std::vector<uint8_t> tbl(32 * ((size_t)st.ns + (size_t)st.ni * N));
+  if (st.ns) std::memcpy(tbl.data(), common, 32 * (size_t)st.ns);
+  if (st.ni) std::memcpy(tbl.data() + 32 * (size_t)st.ns, inst, 32 * (size_t)st.ni * N);
+  return tbl;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- transcripts / scalars -----------------------------------------------------------------------------
+void zkp_transcript_init(uint8_t* t, const uint8_t* label, size_t len) { Transcript(label, len).to_bytes(t); }
+void zkp_transcript_append_message(uint8_t* t, const char* label, const uint8_t* msg, size_t len) {
+  Transcript x = Transcript::from_bytes(t);
+  x.append_message(label, msg, len);
+  x.to_bytes(t);
+}
+void zkp_transcript_challenge_bytes(uint8_t* t, const char* label, uint8_t* out, size_t len) {
+  Transcript x = Transcript::from_bytes(t);
+  x.challenge_bytes(label, out, len);
+  x.to_bytes(t);
+}
+void zkp_scalar_from_wide(uint8_t out[32], const uint8_t in[64]) { Scalar::from_bytes_mod_order_wide(in).to_bytes(out); }
+void zkp_scalar_muladd(uint8_t out[32], const uint8_t a[32], const uint8_t b[32], const uint8_t c[32]) {
+  (Scalar::from_bytes_mod_order(a) * Scalar::from_bytes_mod_order(b) + Scalar::from_bytes_mod_order(c)).to_bytes(out);
+}
+void zkp_scalar_neg(uint8_t out[32], const uint8_t a[32]) { (-Scalar::from_bytes_mod_order(a)).to_bytes(out); }
+
+// ---- statements -------------------------------------------------------------------------------------------
+zkp_statement* zkp_statement_new(const char* proof_label) {
+  auto* st = new zkp_statement();
+  st->label = proof_label ? proof_label : "";
+  return st;
+}
+void zkp_statement_free(zkp_statement* st) { delete st; }
+int zkp_statement_add_secret(zkp_statement* st, const char* name) {
+  if (!st || !name) return ZKP_TB_BAD_STATEMENT;
+  st->secrets.emplace_back(name);
+  return (int)st->secrets.size() - 1;
+}
+int zkp_statement_add_point(zkp_statement* st, const char* name, int is_common) {
+  if (!st || !name) return ZKP_TB_BAD_STATEMENT;
+  st->points.push_back({name, is_common != 0, is_common ? st->ns++ : st->ni++});
+  return (int)st->points.size() - 1;
+}
+int zkp_statement_constrain(zkp_statement* st, uint32_t lhs, uint32_t n_terms, const uint32_t* secrets, const uint32_t* points) {
+  if (!st || lhs >= st->points.size() || (n_terms && (!secrets || !points))) return ZKP_TB_BAD_STATEMENT;
+  zkp_statement::Constraint c;
+  c.lhs = lhs;
+  for (uint32_t i = 0; i < n_terms; ++i) {
+    if (secrets[i] >= st->secrets.size() || points[i] >= st->points.size()) return ZKP_TB_BAD_STATEMENT;
+    c.lc.emplace_back(secrets[i], points[i]);
+  }
+  st->terms += n_terms;
+  st->cons.push_back(std::move(c));
+  return ZKP_TB_OK;
+}
+uint32_t zkp_statement_num_secrets(const zkp_statement* st) { return st ? (uint32_t)st->secrets.size() : 0; }
+uint32_t zkp_statement_num_instance(const zkp_statement* st) { return st ? st->ni : 0; }
+uint32_t zkp_statement_num_common(const zkp_statement* st) { return st ? st->ns : 0; }
+uint32_t zkp_statement_num_constraints(const zkp_statement* st) { return st ? (uint32_t)st->cons.size() : 0; }
+uint32_t zkp_statement_num_terms(const zkp_statement* st) { return st ? st->terms : 0; }
+
+// ---- prover -----------------------------------------------------------------------------------------------
+int zkp_prove_phase_a(const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* secrets, const uint8_t* inst,
+                      const uint8_t* common, const uint8_t* entropy, int n_threads, uint8_t* blindings, uint32_t* off,
+                      uint8_t* scalars, uint32_t* pidx) {
+  if (!stp || !ts || !blindings || !off || !scalars || !pidx || (!secrets && !stp->secrets.empty())) return ZKP_TB_BAD_STATEMENT;
+  const zkp_statement& st = *stp;
+  const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), T = st.terms;
+  apply_prefix(st, N, ts, n_threads);                                  // prover.rs:42, :54
+  std::vector<uint8_t> own_entropy;
+  if (!entropy) {                                                      // prover.rs:82 `thread_rng()`
+    own_entropy.resize(32 * (size_t)N);
+    os_random(own_entropy.data(), own_entropy.size());
+    entropy = own_entropy.data();
+  }
+  parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
+    for (uint32_t j = lo; j < hi; ++j) {
+      Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
+      for (uint32_t p = 0; p < st.points.size(); ++p)                  // prover.rs:69 (encodings are supplied)
+        t.append_point_var(st.points[p].name.c_str(), point_enc(st, p, j, N, inst, common));
+      zkp::host::TranscriptRng rng = t.build_rng();                    // prover.rs:78-82
+      for (uint32_t i = 0; i < m; ++i) rng.rekey_with_witness_bytes("", secrets + 32 * ((size_t)j * m + i), 32);
+      rng.finalize(entropy + 32 * (size_t)j);
+      uint8_t* b = blindings + 32 * (size_t)j * m;
+      for (uint32_t i = 0; i < m; ++i) {                               // prover.rs:85-89 Scalar::random
+        uint8_t wide[64];
+        rng.fill_bytes(wide, 64);
+        Scalar::from_bytes_mod_order_wide(wide).to_bytes(b + 32 * i);
+      }
+      size_t q = (size_t)j * T;                                        // prover.rs:94-97 operand lists
+      for (uint32_t k = 0; k < nc; ++k) {
+        off[(size_t)j * nc + k] = (uint32_t)q;
+        for (const auto& term : st.cons[k].lc) {
+          std::memcpy(scalars + 32 * q, b + 32 * term.first, 32);
+          pidx[q] = table_index(st, term.second, j, N);
+          ++q;
+        }
+      }
+      t.to_bytes(ts + TB * (size_t)j);
+    }
+  });
+  off[(size_t)N * nc] = (uint32_t)((size_t)N * T);
+  return ZKP_TB_OK;
+}
+
+int zkp_prove_phase_b(const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* secrets, const uint8_t* blindings,
+                      const uint8_t* commitments, int n_threads, uint8_t* challenges, uint8_t* responses) {
+  if (!stp || !ts || !commitments || !challenges || !responses) return ZKP_TB_BAD_STATEMENT;
+  const zkp_statement& st = *stp;
+  const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size();
+  parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
+    for (uint32_t j = lo; j < hi; ++j) {
+      Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
+      for (uint32_t k = 0; k < nc; ++k)                                // prover.rs:98-100
+        t.append_blinding_commitment(st.points[st.cons[k].lhs].name.c_str(), commitments + 32 * ((size_t)j * nc + k));
+      uint8_t* c = challenges + 32 * (size_t)j;
+      t.get_challenge("chal", c);                                      // prover.rs:106
+      const Scalar cs = Scalar::from_bytes_mod_order(c);
+      for (uint32_t i = 0; i < m; ++i) {                               // prover.rs:107-109  s * c + b
+        const size_t o = 32 * ((size_t)j * m + i);
+        (Scalar::from_bytes_mod_order(secrets + o) * cs + Scalar::from_bytes_mod_order(blindings + o)).to_bytes(responses + o);
+      }
+      t.to_bytes(ts + TB * (size_t)j);
+    }
+  });
+  return ZKP_TB_OK;
+}
+
+int zkp_prove_batch(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* ts, const uint8_t* secrets,
+                    const uint8_t* inst, const uint8_t* common, const uint8_t* entropy, int n_threads, uint8_t* challenges,
+                    uint8_t* responses, uint8_t* commitments) {
+  if (!ctx || !st) return ZKP_TB_BAD_STATEMENT;
+  if (N == 0) return ZKP_TB_OK;
+  const uint32_t m = (uint32_t)st->secrets.size(), nc = (uint32_t)st->cons.size(), T = st->terms;
+  std::vector<uint8_t> blind(32 * (size_t)N * m), scalars(32 * (size_t)N * T), status((size_t)N * nc);
+  std::vector<uint32_t> off((size_t)N * nc + 1), pidx((size_t)N * T);
+  int rc = zkp_prove_phase_a(st, N, ts, secrets, inst, common, entropy, n_threads, blind.data(), off.data(), scalars.data(), pidx.data());
+  if (rc) return rc;
+  const std::vector<uint8_t> tbl = point_table(*st, N, inst, common);
+  // prover.rs:94 RistrettoPoint::multiscalar_mul for every constraint of every proof, + compress (mod.rs:204)
+  rc = zkp_msm_many(ctx, N * nc, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32), ZKP_CT,
+                    commitments, status.data());
+  if (rc) return rc;
+  for (uint8_t s : status)
+    if (s) return ZKP_TB_INVALID_POINT;     // the reference prover holds decoded points; an undecodable input is a caller bug
+  return zkp_prove_phase_b(st, N, ts, secrets, blind.data(), commitments, n_threads, challenges, responses);
+}
+
+// ---- single-proof verification, batched over N independent proofs -----------------------------------------
+// Verifier::new + allocate_* (verifier.rs:47-77); failed[j] = 1 when an identity point is rejected
+static void build_verifiers(const zkp_statement& st, uint32_t N, uint8_t* ts, const uint8_t* inst, const uint8_t* common,
+                            int n_threads, uint8_t* failed) {
+  apply_prefix(st, N, ts, n_threads);
+  parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
+    for (uint32_t j = lo; j < hi; ++j) {
+      Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
+      for (uint32_t p = 0; p < st.points.size() && !failed[j]; ++p)
+        if (!t.validate_and_append_point_var(st.points[p].name.c_str(), point_enc(st, p, j, N, inst, common))) failed[j] = 1;
+      t.to_bytes(ts + TB * (size_t)j);
+    }
+  });
+}
+
+int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* inst,
+                             const uint8_t* common, const uint8_t* challenges, const uint8_t* responses, int n_threads,
+                             uint8_t* results) {
+  if (!ctx || !stp || !ts || !results || !challenges || !responses) return ZKP_TB_BAD_STATEMENT;
+  if (N == 0) return ZKP_TB_OK;
+  const zkp_statement& st = *stp;
+  const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), T1 = st.terms + nc;
+  std::memset(results, 0, N);
+  build_verifiers(st, N, ts, inst, common, n_threads, results);
+  // verifier.rs:95-106: per constraint, responses over the rhs points and (-c) over the lhs point
+  std::vector<uint8_t> scalars(32 * (size_t)N * T1), coms(32 * (size_t)N * nc), status((size_t)N * nc);
+  std::vector<uint32_t> off((size_t)N * nc + 1), pidx((size_t)N * T1);
+  parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
+    for (uint32_t j = lo; j < hi; ++j) {
+      uint8_t minus_c[32];
+      (-Scalar::from_bytes_mod_order(challenges + 32 * (size_t)j)).to_bytes(minus_c);
+      size_t q = (size_t)j * T1;
+      for (uint32_t k = 0; k < nc; ++k) {
+        off[(size_t)j * nc + k] = (uint32_t)q;
+        for (const auto& term : st.cons[k].lc) {
+          std::memcpy(scalars.data() + 32 * q, responses + 32 * ((size_t)j * m + term.first), 32);
+          pidx[q++] = table_index(st, term.second, j, N);
+        }
+        std::memcpy(scalars.data() + 32 * q, minus_c, 32);
+        pidx[q++] = table_index(st, st.cons[k].lhs, j, N);
+      }
+    }
+  });
+  off[(size_t)N * nc] = (uint32_t)((size_t)N * T1);
+  const std::vector<uint8_t> tbl = point_table(st, N, inst, common);
+  int rc = zkp_msm_many(ctx, N * nc, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32),
+                        ZKP_VARTIME, coms.data(), status.data());
+  if (rc) return rc;
+  // verifier.rs:87-92 decompresses EVERY allocated point, also those no constraint uses
+  const std::vector<uint32_t> unref = unreferenced_points(st);
+  if (!unref.empty()) {
+    std::vector<uint8_t> encs, st8;
+    std::vector<std::pair<uint32_t, int>> owner;     // (proof or ~0 for all, unused)
+    for (uint32_t p : unref) {
+      if (st.points[p].common) { encs.insert(encs.end(), common + 32 * (size_t)st.points[p].rank, common + 32 * (size_t)st.points[p].rank + 32); owner.emplace_back(~0u, 0); }
+      else for (uint32_t j = 0; j < N; ++j) { const uint8_t* e = point_enc(st, p, j, N, inst, common); encs.insert(encs.end(), e, e + 32); owner.emplace_back(j, 0); }
+    }
+    st8.resize(owner.size());
+    rc = zkp_decode_check(ctx, owner.size(), encs.data(), st8.data(), nullptr);
+    if (rc) return rc;
+    for (size_t i = 0; i < owner.size(); ++i)
+      if (st8[i]) {
+        if (owner[i].first == ~0u) std::memset(results, 1, N);
+        else results[owner[i].first] = 1;
+      }
+  }
+  parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
+    for (uint32_t j = lo; j < hi; ++j) {
+      if (results[j]) continue;
+      bool bad = false;
+      for (uint32_t k = 0; k < nc; ++k) bad |= status[(size_t)j * nc + k] != 0;
+      if (bad) { results[j] = 1; continue; }
+      Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
+      for (uint32_t k = 0; k < nc; ++k)                                // verifier.rs:108 (non-validating append)
+        t.append_blinding_commitment(st.points[st.cons[k].lhs].name.c_str(), coms.data() + 32 * ((size_t)j * nc + k));
+      uint8_t c[32], claimed[32];
+      t.get_challenge("chal", c);                                      // verifier.rs:113-119
+      Scalar::from_bytes_mod_order(challenges + 32 * (size_t)j).to_bytes(claimed);
+      results[j] = std::memcmp(c, claimed, 32) == 0 ? 0 : 1;
+      t.to_bytes(ts + TB * (size_t)j);
+    }
+  });
+  return ZKP_TB_OK;
+}
+
+int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* inst,
+                              const uint8_t* common, const uint8_t* commitments, const uint8_t* responses,
+                              const uint8_t* weights16, int n_threads, uint8_t* results) {
+  if (!ctx || !stp || !ts || !results || !commitments || !responses) return ZKP_TB_BAD_STATEMENT;
+  if (N == 0) return ZKP_TB_OK;
+  const zkp_statement& st = *stp;
+  const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), np = (uint32_t)st.points.size();
+  std::memset(results, 0, N);
+  build_verifiers(st, N, ts, inst, common, n_threads, results);
+  std::vector<uint8_t> own_w;
+  if (!weights16) { own_w.resize(16 * (size_t)N * nc); os_random(own_w.data(), own_w.size()); weights16 = own_w.data(); }
+  // one (np + nc)-term MSM per proof over  points || commitments   (verifier.rs:144-166)
+  const uint32_t K = np + nc;
+  std::vector<uint8_t> scalars(32 * (size_t)N * K), out(32 * (size_t)N), status(N);
+  std::vector<uint32_t> off((size_t)N + 1), pidx((size_t)N * K);
+  // point table: common || inst || commitments [N][nc]
+  std::vector<uint8_t> tbl = point_table(st, N, inst, common);
+  const uint32_t com_base = (uint32_t)(tbl.size() / 32);
+  tbl.insert(tbl.end(), commitments, commitments + 32 * (size_t)N * nc);
+  parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
+    std::vector<Scalar> coeffs(K);
+    for (uint32_t j = lo; j < hi; ++j) {
+      off[j] = j * K;
+      if (results[j]) { for (uint32_t i = 0; i < K; ++i) pidx[(size_t)j * K + i] = 0; continue; }
+      Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
+      for (uint32_t k = 0; k < nc && !results[j]; ++k)                 // verifier.rs:134-140
+        if (!t.validate_and_append_blinding_commitment(st.points[st.cons[k].lhs].name.c_str(), commitments + 32 * ((size_t)j * nc + k)))
+          results[j] = 1;
+      uint8_t c[32];
+      t.get_challenge("chal", c);
+      t.to_bytes(ts + TB * (size_t)j);
+      const Scalar minus_c = -Scalar::from_bytes_mod_order(c);         // verifier.rs:142
+      std::fill(coeffs.begin(), coeffs.end(), Scalar::zero());
+      for (uint32_t k = 0; k < nc; ++k) {                              // verifier.rs:151-160
+        const Scalar r = Scalar::from_u128_le(weights16 + 16 * ((size_t)j * nc + k));
+        coeffs[np + k] -= r;
+        coeffs[st.cons[k].lhs] += r * minus_c;
+        for (const auto& term : st.cons[k].lc)
+          coeffs[term.second] += r * Scalar::from_bytes_mod_order(responses + 32 * ((size_t)j * m + term.first));
+      }
+      for (uint32_t i = 0; i < K; ++i) {
+        coeffs[i].to_bytes(scalars.data() + 32 * ((size_t)j * K + i));
+        pidx[(size_t)j * K + i] = i < np ? table_index(st, i, j, N) : com_base + j * nc + (i - np);
+      }
+    }
+  });
+  off[N] = N * K;
+  int rc = zkp_msm_many(ctx, N, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32), ZKP_VARTIME,
+                        out.data(), status.data());
+  if (rc) return rc;
+  static const uint8_t zero[32] = {0};
+  for (uint32_t j = 0; j < N; ++j)                                     // verifier.rs:162-172
+    if (!results[j]) results[j] = (status[j] || std::memcmp(out.data() + 32 * (size_t)j, zero, 32) != 0) ? 1 : 0;
+  return ZKP_TB_OK;
+}
+
+// ---- batch verification --------------------------------------------------------------------------------------
+int zkp_batch_verify_build(const zkp_statement* stp, uint32_t N, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
+                           const uint8_t* common, const uint8_t* commitments, const uint8_t* responses,
+                           const uint8_t* weights16, int n_threads, uint8_t* msm_scalars, uint8_t* msm_points) {
+  if (!stp || !msm_scalars || !msm_points) return ZKP_TB_BAD_STATEMENT;
+  if (n_transcripts != N) return ZKP_TB_BATCH_SIZE_MISMATCH;           // batch_verifier.rs:72-74
+  const zkp_statement& st = *stp;
+  const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), ni = st.ni, ns = st.ns;
+  const size_t rows = (size_t)ni + nc;
+  if (N == 0) { std::memset(msm_scalars, 0, 32 * (size_t)ns); if (ns) std::memcpy(msm_points, common, 32 * (size_t)ns); return ZKP_TB_OK; }
+  std::vector<uint8_t> failed(N, 0);
+  build_verifiers(st, N, ts, inst, common, n_threads, failed.data());  // :75-77, :92-94, :105-107, :125-128
+  for (uint8_t f : failed) if (f) return ZKP_TB_VERIFICATION_FAILURE;
+  std::vector<uint8_t> own_w;
+  if (!weights16) { own_w.resize(16 * (size_t)N * nc); os_random(own_w.data(), own_w.size()); weights16 = own_w.data(); }
+  uint8_t* inst_coeffs = msm_scalars + 32 * (size_t)ns;                // Matrix(rows, N), entries[cols * r + c] (util.rs:24)
+  std::atomic<int> any_fail{0};
+  // per-thread partial sums of the static coefficients, reduced afterwards (:187, :198 sum over the whole batch)
+  unsigned n_workers = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
+  if (n_workers == 0) n_workers = 1;
+  std::vector<std::vector<Scalar>> static_parts;
+  std::vector<Scalar> static_total(ns);
+  std::atomic<unsigned> slot{0};
+  static_parts.resize(n_workers + 1, std::vector<Scalar>(ns));
+  parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
+    std::vector<Scalar>& sp = static_parts[slot.fetch_add(1) % static_parts.size()];
+    std::vector<Scalar> col(rows);
+    for (uint32_t j = lo; j < hi; ++j) {
+      Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
+      for (uint32_t k = 0; k < nc; ++k)                                // :152-160
+        if (!t.validate_and_append_blinding_commitment(st.points[st.cons[k].lhs].name.c_str(), commitments + 32 * ((size_t)j * nc + k))) any_fail = 1;
+      uint8_t c[32];
+      t.get_challenge("chal", c);                                      // :163-167
+      t.to_bytes(ts + TB * (size_t)j);
+      const Scalar minus_c = -Scalar::from_bytes_mod_order(c);
+      std::fill(col.begin(), col.end(), Scalar::zero());
+      for (uint32_t k = 0; k < nc; ++k) {                              // :176-206 (loop order swapped: proof-major)
+        const Scalar r = Scalar::from_u128_le(weights16 + 16 * ((size_t)k * N + j));
+        col[ni + k] -= r;                                              // :183
+        const auto& lhs = st.points[st.cons[k].lhs];
+        if (lhs.common) sp[lhs.rank] += r * minus_c; else col[lhs.rank] += r * minus_c;     // :185-192
+        for (const auto& term : st.cons[k].lc) {                       // :194-204
+          const Scalar rr = r * Scalar::from_bytes_mod_order(responses + 32 * ((size_t)j * m + term.first));
+          const auto& pt = st.points[term.second];
+          if (pt.common) sp[pt.rank] += rr; else col[pt.rank] += rr;
+        }
+      }
+      for (size_t r = 0; r < rows; ++r) col[r].to_bytes(inst_coeffs + 32 * (r * N + j));
+    }
+  });
+  if (any_fail) return ZKP_TB_VERIFICATION_FAILURE;
+  for (const auto& part : static_parts)
+    for (uint32_t i = 0; i < ns; ++i) static_total[i] += part[i];
+  for (uint32_t i = 0; i < ns; ++i) static_total[i].to_bytes(msm_scalars + 32 * (size_t)i);
+  // points: static || instance rows || commitment rows (transposed to row = constraint, column = proof) :208-217
+  if (ns) std::memcpy(msm_points, common, 32 * (size_t)ns);
+  if (ni) std::memcpy(msm_points + 32 * (size_t)ns, inst, 32 * (size_t)ni * N);
+  uint8_t* com_rows = msm_points + 32 * ((size_t)ns + (size_t)ni * N);
+  for (uint32_t j = 0; j < N; ++j)
+    for (uint32_t k = 0; k < nc; ++k) std::memcpy(com_rows + 32 * ((size_t)k * N + j), commitments + 32 * ((size_t)j * nc + k), 32);
+  return ZKP_TB_OK;
+}
+
+int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
+                     const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
+                     int n_threads) {
+  if (!ctx || !st) return ZKP_TB_BAD_STATEMENT;
+  const size_t total = (size_t)st->ns + ((size_t)st->ni + st->cons.size()) * N;
+  std::vector<uint8_t> scalars(32 * total), points(32 * total);
+  int rc = zkp_batch_verify_build(st, N, n_transcripts, ts, inst, common, commitments, responses, weights16, n_threads,
+                                  scalars.data(), points.data());
+  if (rc) return rc;
+  uint8_t out[32];
+  int status = 1;
+  rc = zkp_msm_optional(ctx, total, scalars.data(), points.data(), out, &status);      // batch_verifier.rs:219-228
+  if (rc) return rc;
+  if (status) return ZKP_TB_VERIFICATION_FAILURE;                      // some point failed to decompress -> None
+  static const uint8_t zero[32] = {0};
+  return std::memcmp(out, zero, 32) == 0 ? ZKP_TB_OK : ZKP_TB_VERIFICATION_FAILURE;   // :230-234
+}
+
+}  // extern "C"

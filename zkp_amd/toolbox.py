@@ -1,0 +1,540 @@
+"""Python binding of the host toolbox (include/zkp_toolbox.h -> libzkp_toolbox.so), shaped like the
+reference's API so tests read like the reference's tests:
+
+    reference (Rust)                                   here
+    -------------------------------------------------  ----------------------------------------------
+    Transcript::new(b"..")                             Transcript(b"..")
+    toolbox::prover::Prover::new(label, &mut t)        Prover(label, t, engine)
+    prover.allocate_scalar / allocate_point / constrain / prove_compact / prove_batchable
+    toolbox::verifier::Verifier                        Verifier(label, t, engine)
+    toolbox::batch_verifier::BatchVerifier             BatchVerifier(label, n, transcripts, engine)
+    define_proof! { name, "label", (secrets), (instance), (common) : constraints }
+                                                       define_proof(name, label, secrets, instance, common, constraints)
+
+All arithmetic happens in the C++ host library and, below it, in the HIP library; this file only
+marshals buffers.  Points are 32-byte ristretto255 encodings, scalars 32-byte little-endian strings
+(ints are accepted and reduced mod l for convenience).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .engine import Engine, load_library
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkp_toolbox.so")
+TRANSCRIPT_BYTES = 208
+L = 2**252 + 27742317777372353535851937790883648493
+
+EXPORTS = (
+    "zkp_transcript_init", "zkp_transcript_append_message", "zkp_transcript_challenge_bytes", "zkp_scalar_from_wide",
+    "zkp_scalar_muladd", "zkp_scalar_neg", "zkp_statement_new", "zkp_statement_free", "zkp_statement_add_secret",
+    "zkp_statement_add_point", "zkp_statement_constrain", "zkp_statement_num_secrets", "zkp_statement_num_instance",
+    "zkp_statement_num_common", "zkp_statement_num_constraints", "zkp_statement_num_terms", "zkp_prove_batch",
+    "zkp_verify_compact_batch", "zkp_verify_batchable_each", "zkp_batch_verify", "zkp_batch_verify_build",
+    "zkp_prove_phase_a", "zkp_prove_phase_b",
+)
+
+
+class ProofError(Exception):
+    """src/errors.rs"""
+
+
+class VerificationFailure(ProofError):
+    pass
+
+
+class BatchSizeMismatch(ProofError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        load_library()          # libzkp_mi355x.so must exist: no CPU fallback
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.zkp_statement_new.restype = ctypes.c_void_p
+        _lib.zkp_statement_new.argtypes = [ctypes.c_char_p]
+        _lib.zkp_statement_free.argtypes = [ctypes.c_void_p]
+        _lib.zkp_statement_free.restype = None
+        _lib.zkp_statement_add_secret.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        _lib.zkp_statement_add_point.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        _lib.zkp_statement_constrain.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        for f in ("num_secrets", "num_instance", "num_common", "num_constraints", "num_terms"):
+            getattr(_lib, "zkp_statement_" + f).argtypes = [ctypes.c_void_p]
+            getattr(_lib, "zkp_statement_" + f).restype = ctypes.c_uint32
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def scalar_bytes(x) -> bytes:
+    if isinstance(x, (bytes, bytearray)):
+        assert len(x) == 32
+        return bytes(x)
+    if isinstance(x, np.ndarray):
+        return x.tobytes()
+    return (int(x) % L).to_bytes(32, "little")
+
+
+def _raise(rc: int, what: str):
+    if rc == 1:
+        raise VerificationFailure()
+    if rc == 2:
+        raise BatchSizeMismatch()
+    if rc != 0:
+        from .engine import ZkpError
+        raise ZkpError(f"{what} failed with code {rc}: {load_library().zkp_last_error().decode()}")
+
+
+# ---------------------------------------------------------------------------------------------------
+class Transcript:
+    """merlin::Transcript (plain 208-byte state; clone() is a copy)."""
+
+    def __init__(self, label: bytes = b"", _state: Optional[np.ndarray] = None):
+        if _state is not None:
+            self.state = _state.copy()
+        else:
+            self.state = np.zeros(TRANSCRIPT_BYTES, np.uint8)
+            lib().zkp_transcript_init(_p(self.state), label, ctypes.c_size_t(len(label)))
+
+    def clone(self) -> "Transcript":
+        return Transcript(_state=self.state)
+
+    def append_message(self, label: bytes, message: bytes) -> None:
+        lib().zkp_transcript_append_message(_p(self.state), label, message, ctypes.c_size_t(len(message)))
+
+    def challenge_bytes(self, label: bytes, n: int) -> bytes:
+        out = ctypes.create_string_buffer(n)
+        lib().zkp_transcript_challenge_bytes(_p(self.state), label, out, ctypes.c_size_t(n))
+        return out.raw
+
+
+@dataclass
+class CompactProof:            # src/proofs.rs:15-20
+    challenge: bytes
+    responses: List[bytes]
+
+
+@dataclass
+class BatchableProof:          # src/proofs.rs:27-32
+    commitments: List[bytes]
+    responses: List[bytes]
+
+
+class Statement:
+    """Owns a zkp_statement handle.  Variables are registered in allocation order."""
+
+    def __init__(self, proof_label: bytes):
+        self.proof_label = proof_label
+        self._h = ctypes.c_void_p(lib().zkp_statement_new(proof_label))
+        self.secrets: List[bytes] = []
+        self.points: List[Tuple[bytes, bool]] = []
+        self.constraints: List[Tuple[int, List[Tuple[int, int]]]] = []
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().zkp_statement_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def add_secret(self, name: bytes) -> int:
+        self.secrets.append(name)
+        return lib().zkp_statement_add_secret(self._h, name)
+
+    def add_point(self, name: bytes, common: bool) -> int:
+        self.points.append((name, common))
+        return lib().zkp_statement_add_point(self._h, name, int(common))
+
+    def constrain(self, lhs: int, lc: Sequence[Tuple[int, int]]) -> None:
+        sc = np.array([s for s, _ in lc], dtype=np.uint32)
+        pt = np.array([p for _, p in lc], dtype=np.uint32)
+        rc = lib().zkp_statement_constrain(self._h, lhs, len(lc), _p(sc), _p(pt))
+        if rc != 0:
+            raise ValueError("bad constraint")
+        self.constraints.append((lhs, list(lc)))
+
+    @property
+    def m(self): return len(self.secrets)
+    @property
+    def ni(self): return sum(1 for _, c in self.points if not c)
+    @property
+    def ns(self): return sum(1 for _, c in self.points if c)
+    @property
+    def nc(self): return len(self.constraints)
+    @property
+    def terms(self): return sum(len(lc) for _, lc in self.constraints)
+
+
+def _transcripts_array(transcripts: Sequence[Transcript]) -> np.ndarray:
+    return np.stack([t.state for t in transcripts]) if transcripts else np.zeros((0, TRANSCRIPT_BYTES), np.uint8)
+
+
+def _store_transcripts(transcripts: Sequence[Transcript], arr: np.ndarray) -> None:
+    for t, row in zip(transcripts, arr):
+        t.state[:] = row
+
+
+# ---- batched entry points (numpy arrays in the layouts of include/zkp_toolbox.h) -------------------
+def prove_batch(eng: Engine, st: Statement, transcripts: np.ndarray, secrets: np.ndarray, inst: np.ndarray,
+                common: np.ndarray, entropy: Optional[np.ndarray] = None, threads: int = 0):
+    """-> (challenges[N][32], responses[N][m][32], commitments[N][nc][32]); transcripts advanced in place."""
+    n = len(transcripts)
+    chal = np.zeros((n, 32), np.uint8)
+    resp = np.zeros((n, st.m, 32), np.uint8)
+    coms = np.zeros((n, st.nc, 32), np.uint8)
+    rc = lib().zkp_prove_batch(eng._h, st._h, ctypes.c_uint32(n), _p(transcripts), _p(np.ascontiguousarray(secrets)),
+                               _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                               _p(None if entropy is None else np.ascontiguousarray(entropy)), threads, _p(chal), _p(resp), _p(coms))
+    _raise(rc, "zkp_prove_batch")
+    return chal, resp, coms
+
+
+def verify_compact_batch(eng, st, transcripts, inst, common, challenges, responses, threads: int = 0) -> np.ndarray:
+    n = len(transcripts)
+    res = np.ones(n, np.uint8)
+    rc = lib().zkp_verify_compact_batch(eng._h, st._h, ctypes.c_uint32(n), _p(transcripts), _p(np.ascontiguousarray(inst)),
+                                        _p(np.ascontiguousarray(common)), _p(np.ascontiguousarray(challenges)),
+                                        _p(np.ascontiguousarray(responses)), threads, _p(res))
+    _raise(rc, "zkp_verify_compact_batch")
+    return res
+
+
+def verify_batchable_each(eng, st, transcripts, inst, common, commitments, responses, weights16=None, threads: int = 0) -> np.ndarray:
+    n = len(transcripts)
+    res = np.ones(n, np.uint8)
+    rc = lib().zkp_verify_batchable_each(eng._h, st._h, ctypes.c_uint32(n), _p(transcripts), _p(np.ascontiguousarray(inst)),
+                                         _p(np.ascontiguousarray(common)), _p(np.ascontiguousarray(commitments)),
+                                         _p(np.ascontiguousarray(responses)),
+                                         _p(None if weights16 is None else np.ascontiguousarray(weights16)), threads, _p(res))
+    _raise(rc, "zkp_verify_batchable_each")
+    return res
+
+
+def batch_verify(eng, st, transcripts, inst, common, commitments, responses, weights16=None, threads: int = 0,
+                 batch_size: Optional[int] = None) -> None:
+    """Raises VerificationFailure / BatchSizeMismatch like BatchVerifier::verify_batchable."""
+    n = len(commitments)
+    rc = lib().zkp_batch_verify(eng._h, st._h, ctypes.c_uint32(n if batch_size is None else batch_size),
+                                ctypes.c_uint32(len(transcripts)), _p(transcripts),
+                                _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
+                                _p(None if weights16 is None else np.ascontiguousarray(weights16)), threads)
+    _raise(rc, "zkp_batch_verify")
+
+
+def batch_verify_build(st, transcripts, inst, common, commitments, responses, weights16, threads: int = 0):
+    """Host-only half of batch_verify: the exact MSM operands (no GPU needed)."""
+    n = len(commitments)
+    total = st.ns + (st.ni + st.nc) * n
+    ms = np.zeros((total, 32), np.uint8)
+    mp = np.zeros((total, 32), np.uint8)
+    rc = lib().zkp_batch_verify_build(st._h, ctypes.c_uint32(n), ctypes.c_uint32(len(transcripts)), _p(transcripts),
+                                      _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                      _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
+                                      _p(np.ascontiguousarray(weights16)), threads, _p(ms), _p(mp))
+    _raise(rc, "zkp_batch_verify_build")
+    return ms, mp
+
+
+def prove_phase_a(st, transcripts, secrets, inst, common, entropy, threads: int = 0):
+    n = len(transcripts)
+    blind = np.zeros((n, st.m, 32), np.uint8)
+    off = np.zeros(n * st.nc + 1, np.uint32)
+    sc = np.zeros((n * st.terms, 32), np.uint8)
+    pidx = np.zeros(n * st.terms, np.uint32)
+    rc = lib().zkp_prove_phase_a(st._h, ctypes.c_uint32(n), _p(transcripts), _p(np.ascontiguousarray(secrets)),
+                                 _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                 _p(np.ascontiguousarray(entropy)), threads, _p(blind), _p(off), _p(sc), _p(pidx))
+    _raise(rc, "zkp_prove_phase_a")
+    return blind, off, sc, pidx
+
+
+def prove_phase_b(st, transcripts, secrets, blindings, commitments, threads: int = 0):
+    n = len(transcripts)
+    chal = np.zeros((n, 32), np.uint8)
+    resp = np.zeros((n, st.m, 32), np.uint8)
+    rc = lib().zkp_prove_phase_b(st._h, ctypes.c_uint32(n), _p(transcripts), _p(np.ascontiguousarray(secrets)),
+                                 _p(np.ascontiguousarray(blindings)), _p(np.ascontiguousarray(commitments)), threads, _p(chal), _p(resp))
+    _raise(rc, "zkp_prove_phase_b")
+    return chal, resp
+
+
+# ---- the reference's object API (one proof at a time; the batch functions do the work) ------------
+@dataclass(frozen=True)
+class ScalarVar:
+    idx: int
+
+
+@dataclass(frozen=True)
+class PointVar:
+    idx: int
+
+
+def _enc(e) -> bytes:
+    e = bytes(e) if not isinstance(e, np.ndarray) else e.tobytes()
+    assert len(e) == 32
+    return e
+
+
+class Prover:
+    """toolbox::prover::Prover (src/toolbox/prover.rs).  Points are supplied as encodings."""
+
+    def __init__(self, proof_label: bytes, transcript: Transcript, engine: Engine):
+        self._st = Statement(proof_label)
+        self._t = transcript
+        self._eng = engine
+        self._scalars: List[bytes] = []
+        self._points: List[bytes] = []
+
+    def allocate_scalar(self, label: bytes, assignment) -> ScalarVar:
+        self._scalars.append(scalar_bytes(assignment))
+        return ScalarVar(self._st.add_secret(label))
+
+    def allocate_point(self, label: bytes, assignment) -> Tuple[PointVar, bytes]:
+        e = _enc(assignment)
+        self._points.append(e)
+        return PointVar(self._st.add_point(label, False)), e
+
+    def constrain(self, lhs: PointVar, linear_combination: Sequence[Tuple[ScalarVar, PointVar]]) -> None:
+        self._st.constrain(lhs.idx, [(s.idx, p.idx) for s, p in linear_combination])
+
+    def _prove(self, entropy: Optional[bytes]):
+        ts = self._t.state.reshape(1, -1).copy()
+        secrets = np.frombuffer(b"".join(self._scalars), np.uint8).reshape(1, -1, 32) if self._scalars else np.zeros((1, 0, 32), np.uint8)
+        inst = np.frombuffer(b"".join(self._points), np.uint8).reshape(-1, 1, 32) if self._points else np.zeros((0, 1, 32), np.uint8)
+        ent = None if entropy is None else np.frombuffer(entropy, np.uint8).reshape(1, 32)
+        chal, resp, coms = prove_batch(self._eng, self._st, ts, secrets, inst, np.zeros((0, 32), np.uint8), ent, threads=1)
+        self._t.state[:] = ts[0]
+        return chal[0].tobytes(), [r.tobytes() for r in resp[0]], [c.tobytes() for c in coms[0]]
+
+    def prove_compact(self, entropy: Optional[bytes] = None) -> CompactProof:
+        c, r, _ = self._prove(entropy)
+        return CompactProof(c, r)
+
+    def prove_batchable(self, entropy: Optional[bytes] = None) -> BatchableProof:
+        _, r, k = self._prove(entropy)
+        return BatchableProof(k, r)
+
+
+class Verifier:
+    """toolbox::verifier::Verifier (src/toolbox/verifier.rs)."""
+
+    def __init__(self, proof_label: bytes, transcript: Transcript, engine: Engine):
+        self._st = Statement(proof_label)
+        self._t = transcript
+        self._eng = engine
+        self._points: List[bytes] = []
+
+    def allocate_scalar(self, label: bytes) -> ScalarVar:
+        return ScalarVar(self._st.add_secret(label))
+
+    def allocate_point(self, label: bytes, assignment) -> PointVar:
+        e = _enc(assignment)
+        if e == bytes(32):                      # validate_and_append_point_var, mod.rs:191-193
+            raise VerificationFailure()
+        self._points.append(e)
+        return PointVar(self._st.add_point(label, False))
+
+    def constrain(self, lhs: PointVar, linear_combination) -> None:
+        self._st.constrain(lhs.idx, [(s.idx, p.idx) for s, p in linear_combination])
+
+    def _inst(self):
+        return np.frombuffer(b"".join(self._points), np.uint8).reshape(-1, 1, 32) if self._points else np.zeros((0, 1, 32), np.uint8)
+
+    def verify_compact(self, proof: CompactProof) -> None:
+        if len(proof.responses) != self._st.m:                          # verifier.rs:82-84
+            raise VerificationFailure()
+        ts = self._t.state.reshape(1, -1).copy()
+        resp = np.frombuffer(b"".join(proof.responses), np.uint8).reshape(1, -1, 32) if proof.responses else np.zeros((1, 0, 32), np.uint8)
+        res = verify_compact_batch(self._eng, self._st, ts, self._inst(), np.zeros((0, 32), np.uint8),
+                                   np.frombuffer(proof.challenge, np.uint8).reshape(1, 32), resp, threads=1)
+        self._t.state[:] = ts[0]
+        if res[0]:
+            raise VerificationFailure()
+
+    def verify_batchable(self, proof: BatchableProof, weights: Optional[Sequence[int]] = None) -> None:
+        if len(proof.responses) != self._st.m or len(proof.commitments) != self._st.nc:     # verifier.rs:125-131
+            raise VerificationFailure()
+        ts = self._t.state.reshape(1, -1).copy()
+        resp = np.frombuffer(b"".join(proof.responses), np.uint8).reshape(1, -1, 32) if proof.responses else np.zeros((1, 0, 32), np.uint8)
+        coms = np.frombuffer(b"".join(proof.commitments), np.uint8).reshape(1, -1, 32) if proof.commitments else np.zeros((1, 0, 32), np.uint8)
+        w = None if weights is None else np.frombuffer(b"".join(int(x).to_bytes(16, "little") for x in weights), np.uint8).reshape(1, -1, 16)
+        res = verify_batchable_each(self._eng, self._st, ts, self._inst(), np.zeros((0, 32), np.uint8), coms, resp, w, threads=1)
+        self._t.state[:] = ts[0]
+        if res[0]:
+            raise VerificationFailure()
+
+
+class BatchVerifier:
+    """toolbox::batch_verifier::BatchVerifier (src/toolbox/batch_verifier.rs)."""
+
+    def __init__(self, proof_label: bytes, batch_size: int, transcripts: Sequence[Transcript], engine: Engine):
+        if len(transcripts) != batch_size:                              # batch_verifier.rs:72-74
+            raise BatchSizeMismatch()
+        self._st = Statement(proof_label)
+        self._n = batch_size
+        self._ts = list(transcripts)
+        self._eng = engine
+        self._static: List[bytes] = []
+        self._instance: List[List[bytes]] = []
+
+    def allocate_scalar(self, label: bytes) -> ScalarVar:
+        return ScalarVar(self._st.add_secret(label))
+
+    def allocate_static_point(self, label: bytes, assignment) -> PointVar:
+        e = _enc(assignment)
+        if e == bytes(32):
+            raise VerificationFailure()
+        self._static.append(e)
+        return PointVar(self._st.add_point(label, True))
+
+    def allocate_instance_point(self, label: bytes, assignments: Sequence) -> PointVar:
+        if len(assignments) != self._n:                                 # batch_verifier.rs:120-122
+            raise BatchSizeMismatch()
+        es = [_enc(a) for a in assignments]
+        if any(e == bytes(32) for e in es):
+            raise VerificationFailure()
+        self._instance.append(es)
+        return PointVar(self._st.add_point(label, False))
+
+    def constrain(self, lhs: PointVar, linear_combination) -> None:
+        self._st.constrain(lhs.idx, [(s.idx, p.idx) for s, p in linear_combination])
+
+    def verify_batchable(self, proofs: Sequence[BatchableProof], weights: Optional[Sequence[Sequence[int]]] = None) -> None:
+        if len(proofs) != self._n:                                      # batch_verifier.rs:138-140
+            raise BatchSizeMismatch()
+        for p in proofs:                                                # batch_verifier.rs:142-149
+            if len(p.commitments) != self._st.nc or len(p.responses) != self._st.m:
+                raise VerificationFailure()
+        n = self._n
+        ts = _transcripts_array(self._ts)
+        inst = np.frombuffer(b"".join(e for row in self._instance for e in row), np.uint8).reshape(-1, n, 32) if self._instance else np.zeros((0, n, 32), np.uint8)
+        common = np.frombuffer(b"".join(self._static), np.uint8).reshape(-1, 32) if self._static else np.zeros((0, 32), np.uint8)
+        coms = np.frombuffer(b"".join(c for p in proofs for c in p.commitments), np.uint8).reshape(n, -1, 32) if n and self._st.nc else np.zeros((n, 0, 32), np.uint8)
+        resp = np.frombuffer(b"".join(r for p in proofs for r in p.responses), np.uint8).reshape(n, -1, 32) if n and self._st.m else np.zeros((n, 0, 32), np.uint8)
+        w = None if weights is None else np.frombuffer(b"".join(int(x).to_bytes(16, "little") for row in weights for x in row), np.uint8).reshape(-1, n, 16)
+        try:
+            batch_verify(self._eng, self._st, ts, inst, common, coms, resp, w, batch_size=n)
+        finally:
+            _store_transcripts(self._ts, ts)
+
+
+# ---- define_proof! -----------------------------------------------------------------------------------
+class ProofModule:
+    """What `define_proof!` generates (src/macros.rs:124-370): a statement with fixed labels and allocation
+    order (secrets, instance points, common points) and the five entry points."""
+
+    def __init__(self, name: str, label: bytes, secrets: Sequence[str], instance: Sequence[str], common: Sequence[str],
+                 constraints: Sequence[Tuple[str, Sequence[Tuple[str, str]]]]):
+        self.name, self.label = name, label
+        self.secrets, self.instance, self.common = list(secrets), list(instance), list(common)
+        self.constraints = [(l, list(lc)) for l, lc in constraints]
+        self.statement = Statement(label)
+        sv = {n: self.statement.add_secret(n.encode()) for n in self.secrets}                # macros.rs:215-222
+        pv = {n: self.statement.add_point(n.encode(), False) for n in self.instance}         # macros.rs:229-235
+        pv.update({n: self.statement.add_point(n.encode(), True) for n in self.common})      # macros.rs:236-242
+        for lhs, lc in self.constraints:                                                    # macros.rs:159-170
+            self.statement.constrain(pv[lhs], [(sv[s], pv[p]) for s, p in lc])
+
+    # -- array helpers ----------------------------------------------------------------------------
+    def pack(self, secrets: Sequence[Dict[str, object]], points: Sequence[Dict[str, bytes]]):
+        """list of per-proof dicts -> (secrets[N][m][32], inst[ni][N][32], common[ns][32])"""
+        n = len(points)
+        sec = np.frombuffer(b"".join(scalar_bytes(s[k]) for s in secrets for k in self.secrets), np.uint8).reshape(n, len(self.secrets), 32) if secrets else None
+        inst = np.frombuffer(b"".join(_enc(p[k]) for k in self.instance for p in points), np.uint8).reshape(len(self.instance), n, 32)
+        common = np.frombuffer(b"".join(_enc(points[0][k]) for k in self.common), np.uint8).reshape(len(self.common), 32)
+        return sec, inst, common
+
+    def prove_compact(self, eng, transcript: Transcript, secrets: Dict[str, object], points: Dict[str, bytes], entropy=None) -> CompactProof:
+        c, r, _ = self._prove(eng, transcript, secrets, points, entropy)
+        return CompactProof(c, r)
+
+    def prove_batchable(self, eng, transcript: Transcript, secrets, points, entropy=None) -> BatchableProof:
+        _, r, k = self._prove(eng, transcript, secrets, points, entropy)
+        return BatchableProof(k, r)
+
+    def _prove(self, eng, transcript, secrets, points, entropy):
+        sec, inst, common = self.pack([secrets], [points])
+        ts = transcript.state.reshape(1, -1).copy()
+        ent = None if entropy is None else np.frombuffer(entropy, np.uint8).reshape(1, 32)
+        chal, resp, coms = prove_batch(eng, self.statement, ts, sec, inst, common, ent, threads=1)
+        transcript.state[:] = ts[0]
+        return chal[0].tobytes(), [x.tobytes() for x in resp[0]], [x.tobytes() for x in coms[0]]
+
+    def verify_compact(self, eng, proof: CompactProof, transcript: Transcript, points: Dict[str, bytes]) -> None:
+        if any(_enc(points[k]) == bytes(32) for k in self.instance + self.common) or len(proof.responses) != len(self.secrets):
+            raise VerificationFailure()
+        _, inst, common = self.pack([], [points])
+        ts = transcript.state.reshape(1, -1).copy()
+        res = verify_compact_batch(eng, self.statement, ts, inst, common, np.frombuffer(proof.challenge, np.uint8).reshape(1, 32),
+                                   np.frombuffer(b"".join(proof.responses), np.uint8).reshape(1, -1, 32), threads=1)
+        transcript.state[:] = ts[0]
+        if res[0]:
+            raise VerificationFailure()
+
+    def verify_batchable(self, eng, proof: BatchableProof, transcript: Transcript, points: Dict[str, bytes], weights=None) -> None:
+        if len(proof.responses) != len(self.secrets) or len(proof.commitments) != len(self.constraints):
+            raise VerificationFailure()
+        _, inst, common = self.pack([], [points])
+        ts = transcript.state.reshape(1, -1).copy()
+        w = None if weights is None else np.frombuffer(b"".join(int(x).to_bytes(16, "little") for x in weights), np.uint8).reshape(1, -1, 16)
+        res = verify_batchable_each(eng, self.statement, ts, inst, common,
+                                    np.frombuffer(b"".join(proof.commitments), np.uint8).reshape(1, -1, 32),
+                                    np.frombuffer(b"".join(proof.responses), np.uint8).reshape(1, -1, 32), w, threads=1)
+        transcript.state[:] = ts[0]
+        if res[0]:
+            raise VerificationFailure()
+
+    def batch_verify(self, eng, proofs: Sequence[BatchableProof], transcripts: Sequence[Transcript],
+                     instance_points: Dict[str, Sequence[bytes]], common_points: Dict[str, bytes], weights=None, threads: int = 0) -> None:
+        n = len(proofs)
+        if len(transcripts) != n:
+            raise BatchSizeMismatch()
+        for k in self.instance:
+            if len(instance_points[k]) != n:
+                raise BatchSizeMismatch()
+        ts = _transcripts_array(transcripts)
+        inst = np.frombuffer(b"".join(_enc(e) for k in self.instance for e in instance_points[k]), np.uint8).reshape(len(self.instance), n, 32)
+        common = np.frombuffer(b"".join(_enc(common_points[k]) for k in self.common), np.uint8).reshape(len(self.common), 32)
+        coms = np.frombuffer(b"".join(c for p in proofs for c in p.commitments), np.uint8).reshape(n, -1, 32)
+        resp = np.frombuffer(b"".join(r for p in proofs for r in p.responses), np.uint8).reshape(n, -1, 32)
+        w = None if weights is None else np.frombuffer(b"".join(int(x).to_bytes(16, "little") for row in weights for x in row), np.uint8).reshape(-1, n, 16)
+        try:
+            batch_verify(eng, self.statement, ts, inst, common, coms, resp, w, threads=threads, batch_size=n)
+        finally:
+            _store_transcripts(transcripts, ts)
+
+
+def define_proof(name, label, secrets, instance, common, constraints) -> ProofModule:
+    return ProofModule(name, label if isinstance(label, bytes) else label.encode(), secrets, instance, common, constraints)
+
+
+def dleq_module() -> ProofModule:
+    """define_proof! {dleq, "DLEQ proof", (x), (A, B, H), (G) : A = (x * G), B = (x * H)}  (benches/zkp.rs:49)"""
+    return define_proof("dleq", b"DLEQ proof", ["x"], ["A", "B", "H"], ["G"], [("A", [("x", "G")]), ("B", [("x", "H")])])
+
+
+def cmz_module(n: int = 10) -> ProofModule:
+    """cred_show_10 (benches/zkp.rs:27-46)."""
+    ms = [f"m_{i}" for i in range(1, n + 1)]
+    zs = [f"z_{i}" for i in range(1, n + 1)]
+    cs = [f"C_{i}" for i in range(1, n + 1)]
+    xs = [f"X_{i}" for i in range(1, n + 1)]
+    cons = [(cs[i], [(ms[i], "P"), (zs[i], "A")]) for i in range(n)]
+    cons.append(("V", [(ms[i], xs[i]) for i in range(n)] + [("minus_z_Q", "Q")]))
+    return define_proof(f"cred_show_{n}", f"CMZ cred show n={n}".encode(), ms + zs + ["minus_z_Q"], cs + ["P", "Q", "V"], xs + ["A", "B"], cons)

@@ -85,6 +85,18 @@ __device__ __forceinline__ void store_niels(dev_niels* dst, const ge_niels& q, u
   store_vec<7>(dst, w);
 }
 
+// Pins every limb of p in a VGPR.  Needed where a kernel works on wave-UNIFORM data (one lane, or all lanes
+// reading the same address): hipcc's uniformity analysis would otherwise move the whole field arithmetic to
+// the scalar ALU (s_mul_hi_u32 / s_mul_i32 / s_addc_u32), measured 2.3x slower than v_mad_u64_u32 for a lone
+// wave (tools/microbench/ge_chain.hip: 4.05 us vs 1.74 us per doubling).
+__device__ __forceinline__ void fe_pin_vgpr(fe& a) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(a.v[i]));
+}
+__device__ __forceinline__ void ge_pin_vgpr(ge_p3& p) {
+  fe_pin_vgpr(p.X); fe_pin_vgpr(p.Y); fe_pin_vgpr(p.Z); fe_pin_vgpr(p.T);
+}
+
 // r = p + q for two extended points (9M)
 __device__ __forceinline__ void ge_add_p3(ge_p3& r, const ge_p3& p, const ge_p3& q) {
   ge_cached c;

@@ -385,12 +385,14 @@ k_pip_combine(int W1, int C, const dev_ext* __restrict__ T, const uint32_t* __re
   if (threadIdx.x != 0) return;
   ge_p3 acc, t;
   load_ext(acc, T + (W1 - 1));
+  ge_pin_vgpr(acc);                 // uniform data: keep the arithmetic on the VALU (see dev_layout.h)
 #pragma unroll 1
   for (int k = W1 - 2; k >= 0; --k) {
 #pragma unroll 1
     for (int d = 0; d < C - 1; ++d) ge_double<false>(acc, acc);
     ge_double<true>(acc, acc);
     load_ext(t, T + k);
+    ge_pin_vgpr(t);
     ge_add_p3(acc, acc, t);
   }
   uint32_t o[8];

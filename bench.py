@@ -103,6 +103,7 @@ def main():
     off, pidx, n_pts = cmz_shape(n)
     pts, st = eng.msm_many(np.arange(n_pts + 1, dtype=np.uint32), rand_scalars(n_pts), np.zeros(n_pts, np.uint32), base, ZKP_CT)
     assert not st.any()
+    eng.prepare_fixed_points(pts[:11])         # the issuer parameters X_1..X_10, A are common to every proof (benches/zkp.rs:32)
     n_msm, n_terms = 11 * n, 31 * n
     blind = rand_scalars(n_terms)              # the blinding scalars b[sc_var] of prover.rs:95
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)

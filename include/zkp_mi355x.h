@@ -55,6 +55,14 @@ const char* zkp_last_error(void);
 /* Library / build identification, e.g. "zkp-mi355x 0.1 gfx950". */
 const char* zkp_version(void);
 
+/* Performance hint, never changes a result: declare points that very many terms of later zkp_msm_many calls
+ * will reference -- in the reference's vocabulary the statement's COMMON variables (define_proof!,
+ * macros.rs:84,236-242) / BatchVerifier's static points (batch_verifier.rs:100-112), e.g. the issuer
+ * parameters X_1..X_10, A of the CMZ'13 statement.  The engine builds fixed-base window tables for them once
+ * (64 slots, least-recently-used replacement) and then serves every term on such a point with 65 mixed
+ * additions and no doublings.  encodings = HOST pointer [n][32]; synchronous. */
+int zkp_ctx_prepare_fixed_points(zkp_ctx* ctx, uint32_t n, const uint8_t* encodings);
+
 /* (1) Many small multiscalar multiplications in CSR form, fused with compression.
  *     Replaces, for a whole batch of proofs at once:
  *       prover.rs:94-97   RistrettoPoint::multiscalar_mul(..)            (flags = ZKP_CT)

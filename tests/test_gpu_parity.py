@@ -170,3 +170,49 @@ def test_msm_optional_identity_and_cancellation(eng, base_points):
         scalars.append((-dlog) % M.L)
         got = eng.msm_optional(np.stack([sc(s) for s in scalars]), enc_arr([encs[j] for j in idx]))
         assert got == bytes(32)
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_msm_many_fixed_base_tables(base_points, flags):
+    """zkp_ctx_prepare_fixed_points is a pure performance hint: identical bytes with and without it, for both
+    schedules, including non-canonical scalars (carry window), zero digits, and points that are NOT registered."""
+    from zkp_amd.engine import Engine
+    rng = random.Random(4242 + flags)
+    logs, encs = base_points
+    n_msm = 700                                   # > 1024 terms so the classified path is taken
+    special = [0, 1, 8, M.L - 1, M.L, (1 << 256) - 1, 1 << 255, int("8" * 64, 16), int("7" * 64, 16), (1 << 253) - 1]
+    off, scalars, pidx = [0], [], []
+    for m in range(n_msm):
+        for _ in range([2, 11, 1, 3][m % 4]):
+            scalars.append(special[rng.randrange(len(special))] if rng.random() < 0.2 else rng.randrange(1 << 256))
+            pidx.append(rng.randrange(40))
+        off.append(len(scalars))
+    sc_arr = np.stack([sc(s) for s in scalars])
+    pts = enc_arr(encs[:40])
+    plain = Engine(0)
+    ref_out, ref_st = plain.msm_many(off, sc_arr, pidx, pts, flags)
+    plain.close()
+    hot = Engine(0)
+    bad = bytes.fromhex("0100000000000000000000000000000000000000000000000000000000000000")
+    hot.prepare_fixed_points(enc_arr(encs[:12] + [bad] + [bytes(32)]))      # 12 of the 40 points + junk + identity
+    out, st = hot.msm_many(off, sc_arr, pidx, pts, flags)
+    assert not st.any() and (out == ref_out).all()
+    for m in range(0, n_msm, 37):                                          # and against the oracle definition
+        dlog = sum(scalars[t] * logs[pidx[t]] for t in range(off[m], off[m + 1])) % M.L
+        assert out[m].tobytes() == M.ristretto_encode(M.pt_mul(dlog, M.BASEPOINT))
+    # more registrations than slots: least recently used tables are replaced, results stay exact
+    rp = [M.ristretto_encode(M.pt_mul(rng.randrange(1, M.L), M.BASEPOINT)) for _ in range(70)]
+    hot.prepare_fixed_points(enc_arr(rp))
+    hot.prepare_fixed_points(enc_arr(encs[20:40]))
+    out2, st2 = hot.msm_many(off, sc_arr, pidx, pts, flags)
+    assert not st2.any() and (out2 == ref_out).all()
+    # an invalid point in the table still flags exactly the MSMs that reference it
+    pts_bad = pts.copy()
+    pts_bad[5] = np.frombuffer(bad, np.uint8)
+    out3, st3 = hot.msm_many(off, sc_arr, pidx, pts_bad, flags)
+    for m in range(n_msm):
+        uses = any(pidx[t] == 5 for t in range(off[m], off[m + 1]))
+        assert st3[m] == int(uses)
+        if not uses:
+            assert (out3[m] == ref_out[m]).all()
+    hot.close()

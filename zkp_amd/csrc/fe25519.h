@@ -381,6 +381,16 @@ ZKP_HD void fe_pow22523(fe& out, const fe& z) {
   (void)t3;
 }
 
+// r = 1/z = z^(p-2) = (z^(2^252-3))^8 * z^3   (0 -> 0)
+ZKP_HD void fe_invert(fe& r, const fe& z) {
+  fe t, z3;
+  fe_pow22523(t, z);
+  fe_sqn(t, t, 3);
+  fe_sq(z3, z);
+  fe_mul(z3, z3, z);
+  fe_mul(r, t, z3);
+}
+
 // field constants as limbs (generated by tools/gen_constants.py; checked by tests/host)
 struct fe_const { uint32_t v[9]; };
 ZKP_HD void fe_from_const(fe& r, const fe_const& c) {

@@ -256,6 +256,7 @@ int zkp_prove_batch(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* 
   int rc = zkp_prove_phase_a(st, N, ts, secrets, inst, common, entropy, n_threads, blind.data(), off.data(), scalars.data(), pidx.data());
   if (rc) return rc;
   const std::vector<uint8_t> tbl = point_table(*st, N, inst, common);
+  if (st->ns && N >= 32) { rc = zkp_ctx_prepare_fixed_points(ctx, st->ns, common); if (rc) return rc; }   // common points: fixed-base tables
   // prover.rs:94 RistrettoPoint::multiscalar_mul for every constraint of every proof, + compress (mod.rs:204)
   rc = zkp_msm_many(ctx, N * nc, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32), ZKP_CT,
                     commitments, status.data());
@@ -310,8 +311,10 @@ int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N,
   });
   off[(size_t)N * nc] = (uint32_t)((size_t)N * T1);
   const std::vector<uint8_t> tbl = point_table(st, N, inst, common);
-  int rc = zkp_msm_many(ctx, N * nc, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32),
-                        ZKP_VARTIME, coms.data(), status.data());
+  int rc = (st.ns && N >= 32) ? zkp_ctx_prepare_fixed_points(ctx, st.ns, common) : 0;
+  if (rc) return rc;
+  rc = zkp_msm_many(ctx, N * nc, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32),
+                    ZKP_VARTIME, coms.data(), status.data());
   if (rc) return rc;
   // verifier.rs:87-92 decompresses EVERY allocated point, also those no constraint uses
   const std::vector<uint32_t> unref = unreferenced_points(st);
@@ -397,8 +400,10 @@ int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N
     }
   });
   off[N] = N * K;
-  int rc = zkp_msm_many(ctx, N, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32), ZKP_VARTIME,
-                        out.data(), status.data());
+  int rc = (st.ns && N >= 32) ? zkp_ctx_prepare_fixed_points(ctx, st.ns, common) : 0;
+  if (rc) return rc;
+  rc = zkp_msm_many(ctx, N, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32), ZKP_VARTIME,
+                    out.data(), status.data());
   if (rc) return rc;
   static const uint8_t zero[32] = {0};
   for (uint32_t j = 0; j < N; ++j)                                     // verifier.rs:162-172

@@ -23,7 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <vector>
 #include "../../include/zkp_mi355x.h"
 #include "dev_layout.h"
 
@@ -53,10 +55,12 @@ __device__ __forceinline__ uint32_t sel8(const uint32_t w[8], int j) {
   return r;
 }
 
+#include "hot_tables.h"
+
 // =============================================================================================
 // (A) small-MSM path
 // =============================================================================================
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 k_decode_affine(uint32_t n, const uint8_t* __restrict__ enc, dev_affine* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -70,11 +74,18 @@ k_decode_affine(uint32_t n, const uint8_t* __restrict__ enc, dev_affine* __restr
 // partial[t] = scalars[t] * points[pidx[t]].  Fixed schedule: 128 windows of (2 doublings, 1 unified
 // addition of a masked-selected table entry); no branch or address depends on the scalar, so the
 // same kernel serves ZKP_CT and ZKP_VARTIME.
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx,
-           uint32_t n_points, const dev_affine* __restrict__ pts, dev_ext* __restrict__ partial) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_terms) return;
+           uint32_t n_points, const dev_affine* __restrict__ pts, dev_ext* __restrict__ partial,
+           const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ list) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (list) {                                        // only the terms the fixed-base kernel does not take
+    const uint32_t first = class_start[HOT_SLOTS];
+    if (t >= class_start[HOT_CLASSES] - first) return;
+    t = list[first + t];
+  } else if (t >= n_terms) {
+    return;
+  }
   uint32_t s[8], e[8], top;
   load_vec<2>(s, scalars + 32 * (size_t)t);
   sc_add_pattern(e, top, s, 0xAAAAAAAAu);           // digits e_i - 2 in {-2,-1,0,1}
@@ -112,7 +123,7 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
 }
 
 template <typename STATUS_T>
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 k_reduce_encode(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pidx,
                 uint32_t n_points, const dev_affine* __restrict__ pts, const dev_ext* __restrict__ partial,
                 uint8_t* __restrict__ out, STATUS_T* __restrict__ status) {
@@ -167,7 +178,7 @@ struct pip_cfg {
 };
 
 template <int C>
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 k_pip_prepare(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
               dev_niels* __restrict__ niels, uint32_t* __restrict__ digits, uint32_t* __restrict__ hist,
               uint32_t* __restrict__ invalid) {
@@ -279,7 +290,7 @@ k_pip_scatter(uint32_t n, uint32_t bins, const uint32_t* __restrict__ digits, ui
 // Bucket accumulation, load balanced: virtual lane v of window w sums one part (<= L entries) of one
 // bucket.  Buckets are split because digit distributions are NOT uniform in practice: canonical scalars
 // are < 2^253, so the top window only ever uses a few dozen buckets, each holding n/32 .. n/64 points.
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 k_pip_bucket_part(uint32_t n, uint32_t bins, uint32_t L, uint32_t vmax, const uint32_t* __restrict__ start,
                   const uint32_t* __restrict__ hist, const uint32_t* __restrict__ vstart,
                   const uint32_t* __restrict__ sorted, const dev_niels* __restrict__ niels,
@@ -312,7 +323,7 @@ k_pip_bucket_part(uint32_t n, uint32_t bins, uint32_t L, uint32_t vmax, const ui
   store_ext(parts + (size_t)w * vmax + v, acc);
 }
 
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 k_pip_bucket_merge(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t* __restrict__ vstart,
                    const dev_ext* __restrict__ parts, dev_ext* __restrict__ buckets) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,7 +350,7 @@ k_pip_bucket_merge(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t*
 // One level of the radix-8 evaluation of T = sum_g g * S_g  (g = 0 .. 8^L - 1).
 // Invariant before level l:  T = sum_j ( A_j + 8^l * j * R_j ),  A absent (= 0) at level 0.
 // A lane folds 8 consecutive inputs j = 8j' + i:   R' = sum_i R_i,  A' = sum_i A_i + 8^l * sum_i i R_i.
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t out_stride, int level,
                  const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
                  dev_ext* __restrict__ A_out, dev_ext* __restrict__ R_out) {
@@ -409,7 +420,7 @@ k_pip_combine(int W1, int C, const dev_ext* __restrict__ T, const uint32_t* __re
 // =============================================================================================
 // stand-alone codec kernels
 // =============================================================================================
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 k_decode_check(uint32_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ status, uint8_t* __restrict__ xyzt) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -425,7 +436,7 @@ k_decode_check(uint32_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 k_encode_many(uint32_t n, const uint8_t* __restrict__ xyzt, uint8_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -467,6 +478,15 @@ struct zkp_ctx {
   int n_ev = 0;
   float kernel_ms[ZKP_K_COUNT] = {};
   float total_ms = 0;
+  // fixed-base tables (hot_tables.h): HOT_SLOTS slots, LRU
+  dev_niels* hot_tables = nullptr;
+  uint32_t* hot_reg_words = nullptr;       // device [HOT_SLOTS][8]: encodings of the registered points, densely packed
+  int32_t* hot_reg_slot = nullptr;         // device [HOT_SLOTS]
+  char* hot_scratch = nullptr;             // device: encodings, decoded points, window bases of points being added
+  std::string hot_key[HOT_SLOTS];          // host: encoding held by each slot ("" = free)
+  uint64_t hot_used[HOT_SLOTS] = {};
+  uint64_t hot_tick = 0;
+  uint32_t hot_nreg = 0;
 };
 
 namespace {
@@ -510,26 +530,48 @@ inline dim3 grid1(size_t n, int block) { return dim3((unsigned)((n + block - 1) 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint8_t* d_scalars,
-                   const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms,
+                   const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms, int flags,
                    uint8_t* d_out, uint8_t* d_status8, uint32_t* d_status32, size_t ws_reserved) {
   carve cv;
   cv.off = ws_reserved;
   const size_t o_pts = cv.take((size_t)n_points * sizeof(dev_affine));
   const size_t o_part = cv.take((size_t)n_terms * sizeof(dev_ext));
+  const size_t o_hot = cv.take((size_t)n_points * 4);
+  const size_t o_cls = cv.take(256 * 4);
+  const size_t o_list = cv.take((size_t)n_terms * 4);
   // ensure_ws was done by the caller for ws_reserved + this much; recompute defensively
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
   char* base = static_cast<char*>(c->ws);
   dev_affine* pts = reinterpret_cast<dev_affine*>(base + o_pts);
   dev_ext* part = reinterpret_cast<dev_ext*>(base + o_part);
-  if (n_points) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 128), dim3(128), 0, c->stream, n_points, d_points, pts);
+  if (n_points) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts);
   prof_mark(c, ZKP_K_DECODE);
-  if (n_terms) hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 128), dim3(128), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part);
+  if (n_terms && c->hot_nreg && n_terms >= 1024) {
+    // split the terms: those on a registered fixed-base point (grouped by table) / the rest
+    int32_t* hotmap = reinterpret_cast<int32_t*>(base + o_hot);
+    uint32_t* cls = reinterpret_cast<uint32_t*>(base + o_cls);     // cnt[65] | start[66] | cursor[65] | any
+    uint32_t* class_cnt = cls, *class_start = cls + 80, *cursor = cls + 160, *any_hot = cls + 240;
+    uint32_t* list = reinterpret_cast<uint32_t*>(base + o_list);
+    HIP_TRY(hipMemsetAsync(cls, 0, 256 * 4, c->stream));
+    hipLaunchKernelGGL(k_hot_match, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, c->hot_nreg, c->hot_reg_words, c->hot_reg_slot, hotmap, any_hot);
+    hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, class_cnt);
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor);
+    hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, cursor, list);
+    if (flags == ZKP_CT)
+      hipLaunchKernelGGL(k_terms_hot<true>, grid1(n_terms, 256), dim3(256), 0, c->stream, class_start, list, d_scalars, d_pidx, hotmap, c->hot_tables, part);
+    else
+      hipLaunchKernelGGL(k_terms_hot<false>, grid1(n_terms, 256), dim3(256), 0, c->stream, class_start, list, d_scalars, d_pidx, hotmap, c->hot_tables, part);
+    hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part, class_start, list);
+  } else if (n_terms) {
+    hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+  }
   prof_mark(c, ZKP_K_TERMS);
   if (n_msm) {
     if (d_status8)
-      hipLaunchKernelGGL(k_reduce_encode<uint8_t>, grid1(n_msm, 128), dim3(128), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status8);
+      hipLaunchKernelGGL(k_reduce_encode<uint8_t>, grid1(n_msm, 256), dim3(256), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status8);
     else
-      hipLaunchKernelGGL(k_reduce_encode<uint32_t>, grid1(n_msm, 128), dim3(128), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status32);
+      hipLaunchKernelGGL(k_reduce_encode<uint32_t>, grid1(n_msm, 256), dim3(256), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status32);
   }
   prof_mark(c, ZKP_K_REDUCE);
   HIP_TRY(hipGetLastError());
@@ -539,6 +581,9 @@ size_t terms_path_ws(uint32_t n_points, uint32_t n_terms) {
   carve cv;
   cv.take((size_t)n_points * sizeof(dev_affine));
   cv.take((size_t)n_terms * sizeof(dev_ext));
+  cv.take((size_t)n_points * 4);
+  cv.take(256 * 4);
+  cv.take((size_t)n_terms * 4);
   return cv.off;
 }
 
@@ -590,14 +635,14 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
 
   HIP_TRY(hipMemsetAsync(hist, 0, nb * 4, c->stream));
   HIP_TRY(hipMemsetAsync(invalid, 0, 4, c->stream));
-  hipLaunchKernelGGL(k_pip_prepare<C>, grid1(n, 128), dim3(128), 0, c->stream, n, d_scalars, d_points, niels, digits, hist, invalid);
+  hipLaunchKernelGGL(k_pip_prepare<C>, grid1(n, 256), dim3(256), 0, c->stream, n, d_scalars, d_points, niels, digits, hist, invalid);
   prof_mark(c, ZKP_K_DECODE);
   hipLaunchKernelGGL(k_pip_scan, dim3(cfg::W1), dim3(256), 0, c->stream, cfg::B1, L, hist, start, cursor, vstart);
   hipLaunchKernelGGL(k_pip_scatter, dim3((n + 255) / 256, cfg::W1), dim3(256), 0, c->stream, n, cfg::B1, digits, cursor, sorted);
   prof_mark(c, ZKP_K_SORT);
-  hipLaunchKernelGGL(k_pip_bucket_part, dim3((unsigned)((vmax + 127) / 128), cfg::W1), dim3(128), 0, c->stream, n, cfg::B1, L, (uint32_t)vmax,
+  hipLaunchKernelGGL(k_pip_bucket_part, dim3((unsigned)((vmax + 255) / 256), cfg::W1), dim3(256), 0, c->stream, n, cfg::B1, L, (uint32_t)vmax,
                      start, hist, vstart, sorted, niels, parts);
-  hipLaunchKernelGGL(k_pip_bucket_merge, grid1(nb, 128), dim3(128), 0, c->stream, cfg::B1, (uint32_t)nb, (uint32_t)vmax, vstart, parts, buckets);
+  hipLaunchKernelGGL(k_pip_bucket_merge, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, (uint32_t)nb, (uint32_t)vmax, vstart, parts, buckets);
   prof_mark(c, ZKP_K_BUCKET);
   // radix-8 tree over bucket indices 0 .. B-1 (bucket B is added in k_pip_combine)
   const dev_ext* Ain = nullptr;
@@ -611,7 +656,7 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
     dev_ext* Aout = lvlA + lvl_off;
     dev_ext* Rout = lvlR + lvl_off;
     const uint32_t total = cfg::W1 * n_out;
-    hipLaunchKernelGGL(k_pip_reduce_lvl, grid1(total, 128), dim3(128), 0, c->stream, n_out, total, in_stride, n_out, level, Ain, Rin, Aout, Rout);
+    hipLaunchKernelGGL(k_pip_reduce_lvl, grid1(total, 256), dim3(256), 0, c->stream, n_out, total, in_stride, n_out, level, Ain, Rin, Aout, Rout);
     Ain = Aout;
     Rin = Rout;
     in_stride = n_out;
@@ -668,6 +713,10 @@ void zkp_ctx_destroy(zkp_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   if (c->ws) hipFree(c->ws);
+  if (c->hot_tables) hipFree(c->hot_tables);
+  if (c->hot_reg_words) hipFree(c->hot_reg_words);
+  if (c->hot_reg_slot) hipFree(c->hot_reg_slot);
+  if (c->hot_scratch) hipFree(c->hot_scratch);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -706,6 +755,91 @@ int zkp_ctx_last_timing(zkp_ctx* c, float* kernel_ms, float* total_ms) {
   return ZKP_K_COUNT;
 }
 
+int zkp_ctx_prepare_fixed_points(zkp_ctx* c, uint32_t n, const uint8_t* encodings) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (n == 0) return ZKP_OK;
+  if (!encodings) return fail(ZKP_ERR_ARG, "NULL pointer");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->hot_tables) {
+    HIP_TRY(hipMalloc(&c->hot_tables, sizeof(dev_niels) * HOT_SLOT_NIELS * HOT_SLOTS));
+    HIP_TRY(hipMalloc(&c->hot_reg_words, 32 * HOT_SLOTS));
+    HIP_TRY(hipMalloc(&c->hot_reg_slot, 4 * HOT_SLOTS));
+    HIP_TRY(hipMalloc(&c->hot_scratch, (size_t)HOT_SLOTS * (32 + sizeof(dev_affine) + 4 + sizeof(dev_ext) * HOT_WINDOWS)));
+  }
+  // which encodings are new?  (the last HOT_SLOTS distinct ones win if more are given)
+  ++c->hot_tick;
+  std::vector<std::string> fresh;
+  for (uint32_t i = 0; i < n; ++i) {
+    const std::string key(reinterpret_cast<const char*>(encodings + 32 * (size_t)i), 32);
+    bool found = false;
+    for (int sl = 0; sl < HOT_SLOTS; ++sl)
+      if (c->hot_key[sl] == key) { c->hot_used[sl] = c->hot_tick; found = true; break; }
+    if (!found && std::find(fresh.begin(), fresh.end(), key) == fresh.end()) fresh.push_back(key);
+  }
+  if (fresh.size() > (size_t)HOT_SLOTS) fresh.resize(HOT_SLOTS);
+  if (!fresh.empty()) {
+    const uint32_t nh = (uint32_t)fresh.size();
+    char* sc = c->hot_scratch;
+    uint8_t* d_enc = reinterpret_cast<uint8_t*>(sc);
+    dev_affine* d_aff = reinterpret_cast<dev_affine*>(sc + 32 * HOT_SLOTS);
+    uint32_t* d_slots = reinterpret_cast<uint32_t*>(sc + (32 + sizeof(dev_affine)) * HOT_SLOTS);
+    dev_ext* d_bases = reinterpret_cast<dev_ext*>(sc + (32 + sizeof(dev_affine) + 4) * HOT_SLOTS);
+    std::vector<uint8_t> h_enc(32 * (size_t)nh);
+    for (uint32_t i = 0; i < nh; ++i) memcpy(h_enc.data() + 32 * (size_t)i, fresh[i].data(), 32);
+    HIP_TRY(hipMemcpyAsync(d_enc, h_enc.data(), h_enc.size(), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_decode_affine, grid1(nh, 256), dim3(256), 0, c->stream, nh, d_enc, d_aff);
+    std::vector<dev_affine> h_aff(nh);
+    HIP_TRY(hipMemcpyAsync(h_aff.data(), d_aff, sizeof(dev_affine) * nh, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // slots: free first, then least recently used; undecodable encodings get no table (the generic path reports them)
+    std::vector<uint32_t> h_slots(nh, 0);
+    std::vector<uint32_t> keep;
+    for (uint32_t i = 0; i < nh; ++i) {
+      if (!h_aff[i].valid) continue;
+      int best = -1;
+      for (int sl = 0; sl < HOT_SLOTS; ++sl) {
+        if (c->hot_used[sl] == c->hot_tick) continue;                  // touched by this very call
+        if (c->hot_key[sl].empty()) { best = sl; break; }
+        if (best < 0 || c->hot_used[sl] < c->hot_used[best]) best = sl;
+      }
+      if (best < 0) break;
+      c->hot_key[best] = fresh[i];
+      c->hot_used[best] = c->hot_tick;
+      h_slots[i] = (uint32_t)best;
+      keep.push_back(i);
+    }
+    if (!keep.empty()) {
+      // compact the kept points to the front (decoded form + slot)
+      std::vector<dev_affine> k_aff(keep.size());
+      std::vector<uint32_t> k_slots(keep.size());
+      for (size_t j = 0; j < keep.size(); ++j) { k_aff[j] = h_aff[keep[j]]; k_slots[j] = h_slots[keep[j]]; }
+      const uint32_t nk = (uint32_t)keep.size();
+      HIP_TRY(hipMemcpyAsync(d_aff, k_aff.data(), sizeof(dev_affine) * nk, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(d_slots, k_slots.data(), 4 * nk, hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(k_hot_bases, grid1(nk, 64), dim3(64), 0, c->stream, nk, d_aff, d_bases);
+      hipLaunchKernelGGL(k_hot_rows, grid1((size_t)nk * HOT_WINDOWS, 64), dim3(64), 0, c->stream, nk, d_slots, d_bases, c->hot_tables);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  // densely packed registry for k_hot_match
+  std::vector<uint32_t> words;
+  std::vector<int32_t> slots;
+  for (int sl = 0; sl < HOT_SLOTS; ++sl)
+    if (!c->hot_key[sl].empty()) {
+      uint32_t w[8];
+      memcpy(w, c->hot_key[sl].data(), 32);
+      words.insert(words.end(), w, w + 8);
+      slots.push_back(sl);
+    }
+  c->hot_nreg = (uint32_t)slots.size();
+  if (c->hot_nreg) {
+    HIP_TRY(hipMemcpyAsync(c->hot_reg_words, words.data(), 32 * (size_t)c->hot_nreg, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->hot_reg_slot, slots.data(), 4 * (size_t)c->hot_nreg, hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+}
+
 int zkp_msm_many_dev(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint8_t* d_scalars,
                      const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms,
                      int flags, uint8_t* d_out, uint8_t* d_status) {
@@ -719,7 +853,7 @@ int zkp_msm_many_dev(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const ui
   const int rc = ensure_ws(c, terms_path_ws(n_points, n_terms));
   if (rc) return rc;
   prof_begin(c);
-  return msm_terms_path(c, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms, d_out, d_status, nullptr, 0);
+  return msm_terms_path(c, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms, flags, d_out, d_status, nullptr, 0);
 }
 
 int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t* scalars, const uint32_t* pidx,
@@ -756,7 +890,7 @@ int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t*
   prof_begin(c);
   rc = msm_terms_path(c, n_msm, reinterpret_cast<uint32_t*>(base + o_off), reinterpret_cast<uint8_t*>(base + o_sc),
                       reinterpret_cast<uint32_t*>(base + o_pidx), reinterpret_cast<uint8_t*>(base + o_pts), n_points,
-                      n_terms, reinterpret_cast<uint8_t*>(base + o_out), reinterpret_cast<uint8_t*>(base + o_st), nullptr, reserved);
+                      n_terms, flags, reinterpret_cast<uint8_t*>(base + o_out), reinterpret_cast<uint8_t*>(base + o_st), nullptr, reserved);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(out, base + o_out, (size_t)n_msm * 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(status, base + o_st, (size_t)n_msm, hipMemcpyDeviceToHost, c->stream));
@@ -778,7 +912,7 @@ static int msm_optional_impl(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, c
     uint32_t* pidx = reinterpret_cast<uint32_t*>(base + o_pidx);
     uint32_t* off = reinterpret_cast<uint32_t*>(base + o_off);
     hipLaunchKernelGGL(k_iota_single_msm, grid1(n + 1, 256), dim3(256), 0, c->stream, (uint32_t)n, pidx, off);
-    return msm_terms_path(c, 1, off, d_scalars, pidx, d_points, (uint32_t)n, (uint32_t)n, d_out, nullptr, d_status, inner);
+    return msm_terms_path(c, 1, off, d_scalars, pidx, d_points, (uint32_t)n, (uint32_t)n, ZKP_VARTIME, d_out, nullptr, d_status, inner);
   }
   if (n > 0x7fffffffull) return fail(ZKP_ERR_ARG, "n too large (max 2^31-1 terms per call)");
   const int cbits = pick_c(n);
@@ -867,7 +1001,7 @@ int zkp_decode_check(zkp_ctx* c, uint64_t n, const uint8_t* points, uint8_t* sta
   char* base = static_cast<char*>(c->ws);
   HIP_TRY(hipMemcpyAsync(base + o_pts, points, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
   prof_begin(c);
-  hipLaunchKernelGGL(k_decode_check, grid1(n, 128), dim3(128), 0, c->stream, (uint32_t)n, reinterpret_cast<uint8_t*>(base + o_pts),
+  hipLaunchKernelGGL(k_decode_check, grid1(n, 256), dim3(256), 0, c->stream, (uint32_t)n, reinterpret_cast<uint8_t*>(base + o_pts),
                      reinterpret_cast<uint8_t*>(base + o_st), xyzt ? reinterpret_cast<uint8_t*>(base + o_xyzt) : nullptr);
   prof_mark(c, ZKP_K_DECODE);
   HIP_TRY(hipGetLastError());
@@ -891,7 +1025,7 @@ int zkp_encode_many(zkp_ctx* c, uint64_t n, const uint8_t* xyzt, uint8_t* out) {
   char* base = static_cast<char*>(c->ws);
   HIP_TRY(hipMemcpyAsync(base + o_in, xyzt, (size_t)n * 128, hipMemcpyHostToDevice, c->stream));
   prof_begin(c);
-  hipLaunchKernelGGL(k_encode_many, grid1(n, 128), dim3(128), 0, c->stream, (uint32_t)n, reinterpret_cast<uint8_t*>(base + o_in), reinterpret_cast<uint8_t*>(base + o_out));
+  hipLaunchKernelGGL(k_encode_many, grid1(n, 256), dim3(256), 0, c->stream, (uint32_t)n, reinterpret_cast<uint8_t*>(base + o_in), reinterpret_cast<uint8_t*>(base + o_out));
   prof_mark(c, ZKP_K_REDUCE);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, base + o_out, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));

@@ -22,6 +22,7 @@ EXPORTS = (
     "zkp_ctx_create", "zkp_ctx_destroy", "zkp_ctx_set_stream", "zkp_ctx_synchronize", "zkp_last_error",
     "zkp_version", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
+    "zkp_ctx_prepare_fixed_points",
 )
 
 
@@ -57,6 +58,7 @@ def load_library() -> ctypes.CDLL:
     lib.zkp_encode_many.argtypes = [vp, ctypes.c_uint64, u8p, u8p]
     lib.zkp_ctx_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.zkp_ctx_set_profiling.argtypes = [vp, i32]
+    lib.zkp_ctx_prepare_fixed_points.argtypes = [vp, ctypes.c_uint32, u8p]
     _lib = lib
     return lib
 
@@ -144,6 +146,11 @@ class Engine:
         out = np.zeros((len(xyzt), 32), np.uint8)
         _check(self._lib.zkp_encode_many(self._h, len(xyzt), _ptr(xyzt), _ptr(out)), "zkp_encode_many")
         return out
+
+    def prepare_fixed_points(self, encodings) -> None:
+        """Hint: these points (the statement's common / static points) will be referenced by many terms."""
+        encodings = _u8(encodings, 32) if len(encodings) else np.zeros((0, 32), np.uint8)
+        _check(self._lib.zkp_ctx_prepare_fixed_points(self._h, len(encodings), _ptr(encodings)), "zkp_ctx_prepare_fixed_points")
 
     # ---- device-buffer entry points (raw device pointers, e.g. torch tensor .data_ptr()) ----
     def set_stream(self, hip_stream: int) -> None:

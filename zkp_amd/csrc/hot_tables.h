@@ -144,14 +144,8 @@ k_class_scatter(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_
 
 // ---- the fixed-base term kernel -----------------------------------------------------------------------------------------
 template <bool CT>
-__global__ void __launch_bounds__(256, 2)
-k_terms_hot(const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ list, const uint8_t* __restrict__ scalars,
-            const uint32_t* __restrict__ pidx, const int32_t* __restrict__ hotmap, const dev_niels* __restrict__ tables,
-            dev_ext* __restrict__ partial) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= class_start[HOT_SLOTS]) return;                         // hot terms occupy list[0 .. class_start[64])
-  const uint32_t t = list[i];
-  const dev_niels* T = tables + (size_t)hotmap[pidx[t]] * HOT_SLOT_NIELS;
+__device__ __forceinline__ void term_fixed_base(uint32_t t, const uint8_t* __restrict__ scalars, const dev_niels* __restrict__ T,
+                                                dev_ext* __restrict__ partial) {
   uint32_t s[8], e[8], top;
   load_vec<2>(s, scalars + 32 * (size_t)t);
   sc_add_pattern(e, top, s, 0x88888888u);                          // digits nibble - 8 in [-8, 7]

@@ -74,18 +74,8 @@ k_decode_affine(uint32_t n, const uint8_t* __restrict__ enc, dev_affine* __restr
 // partial[t] = scalars[t] * points[pidx[t]].  Fixed schedule: 128 windows of (2 doublings, 1 unified
 // addition of a masked-selected table entry); no branch or address depends on the scalar, so the
 // same kernel serves ZKP_CT and ZKP_VARTIME.
-__global__ void __launch_bounds__(256, 2)
-k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx,
-           uint32_t n_points, const dev_affine* __restrict__ pts, dev_ext* __restrict__ partial,
-           const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ list) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (list) {                                        // only the terms the fixed-base kernel does not take
-    const uint32_t first = class_start[HOT_SLOTS];
-    if (t >= class_start[HOT_CLASSES] - first) return;
-    t = list[first + t];
-  } else if (t >= n_terms) {
-    return;
-  }
+__device__ __forceinline__ void term_generic(uint32_t t, const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx,
+                                             uint32_t n_points, const dev_affine* __restrict__ pts, dev_ext* __restrict__ partial) {
   uint32_t s[8], e[8], top;
   load_vec<2>(s, scalars + 32 * (size_t)t);
   sc_add_pattern(e, top, s, 0xAAAAAAAAu);           // digits e_i - 2 in {-2,-1,0,1}
@@ -120,6 +110,35 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
     }
   }
   store_ext(partial + t, acc);
+}
+
+// every term through the generic path (no fixed-base point registered)
+__global__ void __launch_bounds__(256, 2)
+k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx,
+           uint32_t n_points, const dev_affine* __restrict__ pts, dev_ext* __restrict__ partial) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_terms) term_generic(t, scalars, pidx, n_points, pts, partial);
+}
+
+// Classified terms in ONE launch: the first blocks take the generic terms (long: 384 point operations per lane), the
+// remaining blocks the fixed-base terms (65 mixed additions), so the short jobs fill the SIMDs the long ones leave idle.
+template <bool CT>
+__global__ void __launch_bounds__(256, 2)
+k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
+              const dev_affine* __restrict__ pts, const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ list,
+              const int32_t* __restrict__ hotmap, const dev_niels* __restrict__ tables, dev_ext* __restrict__ partial) {
+  const uint32_t n_hot = class_start[HOT_SLOTS], n_cold = class_start[HOT_CLASSES] - n_hot;
+  const uint32_t cold_blocks = (n_cold + blockDim.x - 1) / blockDim.x;
+  if (blockIdx.x < cold_blocks) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cold) term_generic(list[n_hot + i], scalars, pidx, n_points, pts, partial);
+  } else {
+    const uint32_t i = (blockIdx.x - cold_blocks) * blockDim.x + threadIdx.x;
+    if (i < n_hot) {
+      const uint32_t t = list[i];
+      term_fixed_base<CT>(t, scalars, tables + (size_t)hotmap[pidx[t]] * HOT_SLOT_NIELS, partial);
+    }
+  }
 }
 
 template <typename STATUS_T>
@@ -557,14 +576,13 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, class_cnt);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor);
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, cursor, list);
+    const dim3 grid((unsigned)((n_terms + 255) / 256 + 1));
     if (flags == ZKP_CT)
-      hipLaunchKernelGGL(k_terms_hot<true>, grid1(n_terms, 256), dim3(256), 0, c->stream, class_start, list, d_scalars, d_pidx, hotmap, c->hot_tables, part);
+      hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, pts, class_start, list, hotmap, c->hot_tables, part);
     else
-      hipLaunchKernelGGL(k_terms_hot<false>, grid1(n_terms, 256), dim3(256), 0, c->stream, class_start, list, d_scalars, d_pidx, hotmap, c->hot_tables, part);
-    hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part, class_start, list);
+      hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, pts, class_start, list, hotmap, c->hot_tables, part);
   } else if (n_terms) {
-    hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part);
   }
   prof_mark(c, ZKP_K_TERMS);
   if (n_msm) {

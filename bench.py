@@ -184,14 +184,22 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n * args.steps / elapsed
-    # dominant kernel: k_terms_r4 (one launch per step).  Algorithmic bytes per launch:
+    # dominant kernel: k_terms_split<CT> (one launch per step).  Algorithmic bytes per launch:
     # 64 B per (scalar, point) term in + 32 B per MSM out = 2,336 B per CMZ proof.
     algo_bytes = 64.0 * n_terms + 32.0 * n_msm
     t_terms = k_prove["terms"] * 1e-3
     achieved = algo_bytes / t_terms / 1e9 if t_terms > 0 else 0.0
-    # executed v_mad_u64_u32 per term: 128 windows x (2 doublings + 1 addition) = 128 x (8 sq x 62 + 15 mul x 98)
-    mads_per_term = 128 * (8 * 62 + 15 * 98)
-    valu = n_terms * mads_per_term / t_terms if t_terms > 0 else 0.0
+    # executed v_mad_u64_u32: generic term = 128 windows x (2 doublings + 1 addition) = 128 x (8 sq x 62 + 15 mul x 98);
+    # fixed-base term (X_1..X_10, A: 20 of the 31 terms of a proof) = 65 mixed additions x 7 mul x 98
+    mads = n * (11 * 128 * (8 * 62 + 15 * 98) + 20 * 65 * 7 * 98)
+    valu = mads / t_terms if t_terms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")       # rocprofv3 --pmc passes of this same command
+    if os.path.exists(pmc) and n == 4096:
+        try:
+            traffic = json.load(open(pmc))["k_terms_split<true>"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
     out = {
         "metric": METRIC, "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
@@ -202,8 +210,8 @@ def main():
         "prove_proofs_per_s": world * n / (k_prove["total"] * 1e-3),
         "batch_verifies_per_s": world * n / (k_verify["total"] * 1e-3),
         "kernel_ms": {"prove": k_prove, "batch_verify": k_verify},
-        "roofline": {"bound": "hbm", "kernel": "k_terms_r4", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": "k_terms_split<CT>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "note": "integer-VALU bound by construction (SURVEY.md 8(d)); see valu_* for the binding roofline",
                      "valu_achieved_mads_per_s": valu, "valu_peak_mads_per_s": VALU_PEAK_MADS, "valu_frac": valu / VALU_PEAK_MADS,
                      "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": k_prove["terms"]},

@@ -1,0 +1,147 @@
+"""Parity at the FULL sizes BASELINE.json names (per-GPU shares of configs 3, 4, 5), through properties that do
+not need the oracle to redo the whole computation:
+
+* every point has a known discrete log (P_j = k_j * B), so an MSM result must equal (sum s_i k_i mod l) * B --
+  one oracle scalar multiplication for millions of terms;
+* checksum of checksums: the sum of ALL outputs of a zkp_msm_many call (taken with a second GPU MSM with unit
+  scalars) must equal the point predicted from the discrete logs;
+* a random sample of individual outputs is recomputed by the C oracle bit for bit;
+* linearity: MSM(s, P) + MSM(s', P) = MSM(s + s', P).
+"""
+import numpy as np
+import pytest
+
+from oracle import cbind as C
+from oracle import model as M
+
+pytestmark = pytest.mark.gpu
+BASE = np.frombuffer(bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"), np.uint8).reshape(1, 32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zkp_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def rand_scalars(rng, k):
+    s = rng.integers(0, 256, size=(k, 32), dtype=np.uint8)
+    s[:, 31] &= 0x0f
+    return s
+
+
+def to_ints(arr):
+    """[n][32] uint8 little-endian -> python ints (vectorised through 4 uint64 words)"""
+    w = arr.view(np.uint64).reshape(-1, 4)
+    return [int(a) | (int(b) << 64) | (int(c) << 128) | (int(d) << 192) for a, b, c, d in w]
+
+
+def expected_point(total_log):
+    return M.ristretto_encode(M.pt_mul(total_log % M.L, M.BASEPOINT))
+
+
+def make_points(eng, rng, n):
+    """n valid points k_j * B made by the engine (checked against the oracle on a sample), with their logs."""
+    ks = rand_scalars(rng, n)
+    pts, st = eng.msm_many(np.arange(n + 1, dtype=np.uint32), ks, np.zeros(n, np.uint32), BASE, 0)
+    assert not st.any()
+    sample = rng.integers(0, n, size=8)
+    exp, _ = C.msm_many(np.arange(9, dtype=np.uint32), ks[sample], np.zeros(8, np.uint32), BASE, 0)
+    assert (pts[sample] == exp).all()
+    return pts, to_ints(ks)
+
+
+def test_config3_batch_msm_2p20_dleq(eng):
+    """BatchVerifier MSM over 2^20 macro-DLEQ proofs: 1 + 5 * 2^20 = 5,242,881 terms (batch_verifier.rs:219)."""
+    rng = np.random.default_rng(303)
+    n = 1 + 5 * (1 << 20)
+    distinct = 1 << 16
+    pts, logs = make_points(eng, rng, distinct)
+    idx = rng.integers(0, distinct, size=n)
+    scal = rand_scalars(rng, n)
+    got = eng.msm_optional(scal, pts[idx])
+    logs_arr = np.array(logs, dtype=object)
+    total = int(np.dot(np.array(to_ints(scal), dtype=object), logs_arr[idx]))
+    assert got == expected_point(total)
+    # linearity at full size: MSM(s) + MSM(s') == MSM(s + s')  (scalars < 2^252 so s + s' needs no reduction below 2^256)
+    scal2 = rand_scalars(rng, n)
+    got2 = eng.msm_optional(scal2, pts[idx])
+    both = np.concatenate([np.frombuffer(got, np.uint8), np.frombuffer(got2, np.uint8)]).reshape(2, 32)
+    one = np.zeros((2, 32), np.uint8)
+    one[:, 0] = 1
+    lhs = eng.msm_optional(one, both)
+    total2 = total + int(np.dot(np.array(to_ints(scal2), dtype=object), logs_arr[idx]))
+    assert lhs == expected_point(total2)
+    # a single undecodable point anywhere -> None
+    bad = pts[idx].copy()
+    bad[n // 3] = np.frombuffer(bytes.fromhex("0100000000000000000000000000000000000000000000000000000000000000"), np.uint8)
+    assert eng.msm_optional(scal, bad) is None
+
+
+def _cmz_csr(n, n_common=11):
+    """CSR of the CMZ commitment MSMs (as in bench.py): points [X_1..X_10, A, P_0, Q_0, P_1, Q_1, ...]"""
+    import bench
+    return bench.cmz_shape(n)
+
+
+def test_config4_share_cmz_prove_524288(eng):
+    """Per-GPU share of config 4: 524,288 CMZ proofs -> 5,767,168 commitment MSMs / 16,252,928 terms, constant-time
+    schedule, with the common points on the fixed-base path."""
+    rng = np.random.default_rng(404)
+    n = 524288
+    off, pidx, n_pts = _cmz_csr(n)
+    pts, logs = make_points(eng, rng, n_pts)
+    eng.prepare_fixed_points(pts[:11])
+    blind = rand_scalars(rng, 31 * n)
+    out, st = eng.msm_many(off, blind, pidx, pts, 1)
+    assert not st.any()
+    # sampled outputs against the C oracle, bit for bit (both MSM shapes: 2 terms and 11 terms)
+    sample = np.concatenate([rng.integers(0, 11 * n, size=24), np.array([10, 21, 11 * n - 1])])
+    for m in sample:
+        lo, hi = int(off[m]), int(off[m + 1])
+        exp, est = C.msm_many(np.array([0, hi - lo], np.uint32), blind[lo:hi], np.arange(hi - lo, dtype=np.uint32), pts[pidx[lo:hi]], 1)
+        assert est[0] == 0 and (out[m] == exp[0]).all(), m
+    # checksum of checksums: sum of all 5.7M outputs == (sum of all scalar * log) * B
+    ones = np.zeros((11 * n, 32), np.uint8)
+    ones[:, 0] = 1
+    total_pt = eng.msm_optional(ones, out)
+    logs_arr = np.array(logs, dtype=object)
+    total = 0
+    step = 1 << 20
+    for a in range(0, 31 * n, step):                       # chunked exact big-integer dot product
+        total += int(np.dot(np.array(to_ints(blind[a:a + step]), dtype=object), logs_arr[pidx[a:a + step]]))
+    assert total_pt == expected_point(total)
+
+
+def test_config5_share_w64_prove_32768(eng):
+    """Per-GPU share of config 5: the wide statement Q = sum_{i<64} x_i G_i (64-term MSM per proof), 32,768 proofs,
+    all 64 generators common (fixed-base path), and its batch-verification MSM of 64 + 2N terms."""
+    rng = np.random.default_rng(505)
+    n = 32768
+    gens, glogs = make_points(eng, rng, 64)
+    eng.prepare_fixed_points(gens)
+    scal = rand_scalars(rng, 64 * n)
+    off = (np.arange(n + 1, dtype=np.uint64) * 64).astype(np.uint32)
+    pidx = np.tile(np.arange(64, dtype=np.uint32), n)
+    out, st = eng.msm_many(off, scal, pidx, gens, 1)
+    assert not st.any()
+    ints = np.array(to_ints(scal), dtype=object).reshape(n, 64)
+    gl = np.array(glogs, dtype=object)
+    for m in list(rng.integers(0, n, size=6)) + [0, n - 1]:
+        assert out[m].tobytes() == expected_point(int(np.dot(ints[m], gl)))
+    ones = np.zeros((n, 32), np.uint8)
+    ones[:, 0] = 1
+    assert eng.msm_optional(ones, out) == expected_point(int(np.dot(ints.sum(axis=0), gl)))
+    # the same products through the vartime schedule must give the same bytes
+    out_v, st_v = eng.msm_many(off, scal, pidx, gens, 0)
+    assert not st_v.any() and (out_v == out).all()
+    # batch-verification shape: 64 static + (Q_j, commitment_j) rows -> 64 + 2N terms
+    nb = 64 + 2 * n
+    bsc = rand_scalars(rng, nb)
+    bpts = np.concatenate([gens, out, out[::-1]])
+    blogs = gl.tolist() + [int(np.dot(ints[m], gl)) % M.L for m in range(n)]
+    blogs = np.array(blogs + blogs[64:][::-1], dtype=object)
+    got = eng.msm_optional(bsc, bpts)
+    assert got == expected_point(int(np.dot(np.array(to_ints(bsc), dtype=object), blogs)))

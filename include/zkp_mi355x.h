@@ -104,6 +104,11 @@ int zkp_decode_check(zkp_ctx* ctx, uint64_t n, const uint8_t* points /*[n][32]*/
  *     32-byte little-endian field element (need not be reduced below p, bit 255 ignored). */
 int zkp_encode_many(zkp_ctx* ctx, uint64_t n, const uint8_t* xyzt /*[n][128]*/, uint8_t* out /*[n][32]*/);
 
+/* Test hook (not part of the drop-in surface): exercises the 4-lane cooperative point arithmetic used by the
+ * latency-bound kernels.  pairs = [n][2][32] encodings (P, Q); out = [n][4][32] = enc(2P), enc(P+Q), enc(P+Q) through
+ * Q's niels form, enc(P-Q) through the negated niels form. */
+int zkp_debug_quad_selftest(zkp_ctx* ctx, uint32_t n, const uint8_t* pairs /*[n][64]*/, uint8_t* out /*[n][128]*/);
+
 /* Timing of the last *_dev / host call on this context, measured with HIP events on the stream the
  * kernels were launched on.  kernel_ms[] is indexed by ZKP_K_*; returns the number of entries. */
 enum {

@@ -216,3 +216,21 @@ def test_msm_many_fixed_base_tables(base_points, flags):
         if not uses:
             assert (out3[m] == ref_out[m]).all()
     hot.close()
+
+
+def test_quad_cooperative_point_ops(eng, base_points):
+    """4-lane cooperative doubling / addition / mixed addition (quad.h) against the oracle, incl. identity operands,
+    P = Q (the unified formulas must double) and P = -Q (sum = identity)."""
+    rng = random.Random(31337)
+    _, encs = base_points
+    ident = bytes(32)
+    negs = [M.ristretto_encode(M.pt_neg(M.ristretto_decode(e))) for e in encs[:4]]
+    pairs = [(ident, ident), (encs[0], ident), (ident, encs[1]), (encs[2], encs[2]), (encs[3], negs[3])]
+    pairs += [(encs[rng.randrange(64)], encs[rng.randrange(64)]) for _ in range(300)]
+    arr = np.frombuffer(b"".join(p + q for p, q in pairs), np.uint8).reshape(-1, 64)
+    out = eng.debug_quad_selftest(arr)
+    for i, (pe, qe) in enumerate(pairs):
+        P, Q = M.ristretto_decode(pe), M.ristretto_decode(qe)
+        exp = [M.pt_double(P), M.pt_add(P, Q), M.pt_add(P, Q), M.pt_add(P, M.pt_neg(Q))]
+        for k in range(4):
+            assert out[i, k].tobytes() == M.ristretto_encode(exp[k]), (i, k)

@@ -56,6 +56,7 @@ __device__ __forceinline__ uint32_t sel8(const uint32_t w[8], int j) {
 }
 
 #include "hot_tables.h"
+#include "quad.h"
 
 // =============================================================================================
 // (A) small-MSM path
@@ -199,8 +200,7 @@ struct pip_cfg {
 template <int C>
 __global__ void __launch_bounds__(256, 2)
 k_pip_prepare(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
-              dev_niels* __restrict__ niels, uint32_t* __restrict__ digits, uint32_t* __restrict__ hist,
-              uint32_t* __restrict__ invalid) {
+              dev_niels* __restrict__ niels, uint32_t* __restrict__ digits, uint32_t* __restrict__ invalid) {
   using cfg = pip_cfg<C>;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -241,7 +241,6 @@ k_pip_prepare(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __
       mag = v;
     }
     digits[(size_t)w * n + i] = mag | (neg << 31);
-    if (mag) atomicAdd(&hist[(size_t)w * cfg::B1 + mag], 1u);
   }
 }
 
@@ -293,17 +292,77 @@ k_pip_scan(uint32_t bins, uint32_t L, const uint32_t* __restrict__ hist, uint32_
   if (tid == 255) vstart[(size_t)w * (bins + 1) + bins] = vpart[255];
 }
 
+// Counting sort of (term, window) keys by bucket WITHOUT device-scope atomics (measured at only ~8 G/s on MI355X:
+// they execute beyond the per-XCD L2s).  Each block owns a tile of terms of one window and counts / ranks in LDS;
+// tile histograms go through HBM:  hist pass -> per-bucket totals -> scans -> tile base offsets -> scatter pass.
+template <int C>
+struct sort_cfg {
+  static constexpr int THREADS = C >= 16 ? 1024 : 256;
+  static constexpr uint32_t TILE = C >= 16 ? 65536u : 2048u;      // LDS = B1 * 4 bytes: 16 KiB (c = 13) ... 128 KiB (c = 16)
+};
+
+template <int C>
+__global__ void __launch_bounds__(sort_cfg<C>::THREADS)
+k_pip_tile_hist(uint32_t n, const uint32_t* __restrict__ digits, uint32_t* __restrict__ tilehist) {
+  using cfg = pip_cfg<C>;
+  __shared__ uint32_t h[cfg::B1];
+  const uint32_t w = blockIdx.y, t = blockIdx.x, tiles = gridDim.x;
+  for (uint32_t b = threadIdx.x; b < cfg::B1; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  const uint32_t lo = t * sort_cfg<C>::TILE, hi = min(n, lo + sort_cfg<C>::TILE);
+  const uint32_t* d = digits + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const uint32_t mag = d[i] & 0x7fffffffu;
+    if (mag) atomicAdd(&h[mag], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = tilehist + ((size_t)w * tiles + t) * cfg::B1;
+  for (uint32_t b = threadIdx.x; b < cfg::B1; b += blockDim.x) out[b] = h[b];
+}
+
+// hist[w][b] = sum over tiles
 __global__ void __launch_bounds__(256)
-k_pip_scatter(uint32_t n, uint32_t bins, const uint32_t* __restrict__ digits, uint32_t* __restrict__ cursor,
-              uint32_t* __restrict__ sorted) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t w = blockIdx.y;
-  if (i >= n) return;
-  const uint32_t key = digits[(size_t)w * n + i];
-  const uint32_t mag = key & 0x7fffffffu;
-  if (!mag) return;
-  const uint32_t slot = atomicAdd(&cursor[(size_t)w * bins + mag], 1u);
-  sorted[(size_t)w * n + slot] = i | (key & 0x80000000u);
+k_pip_tile_total(uint32_t bins, uint32_t tiles, uint32_t total, const uint32_t* __restrict__ tilehist, uint32_t* __restrict__ hist) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const uint32_t w = g / bins, b = g - w * bins;
+  const uint32_t* p = tilehist + (size_t)w * tiles * bins + b;
+  uint32_t sum = 0;
+  for (uint32_t t = 0; t < tiles; ++t) sum += p[(size_t)t * bins];
+  hist[g] = sum;
+}
+// tilehist[w][t][b] <- first slot of (tile t, bucket b) in the window's sorted list
+__global__ void __launch_bounds__(256)
+k_pip_tile_base(uint32_t bins, uint32_t tiles, uint32_t total, const uint32_t* __restrict__ start, uint32_t* __restrict__ tilehist) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const uint32_t w = g / bins, b = g - w * bins;
+  uint32_t* p = tilehist + (size_t)w * tiles * bins + b;
+  uint32_t run = start[g];
+  for (uint32_t t = 0; t < tiles; ++t) {
+    const uint32_t c = p[(size_t)t * bins];
+    p[(size_t)t * bins] = run;
+    run += c;
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(sort_cfg<C>::THREADS)
+k_pip_tile_scatter(uint32_t n, const uint32_t* __restrict__ digits, const uint32_t* __restrict__ tilehist,
+                   uint32_t* __restrict__ sorted) {
+  using cfg = pip_cfg<C>;
+  __shared__ uint32_t base[cfg::B1];
+  const uint32_t w = blockIdx.y, t = blockIdx.x, tiles = gridDim.x;
+  const uint32_t* in = tilehist + ((size_t)w * tiles + t) * cfg::B1;
+  for (uint32_t b = threadIdx.x; b < cfg::B1; b += blockDim.x) base[b] = in[b];
+  __syncthreads();
+  const uint32_t lo = t * sort_cfg<C>::TILE, hi = min(n, lo + sort_cfg<C>::TILE);
+  const uint32_t* d = digits + (size_t)w * n;
+  uint32_t* out = sorted + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const uint32_t key = d[i], mag = key & 0x7fffffffu;
+    if (mag) out[atomicAdd(&base[mag], 1u)] = i | (key & 0x80000000u);
+  }
 }
 
 // Bucket accumulation, load balanced: virtual lane v of window w sums one part (<= L entries) of one
@@ -331,39 +390,50 @@ k_pip_bucket_part(uint32_t n, uint32_t bins, uint32_t L, uint32_t vmax, const ui
   const uint32_t* lst = sorted + (size_t)w * n + start[g] + first;
   ge_p3 acc;
   ge_identity(acc);
+  // software pipelined: the gather of entry k+1 is in flight while entry k is added
+  uint32_t idx_next = cnt ? lst[0] : 0u;
+  ge_niels q_next;
+  ge_niels_identity(q_next);
+  if (cnt) load_niels(q_next, niels + (idx_next & 0x7fffffffu));
 #pragma unroll 1
   for (uint32_t k = 0; k < cnt; ++k) {
-    const uint32_t idx = lst[k];
-    ge_niels q;
-    load_niels(q, niels + (idx & 0x7fffffffu));
+    ge_niels q = q_next;
+    const uint32_t idx = idx_next;
+    if (k + 1 < cnt) {
+      idx_next = lst[k + 1];
+      load_niels(q_next, niels + (idx_next & 0x7fffffffu));
+    }
     ge_niels_cneg(q, idx >> 31);
     ge_madd(acc, acc, q);
   }
   store_ext(parts + (size_t)w * vmax + v, acc);
 }
 
+// one QUAD of lanes per bucket (quad.h): the top window's buckets have ~sqrt(cnt) parts each, a latency-bound chain
 __global__ void __launch_bounds__(256, 2)
 k_pip_bucket_merge(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t* __restrict__ vstart,
                    const dev_ext* __restrict__ parts, dev_ext* __restrict__ buckets) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = gt >> 2;
+  const int q = (int)(gt & 3u);
   if (g >= total) return;
   const uint32_t w = g / bins, b = g - w * bins;
   const uint32_t* vs = vstart + (size_t)w * (bins + 1);
   const uint32_t v0 = vs[b], v1 = vs[b + 1];
   const dev_ext* p = parts + (size_t)w * vmax;
-  ge_p3 acc;
+  qpt acc;
   if (v1 == v0) {
-    ge_identity(acc);
+    q_identity(acc, q);
   } else {
-    load_ext(acc, p + v0);
+    q_load_ext(acc, p + v0, q);
 #pragma unroll 1
     for (uint32_t v = v0 + 1; v < v1; ++v) {
-      ge_p3 q;
-      load_ext(q, p + v);
-      ge_add_p3(acc, acc, q);
+      qpt t;
+      q_load_ext(t, p + v, q);
+      q_add(acc, acc, t, q);
     }
   }
-  store_ext(buckets + g, acc);
+  q_store_ext(buckets + g, acc, q);
 }
 
 // One level of the radix-8 evaluation of T = sum_g g * S_g  (g = 0 .. 8^L - 1).
@@ -373,60 +443,63 @@ __global__ void __launch_bounds__(256, 2)
 k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t out_stride, int level,
                  const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
                  dev_ext* __restrict__ A_out, dev_ext* __restrict__ R_out) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = gt >> 2;                        // one quad of lanes per output (quad.h)
+  const int q = (int)(gt & 3u);
   if (g >= total) return;
   const uint32_t w = g / n_out, j = g - w * n_out;
   const dev_ext* rin = R_in + (size_t)w * in_stride + 8 * (size_t)j;
-  ge_p3 run, U, q;
-  ge_identity(run);
-  ge_identity(U);
+  qpt run, U, t;
+  q_identity(run, q);
+  q_identity(U, q);
   if (level == 0 && j == n_out - 1) {
     // bucket index B = 8^L (digit -2^(C-1)) sits one past the tree's range: treat it as local index 8 of the
     // last chunk, i.e. seed the running sums with it (it is then counted 8 times in U and once in R')
-    load_ext(run, rin + 8);
+    q_load_ext(run, rin + 8, q);
     U = run;
   }
 #pragma unroll 1
   for (int i = 7; i >= 1; --i) {
-    load_ext(q, rin + i);
-    ge_add_p3(run, run, q);
-    ge_add_p3(U, U, run);
+    q_load_ext(t, rin + i, q);
+    q_add(run, run, t, q);
+    q_add(U, U, run, q);
   }
-  load_ext(q, rin);
-  ge_add_p3(run, run, q);
+  q_load_ext(t, rin, q);
+  q_add(run, run, t, q);
 #pragma unroll 1
-  for (int k = 0; k < 3 * level; ++k) ge_double<true>(U, U);
+  for (int k = 0; k < 3 * level; ++k) q_double(U, U, q);
   if (level > 0) {
     const dev_ext* ain = A_in + (size_t)w * in_stride + 8 * (size_t)j;
 #pragma unroll 1
     for (int i = 0; i < 8; ++i) {
-      load_ext(q, ain + i);
-      ge_add_p3(U, U, q);
+      q_load_ext(t, ain + i, q);
+      q_add(U, U, t, q);
     }
   }
-  store_ext(A_out + (size_t)w * out_stride + j, U);
-  store_ext(R_out + (size_t)w * out_stride + j, run);
+  q_store_ext(A_out + (size_t)w * out_stride + j, U, q);
+  q_store_ext(R_out + (size_t)w * out_stride + j, run, q);
 }
 
 // result = sum_w 2^(C w) T_w  (Horner, one lane: 256 inherently sequential doublings);  encode.
 __global__ void __launch_bounds__(64)
 k_pip_combine(int W1, int C, const dev_ext* __restrict__ T, const uint32_t* __restrict__ invalid,
               uint8_t* __restrict__ out_point, uint32_t* __restrict__ status) {
-  if (threadIdx.x != 0) return;
-  ge_p3 acc, t;
-  load_ext(acc, T + (W1 - 1));
-  ge_pin_vgpr(acc);                 // uniform data: keep the arithmetic on the VALU (see dev_layout.h)
+  if (threadIdx.x >= 4) return;                    // one quad of lanes (quad.h)
+  const int q = (int)threadIdx.x;
+  qpt acc, t;
+  q_load_ext(acc, T + (W1 - 1), q);
 #pragma unroll 1
   for (int k = W1 - 2; k >= 0; --k) {
 #pragma unroll 1
-    for (int d = 0; d < C - 1; ++d) ge_double<false>(acc, acc);
-    ge_double<true>(acc, acc);
-    load_ext(t, T + k);
-    ge_pin_vgpr(t);
-    ge_add_p3(acc, acc, t);
+    for (int d = 0; d < C; ++d) q_double(acc, acc, q);
+    q_load_ext(t, T + k, q);
+    q_add(acc, acc, t, q);
   }
+  ge_p3 full;
+  q_gather(full, acc);
   uint32_t o[8];
-  ristretto_encode(o, acc);
+  ristretto_encode(o, full);
+  if (q != 0) return;
   const uint32_t bad = *invalid;
   if (bad) {
 #pragma unroll
@@ -434,6 +507,40 @@ k_pip_combine(int W1, int C, const dev_ext* __restrict__ T, const uint32_t* __re
   }
   store_vec<2>(out_point, o);
   *status = bad ? 1u : 0u;
+}
+
+// self-test hook for the 4-lane cooperative arithmetic: for pair i (P, Q): out[i] = enc(2P), enc(P+Q), enc(P+Q) via the
+// niels form of Q, enc(P-Q) via the negated niels form
+__global__ void __launch_bounds__(256, 2)
+k_debug_quad(uint32_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ out) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = gt >> 2;
+  const int q = (int)(gt & 3u);
+  if (i >= n) return;
+  uint32_t w[8];
+  ge_p3 P, Q, R;
+  load_vec<2>(w, enc + 64 * (size_t)i);
+  ristretto_decode(P, w);
+  load_vec<2>(w, enc + 64 * (size_t)i + 32);
+  ristretto_decode(Q, w);
+  // stage the operands through LDS-free scratch: build quad forms from the full points of this lane
+  qpt p, s, r;
+  p.c = q == 0 ? P.X : (q == 1 ? P.Y : (q == 2 ? P.Z : P.T));
+  s.c = q == 0 ? Q.X : (q == 1 ? Q.Y : (q == 2 ? Q.Z : Q.T));
+  __shared__ dev_niels nl[64];
+  ge_niels qn;
+  ge_affine_to_niels(qn, Q);
+  if (q == 0) store_niels(&nl[threadIdx.x >> 2], qn, 1u);
+  __syncthreads();
+  uint32_t o[8];
+  for (int op = 0; op < 4; ++op) {
+    if (op == 0) q_double(r, p, q);
+    else if (op == 1) q_add(r, p, s, q);
+    else { qcached c; q_load_niels(c, &nl[threadIdx.x >> 2], q, op == 3 ? 1u : 0u); q_add_cached(r, p, c, q); }
+    q_gather(R, r);
+    ristretto_encode(o, R);
+    if (q == 0) store_vec<2>(out + 128 * (size_t)i + 32 * op, o);
+  }
 }
 
 // =============================================================================================
@@ -611,6 +718,9 @@ template <int C>
 size_t pip_vmax(uint64_t n) { return (size_t)(n / pip_part_len(n)) + pip_cfg<C>::B1 + 1; }
 
 template <int C>
+uint32_t pip_tiles(uint64_t n) { return (uint32_t)((n + sort_cfg<C>::TILE - 1) / sort_cfg<C>::TILE); }
+
+template <int C>
 size_t pip_ws(uint64_t n) {
   using cfg = pip_cfg<C>;
   carve cv;
@@ -619,6 +729,7 @@ size_t pip_ws(uint64_t n) {
   cv.take((size_t)cfg::W1 * n * 4);            // sorted
   cv.take((size_t)cfg::W1 * cfg::B1 * 4 * 3);  // hist, start, cursor
   cv.take((size_t)cfg::W1 * (cfg::B1 + 1) * 4);               // vstart
+  cv.take((size_t)cfg::W1 * pip_tiles<C>(n) * cfg::B1 * 4);   // tile histograms / tile base offsets
   cv.take((size_t)cfg::W1 * pip_vmax<C>(n) * sizeof(dev_ext)); // bucket parts
   cv.take(256);                                // invalid flag
   cv.take((size_t)cfg::W1 * cfg::B1 * sizeof(dev_ext));       // buckets
@@ -641,6 +752,8 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   uint32_t* start = hist + nb;
   uint32_t* cursor = start + nb;
   uint32_t* vstart = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * (cfg::B1 + 1) * 4));
+  const uint32_t tiles = pip_tiles<C>(n);
+  uint32_t* tilehist = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * tiles * cfg::B1 * 4));
   const uint32_t L = pip_part_len(n);
   const size_t vmax = pip_vmax<C>(n);
   dev_ext* parts = reinterpret_cast<dev_ext*>(base + cv.take((size_t)cfg::W1 * vmax * sizeof(dev_ext)));
@@ -651,16 +764,18 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   dev_ext* lvlR = lvlA + lvl_cap;
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
 
-  HIP_TRY(hipMemsetAsync(hist, 0, nb * 4, c->stream));
   HIP_TRY(hipMemsetAsync(invalid, 0, 4, c->stream));
-  hipLaunchKernelGGL(k_pip_prepare<C>, grid1(n, 256), dim3(256), 0, c->stream, n, d_scalars, d_points, niels, digits, hist, invalid);
+  hipLaunchKernelGGL(k_pip_prepare<C>, grid1(n, 256), dim3(256), 0, c->stream, n, d_scalars, d_points, niels, digits, invalid);
   prof_mark(c, ZKP_K_DECODE);
+  hipLaunchKernelGGL(k_pip_tile_hist<C>, dim3(tiles, cfg::W1), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist);
+  hipLaunchKernelGGL(k_pip_tile_total, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, tiles, (uint32_t)nb, tilehist, hist);
   hipLaunchKernelGGL(k_pip_scan, dim3(cfg::W1), dim3(256), 0, c->stream, cfg::B1, L, hist, start, cursor, vstart);
-  hipLaunchKernelGGL(k_pip_scatter, dim3((n + 255) / 256, cfg::W1), dim3(256), 0, c->stream, n, cfg::B1, digits, cursor, sorted);
+  hipLaunchKernelGGL(k_pip_tile_base, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, tiles, (uint32_t)nb, start, tilehist);
+  hipLaunchKernelGGL(k_pip_tile_scatter<C>, dim3(tiles, cfg::W1), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist, sorted);
   prof_mark(c, ZKP_K_SORT);
   hipLaunchKernelGGL(k_pip_bucket_part, dim3((unsigned)((vmax + 255) / 256), cfg::W1), dim3(256), 0, c->stream, n, cfg::B1, L, (uint32_t)vmax,
                      start, hist, vstart, sorted, niels, parts);
-  hipLaunchKernelGGL(k_pip_bucket_merge, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, (uint32_t)nb, (uint32_t)vmax, vstart, parts, buckets);
+  hipLaunchKernelGGL(k_pip_bucket_merge, grid1(nb * 4, 256), dim3(256), 0, c->stream, cfg::B1, (uint32_t)nb, (uint32_t)vmax, vstart, parts, buckets);
   prof_mark(c, ZKP_K_BUCKET);
   // radix-8 tree over bucket indices 0 .. B-1 (bucket B is added in k_pip_combine)
   const dev_ext* Ain = nullptr;
@@ -674,7 +789,7 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
     dev_ext* Aout = lvlA + lvl_off;
     dev_ext* Rout = lvlR + lvl_off;
     const uint32_t total = cfg::W1 * n_out;
-    hipLaunchKernelGGL(k_pip_reduce_lvl, grid1(total, 256), dim3(256), 0, c->stream, n_out, total, in_stride, n_out, level, Ain, Rin, Aout, Rout);
+    hipLaunchKernelGGL(k_pip_reduce_lvl, grid1((size_t)total * 4, 256), dim3(256), 0, c->stream, n_out, total, in_stride, n_out, level, Ain, Rin, Aout, Rout);
     Ain = Aout;
     Rin = Rout;
     in_stride = n_out;
@@ -1025,6 +1140,24 @@ int zkp_decode_check(zkp_ctx* c, uint64_t n, const uint8_t* points, uint8_t* sta
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(status, base + o_st, (size_t)n, hipMemcpyDeviceToHost, c->stream));
   if (xyzt) HIP_TRY(hipMemcpyAsync(xyzt, base + o_xyzt, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+}
+
+int zkp_debug_quad_selftest(zkp_ctx* c, uint32_t n, const uint8_t* pairs, uint8_t* out) {
+  if (!c || !pairs || !out) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (n == 0) return ZKP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  carve cv;
+  const size_t o_in = cv.take((size_t)n * 64);
+  const size_t o_out = cv.take((size_t)n * 128);
+  const int rc = ensure_ws(c, cv.off);
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  HIP_TRY(hipMemcpyAsync(base + o_in, pairs, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_debug_quad, grid1((size_t)n * 4, 256), dim3(256), 0, c->stream, n, reinterpret_cast<uint8_t*>(base + o_in), reinterpret_cast<uint8_t*>(base + o_out));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, base + o_out, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ZKP_OK;
 }

@@ -22,7 +22,7 @@ EXPORTS = (
     "zkp_ctx_create", "zkp_ctx_destroy", "zkp_ctx_set_stream", "zkp_ctx_synchronize", "zkp_last_error",
     "zkp_version", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
-    "zkp_ctx_prepare_fixed_points",
+    "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest",
 )
 
 
@@ -59,6 +59,7 @@ def load_library() -> ctypes.CDLL:
     lib.zkp_ctx_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.zkp_ctx_set_profiling.argtypes = [vp, i32]
     lib.zkp_ctx_prepare_fixed_points.argtypes = [vp, ctypes.c_uint32, u8p]
+    lib.zkp_debug_quad_selftest.argtypes = [vp, ctypes.c_uint32, u8p, u8p]
     _lib = lib
     return lib
 
@@ -145,6 +146,12 @@ class Engine:
         xyzt = _u8(xyzt, 128) if len(xyzt) else np.zeros((0, 128), np.uint8)
         out = np.zeros((len(xyzt), 32), np.uint8)
         _check(self._lib.zkp_encode_many(self._h, len(xyzt), _ptr(xyzt), _ptr(out)), "zkp_encode_many")
+        return out
+
+    def debug_quad_selftest(self, pairs) -> np.ndarray:
+        pairs = _u8(pairs, 64)
+        out = np.zeros((len(pairs), 4, 32), np.uint8)
+        _check(self._lib.zkp_debug_quad_selftest(self._h, len(pairs), _ptr(pairs), _ptr(out)), "zkp_debug_quad_selftest")
         return out
 
     def prepare_fixed_points(self, encodings) -> None:

@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU per step (BASELINE configs[1]: 4096)")
+    ap.add_argument("--streams", type=int, default=4, help="independent batches in flight, each on its own HIP stream / engine context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,6 +90,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     eng = Engine(local_rank)
+    engines = [eng] + [Engine(local_rank) for _ in range(max(1, args.streams) - 1)]
 
     n = args.batch
     rng = np.random.default_rng(1000 + rank)
@@ -103,7 +105,8 @@ def main():
     off, pidx, n_pts = cmz_shape(n)
     pts, st = eng.msm_many(np.arange(n_pts + 1, dtype=np.uint32), rand_scalars(n_pts), np.zeros(n_pts, np.uint32), base, ZKP_CT)
     assert not st.any()
-    eng.prepare_fixed_points(pts[:11])         # the issuer parameters X_1..X_10, A are common to every proof (benches/zkp.rs:32)
+    for e_ in engines:                         # the issuer parameters X_1..X_10, A are common to every proof (benches/zkp.rs:32)
+        e_.prepare_fixed_points(pts[:11])
     n_msm, n_terms = 11 * n, 31 * n
     blind = rand_scalars(n_terms)              # the blinding scalars b[sc_var] of prover.rs:95
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -128,27 +131,39 @@ def main():
     d_bv_pts[12 + 13 * n:] = d_coms
     torch.cuda.synchronize()
 
-    def step():
-        eng.msm_many_dev(n_msm, d_off.data_ptr(), d_blind.data_ptr(), d_pidx.data_ptr(), d_pts.data_ptr(), n_pts, n_terms,
-                         ZKP_CT, d_coms.data_ptr(), d_cstat.data_ptr())
-        eng.msm_optional_dev(n_bv, d_bv_sc.data_ptr(), d_bv_pts.data_ptr(), d_bv_out.data_ptr(), d_bv_st.data_ptr())
+    # per-stream output buffers; inputs are shared (read-only)
+    outs = [(d_coms, d_cstat, d_bv_out, d_bv_st)] + [
+        (torch.zeros_like(d_coms), torch.zeros_like(d_cstat), torch.zeros_like(d_bv_out), torch.zeros_like(d_bv_st)) for _ in engines[1:]]
+
+    def step(i):
+        # one batch: (i) commitments of all N proofs, (ii) the batch-verification MSM.  Consecutive batches go to
+        # different engine contexts = different HIP streams, so the single-wave tails of one batch (Horner, reduction
+        # tree) overlap with the wide kernels of the next.
+        e_ = engines[i % len(engines)]
+        coms, cstat, bv_out, bv_st = outs[i % len(engines)]
+        e_.msm_many_dev(n_msm, d_off.data_ptr(), d_blind.data_ptr(), d_pidx.data_ptr(), d_pts.data_ptr(), n_pts, n_terms,
+                        ZKP_CT, coms.data_ptr(), cstat.data_ptr())
+        e_.msm_optional_dev(n_bv, d_bv_sc.data_ptr(), d_bv_pts.data_ptr(), bv_out.data_ptr(), bv_st.data_ptr())
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        eng.synchronize()
+        for e_ in engines:
+            e_.synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup * len(engines)):
+        step(i)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     if dist is not None:
         # the only cross-GPU exchange of the path: AND of the per-GPU verdict bits (int32 MIN all-reduce over RCCL)
-        eng.synchronize()
-        verdict.copy_((d_bv_st == 0).to(torch.int32))
+        for e_ in engines:
+            e_.synchronize()
+        ok_local = all(int(o[3].item()) == 0 for o in outs)
+        verdict.fill_(1 if ok_local else 0)
         dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -156,7 +171,9 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert not bool(d_cstat.any().item()) and int(d_bv_st.item()) == 0, "engine reported a decode failure on valid inputs"
+    for o in outs:
+        assert not bool(o[1].any().item()) and int(o[3].item()) == 0, "engine reported a decode failure on valid inputs"
+    assert all(bool((o[0] == outs[0][0]).all().item()) and bool((o[2] == outs[0][2]).all().item()) for o in outs), "streams disagree"
 
     # ---- per-kernel timing with HIP events on the engine's stream (separate, profiled passes) ---------
     eng.set_profiling(True)
@@ -206,7 +223,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "CMZ'13 10-hidden-attribute credential, batch of %d proofs per GPU: prover commitment MSMs "
                                "(11 MSMs / 31 terms per proof, constant-time) + one batch-verification MSM (12 + 24 N terms)" % n,
-                   "batch_per_gpu": n, "sharding": "independent proof ranges per GPU, AND of verdict bits"},
+                   "batch_per_gpu": n, "streams": len(engines), "sharding": "independent proof ranges per GPU, AND of verdict bits"},
         "prove_proofs_per_s": world * n / (k_prove["total"] * 1e-3),
         "batch_verifies_per_s": world * n / (k_verify["total"] * 1e-3),
         "kernel_ms": {"prove": k_prove, "batch_verify": k_verify},

@@ -11,32 +11,49 @@ constexpr uint64_t kRoundConstants[24] = {
     0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
     0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
     0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-inline uint64_t rotl(uint64_t x, unsigned n) { return n ? (x << n) | (x >> (64 - n)) : x; }
 }  // namespace
 
-// Straightforward theta / rho+pi / chi / iota on a 5x5 lane matrix A[x + 5y]; rho offsets are generated from
-// the (x, y) -> (y, 2x + 3y) walk of the specification rather than tabulated.
+// Keccak-f[1600] on 25 named lanes (A[x + 5y]), rho/pi written out with constant rotation amounts so the compiler
+// keeps the state in registers: this is the host's hot loop once the MSMs live on the GPU (59 permutations per CMZ proof).
+#define KROT(v, n) (((v) << (n)) | ((v) >> (64 - (n))))
 void keccak_f1600(uint64_t A[25]) {
+  uint64_t a00 = A[0], a10 = A[1], a20 = A[2], a30 = A[3], a40 = A[4];
+  uint64_t a01 = A[5], a11 = A[6], a21 = A[7], a31 = A[8], a41 = A[9];
+  uint64_t a02 = A[10], a12 = A[11], a22 = A[12], a32 = A[13], a42 = A[14];
+  uint64_t a03 = A[15], a13 = A[16], a23 = A[17], a33 = A[18], a43 = A[19];
+  uint64_t a04 = A[20], a14 = A[21], a24 = A[22], a34 = A[23], a44 = A[24];
   for (int round = 0; round < 24; ++round) {
-    uint64_t Cx[5], D[5];
-    for (int x = 0; x < 5; ++x) Cx[x] = A[x] ^ A[x + 5] ^ A[x + 10] ^ A[x + 15] ^ A[x + 20];
-    for (int x = 0; x < 5; ++x) D[x] = Cx[(x + 4) % 5] ^ rotl(Cx[(x + 1) % 5], 1);
-    for (int i = 0; i < 25; ++i) A[i] ^= D[i % 5];
-    uint64_t B[25];
-    B[0] = A[0];
-    int x = 1, y = 0;
-    for (int t = 0; t < 24; ++t) {
-      const unsigned r = (unsigned)(((t + 1) * (t + 2) / 2) % 64);
-      const int nx = y, ny = (2 * x + 3 * y) % 5;
-      B[nx + 5 * ny] = rotl(A[x + 5 * y], r);
-      x = nx;
-      y = ny;
-    }
-    for (int yy = 0; yy < 25; yy += 5)
-      for (int xx = 0; xx < 5; ++xx) A[yy + xx] = B[yy + xx] ^ (~B[yy + (xx + 1) % 5] & B[yy + (xx + 2) % 5]);
-    A[0] ^= kRoundConstants[round];
+    // theta
+    const uint64_t c0 = a00 ^ a01 ^ a02 ^ a03 ^ a04, c1 = a10 ^ a11 ^ a12 ^ a13 ^ a14, c2 = a20 ^ a21 ^ a22 ^ a23 ^ a24,
+                   c3 = a30 ^ a31 ^ a32 ^ a33 ^ a34, c4 = a40 ^ a41 ^ a42 ^ a43 ^ a44;
+    const uint64_t d0 = c4 ^ KROT(c1, 1), d1 = c0 ^ KROT(c2, 1), d2 = c1 ^ KROT(c3, 1), d3 = c2 ^ KROT(c4, 1), d4 = c3 ^ KROT(c0, 1);
+    a00 ^= d0; a01 ^= d0; a02 ^= d0; a03 ^= d0; a04 ^= d0;
+    a10 ^= d1; a11 ^= d1; a12 ^= d1; a13 ^= d1; a14 ^= d1;
+    a20 ^= d2; a21 ^= d2; a22 ^= d2; a23 ^= d2; a24 ^= d2;
+    a30 ^= d3; a31 ^= d3; a32 ^= d3; a33 ^= d3; a34 ^= d3;
+    a40 ^= d4; a41 ^= d4; a42 ^= d4; a43 ^= d4; a44 ^= d4;
+    // rho + pi:  B[y][2x+3y] = rot(A[x][y], r[x][y])
+    const uint64_t b00 = a00,           b13 = KROT(a01, 36), b21 = KROT(a02, 3),  b34 = KROT(a03, 41), b42 = KROT(a04, 18);
+    const uint64_t b02 = KROT(a10, 1),  b10 = KROT(a11, 44), b23 = KROT(a12, 10), b31 = KROT(a13, 45), b44 = KROT(a14, 2);
+    const uint64_t b04 = KROT(a20, 62), b12 = KROT(a21, 6),  b20 = KROT(a22, 43), b33 = KROT(a23, 15), b41 = KROT(a24, 61);
+    const uint64_t b01 = KROT(a30, 28), b14 = KROT(a31, 55), b22 = KROT(a32, 25), b30 = KROT(a33, 21), b43 = KROT(a34, 56);
+    const uint64_t b03 = KROT(a40, 27), b11 = KROT(a41, 20), b24 = KROT(a42, 39), b32 = KROT(a43, 8),  b40 = KROT(a44, 14);
+    // chi
+    a00 = b00 ^ (~b10 & b20); a10 = b10 ^ (~b20 & b30); a20 = b20 ^ (~b30 & b40); a30 = b30 ^ (~b40 & b00); a40 = b40 ^ (~b00 & b10);
+    a01 = b01 ^ (~b11 & b21); a11 = b11 ^ (~b21 & b31); a21 = b21 ^ (~b31 & b41); a31 = b31 ^ (~b41 & b01); a41 = b41 ^ (~b01 & b11);
+    a02 = b02 ^ (~b12 & b22); a12 = b12 ^ (~b22 & b32); a22 = b22 ^ (~b32 & b42); a32 = b32 ^ (~b42 & b02); a42 = b42 ^ (~b02 & b12);
+    a03 = b03 ^ (~b13 & b23); a13 = b13 ^ (~b23 & b33); a23 = b23 ^ (~b33 & b43); a33 = b33 ^ (~b43 & b03); a43 = b43 ^ (~b03 & b13);
+    a04 = b04 ^ (~b14 & b24); a14 = b14 ^ (~b24 & b34); a24 = b24 ^ (~b34 & b44); a34 = b34 ^ (~b44 & b04); a44 = b44 ^ (~b04 & b14);
+    // iota
+    a00 ^= kRoundConstants[round];
   }
+  A[0] = a00; A[1] = a10; A[2] = a20; A[3] = a30; A[4] = a40;
+  A[5] = a01; A[6] = a11; A[7] = a21; A[8] = a31; A[9] = a41;
+  A[10] = a02; A[11] = a12; A[12] = a22; A[13] = a32; A[14] = a42;
+  A[15] = a03; A[16] = a13; A[17] = a23; A[18] = a33; A[19] = a43;
+  A[20] = a04; A[21] = a14; A[22] = a24; A[23] = a34; A[24] = a44;
 }
+#undef KROT
 
 // ---- STROBE-128 (v1.0.2), exactly the subset Merlin uses -------------------------------------------
 Strobe128::Strobe128(const char* protocol_label) {

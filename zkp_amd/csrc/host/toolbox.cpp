@@ -9,6 +9,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -37,19 +40,81 @@ namespace {
 
 constexpr size_t TB = ZKP_TRANSCRIPT_BYTES;
 
+// Persistent worker pool: the three host phases of a batch call (prefix, phase A, phase B) would otherwise each
+// pay thread creation for up to 64 threads (~1-2 ms, more than the GPU part of the call).
+class Pool {
+ public:
+  static Pool& instance() { static Pool p; return p; }
+  // runs fn(0) .. fn(k-1) concurrently (fn(0) on the calling thread) and returns when all are done
+  void run(unsigned k, const std::function<void(unsigned)>& fn) {
+    if (k <= 1) { fn(0); return; }
+    std::unique_lock<std::mutex> call_lock(call_mu_);          // one parallel region at a time
+    ensure_workers(k - 1);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = &fn;
+      active_ = k - 1;
+      pending_ = k - 1;
+      ++generation_;
+    }
+    cv_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+
+ private:
+  void ensure_workers(unsigned k) {
+    while (workers_.size() < k) {
+      const unsigned id = (unsigned)workers_.size();
+      unsigned gen;
+      { std::lock_guard<std::mutex> lk(mu_); gen = generation_; }
+      workers_.emplace_back([this, id, gen] { loop(id, gen); });
+    }
+  }
+  void loop(unsigned id, unsigned seen) {
+    for (;;) {
+      const std::function<void(unsigned)>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+        if (id < active_) job = job_;
+      }
+      if (job) {
+        (*job)(id + 1);
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--pending_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  std::mutex call_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> workers_;
+  const std::function<void(unsigned)>* job_ = nullptr;
+  unsigned active_ = 0, pending_ = 0, generation_ = 0;
+  bool stop_ = false;
+};
+
 template <typename F>
 void parallel_for(uint32_t n, int n_threads, F&& body) {
   unsigned t = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
   if (t == 0) t = 1;
-  t = std::min<unsigned>(t, (n + 63) / 64 ? (n + 63) / 64 : 1);      // at least ~64 proofs per thread
+  t = std::min<unsigned>(t, (n + 31) / 32 ? (n + 31) / 32 : 1);      // at least ~32 proofs per thread
+  t = std::min<unsigned>(t, 128);
   if (t <= 1) { body(0u, n); return; }
-  std::vector<std::thread> pool;
   const uint32_t chunk = (n + t - 1) / t;
-  for (unsigned k = 0; k < t; ++k) {
+  Pool::instance().run(t, [&](unsigned k) {
     const uint32_t lo = std::min<uint32_t>(n, k * chunk), hi = std::min<uint32_t>(n, lo + chunk);
-    if (lo < hi) pool.emplace_back([&body, lo, hi] { body(lo, hi); });
-  }
-  for (auto& th : pool) th.join();
+    if (lo < hi) body(lo, hi);
+  });
 }
 
 void os_random(uint8_t* out, size_t len) {
@@ -434,7 +499,7 @@ int zkp_batch_verify_build(const zkp_statement* stp, uint32_t N, uint32_t n_tran
   std::vector<std::vector<Scalar>> static_parts;
   std::vector<Scalar> static_total(ns);
   std::atomic<unsigned> slot{0};
-  static_parts.resize(n_workers + 1, std::vector<Scalar>(ns));
+  static_parts.resize(std::max(n_workers, 128u) + 1, std::vector<Scalar>(ns));
   parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
     std::vector<Scalar>& sp = static_parts[slot.fetch_add(1) % static_parts.size()];
     std::vector<Scalar> col(rows);

@@ -57,14 +57,18 @@ def test_create_and_verify_compact(eng):
     x, points = _dleq_assignments()
     transcript = T.Transcript(b"DLEQTest")
     proof = dleq.prove_compact(eng, transcript, {"x": x}, points)
+    # Serialize and parse the bincode representation (tests/zkp.rs:53-54)
+    proof_bytes = proof.to_bytes()
+    assert len(proof_bytes) == 32 + 8 + 32
+    parsed_proof = T.CompactProof.from_bytes(proof_bytes)
     transcript = T.Transcript(b"DLEQTest")
-    dleq.verify_compact(eng, proof, transcript, points)             # is_ok()
-    assert len(proof.challenge) == 32 and len(proof.responses) == 1
+    dleq.verify_compact(eng, parsed_proof, transcript, points)      # is_ok()
 
 
 def test_create_and_verify_batchable(eng):
     x, points = _dleq_assignments()
     proof = dleq.prove_batchable(eng, T.Transcript(b"DLEQTest"), {"x": x}, points)
+    proof = T.BatchableProof.from_bytes(proof.to_bytes())           # tests/zkp.rs:96-97
     dleq.verify_batchable(eng, proof, T.Transcript(b"DLEQTest"), points)
 
 

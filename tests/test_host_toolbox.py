@@ -200,3 +200,21 @@ def test_batch_verify_build_constraint_api_order():
     rc, es, ep = C.batch_verify(cst, label, n, inst, common, coms, resps, w16, want_msm_inputs=True)
     assert rc == 0 and (ms == es).all() and (mp == ep).all()
     assert C.msm_optional(ms, mp) == bytes(32)
+
+
+def test_proof_wire_format_roundtrip_and_rejects():
+    rng = random.Random(12)
+    r = [sc(rng.randrange(M.L)) for _ in range(3)]
+    cp = T.CompactProof(sc(rng.randrange(M.L)), r)
+    assert T.CompactProof.from_bytes(cp.to_bytes()) == cp and len(cp.to_bytes()) == 32 + 8 + 96
+    bp = T.BatchableProof([bytes([i]) * 32 for i in range(1, 3)], r)
+    assert T.BatchableProof.from_bytes(bp.to_bytes()) == bp and len(bp.to_bytes()) == 8 + 64 + 8 + 96
+    assert T.CompactProof.from_bytes(T.CompactProof(sc(0), []).to_bytes()).responses == []
+    for bad in (cp.to_bytes()[:-1], cp.to_bytes() + b"\0", b"", cp.to_bytes()[:32] + (1 << 60).to_bytes(8, "little")):
+        with pytest.raises(ValueError):
+            T.CompactProof.from_bytes(bad)
+    noncanon = T.CompactProof(M.L.to_bytes(32, "little"), r).to_bytes()         # challenge == l: dalek's from_canonical_bytes refuses
+    with pytest.raises(ValueError):
+        T.CompactProof.from_bytes(noncanon)
+    with pytest.raises(ValueError):
+        T.BatchableProof.from_bytes(T.BatchableProof([], [((1 << 256) - 1).to_bytes(32, "little")]).to_bytes())

@@ -122,16 +122,63 @@ class Transcript:
         return out.raw
 
 
+def _scalar_canonical(b: bytes) -> bool:
+    return len(b) == 32 and int.from_bytes(b, "little") < L
+
+
+def _read_vec32(buf: bytes, pos: int):
+    """bincode Vec<[u8; 32]-like>: u64 little-endian element count, then the elements back to back."""
+    if pos + 8 > len(buf):
+        raise ValueError("truncated proof")
+    n = int.from_bytes(buf[pos:pos + 8], "little")
+    pos += 8
+    if n > (len(buf) - pos) // 32:
+        raise ValueError("truncated proof")
+    return [buf[pos + 32 * i:pos + 32 * i + 32] for i in range(n)], pos + 32 * n
+
+
 @dataclass
 class CompactProof:            # src/proofs.rs:15-20
     challenge: bytes
     responses: List[bytes]
+
+    # Wire format = what `bincode::serialize` (bincode 1.x defaults: fixed-width little-endian integers, u64 sequence
+    # lengths) produces for the serde-derived struct (proofs.rs:14): Scalar serialises as a 32-byte tuple (no length),
+    # Vec<Scalar> as u64 length + elements.  The reference's tests only round-trip it (tests/zkp.rs:53-54), so there
+    # are no golden bytes to pin; dalek rejects non-canonical scalars on deserialisation, and so does from_bytes.
+    def to_bytes(self) -> bytes:
+        return self.challenge + len(self.responses).to_bytes(8, "little") + b"".join(self.responses)
+
+    @classmethod
+    def from_bytes(cls, buf: bytes) -> "CompactProof":
+        if len(buf) < 32:
+            raise ValueError("truncated proof")
+        resp, pos = _read_vec32(buf, 32)
+        if pos != len(buf):
+            raise ValueError("trailing bytes")
+        if not _scalar_canonical(buf[:32]) or not all(_scalar_canonical(r) for r in resp):
+            raise ValueError("scalar was not canonically encoded")
+        return cls(buf[:32], resp)
 
 
 @dataclass
 class BatchableProof:          # src/proofs.rs:27-32
     commitments: List[bytes]
     responses: List[bytes]
+
+    def to_bytes(self) -> bytes:
+        return (len(self.commitments).to_bytes(8, "little") + b"".join(self.commitments) +
+                len(self.responses).to_bytes(8, "little") + b"".join(self.responses))
+
+    @classmethod
+    def from_bytes(cls, buf: bytes) -> "BatchableProof":
+        coms, pos = _read_vec32(buf, 0)
+        resp, pos = _read_vec32(buf, pos)
+        if pos != len(buf):
+            raise ValueError("trailing bytes")
+        if not all(_scalar_canonical(r) for r in resp):
+            raise ValueError("scalar was not canonically encoded")
+        return cls(coms, resp)      # CompressedRistretto deserialises from any 32 bytes; validity is checked at decompress
 
 
 class Statement:

@@ -110,12 +110,17 @@ __device__ __forceinline__ uint32_t term_class(uint32_t t, const uint32_t* pidx,
 }
 __global__ void __launch_bounds__(256)
 k_class_count(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_points, const int32_t* __restrict__ hotmap,
-              uint32_t* __restrict__ class_cnt) {
+              uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ needs_comb) {
   __shared__ uint32_t h[HOT_CLASSES];
   if (threadIdx.x < HOT_CLASSES) h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n_terms) atomicAdd(&h[term_class(t, pidx, n_points, hotmap)], 1u);
+  if (t < n_terms) {
+    const uint32_t c = term_class(t, pidx, n_points, hotmap);
+    atomicAdd(&h[c], 1u);
+    const uint32_t pi = pidx[t];
+    if (c == (uint32_t)HOT_SLOTS && pi < n_points) needs_comb[pi] = 1u;      // this point gets a comb table (comb_tables.h)
+  }
   __syncthreads();
   if (threadIdx.x < HOT_CLASSES && h[threadIdx.x]) atomicAdd(&class_cnt[threadIdx.x], h[threadIdx.x]);
 }

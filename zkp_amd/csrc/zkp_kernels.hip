@@ -57,6 +57,7 @@ __device__ __forceinline__ uint32_t sel8(const uint32_t w[8], int j) {
 
 #include "hot_tables.h"
 #include "quad.h"
+#include "comb_tables.h"
 
 // =============================================================================================
 // (A) small-MSM path
@@ -121,18 +122,22 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
   if (t < n_terms) term_generic(t, scalars, pidx, n_points, pts, partial);
 }
 
-// Classified terms in ONE launch: the first blocks take the generic terms (long: 384 point operations per lane), the
-// remaining blocks the fixed-base terms (65 mixed additions), so the short jobs fill the SIMDs the long ones leave idle.
+// Classified terms in ONE launch: the first blocks take the terms on per-proof points (comb tables: 128 point operations
+// per lane), the remaining blocks the fixed-base terms (65 mixed additions), which fill the SIMDs the former leave idle.
 template <bool CT>
 __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
-              const dev_affine* __restrict__ pts, const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ list,
+              const dev_ext* __restrict__ comb, const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ list,
               const int32_t* __restrict__ hotmap, const dev_niels* __restrict__ tables, dev_ext* __restrict__ partial) {
   const uint32_t n_hot = class_start[HOT_SLOTS], n_cold = class_start[HOT_CLASSES] - n_hot;
   const uint32_t cold_blocks = (n_cold + blockDim.x - 1) / blockDim.x;
   if (blockIdx.x < cold_blocks) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_cold) term_generic(list[n_hot + i], scalars, pidx, n_points, pts, partial);
+    if (i < n_cold) {
+      const uint32_t t = list[n_hot + i];
+      const uint32_t pi = pidx[t];
+      if (pi < n_points) term_comb<CT>(t, scalars, comb + (size_t)pi * COMB_ENTRIES, partial);   // (out of range: flagged by k_reduce_encode)
+    }
   } else {
     const uint32_t i = (blockIdx.x - cold_blocks) * blockDim.x + threadIdx.x;
     if (i < n_hot) {
@@ -665,6 +670,8 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
   const size_t o_hot = cv.take((size_t)n_points * 4);
   const size_t o_cls = cv.take(256 * 4);
   const size_t o_list = cv.take((size_t)n_terms * 4);
+  const size_t o_needs = cv.take((size_t)n_points * 4);
+  const size_t o_comb = cv.take(n_terms >= 1024 ? (size_t)n_points * COMB_ENTRIES * sizeof(dev_ext) : 0);
   // ensure_ws was done by the caller for ws_reserved + this much; recompute defensively
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
   char* base = static_cast<char*>(c->ws);
@@ -672,22 +679,30 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
   dev_ext* part = reinterpret_cast<dev_ext*>(base + o_part);
   if (n_points) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts);
   prof_mark(c, ZKP_K_DECODE);
-  if (n_terms && c->hot_nreg && n_terms >= 1024) {
-    // split the terms: those on a registered fixed-base point (grouped by table) / the rest
+  if (n_terms >= 1024) {
+    // split the terms: those on a registered fixed-base point (grouped by table) / the rest, which go through per-point
+    // comb tables built here for exactly the points they reference
     int32_t* hotmap = reinterpret_cast<int32_t*>(base + o_hot);
     uint32_t* cls = reinterpret_cast<uint32_t*>(base + o_cls);     // cnt[65] | start[66] | cursor[65] | any
     uint32_t* class_cnt = cls, *class_start = cls + 80, *cursor = cls + 160, *any_hot = cls + 240;
     uint32_t* list = reinterpret_cast<uint32_t*>(base + o_list);
+    uint32_t* needs = reinterpret_cast<uint32_t*>(base + o_needs);
+    dev_ext* comb = reinterpret_cast<dev_ext*>(base + o_comb);
     HIP_TRY(hipMemsetAsync(cls, 0, 256 * 4, c->stream));
-    hipLaunchKernelGGL(k_hot_match, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, c->hot_nreg, c->hot_reg_words, c->hot_reg_slot, hotmap, any_hot);
-    hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, class_cnt);
+    HIP_TRY(hipMemsetAsync(needs, 0, (size_t)n_points * 4, c->stream));
+    if (c->hot_nreg)
+      hipLaunchKernelGGL(k_hot_match, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, c->hot_nreg, c->hot_reg_words, c->hot_reg_slot, hotmap, any_hot);
+    else
+      HIP_TRY(hipMemsetAsync(hotmap, 0xff, (size_t)n_points * 4, c->stream));
+    hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, class_cnt, needs);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor);
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, cursor, list);
+    hipLaunchKernelGGL(k_comb_tables, grid1((size_t)n_points * 4, 256), dim3(256), 0, c->stream, n_points, needs, pts, comb);
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 1));
     if (flags == ZKP_CT)
-      hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, pts, class_start, list, hotmap, c->hot_tables, part);
+      hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, part);
     else
-      hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, pts, class_start, list, hotmap, c->hot_tables, part);
+      hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, part);
   } else if (n_terms) {
     hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part);
   }
@@ -709,6 +724,8 @@ size_t terms_path_ws(uint32_t n_points, uint32_t n_terms) {
   cv.take((size_t)n_points * 4);
   cv.take(256 * 4);
   cv.take((size_t)n_terms * 4);
+  cv.take((size_t)n_points * 4);
+  cv.take(n_terms >= 1024 ? (size_t)n_points * COMB_ENTRIES * sizeof(dev_ext) : 0);
   return cv.off;
 }
 

@@ -128,9 +128,9 @@ def test_msm_many_invalid_point_sets_status(eng, base_points):
     assert out[0].tobytes() != bytes(32)
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 36, 191, 192, 193, 300, 4095, 4096, 5000, 33000, 70000])
+@pytest.mark.parametrize("n", [0, 1, 2, 36, 191, 192, 193, 300, 4095, 4096, 5000, 8191, 8192, 33000, 70000])
 def test_msm_optional_sizes(eng, base_points, n):
-    """Covers the per-term path (n <= 192) and every Pippenger window size (c = 7, 10, 13)."""
+    """Covers the per-term path (n <= 192) and the Pippenger window sizes c = 7, 10, 11 (c = 16: tests/test_gpu_fullsize.py)."""
     rng = random.Random(1000 + n)
     logs, encs = base_points
     idx = [rng.randrange(64) for _ in range(n)]

@@ -373,43 +373,47 @@ k_pip_tile_scatter(uint32_t n, const uint32_t* __restrict__ digits, const uint32
 // Bucket accumulation, load balanced: virtual lane v of window w sums one part (<= L entries) of one
 // bucket.  Buckets are split because digit distributions are NOT uniform in practice: canonical scalars
 // are < 2^253, so the top window only ever uses a few dozen buckets, each holding n/32 .. n/64 points.
+// vmap[w][v] = bucket of virtual lane v (replaces a 13-step binary search over vstart: 13 dependent global loads)
+__global__ void __launch_bounds__(256)
+k_pip_vmap(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t* __restrict__ vstart, uint32_t* __restrict__ vmap) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const uint32_t w = g / bins, b = g - w * bins;
+  const uint32_t* vs = vstart + (size_t)w * (bins + 1);
+  for (uint32_t v = vs[b]; v < vs[b + 1]; ++v) vmap[(size_t)w * vmax + v] = b;
+}
+
 __global__ void __launch_bounds__(256, 2)
 k_pip_bucket_part(uint32_t n, uint32_t bins, uint32_t L, uint32_t vmax, const uint32_t* __restrict__ start,
-                  const uint32_t* __restrict__ hist, const uint32_t* __restrict__ vstart,
+                  const uint32_t* __restrict__ hist, const uint32_t* __restrict__ vstart, const uint32_t* __restrict__ vmap,
                   const uint32_t* __restrict__ sorted, const dev_niels* __restrict__ niels,
                   dev_ext* __restrict__ parts) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t w = blockIdx.y;
   const uint32_t* vs = vstart + (size_t)w * (bins + 1);
   if (v >= vs[bins]) return;
-  // largest b with vs[b] <= v  (vs is non-decreasing; empty buckets repeat a value, so take the last one)
-  uint32_t lo = 0, hi = bins;                 // invariant: vs[lo] <= v < vs[hi]
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (vs[mid] <= v) lo = mid; else hi = mid;
-  }
-  const uint32_t b = lo, g = w * bins + b;
+  const uint32_t b = vmap[(size_t)w * vmax + v], g = w * bins + b;
   const uint32_t pl = part_len(hist[g], L);
   const uint32_t first = (v - vs[b]) * pl;
   const uint32_t cnt = min(pl, hist[g] - first);
   const uint32_t* lst = sorted + (size_t)w * n + start[g] + first;
   ge_p3 acc;
   ge_identity(acc);
-  // software pipelined: the gather of entry k+1 is in flight while entry k is added
-  uint32_t idx_next = cnt ? lst[0] : 0u;
-  ge_niels q_next;
-  ge_niels_identity(q_next);
-  if (cnt) load_niels(q_next, niels + (idx_next & 0x7fffffffu));
+  // ping-pong software pipeline: the gather of the next entry is in flight while the current one is added, and the
+  // two buffers are distinct registers so that no copy (and therefore no early wait) sits between load and use
+  ge_niels qa, qb;
+  uint32_t ia = 0, ib = 0;
+  if (cnt) { ia = lst[0]; load_niels(qa, niels + (ia & 0x7fffffffu)); }
 #pragma unroll 1
-  for (uint32_t k = 0; k < cnt; ++k) {
-    ge_niels q = q_next;
-    const uint32_t idx = idx_next;
+  for (uint32_t k = 0; k < cnt; k += 2) {
+    if (k + 1 < cnt) { ib = lst[k + 1]; load_niels(qb, niels + (ib & 0x7fffffffu)); }
+    ge_niels_cneg(qa, ia >> 31);
+    ge_madd(acc, acc, qa);
     if (k + 1 < cnt) {
-      idx_next = lst[k + 1];
-      load_niels(q_next, niels + (idx_next & 0x7fffffffu));
+      if (k + 2 < cnt) { ia = lst[k + 2]; load_niels(qa, niels + (ia & 0x7fffffffu)); }
+      ge_niels_cneg(qb, ib >> 31);
+      ge_madd(acc, acc, qb);
     }
-    ge_niels_cneg(q, idx >> 31);
-    ge_madd(acc, acc, q);
   }
   store_ext(parts + (size_t)w * vmax + v, acc);
 }
@@ -441,11 +445,12 @@ k_pip_bucket_merge(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t*
   q_store_ext(buckets + g, acc, q);
 }
 
-// One level of the radix-8 evaluation of T = sum_g g * S_g  (g = 0 .. 8^L - 1).
-// Invariant before level l:  T = sum_j ( A_j + 8^l * j * R_j ),  A absent (= 0) at level 0.
-// A lane folds 8 consecutive inputs j = 8j' + i:   R' = sum_i R_i,  A' = sum_i A_i + 8^l * sum_i i R_i.
+// One level of the tree evaluation of T = sum_g g * S_g  (g = 0 .. B-1, B a power of two).
+// Invariant before a level:  T = sum_j ( A_j + M * j * R_j ),  A absent (= 0) and M = 1 at level 0.
+// A quad folds m <= 8 consecutive inputs j = m j' + i:   R' = sum_i R_i,  A' = sum_i A_i + M * sum_i i R_i,  M' = M m.
+// (M = 2^shift; chunk sizes: 8 everywhere except a first level of 2 or 4 when log2 B is not a multiple of 3.)
 __global__ void __launch_bounds__(256, 2)
-k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t out_stride, int level,
+k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t out_stride, int level, int m, int shift,
                  const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
                  dev_ext* __restrict__ A_out, dev_ext* __restrict__ R_out) {
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -453,18 +458,18 @@ k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t ou
   const int q = (int)(gt & 3u);
   if (g >= total) return;
   const uint32_t w = g / n_out, j = g - w * n_out;
-  const dev_ext* rin = R_in + (size_t)w * in_stride + 8 * (size_t)j;
+  const dev_ext* rin = R_in + (size_t)w * in_stride + (size_t)m * j;
   qpt run, U, t;
   q_identity(run, q);
   q_identity(U, q);
   if (level == 0 && j == n_out - 1) {
-    // bucket index B = 8^L (digit -2^(C-1)) sits one past the tree's range: treat it as local index 8 of the
-    // last chunk, i.e. seed the running sums with it (it is then counted 8 times in U and once in R')
-    q_load_ext(run, rin + 8, q);
+    // bucket index B (digit -2^(C-1)) sits one past the tree's range: treat it as local index m of the last chunk,
+    // i.e. seed the running sums with it (it is then counted m times in U and once in R')
+    q_load_ext(run, rin + m, q);
     U = run;
   }
 #pragma unroll 1
-  for (int i = 7; i >= 1; --i) {
+  for (int i = m - 1; i >= 1; --i) {
     q_load_ext(t, rin + i, q);
     q_add(run, run, t, q);
     q_add(U, U, run, q);
@@ -472,11 +477,11 @@ k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t ou
   q_load_ext(t, rin, q);
   q_add(run, run, t, q);
 #pragma unroll 1
-  for (int k = 0; k < 3 * level; ++k) q_double(U, U, q);
+  for (int k = 0; k < shift; ++k) q_double(U, U, q);
   if (level > 0) {
-    const dev_ext* ain = A_in + (size_t)w * in_stride + 8 * (size_t)j;
+    const dev_ext* ain = A_in + (size_t)w * in_stride + (size_t)m * j;
 #pragma unroll 1
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < m; ++i) {
       q_load_ext(t, ain + i, q);
       q_add(U, U, t, q);
     }
@@ -748,9 +753,10 @@ size_t pip_ws(uint64_t n) {
   cv.take((size_t)cfg::W1 * (cfg::B1 + 1) * 4);               // vstart
   cv.take((size_t)cfg::W1 * pip_tiles<C>(n) * cfg::B1 * 4);   // tile histograms / tile base offsets
   cv.take((size_t)cfg::W1 * pip_vmax<C>(n) * sizeof(dev_ext)); // bucket parts
+  cv.take((size_t)cfg::W1 * pip_vmax<C>(n) * 4);               // vmap
   cv.take(256);                                // invalid flag
   cv.take((size_t)cfg::W1 * cfg::B1 * sizeof(dev_ext));       // buckets
-  cv.take((size_t)cfg::W1 * (cfg::B / 7 + 8) * sizeof(dev_ext) * 2);  // reduction levels (A and R)
+  cv.take((size_t)cfg::W1 * (cfg::B + 8) * sizeof(dev_ext) * 2);  // reduction levels (A and R)
   return cv.off;
 }
 
@@ -774,9 +780,10 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   const uint32_t L = pip_part_len(n);
   const size_t vmax = pip_vmax<C>(n);
   dev_ext* parts = reinterpret_cast<dev_ext*>(base + cv.take((size_t)cfg::W1 * vmax * sizeof(dev_ext)));
+  uint32_t* vmap = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * vmax * 4));
   uint32_t* invalid = reinterpret_cast<uint32_t*>(base + cv.take(256));
   dev_ext* buckets = reinterpret_cast<dev_ext*>(base + cv.take(nb * sizeof(dev_ext)));
-  const size_t lvl_cap = (size_t)cfg::W1 * (cfg::B / 7 + 8);
+  const size_t lvl_cap = (size_t)cfg::W1 * (cfg::B + 8);
   dev_ext* lvlA = reinterpret_cast<dev_ext*>(base + cv.take(lvl_cap * sizeof(dev_ext) * 2));
   dev_ext* lvlR = lvlA + lvl_cap;
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
@@ -790,8 +797,9 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   hipLaunchKernelGGL(k_pip_tile_base, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, tiles, (uint32_t)nb, start, tilehist);
   hipLaunchKernelGGL(k_pip_tile_scatter<C>, dim3(tiles, cfg::W1), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist, sorted);
   prof_mark(c, ZKP_K_SORT);
+  hipLaunchKernelGGL(k_pip_vmap, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, (uint32_t)nb, (uint32_t)vmax, vstart, vmap);
   hipLaunchKernelGGL(k_pip_bucket_part, dim3((unsigned)((vmax + 255) / 256), cfg::W1), dim3(256), 0, c->stream, n, cfg::B1, L, (uint32_t)vmax,
-                     start, hist, vstart, sorted, niels, parts);
+                     start, hist, vstart, vmap, sorted, niels, parts);
   hipLaunchKernelGGL(k_pip_bucket_merge, grid1(nb * 4, 256), dim3(256), 0, c->stream, cfg::B1, (uint32_t)nb, (uint32_t)vmax, vstart, parts, buckets);
   prof_mark(c, ZKP_K_BUCKET);
   // radix-8 tree over bucket indices 0 .. B-1 (bucket B is added in k_pip_combine)
@@ -801,18 +809,24 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   size_t lvl_off = 0;
   int level = 0;
   const dev_ext* Afinal = nullptr;
+  int shift = 0;
   while (n_in > 1) {
-    const uint32_t n_out = n_in / 8;
+    int lg = 0;
+    while ((1u << lg) < n_in) ++lg;
+    const int mbits = (level == 0 && lg % 3) ? lg % 3 : 3;            // first level absorbs the odd bits
+    const uint32_t m = 1u << mbits, n_out = n_in >> mbits;
     dev_ext* Aout = lvlA + lvl_off;
     dev_ext* Rout = lvlR + lvl_off;
     const uint32_t total = cfg::W1 * n_out;
-    hipLaunchKernelGGL(k_pip_reduce_lvl, grid1((size_t)total * 4, 256), dim3(256), 0, c->stream, n_out, total, in_stride, n_out, level, Ain, Rin, Aout, Rout);
+    hipLaunchKernelGGL(k_pip_reduce_lvl, grid1((size_t)total * 4, 256), dim3(256), 0, c->stream, n_out, total, in_stride, n_out, level, (int)m, shift,
+                       Ain, Rin, Aout, Rout);
     Ain = Aout;
     Rin = Rout;
     in_stride = n_out;
     n_in = n_out;
     lvl_off += total;
     Afinal = Aout;
+    shift += mbits;
     ++level;
   }
   hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(64), 0, c->stream, cfg::W1, C, Afinal, invalid, d_out, d_status);
@@ -823,9 +837,12 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
 
 // window size by problem size (bucket work ~ n * 257/c madds, reduction work ~ 2^c * 257/c adds)
 int pick_c(uint64_t n) {
+  // Canonical scalars are < l ~ 2^252, so the windows that matter are those below bit 253.  c = 11 divides 253 exactly
+  // (23 full windows, nothing spills into a carry window); c = 13 would leave a 6-bit top window whose ~32 buckets hold
+  // n/32 points each (a 2 x sqrt(n/32)-long dependent chain), c = 10 a 3-bit one.  c = 16 leaves 13 bits: fine.
   if (n < (1u << 12)) return 7;
-  if (n < (1u << 15)) return 10;
-  if (n < (1u << 21)) return 13;
+  if (n < (1u << 13)) return 10;
+  if (n < (1u << 21)) return 11;
   return 16;
 }
 constexpr uint64_t kSmallOptional = 192;   // below this, zkp_msm_optional uses the per-term path
@@ -1070,7 +1087,7 @@ static int msm_optional_impl(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, c
   switch (cbits) {
     case 7: need = pip_ws<7>(n); break;
     case 10: need = pip_ws<10>(n); break;
-    case 13: need = pip_ws<13>(n); break;
+    case 11: need = pip_ws<11>(n); break;
     default: need = pip_ws<16>(n); break;
   }
   int rc = ensure_ws(c, reserved + need);
@@ -1078,7 +1095,7 @@ static int msm_optional_impl(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, c
   switch (cbits) {
     case 7: return pip_run<7>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
     case 10: return pip_run<10>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
-    case 13: return pip_run<13>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
+    case 11: return pip_run<11>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
     default: return pip_run<16>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
   }
 }
@@ -1113,8 +1130,8 @@ int zkp_msm_optional(zkp_ctx* c, uint64_t n, const uint8_t* scalars, const uint8
     switch (pick_c(n)) {
       case 7: need = pip_ws<7>(n); break;
       case 10: need = pip_ws<10>(n); break;
-      case 13: need = pip_ws<13>(n); break;
-      default: need = pip_ws<16>(n); break;
+      case 11: need = pip_ws<11>(n); break;
+        default: need = pip_ws<16>(n); break;
     }
   }
   int rc = ensure_ws(c, reserved + need);

@@ -207,9 +207,12 @@ def main():
     algo_bytes = 64.0 * n_terms + 32.0 * n_msm
     t_terms = k_prove["terms"] * 1e-3
     achieved = algo_bytes / t_terms / 1e9 if t_terms > 0 else 0.0
-    # executed v_mad_u64_u32: generic term = 128 windows x (2 doublings + 1 addition) = 128 x (8 sq x 62 + 15 mul x 98);
-    # fixed-base term (X_1..X_10, A: 20 of the 31 terms of a proof) = 65 mixed additions x 7 mul x 98
-    mads = n * (11 * 128 * (8 * 62 + 15 * 98) + 20 * 65 * 7 * 98)
+    # executed v_mad_u64_u32 in that launch (fe_sq = 62, fe_mul = 98):
+    #   term on a per-proof point (11 of 31 per proof), comb walk: 16 windows x (4 doublings + 4 additions) + 1 addition
+    #   term on a common point X_1..X_10, A (20 of 31), fixed-base walk: 65 mixed additions (7 mul each)
+    mads_comb_term = 16 * (16 * 62 + (3 + 3 + 3 + 4 + 4 * 8) * 98) + 8 * 98
+    mads_fixed_term = 65 * 7 * 98
+    mads = n * (11 * mads_comb_term + 20 * mads_fixed_term)
     valu = mads / t_terms if t_terms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")       # rocprofv3 --pmc passes of this same command

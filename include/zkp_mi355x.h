@@ -115,7 +115,8 @@ enum {
   ZKP_K_DECODE = 0,      /* ristretto decode (+ affine-niels conversion, digit extraction)       */
   ZKP_K_TERMS = 1,       /* per-term scalar multiplication (small-MSM path)                       */
   ZKP_K_REDUCE = 2,      /* per-MSM sum of partials + compress                                    */
-  ZKP_K_SORT = 3,        /* Pippenger: histogram + scan + scatter                                 */
+  ZKP_K_SORT = 3,        /* Pippenger: histogram + scan + scatter; small-MSM path: term classification    */
+                         /* + comb-table construction                                                     */
   ZKP_K_BUCKET = 4,      /* Pippenger: bucket accumulation                                        */
   ZKP_K_COMBINE = 5,     /* Pippenger: bucket reduction + window combination + compress           */
   ZKP_K_COUNT = 6

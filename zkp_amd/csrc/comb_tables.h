@@ -99,13 +99,19 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
       ge_cached sel;
       ge_cached_identity(sel);
       if (CT) {
-        ge_cached cur, nxt;                                     // software pipelined masked scan of the row
-        load_comb_entry(cur, row);
+        // masked scan of the 8-entry row, four entries (36 independent 16-byte loads) in flight at a time: the scan is
+        // latency bound (each lane reads 1152 B from L1/L2), so it is issued as two rounds instead of eight
 #pragma unroll 1
-        for (uint32_t m = 1; m <= 8; ++m) {
-          if (m < 8) load_comb_entry(nxt, row + m);
-          ge_cached_cmov(sel, cur, (uint32_t)(m == mag));
-          cur = nxt;
+        for (uint32_t h = 0; h < 2; ++h) {
+          ge_cached c0, c1, c2, c3;
+          load_comb_entry(c0, row + 4 * h + 0);
+          load_comb_entry(c1, row + 4 * h + 1);
+          load_comb_entry(c2, row + 4 * h + 2);
+          load_comb_entry(c3, row + 4 * h + 3);
+          ge_cached_cmov(sel, c0, (uint32_t)(mag == 4 * h + 1));
+          ge_cached_cmov(sel, c1, (uint32_t)(mag == 4 * h + 2));
+          ge_cached_cmov(sel, c2, (uint32_t)(mag == 4 * h + 3));
+          ge_cached_cmov(sel, c3, (uint32_t)(mag == 4 * h + 4));
         }
       } else if (mag) {
         load_comb_entry(sel, row + (mag - 1));

@@ -134,23 +134,25 @@ ZKP_HD void fe_carry(fe& r, const fe& a) {
   FE_TRACK(fe_set_ub_tight(r));
 }
 
-// select: r = flag ? b : a   (flag is 0/1; data-independent instruction stream)
+// select: r = flag ? b : r   (flag is 0/1).  Written as a per-limb select so that gfx950 gets one v_cndmask_b32 per
+// limb (the masked-xor form costs three VALU ops per limb, and the table scans of the term kernels are made of
+// these); v_cndmask has no data-dependent timing, and no branch is involved.
 ZKP_HD void fe_cmov(fe& r, const fe& b, uint32_t flag) {
-  const uint32_t m = 0u - flag;
+  const bool f = flag != 0;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     FE_TRACK(if (b.ub[i] > r.ub[i]) r.ub[i] = b.ub[i]);
-    r.v[i] ^= m & (r.v[i] ^ b.v[i]);
+    r.v[i] = f ? b.v[i] : r.v[i];
   }
 }
 ZKP_HD void fe_cswap(fe& a, fe& b, uint32_t flag) {
-  const uint32_t m = 0u - flag;
+  const bool f = flag != 0;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     FE_TRACK(uint64_t mx = a.ub[i] > b.ub[i] ? a.ub[i] : b.ub[i]; a.ub[i] = mx; b.ub[i] = mx);
-    const uint32_t t = m & (a.v[i] ^ b.v[i]);
-    a.v[i] ^= t;
-    b.v[i] ^= t;
+    const uint32_t x = a.v[i], y = b.v[i];
+    a.v[i] = f ? y : x;
+    b.v[i] = f ? x : y;
   }
 }
 

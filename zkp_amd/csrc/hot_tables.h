@@ -169,14 +169,22 @@ __device__ __forceinline__ void term_fixed_base(uint32_t t, const uint8_t* __res
       ge_niels q;
       if (CT) {
         ge_niels_identity(q);
+        // masked scan, four entries (28 independent 16-byte loads) in flight at a time
 #pragma unroll 1
-        for (uint32_t m = 1; m <= 8; ++m) {
-          ge_niels c;
-          load_niels(c, row + (m - 1));
-          const uint32_t hit = (uint32_t)(m == mag);
-          fe_cmov(q.ypx, c.ypx, hit);
-          fe_cmov(q.ymx, c.ymx, hit);
-          fe_cmov(q.xy2d, c.xy2d, hit);
+        for (uint32_t h = 0; h < 2; ++h) {
+          ge_niels c0, c1, c2, c3;
+          load_niels(c0, row + 4 * h + 0);
+          load_niels(c1, row + 4 * h + 1);
+          load_niels(c2, row + 4 * h + 2);
+          load_niels(c3, row + 4 * h + 3);
+          const ge_niels* cs[4] = {&c0, &c1, &c2, &c3};
+#pragma unroll
+          for (uint32_t m = 0; m < 4; ++m) {
+            const uint32_t hit = (uint32_t)(mag == 4 * h + m + 1);
+            fe_cmov(q.ypx, cs[m]->ypx, hit);
+            fe_cmov(q.ymx, cs[m]->ymx, hit);
+            fe_cmov(q.xy2d, cs[m]->xy2d, hit);
+          }
         }
       } else {
         ge_niels_identity(q);

@@ -703,6 +703,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor);
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, cursor, list);
     hipLaunchKernelGGL(k_comb_tables, grid1((size_t)n_points * 4, 256), dim3(256), 0, c->stream, n_points, needs, pts, comb);
+    prof_mark(c, ZKP_K_SORT);          // path A: term classification + comb-table construction
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 1));
     if (flags == ZKP_CT)
       hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, part);

@@ -99,19 +99,14 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
       ge_cached sel;
       ge_cached_identity(sel);
       if (CT) {
-        // masked scan of the 8-entry row, four entries (36 independent 16-byte loads) in flight at a time: the scan is
-        // latency bound (each lane reads 1152 B from L1/L2), so it is issued as two rounds instead of eight
+        // masked scan of the 8-entry row, two entries (18 independent 16-byte loads) in flight at a time
 #pragma unroll 1
-        for (uint32_t h = 0; h < 2; ++h) {
-          ge_cached c0, c1, c2, c3;
-          load_comb_entry(c0, row + 4 * h + 0);
-          load_comb_entry(c1, row + 4 * h + 1);
-          load_comb_entry(c2, row + 4 * h + 2);
-          load_comb_entry(c3, row + 4 * h + 3);
-          ge_cached_cmov(sel, c0, (uint32_t)(mag == 4 * h + 1));
-          ge_cached_cmov(sel, c1, (uint32_t)(mag == 4 * h + 2));
-          ge_cached_cmov(sel, c2, (uint32_t)(mag == 4 * h + 3));
-          ge_cached_cmov(sel, c3, (uint32_t)(mag == 4 * h + 4));
+        for (uint32_t h = 0; h < 4; ++h) {
+          ge_cached c0, c1;
+          load_comb_entry(c0, row + 2 * h + 0);
+          load_comb_entry(c1, row + 2 * h + 1);
+          ge_cached_cmov(sel, c0, (uint32_t)(mag == 2 * h + 1));
+          ge_cached_cmov(sel, c1, (uint32_t)(mag == 2 * h + 2));
         }
       } else if (mag) {
         load_comb_entry(sel, row + (mag - 1));

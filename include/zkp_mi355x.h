@@ -92,6 +92,31 @@ int zkp_msm_optional(zkp_ctx* ctx, uint64_t n, const uint8_t* scalars /*[n][32]*
 int zkp_msm_optional_dev(zkp_ctx* ctx, uint64_t n, const uint8_t* d_scalars, const uint8_t* d_points,
                          uint8_t* d_out_point /*[32]*/, uint32_t* d_status /*[1]*/);
 
+/* (2b) Batch verification with the coefficient build ON THE GPU.
+ *     Replaces batch_verifier.rs:173-234 in one call: the random-linear-combination coefficients
+ *       static_coeffs[s]        = sum_j sum_{constraint i touching s} r_ij * (minus_c_j | resp_j[sc])      (:185-204)
+ *       Matrix[(var, j)]        likewise for instance variables, and  Matrix[(n_i + i, j)] = -r_ij        (:183)
+ *     are computed with on-device arithmetic mod l, laid out as the reference chains them (:219-223: static
+ *     coefficients, then the matrix row-major), and fed to the same MSM as zkp_msm_optional together with
+ *     static_points || instance_points || commitment rows.  Point ids: 0 .. n_static-1 = static points,
+ *     n_static .. n_static+n_instance-1 = instance points.  All pointers are HOST pointers.
+ *     minus_c [N][32] = the negated per-proof challenges (:163-167, computed by the caller's transcripts);
+ *     responses [N][n_secrets][32]; weights16 [n_constraints][N][16] = the u128 random factors (:179), little endian;
+ *     instance_points [n_instance][N][32]; commitments [N][n_constraints][32].
+ *     *status as in zkp_msm_optional.  debug_scalars (NULL or [n_static + (n_instance+n_constraints)*N][32]) receives
+ *     the coefficient vector for tests. */
+typedef struct {
+  uint32_t n_secrets, n_static, n_instance, n_constraints;
+  const uint32_t* cons_lhs;   /* [n_constraints] point id of the left-hand side          */
+  const uint32_t* cons_off;   /* [n_constraints + 1] offsets into cons_sc / cons_pt      */
+  const uint32_t* cons_sc;    /* secret index of each right-hand-side term               */
+  const uint32_t* cons_pt;    /* point id of each right-hand-side term                   */
+} zkp_batch_statement;
+int zkp_batch_check(zkp_ctx* ctx, const zkp_batch_statement* st, uint32_t N, const uint8_t* minus_c,
+                    const uint8_t* responses, const uint8_t* weights16, const uint8_t* static_points,
+                    const uint8_t* instance_points, const uint8_t* commitments, uint8_t out_point[32], int* status,
+                    uint8_t* debug_scalars);
+
 /* (3) Stand-alone decode / validity check, batched.  Replaces the
  *     `.map(|pt| pt.decompress()).collect::<Option<Vec<_>>>()` of verifier.rs:87-92.
  *     status[i] = 0 valid | 1 decompress() would return None.  If xyzt != NULL it receives the

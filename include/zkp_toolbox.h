@@ -94,6 +94,13 @@ int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t
                      const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
                      const uint8_t* responses, const uint8_t* weights16, int n_threads);
 
+/* zkp_batch_verify, additionally returning the coefficient vector the GPU built (zkp_batch_check's debug_scalars:
+ * ns + (ni + nc) * N scalars in the operand order of batch_verifier.rs:219-223), so tests can compare it with the
+ * host/oracle restatement of batch_verifier.rs:173-206. */
+int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* transcripts,
+                            const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
+                            const uint8_t* responses, const uint8_t* weights16, int n_threads, uint8_t* coeffs);
+
 /* ---- host-only halves, exposed so the host logic can be tested without a GPU ----------------------- */
 /* Everything of zkp_batch_verify up to (not including) the MSM: writes the exact operand sequence of
  * batch_verifier.rs:219-228, ns + (ni + nc) * N scalars and encodings.  Returns 0 or the error the

@@ -3,6 +3,7 @@
 // Built twice by tests/test_host_field.py: plain, and with -DZKP_FE_TRACK (interval bound tracker:
 // aborts if any lazy add/sub chain could overflow a 64-bit column or a 32-bit limb).
 #include "../../zkp_amd/csrc/ge25519.h"
+#include "../../zkp_amd/csrc/sc25519.h"
 #include <cstring>
 using namespace zkp;
 
@@ -74,5 +75,19 @@ int t_scalarmult(const uint8_t* s, const uint8_t* pe, uint8_t* out) {
   }
   enc(out, acc);
   return ok;
+}
+// scalar arithmetic mod l (device header sc25519.h): op 0 mul, 1 add, 2 neg(a), 3 reduce(a), 4 mont(to_mont(a), b)
+void t_sc_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  sc x, y, r;
+  memcpy(x.v, a, 32); memcpy(y.v, b, 32);
+  switch (op) {
+    case 0: sc_mul(r, x, y); break;
+    case 1: sc_add(r, x, y); break;
+    case 2: sc_neg(r, x); break;
+    case 3: sc_reduce(r, x); break;
+    case 4: { sc t; sc_to_mont(t, x); sc_mont(r, t, y); break; }
+    default: sc_zero(r);
+  }
+  memcpy(out, r.v, 32);
 }
 }

@@ -353,3 +353,46 @@ def test_unreferenced_point_must_still_decode(eng):
     ts = np.stack([T.Transcript(label).state] * 4)
     with pytest.raises(T.VerificationFailure):
         T.batch_verify(eng, mod.statement, ts, inst, badc, coms, resp)
+
+
+@pytest.mark.parametrize("n", [1, 3, 300, 4096])
+def test_gpu_coefficient_build_matches_host_and_oracle(eng, n):
+    """batch_verifier.rs:173-206 computed on the GPU (scalar arithmetic mod l in sc25519.h) gives,
+    bit for bit, the coefficient vector of the host restatement (zkp_batch_verify_build, itself checked against the
+    oracle in test_host_toolbox.py) -- for CMZ (static + instance points) and DLEQ (shared secret, two constraints)."""
+    rng = np.random.default_rng(100 + n)
+    mod, secrets, inst, common = _cmz_batch(n, 31)
+    label = b"Benchmark"
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ts = np.stack([T.Transcript(label).state] * n)
+    chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, common, entropy)
+    w = rng.integers(0, 256, size=(mod.statement.nc, n, 16), dtype=np.uint8)
+    w[0, 0] = 0                                                      # a zero weight: -0 must stay 0, not l
+    w[1 % mod.statement.nc, n - 1] = 255                             # the largest u128
+    ts = np.stack([T.Transcript(label).state] * n)
+    want_sc, _ = T.batch_verify_build(mod.statement, ts, inst, common, coms, resp, w)
+    ts = np.stack([T.Transcript(label).state] * n)
+    ok, got = T.batch_verify_coeffs(eng, mod.statement, ts, inst, common, coms, resp, w)
+    assert ok
+    assert (got == want_sc).all()
+    if n <= 300:                                                     # the oracle's own build of the same operands
+        cst = C.Statement.from_model(M.cmz_statement(10))
+        rc, osc, _ = C.batch_verify(cst, label, n, inst, common, coms, resp, w, want_msm_inputs=True)
+        assert rc == 0 and (osc == got).all()
+    # non-canonical responses (>= l) are reduced like Scalar::from_bytes_mod_order would; verdict = failure or ok
+    # according to the value, coefficients still equal the host's
+    big = resp.copy()
+    big[0, 0] = np.frombuffer(((int.from_bytes(resp[0, 0].tobytes(), "little") + M.L)).to_bytes(32, "little"), np.uint8)
+    ts = np.stack([T.Transcript(label).state] * n)
+    want_sc, _ = T.batch_verify_build(mod.statement, ts, inst, common, coms, big, w)
+    ts = np.stack([T.Transcript(label).state] * n)
+    ok, got = T.batch_verify_coeffs(eng, mod.statement, ts, inst, common, coms, big, w)
+    assert ok and (got == want_sc).all()
+    # tampered response: coefficients still match the host's, verdict is failure
+    bad = resp.copy()
+    bad[n // 2, 3, 1] ^= 4
+    ts = np.stack([T.Transcript(label).state] * n)
+    want_sc, _ = T.batch_verify_build(mod.statement, ts, inst, common, coms, bad, w)
+    ts = np.stack([T.Transcript(label).state] * n)
+    ok, got = T.batch_verify_coeffs(eng, mod.statement, ts, inst, common, coms, bad, w)
+    assert not ok and (got == want_sc).all()

@@ -18,7 +18,7 @@ SRC = os.path.join(HERE, "host", "fe_host_lib.cpp")
 
 def _build(track: bool):
     out = os.path.join(HERE, "host", "fe_host_lib_track.so" if track else "fe_host_lib.so")
-    deps = [SRC] + [os.path.join(HERE, "..", "zkp_amd", "csrc", f) for f in ("fe25519.h", "ge25519.h", "fe_constants.h")]
+    deps = [SRC] + [os.path.join(HERE, "..", "zkp_amd", "csrc", f) for f in ("fe25519.h", "ge25519.h", "fe_constants.h", "sc25519.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         cmd = ["g++", "-O1", "-std=c++17", "-shared", "-fPIC", SRC, "-o", out]
         if track:
@@ -185,3 +185,22 @@ def test_scalarmult_long_chain(lib):
         p = _rand_point(rng)
         lib.t_scalarmult(s.to_bytes(32, "little"), M.ristretto_encode(p), out)
         assert out.raw == M.ristretto_encode(M.pt_mul(s % M.L, p)), s
+
+
+def test_scalar_arithmetic_mod_l(lib):
+    """sc25519.h (device header, used by the GPU coefficient build) against Python integers."""
+    rng = random.Random(12)
+    out = ctypes.create_string_buffer(32)
+    b32 = lambda x: x.to_bytes(32, "little")
+    edge = [0, 1, 2, M.L - 1, M.L - 2, (1 << 252), (1 << 128) - 1, (1 << 252) - 1]
+    vals = edge + [rng.randrange(M.L) for _ in range(200)]
+    for _ in range(600):
+        a, b = rng.choice(vals), rng.choice(vals)
+        for op, e in {0: a * b % M.L, 1: (a + b) % M.L, 2: (-a) % M.L, 4: a * b % M.L}.items():
+            lib.t_sc_op(op, b32(a), b32(b), out)
+            assert out.raw == b32(e), (op, a, b)
+    for a in [M.L, M.L + 1, (1 << 256) - 1, 1 << 255, 15 * M.L + 3] + [rng.randrange(1 << 256) for _ in range(100)]:
+        lib.t_sc_op(3, b32(a), b32(0), out)                 # reduce any 256-bit value
+        assert out.raw == b32(a % M.L)
+        lib.t_sc_op(0, b32(a), b32(7), out)                 # first operand of a product may be non-canonical
+        assert out.raw == b32(a * 7 % M.L)

@@ -539,22 +539,58 @@ int zkp_batch_verify_build(const zkp_statement* stp, uint32_t N, uint32_t n_tran
   return ZKP_TB_OK;
 }
 
-int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
-                     const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
-                     int n_threads) {
-  if (!ctx || !st) return ZKP_TB_BAD_STATEMENT;
-  const size_t total = (size_t)st->ns + ((size_t)st->ni + st->cons.size()) * N;
-  std::vector<uint8_t> scalars(32 * total), points(32 * total);
-  int rc = zkp_batch_verify_build(st, N, n_transcripts, ts, inst, common, commitments, responses, weights16, n_threads,
-                                  scalars.data(), points.data());
-  if (rc) return rc;
+// Same checks, with the coefficient build on the GPU (zkp_batch_check): the host keeps the transcripts (validation,
+// commitments, challenges :152-167), the device does :173-228 -- scalar arithmetic mod l included.
+int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
+                            const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
+                            int n_threads, uint8_t* coeffs) {
+  if (!ctx || !stp) return ZKP_TB_BAD_STATEMENT;
+  if (n_transcripts != N) return ZKP_TB_BATCH_SIZE_MISMATCH;           // batch_verifier.rs:72-74
+  const zkp_statement& st = *stp;
+  const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), ni = st.ni, ns = st.ns;
+  std::vector<uint8_t> minus_c(32 * (size_t)N);
+  if (N) {
+    std::vector<uint8_t> failed(N, 0);
+    build_verifiers(st, N, ts, inst, common, n_threads, failed.data());  // :75-77, :92-94, :105-107, :125-128
+    for (uint8_t f : failed) if (f) return ZKP_TB_VERIFICATION_FAILURE;
+    std::atomic<int> any_fail{0};
+    parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
+      for (uint32_t j = lo; j < hi; ++j) {
+        Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
+        for (uint32_t k = 0; k < nc; ++k)                                // :152-160
+          if (!t.validate_and_append_blinding_commitment(st.points[st.cons[k].lhs].name.c_str(), commitments + 32 * ((size_t)j * nc + k))) any_fail = 1;
+        uint8_t c[32];
+        t.get_challenge("chal", c);                                      // :163-167
+        t.to_bytes(ts + TB * (size_t)j);
+        (-Scalar::from_bytes_mod_order(c)).to_bytes(minus_c.data() + 32 * (size_t)j);
+      }
+    });
+    if (any_fail) return ZKP_TB_VERIFICATION_FAILURE;
+  }
+  std::vector<uint8_t> own_w;
+  if (!weights16) { own_w.resize(16 * (size_t)N * nc); os_random(own_w.data(), own_w.size()); weights16 = own_w.data(); }
+  // statement incidence in point-id form (static ids first, then instance ids)
+  auto pid = [&](uint32_t v) { return st.points[v].common ? st.points[v].rank : ns + st.points[v].rank; };
+  std::vector<uint32_t> lhs(nc), off(nc + 1, 0), csc, cpt;
+  for (uint32_t k = 0; k < nc; ++k) {
+    lhs[k] = pid(st.cons[k].lhs);
+    for (const auto& term : st.cons[k].lc) { csc.push_back(term.first); cpt.push_back(pid(term.second)); }
+    off[k + 1] = (uint32_t)csc.size();
+  }
+  zkp_batch_statement bs{m, ns, ni, nc, lhs.data(), off.data(), csc.data(), cpt.data()};
   uint8_t out[32];
   int status = 1;
-  rc = zkp_msm_optional(ctx, total, scalars.data(), points.data(), out, &status);      // batch_verifier.rs:219-228
+  int rc = zkp_batch_check(ctx, &bs, N, minus_c.data(), responses, weights16, common, inst, commitments, out, &status, coeffs);
   if (rc) return rc;
   if (status) return ZKP_TB_VERIFICATION_FAILURE;                      // some point failed to decompress -> None
   static const uint8_t zero[32] = {0};
   return std::memcmp(out, zero, 32) == 0 ? ZKP_TB_OK : ZKP_TB_VERIFICATION_FAILURE;   // :230-234
+}
+
+int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
+                     const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
+                     int n_threads) {
+  return zkp_batch_verify_coeffs(ctx, st, N, n_transcripts, ts, inst, common, commitments, responses, weights16, n_threads, nullptr);
 }
 
 }  // extern "C"

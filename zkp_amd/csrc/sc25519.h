@@ -1,0 +1,125 @@
+// Scalars modulo l = 2^252 + 27742317777372353535851937790883648493 on the GPU: eight 32-bit limbs, Montgomery
+// multiplication (R = 2^256) built from the same full-rate v_mad_u64_u32 the field code uses.
+// Needed by the batch-verification coefficient build (reference src/toolbox/batch_verifier.rs:173-206:
+// `random_factor * minus_c[j]`, `random_factor * resp`, accumulation into the coefficient matrix).
+// Host + device header, tested on the CPU against Python integers (tests/test_host_field.py).
+#pragma once
+#include <stdint.h>
+#include "fe25519.h"   // ZKP_HD
+
+namespace zkp {
+
+struct sc { uint32_t v[8]; };     // little-endian limbs, always < l unless stated otherwise
+
+ZKP_HD uint32_t sc_l(int i) {
+  return i == 0 ? 0x5cf5d3edu : i == 1 ? 0x5812631au : i == 2 ? 0xa2f79cd6u : i == 3 ? 0x14def9deu : i == 4 ? 0x00000000u : i == 5 ? 0x00000000u : i == 6 ? 0x00000000u : 0x10000000u;
+}
+// R^2 mod l, R = 2^256 (generated: pow(2, 512, l))
+ZKP_HD uint32_t sc_rr(int i) {
+  return i == 0 ? 0x449c0f01u : i == 1 ? 0xa40611e3u : i == 2 ? 0x68859347u : i == 3 ? 0xd00e1ba7u : i == 4 ? 0x17f5be65u : i == 5 ? 0xceec73d2u : i == 6 ? 0x7c309a3du : 0x0399411bu;
+}
+constexpr uint32_t SC_N0INV = 0x12547e1bu;      // -l^-1 mod 2^32
+
+ZKP_HD void sc_zero(sc& r) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = 0;
+}
+// a -= l if a >= l   (a < 2 l)
+ZKP_HD void sc_cond_sub_l(sc& a) {
+  uint32_t d[8];
+  uint64_t br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t t = (uint64_t)a.v[i] - sc_l(i) - br;
+    d[i] = (uint32_t)t;
+    br = (t >> 63) & 1u;
+  }
+  const bool ge = br == 0;                    // no borrow: a >= l
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a.v[i] = ge ? d[i] : a.v[i];
+}
+// r = a + b mod l   (a, b < l)
+ZKP_HD void sc_add(sc& r, const sc& a, const sc& b) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (uint64_t)a.v[i] + b.v[i];
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  sc_cond_sub_l(r);                           // a + b < 2 l < 2^254: no carry out
+}
+// r = -a mod l   (a < l)
+ZKP_HD void sc_neg(sc& r, const sc& a) {
+  uint32_t nz = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) nz |= a.v[i];
+  const uint32_t m = 0u - (uint32_t)(nz != 0);
+  uint64_t br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t t = (uint64_t)sc_l(i) - a.v[i] - br;
+    r.v[i] = (uint32_t)t & m;
+    br = (t >> 63) & 1u;
+  }
+}
+// Montgomery product a * b * 2^-256 mod l.  b < l; a any 256-bit value.  Result < l.
+ZKP_HD void sc_mont(sc& r, const sc& a, const sc& b) {
+  uint32_t t[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      c += (uint64_t)a.v[i] * b.v[j] + t[j];
+      t[j] = (uint32_t)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[8] = (uint32_t)c;
+    t[9] = (uint32_t)(c >> 32);
+    const uint32_t m = t[0] * SC_N0INV;
+    c = (uint64_t)m * sc_l(0) + t[0];
+    c >>= 32;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      c += (uint64_t)m * sc_l(j) + t[j];
+      t[j - 1] = (uint32_t)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[7] = (uint32_t)c;
+    t[8] = t[9] + (uint32_t)(c >> 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+  sc_cond_sub_l(r);                           // < 2 l before
+}
+// r = a * b mod l   (two Montgomery products)
+ZKP_HD void sc_mul(sc& r, const sc& a, const sc& b) {
+  sc t, rr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rr.v[i] = sc_rr(i);
+  sc_mont(t, a, b);
+  sc_mont(r, t, rr);
+}
+// to Montgomery form: a * R mod l  (so that sc_mont(to_mont(a), b) = a * b)
+ZKP_HD void sc_to_mont(sc& r, const sc& a) {
+  sc rr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rr.v[i] = sc_rr(i);
+  sc_mont(r, a, rr);
+}
+// any 256-bit value -> canonical representative
+ZKP_HD void sc_reduce(sc& r, const sc& a) {
+  sc one;
+  sc_zero(one);
+  one.v[0] = 1;
+  sc t;
+  sc_to_mont(t, a);          // a R mod l   (a may be >= l: sc_mont allows it in the first operand)
+  sc_mont(r, t, one);        // a
+}
+
+}  // namespace zkp

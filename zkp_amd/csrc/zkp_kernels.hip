@@ -58,6 +58,7 @@ __device__ __forceinline__ uint32_t sel8(const uint32_t w[8], int j) {
 #include "hot_tables.h"
 #include "quad.h"
 #include "comb_tables.h"
+#include "sc25519.h"
 
 // =============================================================================================
 // (A) small-MSM path
@@ -551,6 +552,90 @@ k_debug_quad(uint32_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ 
     ristretto_encode(o, R);
     if (q == 0) store_vec<2>(out + 128 * (size_t)i + 32 * op, o);
   }
+}
+
+// =============================================================================================
+// batch-verification coefficient build (batch_verifier.rs:173-206) with scalar arithmetic mod l on the device
+// =============================================================================================
+// incidence of point id p: entries inc_off[p] .. inc_off[p+1]) of (constraint k, secret index or ~0 for "p is the lhs")
+__device__ __forceinline__ void coeff_of_point(sc& acc, uint32_t p, uint32_t j, uint32_t N, uint32_t m,
+                                               const uint32_t* __restrict__ inc_off, const uint32_t* __restrict__ inc_k,
+                                               const uint32_t* __restrict__ inc_sc, const uint8_t* __restrict__ minus_c,
+                                               const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16) {
+  sc_zero(acc);
+  for (uint32_t e = inc_off[p]; e < inc_off[p + 1]; ++e) {
+    const uint32_t k = inc_k[e], svar = inc_sc[e];
+    sc r, rm, x, t;
+    sc_zero(r);
+    load_vec<1>(r.v, weights16 + 16 * ((size_t)k * N + j));        // Scalar::from(u128)
+    sc_to_mont(rm, r);
+    const uint8_t* src = svar == 0xffffffffu ? minus_c + 32 * (size_t)j : responses + 32 * ((size_t)j * m + svar);
+    load_vec<2>(x.v, src);
+    sc_mont(t, x, rm);                                             // x * r mod l (x may be any 256-bit value)
+    sc_add(acc, acc, t);
+  }
+}
+
+// instance rows and commitment rows of the coefficient matrix: lane (row, proof)
+__global__ void __launch_bounds__(256)
+k_coeff_matrix(uint32_t N, uint32_t m, uint32_t ns, uint32_t ni, uint32_t nc, const uint32_t* __restrict__ inc_off,
+               const uint32_t* __restrict__ inc_k, const uint32_t* __restrict__ inc_sc, const uint8_t* __restrict__ minus_c,
+               const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16, uint8_t* __restrict__ scalars) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t row = blockIdx.y;
+  if (j >= N) return;
+  sc acc;
+  if (row < ni) {
+    coeff_of_point(acc, ns + row, j, N, m, inc_off, inc_k, inc_sc, minus_c, responses, weights16);
+  } else {
+    sc r;
+    sc_zero(r);
+    load_vec<1>(r.v, weights16 + 16 * ((size_t)(row - ni) * N + j));
+    sc_neg(acc, r);                                                // batch_verifier.rs:183
+  }
+  store_vec<2>(scalars + 32 * ((size_t)ns + (size_t)row * N + j), acc.v);
+}
+
+// static coefficients: block-level partial sums over proofs, then one block per static point
+__global__ void __launch_bounds__(256)
+k_coeff_static_partial(uint32_t N, uint32_t m, const uint32_t* __restrict__ inc_off, const uint32_t* __restrict__ inc_k,
+                       const uint32_t* __restrict__ inc_sc, const uint8_t* __restrict__ minus_c,
+                       const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16,
+                       uint32_t* __restrict__ partial /*[ns][gridDim.x][8]*/) {
+  __shared__ uint32_t red[256][8];
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t s = blockIdx.y;
+  sc acc;
+  sc_zero(acc);
+  if (j < N) coeff_of_point(acc, s, j, N, m, inc_off, inc_k, inc_sc, minus_c, responses, weights16);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc.v[i];
+  __syncthreads();
+  for (uint32_t d = 128; d >= 1; d >>= 1) {
+    if (threadIdx.x < d) {
+      sc a, b;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { a.v[i] = red[threadIdx.x][i]; b.v[i] = red[threadIdx.x + d][i]; }
+      sc_add(a, a, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = a.v[i];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 8) partial[((size_t)s * gridDim.x + blockIdx.x) * 8 + threadIdx.x] = red[0][threadIdx.x];
+}
+__global__ void __launch_bounds__(64)
+k_coeff_static_final(uint32_t nblocks, const uint32_t* __restrict__ partial, uint8_t* __restrict__ scalars) {
+  if (threadIdx.x != 0) return;
+  const uint32_t s = blockIdx.x;
+  sc acc, t;
+  sc_zero(acc);
+  for (uint32_t b = 0; b < nblocks; ++b) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.v[i] = partial[((size_t)s * nblocks + b) * 8 + i];
+    sc_add(acc, acc, t);
+  }
+  store_vec<2>(scalars + 32 * (size_t)s, acc.v);
 }
 
 // =============================================================================================
@@ -1151,6 +1236,109 @@ int zkp_msm_optional(zkp_ctx* c, uint64_t n, const uint8_t* scalars, const uint8
   HIP_TRY(hipMemcpyAsync(&st, static_cast<char*>(c->ws) + o_st, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *status = (int)st;
+  return ZKP_OK;
+}
+
+int zkp_batch_check(zkp_ctx* c, const zkp_batch_statement* st, uint32_t N, const uint8_t* minus_c, const uint8_t* responses,
+                    const uint8_t* weights16, const uint8_t* static_points, const uint8_t* instance_points,
+                    const uint8_t* commitments, uint8_t out_point[32], int* status, uint8_t* debug_scalars) {
+  if (!c || !st || !out_point || !status) return fail(ZKP_ERR_ARG, "NULL pointer");
+  const uint32_t m = st->n_secrets, ns = st->n_static, ni = st->n_instance, nc = st->n_constraints, np = ns + ni;
+  if (nc && (!st->cons_lhs || !st->cons_off)) return fail(ZKP_ERR_ARG, "statement without constraint arrays");
+  if (N && ((!minus_c) || (m && !responses) || (nc && (!weights16 || !commitments)) || (ni && !instance_points)))
+    return fail(ZKP_ERR_ARG, "NULL input pointer");
+  if (ns && !static_points) return fail(ZKP_ERR_ARG, "NULL static points");
+  // incidence lists per point id: (constraint, secret index | ~0 when the point is the constraint's left-hand side)
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> inc(np);
+  for (uint32_t k = 0; k < nc; ++k) {
+    if (st->cons_lhs[k] >= np) return fail(ZKP_ERR_ARG, "constraint lhs out of range");
+    inc[st->cons_lhs[k]].emplace_back(k, 0xffffffffu);
+    for (uint32_t q = st->cons_off[k]; q < st->cons_off[k + 1]; ++q) {
+      if (st->cons_pt[q] >= np || st->cons_sc[q] >= m) return fail(ZKP_ERR_ARG, "constraint term out of range");
+      inc[st->cons_pt[q]].emplace_back(k, st->cons_sc[q]);
+    }
+  }
+  std::vector<uint32_t> inc_off(np + 1, 0), inc_k, inc_sc;
+  for (uint32_t p = 0; p < np; ++p) {
+    for (auto& e : inc[p]) { inc_k.push_back(e.first); inc_sc.push_back(e.second); }
+    inc_off[p + 1] = (uint32_t)inc_k.size();
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t rows = (size_t)ni + nc, total = (size_t)ns + rows * N;
+  const uint32_t nblk = (N + 255) / 256;
+  carve cv;
+  const size_t o_sc = cv.take(total * 32 + 32);
+  const size_t o_pts = cv.take(total * 32 + 32);
+  const size_t o_out = cv.take(32);
+  const size_t o_st = cv.take(4);
+  const size_t o_mc = cv.take((size_t)N * 32);
+  const size_t o_resp = cv.take((size_t)N * m * 32);
+  const size_t o_w = cv.take((size_t)nc * N * 16);
+  const size_t o_inc = cv.take((inc_off.size() + inc_k.size() * 2 + 4) * 4);
+  const size_t o_part = cv.take((size_t)(ns ? ns : 1) * (nblk ? nblk : 1) * 32);
+  const size_t reserved = cv.off;
+  size_t need = 0;
+  if (total <= kSmallOptional) {
+    need = 1024 + (total + 1) * 4 + terms_path_ws((uint32_t)total, (uint32_t)total);
+  } else {
+    switch (pick_c(total)) {
+      case 7: need = pip_ws<7>(total); break;
+      case 10: need = pip_ws<10>(total); break;
+      case 11: need = pip_ws<11>(total); break;
+      default: need = pip_ws<16>(total); break;
+    }
+  }
+  int rc = ensure_ws(c, reserved + need);
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  uint8_t* d_sc = reinterpret_cast<uint8_t*>(base + o_sc);
+  uint8_t* d_pts = reinterpret_cast<uint8_t*>(base + o_pts);
+  uint32_t* d_inc_off = reinterpret_cast<uint32_t*>(base + o_inc);
+  uint32_t* d_inc_k = d_inc_off + inc_off.size();
+  uint32_t* d_inc_sc = d_inc_k + inc_k.size();
+  // operands of batch_verifier.rs:219-228: points = static || instance rows || commitment rows (row = constraint)
+  if (ns) HIP_TRY(hipMemcpyAsync(d_pts, static_points, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
+  if (ni && N) HIP_TRY(hipMemcpyAsync(d_pts + 32 * (size_t)ns, instance_points, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
+  std::vector<uint8_t> com_rows((size_t)nc * N * 32);
+  for (uint32_t j = 0; j < N; ++j)
+    for (uint32_t k = 0; k < nc; ++k) memcpy(com_rows.data() + 32 * ((size_t)k * N + j), commitments + 32 * ((size_t)j * nc + k), 32);
+  if (nc && N) {
+    HIP_TRY(hipMemcpyAsync(d_pts + 32 * ((size_t)ns + (size_t)ni * N), com_rows.data(), com_rows.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(base + o_w, weights16, (size_t)nc * N * 16, hipMemcpyHostToDevice, c->stream));
+  }
+  if (N) {
+    HIP_TRY(hipMemcpyAsync(base + o_mc, minus_c, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
+    if (m) HIP_TRY(hipMemcpyAsync(base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(d_inc_off, inc_off.data(), inc_off.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if (!inc_k.empty()) {
+    HIP_TRY(hipMemcpyAsync(d_inc_k, inc_k.data(), inc_k.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_inc_sc, inc_sc.data(), inc_sc.size() * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  prof_begin(c);
+  const uint8_t* d_mc = reinterpret_cast<uint8_t*>(base + o_mc);
+  const uint8_t* d_resp = reinterpret_cast<uint8_t*>(base + o_resp);
+  const uint8_t* d_w = reinterpret_cast<uint8_t*>(base + o_w);
+  if (N && rows)
+    hipLaunchKernelGGL(k_coeff_matrix, dim3(nblk, (unsigned)rows), dim3(256), 0, c->stream, N, m, ns, ni, nc, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, d_sc);
+  if (ns) {
+    uint32_t* part = reinterpret_cast<uint32_t*>(base + o_part);
+    if (N) {
+      hipLaunchKernelGGL(k_coeff_static_partial, dim3(nblk, ns), dim3(256), 0, c->stream, N, m, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, part);
+      hipLaunchKernelGGL(k_coeff_static_final, dim3(ns), dim3(64), 0, c->stream, nblk, part, d_sc);
+    } else {
+      HIP_TRY(hipMemsetAsync(d_sc, 0, (size_t)ns * 32, c->stream));
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, d_sc, total * 32, hipMemcpyDeviceToHost, c->stream));
+  rc = msm_optional_impl(c, total, d_sc, d_pts, reinterpret_cast<uint8_t*>(base + o_out), reinterpret_cast<uint32_t*>(base + o_st), reserved);
+  if (rc) return rc;
+  uint32_t stv = 1;
+  HIP_TRY(hipMemcpyAsync(out_point, static_cast<char*>(c->ws) + o_out, 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&stv, static_cast<char*>(c->ws) + o_st, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *status = (int)stv;
   return ZKP_OK;
 }
 

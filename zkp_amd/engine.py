@@ -22,7 +22,7 @@ EXPORTS = (
     "zkp_ctx_create", "zkp_ctx_destroy", "zkp_ctx_set_stream", "zkp_ctx_synchronize", "zkp_last_error",
     "zkp_version", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
-    "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest",
+    "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest", "zkp_batch_check",
 )
 
 

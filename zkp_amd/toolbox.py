@@ -36,7 +36,7 @@ EXPORTS = (
     "zkp_scalar_muladd", "zkp_scalar_neg", "zkp_statement_new", "zkp_statement_free", "zkp_statement_add_secret",
     "zkp_statement_add_point", "zkp_statement_constrain", "zkp_statement_num_secrets", "zkp_statement_num_instance",
     "zkp_statement_num_common", "zkp_statement_num_constraints", "zkp_statement_num_terms", "zkp_prove_batch",
-    "zkp_verify_compact_batch", "zkp_verify_batchable_each", "zkp_batch_verify", "zkp_batch_verify_build",
+    "zkp_verify_compact_batch", "zkp_verify_batchable_each", "zkp_batch_verify", "zkp_batch_verify_coeffs", "zkp_batch_verify_build",
     "zkp_prove_phase_a", "zkp_prove_phase_b",
 )
 
@@ -282,6 +282,20 @@ def batch_verify(eng, st, transcripts, inst, common, commitments, responses, wei
                                 _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
                                 _p(None if weights16 is None else np.ascontiguousarray(weights16)), threads)
     _raise(rc, "zkp_batch_verify")
+
+
+def batch_verify_coeffs(eng, st, transcripts, inst, common, commitments, responses, weights16, threads: int = 0):
+    """batch_verify that also returns the coefficient vector built on the GPU; (ok: bool, coeffs [total][32])."""
+    n = len(commitments)
+    total = st.ns + (st.ni + st.nc) * n
+    co = np.zeros((total, 32), np.uint8)
+    rc = lib().zkp_batch_verify_coeffs(eng._h, st._h, ctypes.c_uint32(n), ctypes.c_uint32(len(transcripts)), _p(transcripts),
+                                       _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                       _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
+                                       _p(np.ascontiguousarray(weights16)), threads, _p(co))
+    if rc not in (0, 1):
+        _raise(rc, "zkp_batch_verify_coeffs")
+    return rc == 0, co
 
 
 def batch_verify_build(st, transcripts, inst, common, commitments, responses, weights16, threads: int = 0):

@@ -76,7 +76,7 @@ int t_scalarmult(const uint8_t* s, const uint8_t* pe, uint8_t* out) {
   enc(out, acc);
   return ok;
 }
-// scalar arithmetic mod l (device header sc25519.h): op 0 mul, 1 add, 2 neg(a), 3 reduce(a), 4 mont(to_mont(a), b)
+// scalar arithmetic mod l (device header sc25519.h): op 0 mul, 1 add, 2 neg(a), 3 reduce(a), 4 mont(to_mont(a), b), 5 from_wide(lo=a, hi=b)
 void t_sc_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
   sc x, y, r;
   memcpy(x.v, a, 32); memcpy(y.v, b, 32);
@@ -86,6 +86,7 @@ void t_sc_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 2: sc_neg(r, x); break;
     case 3: sc_reduce(r, x); break;
     case 4: { sc t; sc_to_mont(t, x); sc_mont(r, t, y); break; }
+    case 5: sc_from_wide(r, x, y); break;      // a + b * 2^256
     default: sc_zero(r);
   }
   memcpy(out, r.v, 32);

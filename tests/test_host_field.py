@@ -204,3 +204,7 @@ def test_scalar_arithmetic_mod_l(lib):
         assert out.raw == b32(a % M.L)
         lib.t_sc_op(0, b32(a), b32(7), out)                 # first operand of a product may be non-canonical
         assert out.raw == b32(a * 7 % M.L)
+    wide = [0, (1 << 512) - 1, (1 << 256), M.L << 256, (M.L << 256) - 1] + [rng.randrange(1 << 512) for _ in range(300)]
+    for x in wide:                                          # Scalar::from_bytes_mod_order_wide
+        lib.t_sc_op(5, b32(x & ((1 << 256) - 1)), b32(x >> 256), out)
+        assert out.raw == b32(x % M.L)

@@ -1,0 +1,325 @@
+// Batched Merlin transcripts on the GPU (src/toolbox/mod.rs:165-228 over merlin 2.x / STROBE-128).
+//
+// Every proof of one batch call runs the SAME sequence of transcript operations (same labels, same lengths); only
+// the 32-byte values differ.  STROBE's byte position is therefore known on the host, and a transcript "program" can
+// be compiled once per call: per Keccak block, a handful of 64-bit word operations
+//        state[w] = (state[w] & keep) ^ cx ^ (bytes from this proof's inputs << 8*lb)        [+ emit bytes of state[w]]
+// followed by the permutation.  Constants (labels, length prefixes, STROBE framing and padding, common points) are
+// folded into keep/cx at compile time; the GPU interprets the word list with one lane per proof, the state in an
+// LDS column (dynamic word index without scratch), and no divergence.
+//
+// TrCompiler mirrors the host classes in host/merlin.hpp method for method; tests/test_host_field.py runs compiled
+// programs through tr_run_one on the CPU and compares with the host Merlin byte for byte.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include "fe25519.h"   // ZKP_HD
+
+namespace zkp {
+
+constexpr int TR_MAX_BUFS = 8;
+constexpr uint8_t TR_PERMUTE = 1, TR_SAVE = 2, TR_RESTORE = 4, TR_CHECK_NONZERO = 8;
+
+struct tr_op {                      // 48 bytes
+  uint64_t keep, cx;
+  uint64_t src_off, dst_off;        // byte offsets inside buffer (before + j * stride)
+  uint32_t src_stride, dst_stride;  // bytes per proof
+  uint8_t w, nb, lb, src_buf;       // src_buf / dst_buf: 0 = none, else 1 + index into tr_bufs
+  uint8_t dst_buf, flags, dnb, dlb; // dnb/dlb: byte count / position of the emitted bytes
+};
+static_assert(sizeof(tr_op) == 48, "tr_op layout");
+
+struct tr_bufs {
+  const uint8_t* src[TR_MAX_BUFS];
+  uint8_t* dst[TR_MAX_BUFS];
+};
+
+ZKP_HD uint64_t tr_rotl(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
+
+// Keccak-f[1600] on a strided column (S[i * stride]), 25 lanes held in registers for the 24 rounds.
+ZKP_HD void keccak_f1600_col(uint64_t* S, int stride) {
+  const uint64_t RC[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+      0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+      0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+      0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  uint64_t a00 = S[0 * stride], a10 = S[1 * stride], a20 = S[2 * stride], a30 = S[3 * stride], a40 = S[4 * stride];
+  uint64_t a01 = S[5 * stride], a11 = S[6 * stride], a21 = S[7 * stride], a31 = S[8 * stride], a41 = S[9 * stride];
+  uint64_t a02 = S[10 * stride], a12 = S[11 * stride], a22 = S[12 * stride], a32 = S[13 * stride], a42 = S[14 * stride];
+  uint64_t a03 = S[15 * stride], a13 = S[16 * stride], a23 = S[17 * stride], a33 = S[18 * stride], a43 = S[19 * stride];
+  uint64_t a04 = S[20 * stride], a14 = S[21 * stride], a24 = S[22 * stride], a34 = S[23 * stride], a44 = S[24 * stride];
+#pragma unroll 1
+  for (int round = 0; round < 24; ++round) {
+    const uint64_t c0 = a00 ^ a01 ^ a02 ^ a03 ^ a04, c1 = a10 ^ a11 ^ a12 ^ a13 ^ a14, c2 = a20 ^ a21 ^ a22 ^ a23 ^ a24,
+                   c3 = a30 ^ a31 ^ a32 ^ a33 ^ a34, c4 = a40 ^ a41 ^ a42 ^ a43 ^ a44;
+    const uint64_t d0 = c4 ^ tr_rotl(c1, 1), d1 = c0 ^ tr_rotl(c2, 1), d2 = c1 ^ tr_rotl(c3, 1), d3 = c2 ^ tr_rotl(c4, 1),
+                   d4 = c3 ^ tr_rotl(c0, 1);
+    a00 ^= d0; a01 ^= d0; a02 ^= d0; a03 ^= d0; a04 ^= d0;
+    a10 ^= d1; a11 ^= d1; a12 ^= d1; a13 ^= d1; a14 ^= d1;
+    a20 ^= d2; a21 ^= d2; a22 ^= d2; a23 ^= d2; a24 ^= d2;
+    a30 ^= d3; a31 ^= d3; a32 ^= d3; a33 ^= d3; a34 ^= d3;
+    a40 ^= d4; a41 ^= d4; a42 ^= d4; a43 ^= d4; a44 ^= d4;
+    const uint64_t b00 = a00,               b13 = tr_rotl(a01, 36), b21 = tr_rotl(a02, 3),  b34 = tr_rotl(a03, 41), b42 = tr_rotl(a04, 18);
+    const uint64_t b02 = tr_rotl(a10, 1),   b10 = tr_rotl(a11, 44), b23 = tr_rotl(a12, 10), b31 = tr_rotl(a13, 45), b44 = tr_rotl(a14, 2);
+    const uint64_t b04 = tr_rotl(a20, 62),  b12 = tr_rotl(a21, 6),  b20 = tr_rotl(a22, 43), b33 = tr_rotl(a23, 15), b41 = tr_rotl(a24, 61);
+    const uint64_t b01 = tr_rotl(a30, 28),  b14 = tr_rotl(a31, 55), b22 = tr_rotl(a32, 25), b30 = tr_rotl(a33, 21), b43 = tr_rotl(a34, 56);
+    const uint64_t b03 = tr_rotl(a40, 27),  b11 = tr_rotl(a41, 20), b24 = tr_rotl(a42, 39), b32 = tr_rotl(a43, 8),  b40 = tr_rotl(a44, 14);
+    a00 = b00 ^ (~b10 & b20); a10 = b10 ^ (~b20 & b30); a20 = b20 ^ (~b30 & b40); a30 = b30 ^ (~b40 & b00); a40 = b40 ^ (~b00 & b10);
+    a01 = b01 ^ (~b11 & b21); a11 = b11 ^ (~b21 & b31); a21 = b21 ^ (~b31 & b41); a31 = b31 ^ (~b41 & b01); a41 = b41 ^ (~b01 & b11);
+    a02 = b02 ^ (~b12 & b22); a12 = b12 ^ (~b22 & b32); a22 = b22 ^ (~b32 & b42); a32 = b32 ^ (~b42 & b02); a42 = b42 ^ (~b02 & b12);
+    a03 = b03 ^ (~b13 & b23); a13 = b13 ^ (~b23 & b33); a23 = b23 ^ (~b33 & b43); a33 = b33 ^ (~b43 & b03); a43 = b43 ^ (~b03 & b13);
+    a04 = b04 ^ (~b14 & b24); a14 = b14 ^ (~b24 & b34); a24 = b24 ^ (~b34 & b44); a34 = b34 ^ (~b44 & b04); a44 = b44 ^ (~b04 & b14);
+    a00 ^= RC[round];
+  }
+  S[0 * stride] = a00; S[1 * stride] = a10; S[2 * stride] = a20; S[3 * stride] = a30; S[4 * stride] = a40;
+  S[5 * stride] = a01; S[6 * stride] = a11; S[7 * stride] = a21; S[8 * stride] = a31; S[9 * stride] = a41;
+  S[10 * stride] = a02; S[11 * stride] = a12; S[12 * stride] = a22; S[13 * stride] = a32; S[14 * stride] = a42;
+  S[15 * stride] = a03; S[16 * stride] = a13; S[17 * stride] = a23; S[18 * stride] = a33; S[19 * stride] = a43;
+  S[20 * stride] = a04; S[21 * stride] = a14; S[22 * stride] = a24; S[23 * stride] = a34; S[24 * stride] = a44;
+}
+
+ZKP_HD uint64_t tr_bytemask(uint32_t nb) { return nb >= 8 ? ~0ULL : ((1ULL << (8 * nb)) - 1); }
+
+// Runs the program for proof j on the state column S (stride in words).  `saved` = this proof's clone slot
+// (saved[i * saved_stride]); *failed is set when a checked encoding is all zero (mod.rs:191, :215).
+ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, uint64_t j, const tr_bufs& bufs, uint64_t* S, int stride,
+                       uint64_t* saved, size_t saved_stride, uint32_t* failed) {
+  for (uint32_t q = 0; q < n_ops; ++q) {
+    const tr_op op = prog[q];
+    if (op.flags & TR_RESTORE)
+      for (int i = 0; i < 25; ++i) S[i * stride] = saved[i * saved_stride];
+    if (op.flags & TR_CHECK_NONZERO) {
+      const uint64_t* p = reinterpret_cast<const uint64_t*>(bufs.src[op.src_buf - 1] + j * op.src_stride + op.src_off);
+      if ((p[0] | p[1] | p[2] | p[3]) == 0) *failed = 1;
+      continue;
+    }
+    uint64_t v = S[op.w * stride];
+    if (op.dst_buf) {
+      uint8_t* d = bufs.dst[op.dst_buf - 1] + j * op.dst_stride + op.dst_off;
+      const uint64_t e = v >> (8 * op.dlb);
+      for (uint32_t i = 0; i < op.dnb; ++i) d[i] = (uint8_t)(e >> (8 * i));
+    }
+    uint64_t x = 0;
+    if (op.src_buf) {
+      const uint64_t addr = j * op.src_stride + op.src_off;
+      const uint32_t sh = (uint32_t)(addr & 7);
+      const uint64_t* p = reinterpret_cast<const uint64_t*>(bufs.src[op.src_buf - 1] + (addr - sh));
+      x = p[0] >> (8 * sh);
+      if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
+      x = (x & tr_bytemask(op.nb)) << (8 * op.lb);
+    }
+    S[op.w * stride] = (v & op.keep) ^ op.cx ^ x;
+    if (op.flags & TR_PERMUTE) keccak_f1600_col(S, stride);
+    if (op.flags & TR_SAVE)
+      for (int i = 0; i < 25; ++i) saved[i * saved_stride] = S[i * stride];
+  }
+}
+
+}  // namespace zkp
+
+#ifndef __HIP_DEVICE_COMPILE__
+#include <string>
+#include <vector>
+namespace zkp {
+
+struct tr_ref { uint8_t buf; uint32_t stride; uint64_t off; };     // buf = index into tr_bufs (src or dst)
+
+// Compile-time mirror of Strobe128 / merlin::Transcript / TranscriptRng / TranscriptProtocol (host/merlin.cpp).
+class TrCompiler {
+ public:
+  TrCompiler(uint8_t pos, uint8_t pos_begin, uint8_t cur_flags) : pos_(pos), pos_begin_(pos_begin), cur_flags_(cur_flags) { reset_block(); }
+
+  // ---- merlin::Transcript ----
+  void append_message(const char* label, const void* msg, size_t len) {
+    frame(label, len);
+    begin_op(kA, false);
+    absorb_const(static_cast<const uint8_t*>(msg), len);
+  }
+  void append_message_var(const char* label, tr_ref src, size_t len) {
+    frame(label, len);
+    begin_op(kA, false);
+    for (size_t i = 0; i < len; ++i) data_byte(0xff, 0, &src, i, nullptr, 0);
+  }
+  void challenge_bytes(const char* label, tr_ref dst, size_t len) {
+    frame(label, len);
+    begin_op(kI | kA | kC, false);
+    for (size_t i = 0; i < len; ++i) data_byte(0, 0, nullptr, 0, &dst, i);
+  }
+  // ---- merlin::TranscriptRng (build_rng = save ... restore around the rng's operations) ----
+  void save() { flush(false); marker(TR_SAVE); s_pos_ = pos_; s_pos_begin_ = pos_begin_; s_cur_flags_ = cur_flags_; }
+  void restore() { flush(false); marker(TR_RESTORE); pos_ = s_pos_; pos_begin_ = s_pos_begin_; cur_flags_ = s_cur_flags_; }
+  void rng_rekey_with_witness_var(const char* label, tr_ref src, size_t len) {
+    frame(label, len);
+    begin_op(kA | kC, false);
+    for (size_t i = 0; i < len; ++i) data_byte(0, 0, &src, i, nullptr, 0);
+  }
+  void rng_finalize_var(tr_ref entropy) {
+    begin_op(kM | kA, false);
+    absorb_const(reinterpret_cast<const uint8_t*>("rng"), 3);
+    begin_op(kA | kC, false);
+    for (size_t i = 0; i < 32; ++i) data_byte(0, 0, &entropy, i, nullptr, 0);
+  }
+  void rng_fill_bytes(tr_ref dst, size_t len) {
+    uint8_t l[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)(len >> 24)};
+    begin_op(kM | kA, false);
+    absorb_const(l, 4);
+    begin_op(kI | kA | kC, false);
+    for (size_t i = 0; i < len; ++i) data_byte(0, 0, nullptr, 0, &dst, i);
+  }
+  // ---- TranscriptProtocol (src/toolbox/mod.rs:165-228) ----
+  void domain_sep(const char* label) {
+    append_message("dom-sep", "schnorrzkp/1.0/ristretto255", 27);
+    append_message("dom-sep", label, strlen(label));
+  }
+  void append_scalar_var(const char* label) { append_message("scvar", label, strlen(label)); }
+  void append_point_var(const char* label, const uint8_t enc[32]) {
+    append_message("ptvar", label, strlen(label));
+    append_message("val", enc, 32);
+  }
+  void append_point_var_var(const char* label, tr_ref enc, bool validate) {
+    if (validate) check_nonzero(enc);
+    append_message("ptvar", label, strlen(label));
+    append_message_var("val", enc, 32);
+  }
+  void append_blinding_commitment_var(const char* label, tr_ref enc, bool validate) {
+    if (validate) check_nonzero(enc);
+    append_message("blindcom", label, strlen(label));
+    append_message_var("val", enc, 32);
+  }
+  void get_challenge_wide(const char* label, tr_ref dst) { challenge_bytes(label, dst, 64); }
+
+  void check_nonzero(tr_ref src) {
+    flush(false);
+    tr_op op{};
+    op.keep = ~0ULL;
+    op.flags = TR_CHECK_NONZERO;
+    op.src_buf = (uint8_t)(src.buf + 1);
+    op.src_stride = src.stride;
+    op.src_off = src.off;
+    ops_.push_back(op);
+  }
+  // ends the program; the transcript's trailing bytes (pos, pos_begin, cur_flags) after it
+  std::vector<tr_op> finish(uint8_t tail[3]) {
+    flush(false);
+    tail[0] = pos_; tail[1] = pos_begin_; tail[2] = cur_flags_;
+    return ops_;
+  }
+  size_t permutations() const { return n_perm_; }
+
+ private:
+  static constexpr unsigned kRate = 166;
+  enum : uint8_t { kI = 1, kA = 2, kC = 4, kT = 8, kM = 16, kK = 32 };
+  struct ByteEff { uint8_t keep, cx; bool has_src, has_dst; tr_ref src, dst; };
+
+  void frame(const char* label, size_t len) {
+    uint8_t l[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)(len >> 24)};
+    begin_op(kM | kA, false);
+    absorb_const(reinterpret_cast<const uint8_t*>(label), strlen(label));
+    absorb_const(l, 4);                     // meta_ad(.., more = true): continuation, no new header
+  }
+  void reset_block() {
+    for (auto& e : eff_) e = ByteEff{0xff, 0, false, false, {}, {}};
+    dirty_ = false;
+  }
+  void data_byte(uint8_t keep, uint8_t cx, const tr_ref* src, size_t si, const tr_ref* dst, size_t di) {
+    ByteEff& e = eff_[pos_];
+    e.keep &= keep;
+    e.cx = (uint8_t)((e.cx & keep) ^ cx);
+    if (src) { e.has_src = true; e.src = *src; e.src.off += si; }
+    if (dst) { e.has_dst = true; e.dst = *dst; e.dst.off += di; }
+    dirty_ = true;
+    if (++pos_ == kRate) run_f();
+  }
+  void absorb_const(const uint8_t* d, size_t n) { for (size_t i = 0; i < n; ++i) data_byte(0xff, d[i], nullptr, 0, nullptr, 0); }
+  void run_f() {
+    eff_[pos_].cx ^= pos_begin_;
+    eff_[pos_ + 1].cx ^= 0x04;
+    eff_[kRate + 1].cx ^= 0x80;
+    dirty_ = true;
+    flush(true);
+    pos_ = 0;
+    pos_begin_ = 0;
+  }
+  void begin_op(uint8_t flags, bool more) {
+    if (more) return;
+    const uint8_t old_begin = pos_begin_;
+    pos_begin_ = (uint8_t)(pos_ + 1);
+    cur_flags_ = flags;
+    const uint8_t hdr[2] = {old_begin, flags};
+    absorb_const(hdr, 2);
+    if ((flags & (kC | kK)) && pos_ != 0) run_f();
+  }
+  void marker(uint8_t flag) {
+    tr_op op{};
+    op.keep = ~0ULL;
+    op.flags = flag;
+    ops_.push_back(op);
+  }
+  // emit the pending byte effects as word operations; permute = the block ends here
+  void flush(bool permute) {
+    if (!dirty_ && !permute) return;
+    const size_t first = ops_.size();
+    for (unsigned w = 0; w < 21; ++w) {
+      const ByteEff* e = &eff_[8 * w];
+      // bytes leaving the state (squeeze), grouped into runs with contiguous destinations
+      for (unsigned b = 0; b < 8;) {
+        if (!e[b].has_dst) { ++b; continue; }
+        unsigned n = 1;
+        while (b + n < 8 && e[b + n].has_dst && e[b + n].dst.buf == e[b].dst.buf && e[b + n].dst.off == e[b].dst.off + n) ++n;
+        tr_op op{};
+        op.keep = ~0ULL;
+        op.w = (uint8_t)w;
+        op.dst_buf = (uint8_t)(e[b].dst.buf + 1);
+        op.dst_stride = e[b].dst.stride;
+        op.dst_off = e[b].dst.off;
+        op.dnb = (uint8_t)n;
+        op.dlb = (uint8_t)b;
+        ops_.push_back(op);
+        b += n;
+      }
+      uint64_t keep = 0, cx = 0;
+      for (unsigned b = 0; b < 8; ++b) { keep |= (uint64_t)e[b].keep << (8 * b); cx |= (uint64_t)e[b].cx << (8 * b); }
+      if (keep != ~0ULL || cx != 0) {
+        tr_op op{};
+        op.keep = keep;
+        op.cx = cx;
+        op.w = (uint8_t)w;
+        ops_.push_back(op);
+      }
+      for (unsigned b = 0; b < 8;) {
+        if (!e[b].has_src) { ++b; continue; }
+        unsigned n = 1;
+        // a run must stay inside one 32-byte source item so that the two aligned loads of tr_run_one do too
+        while (b + n < 8 && e[b + n].has_src && e[b + n].src.buf == e[b].src.buf && e[b + n].src.off == e[b].src.off + n &&
+               ((e[b].src.off + n) & 31) != 0) ++n;
+        tr_op op{};
+        op.keep = ~0ULL;
+        op.w = (uint8_t)w;
+        op.src_buf = (uint8_t)(e[b].src.buf + 1);
+        op.src_stride = e[b].src.stride;
+        op.src_off = e[b].src.off;
+        op.nb = (uint8_t)n;
+        op.lb = (uint8_t)b;
+        ops_.push_back(op);
+        b += n;
+      }
+    }
+    if (permute) {
+      if (ops_.size() == first) marker(0);
+      ops_.back().flags |= TR_PERMUTE;
+      ++n_perm_;
+    }
+    reset_block();
+  }
+
+  std::vector<tr_op> ops_;
+  ByteEff eff_[168];
+  bool dirty_ = false;
+  uint8_t pos_, pos_begin_, cur_flags_;
+  uint8_t s_pos_ = 0, s_pos_begin_ = 0, s_cur_flags_ = 0;
+  size_t n_perm_ = 0;
+};
+
+}  // namespace zkp
+#endif

@@ -18,6 +18,10 @@ ZKP_HD uint32_t sc_l(int i) {
 ZKP_HD uint32_t sc_rr(int i) {
   return i == 0 ? 0x449c0f01u : i == 1 ? 0xa40611e3u : i == 2 ? 0x68859347u : i == 3 ? 0xd00e1ba7u : i == 4 ? 0x17f5be65u : i == 5 ? 0xceec73d2u : i == 6 ? 0x7c309a3du : 0x0399411bu;
 }
+// R mod l
+ZKP_HD uint32_t sc_r1(int i) {
+  return i == 0 ? 0x8d98951du : i == 1 ? 0xd6ec3174u : i == 2 ? 0x737dcf70u : i == 3 ? 0xc6ef5bf4u : i == 4 ? 0xfffffffeu : i == 5 ? 0xffffffffu : i == 6 ? 0xffffffffu : 0x0fffffffu;
+}
 constexpr uint32_t SC_N0INV = 0x12547e1bu;      // -l^-1 mod 2^32
 
 ZKP_HD void sc_zero(sc& r) {
@@ -120,6 +124,16 @@ ZKP_HD void sc_reduce(sc& r, const sc& a) {
   sc t;
   sc_to_mont(t, a);          // a R mod l   (a may be >= l: sc_mont allows it in the first operand)
   sc_mont(r, t, one);        // a
+}
+
+// 512-bit little-endian value (lo + hi * 2^256) -> canonical scalar: Scalar::from_bytes_mod_order_wide
+ZKP_HD void sc_from_wide(sc& r, const sc& lo, const sc& hi) {
+  sc r1, rr, a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { r1.v[i] = sc_r1(i); rr.v[i] = sc_rr(i); }
+  sc_mont(a, lo, r1);        // lo * R / R = lo mod l
+  sc_mont(b, hi, rr);        // hi * R^2 / R = hi * 2^256 mod l
+  sc_add(r, a, b);
 }
 
 }  // namespace zkp

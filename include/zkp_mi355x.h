@@ -117,6 +117,39 @@ int zkp_batch_check(zkp_ctx* ctx, const zkp_batch_statement* st, uint32_t N, con
                     const uint8_t* instance_points, const uint8_t* commitments, uint8_t out_point[32], int* status,
                     uint8_t* debug_scalars);
 
+/* (2c) Fused statement flows: a whole batch of proofs of ONE statement handled
+ *     on the device -- Merlin/STROBE transcripts (src/toolbox/mod.rs:165-228 over merlin 2.x), blinding factors
+ *     (prover.rs:78-89), scalar arithmetic mod l (prover.rs:107-109, batch_verifier.rs:173-206), MSM operand assembly
+ *     and the MSMs themselves.  The host uploads inputs and downloads proofs or verdicts; nothing else crosses PCIe.
+ *     `transcripts` = [N][208] transcript blobs (layout of zkp_toolbox.h: 200 bytes of STROBE state, then pos,
+ *     pos_begin, cur_flags), updated in place exactly as the reference updates its `&mut Transcript`s.  All N blobs
+ *     must stand at the same STROBE position (same pos / pos_begin / cur_flags bytes), which holds whenever they were
+ *     produced by the same sequence of appends with equal lengths; otherwise ZKP_ERR_ARG (callers then use the
+ *     per-proof host transcripts of zkp_toolbox.h).  Layouts: secrets / responses [N][n_secrets][32];
+ *     inst [n_instance][N][32]; common [n_static][32]; commitments [N][n_constraints][32]; entropy [N][32] (the 32
+ *     bytes the external RNG contributes to each proof's TranscriptRng, prover.rs:82). */
+typedef struct {
+  zkp_batch_statement shape;
+  const char* label;                  /* the proof label of `domain_sep` (mod.rs:166-169)                                  */
+  const char* const* secret_labels;   /* [n_secrets]                                                                      */
+  const char* const* point_labels;    /* [n_static + n_instance], indexed by point id                                     */
+  const uint32_t* alloc_order;        /* [n_static + n_instance] point ids in allocation (= transcript) order             */
+} zkp_fused_statement;
+/* N x { build_prover (macros.rs:206-258) ; Prover::prove_impl (prover.rs:76-112) }.  *invalid_point = 1 if some input
+ * encoding did not decode (the reference prover holds decoded points, so this is a caller bug there). */
+int zkp_fused_prove(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
+                    const uint8_t* inst, const uint8_t* common, const uint8_t* entropy, uint8_t* challenges,
+                    uint8_t* responses, uint8_t* commitments, int* invalid_point);
+/* N x { build_verifier (macros.rs:280-311) ; Verifier::verify_compact (verifier.rs:80-120) }.  results[j]: 0 = accepted. */
+int zkp_fused_verify_compact(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts,
+                             const uint8_t* inst, const uint8_t* common, const uint8_t* challenges,
+                             const uint8_t* responses, uint8_t* results);
+/* batch_verify (macros.rs:336-370 ; batch_verifier.rs:67-235) without the batch-shape checks, which stay with the
+ * caller.  weights16 [n_constraints][N][16].  *verdict: 0 = the batch verifies.  debug_scalars as in zkp_batch_check. */
+int zkp_fused_batch_verify(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts,
+                           const uint8_t* inst, const uint8_t* common, const uint8_t* commitments,
+                           const uint8_t* responses, const uint8_t* weights16, int* verdict, uint8_t* debug_scalars);
+
 /* (3) Stand-alone decode / validity check, batched.  Replaces the
  *     `.map(|pt| pt.decompress()).collect::<Option<Vec<_>>>()` of verifier.rs:87-92.
  *     status[i] = 0 valid | 1 decompress() would return None.  If xyzt != NULL it receives the
@@ -144,7 +177,9 @@ enum {
                          /* + comb-table construction                                                     */
   ZKP_K_BUCKET = 4,      /* Pippenger: bucket accumulation                                        */
   ZKP_K_COMBINE = 5,     /* Pippenger: bucket reduction + window combination + compress           */
-  ZKP_K_COUNT = 6
+  ZKP_K_TRANSCRIPT = 6,  /* fused flows: batched Merlin/STROBE transcript programs                 */
+  ZKP_K_SCALARS = 7,     /* fused flows: scalar arithmetic mod l (blindings, responses, coefficients, operand assembly) */
+  ZKP_K_COUNT = 8
 };
 int zkp_ctx_last_timing(zkp_ctx* ctx, float* kernel_ms /*[ZKP_K_COUNT]*/, float* total_ms);
 /* Enable (1) / disable (0) per-kernel event timing (off by default: events add launch gaps). */

@@ -101,6 +101,13 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, u
                             const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
                             const uint8_t* responses, const uint8_t* weights16, int n_threads, uint8_t* coeffs);
 
+/* Batches of at least this many proofs whose transcripts stand at one STROBE position run entirely on the device
+ * (zkp_mi355x.h section 2c: transcripts, scalars and MSMs); smaller or ragged batches hash their transcripts on the
+ * host threads and use the GPU for the group arithmetic only.  Both routes produce the same bytes.  Default 256;
+ * 0 = always fused, UINT32_MAX = never. */
+void zkp_toolbox_set_fused_min_batch(uint32_t n);
+uint32_t zkp_toolbox_get_fused_min_batch(void);
+
 /* ---- host-only halves, exposed so the host logic can be tested without a GPU ----------------------- */
 /* Everything of zkp_batch_verify up to (not including) the MSM: writes the exact operand sequence of
  * batch_verifier.rs:219-228, ns + (ni + nc) * N scalars and encodings.  Returns 0 or the error the

@@ -1,0 +1,160 @@
+"""Fused device flows (include/zkp_mi355x.h section 2c: Merlin transcripts, scalars mod l and MSMs all on the GPU)
+against the host-transcript route of the same toolbox calls: proofs, verdicts and the transcripts left behind must be
+identical byte for byte, for every batch size (the route is chosen by zkp_toolbox_set_fused_min_batch), and both
+agree with the C oracle on sampled proofs.  Reference behaviour covered: prover.rs:76-112, verifier.rs:80-120,
+batch_verifier.rs:67-235, mod.rs:165-228 (identity rejection included)."""
+import numpy as np
+import pytest
+
+from oracle import cbind as C
+from oracle import model as M
+from zkp_amd import toolbox as T
+from tests.test_gpu_toolbox import BASEPOINT, _cmz_batch
+
+pytestmark = pytest.mark.gpu
+NEVER = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zkp_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+    T.set_fused_min_batch(256)
+
+
+def _fresh(label, n, extra=None):
+    t = T.Transcript(label)
+    if extra is not None:
+        t.append_message(b"ctx", extra)
+    return np.stack([t.state] * n)
+
+
+def _dleq_batch(n, seed):
+    rng = np.random.default_rng(seed)
+    mod = T.dleq_module()
+    x = rng.integers(0, 256, size=(n, 1, 32), dtype=np.uint8)
+    x[:, :, 31] &= 0x0f
+    base = np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32)
+    hs = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    hs[:, 31] &= 0x0f
+    H, _ = C.msm_many(np.arange(n + 1, dtype=np.uint32), hs, np.zeros(n, np.uint32), base, 0)
+    A, _ = C.msm_many(np.arange(n + 1, dtype=np.uint32), x[:, 0], np.zeros(n, np.uint32), base, 0)
+    B, _ = C.msm_many(np.arange(n + 1, dtype=np.uint32), x[:, 0], np.arange(n, dtype=np.uint32), H, 0)
+    return mod, x, A, B, H
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 333, 4096])
+def test_cmz_fused_equals_host_route(eng, n):
+    mod, secrets, inst, common = _cmz_batch(n, 41)
+    st = mod.statement
+    label = b"Benchmark"
+    rng = np.random.default_rng(n)
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    w = rng.integers(0, 256, size=(st.nc, n, 16), dtype=np.uint8)
+    out = {}
+    for route, thr in (("host", NEVER), ("fused", 0)):
+        T.set_fused_min_batch(thr)
+        assert T.get_fused_min_batch() == thr
+        ts = _fresh(label, n, b"some context")
+        chal, resp, coms = T.prove_batch(eng, st, ts, secrets, inst, common, entropy)
+        ts_p = ts.copy()
+        ts = _fresh(label, n, b"some context")
+        res = T.verify_compact_batch(eng, st, ts, inst, common, chal, resp)
+        ts_v = ts.copy()
+        ts = _fresh(label, n, b"some context")
+        ok, coeffs = T.batch_verify_coeffs(eng, st, ts, inst, common, coms, resp, w)
+        ts_b = ts.copy()
+        # a wrong response, a wrong challenge, an identity instance point, an undecodable instance point
+        k = n // 2
+        bad_resp = resp.copy(); bad_resp[k, 3, 0] ^= 1
+        bad_chal = chal.copy(); bad_chal[k, 5] ^= 8
+        ts = _fresh(label, n, b"some context")
+        r1 = T.verify_compact_batch(eng, st, ts, inst, common, chal, bad_resp)
+        ts = _fresh(label, n, b"some context")
+        r2 = T.verify_compact_batch(eng, st, ts, inst, common, bad_chal, resp)
+        ident = inst.copy(); ident[2, k] = 0
+        ts = _fresh(label, n, b"some context")
+        r3 = T.verify_compact_batch(eng, st, ts, ident, common, chal, resp)
+        junk = inst.copy(); junk[4, k] = np.frombuffer(bytes([1] + [0] * 31), np.uint8)
+        ts = _fresh(label, n, b"some context")
+        r4 = T.verify_compact_batch(eng, st, ts, junk, common, chal, resp)
+        ts = _fresh(label, n, b"some context")
+        ok_bad, _ = T.batch_verify_coeffs(eng, st, ts, inst, common, coms, bad_resp, w)
+        ts = _fresh(label, n, b"some context")
+        ok_ident, _ = T.batch_verify_coeffs(eng, st, ts, ident, common, coms, resp, w)
+        zc = coms.copy(); zc[k, 0] = 0
+        ts = _fresh(label, n, b"some context")
+        ok_zc, _ = T.batch_verify_coeffs(eng, st, ts, inst, common, zc, resp, w)
+        out[route] = dict(chal=chal, resp=resp, coms=coms, ts_p=ts_p, res=res, ts_v=ts_v, ok=ok, coeffs=coeffs, ts_b=ts_b,
+                          r1=r1, r2=r2, r3=r3, r4=r4, ok_bad=ok_bad, ok_ident=ok_ident, ok_zc=ok_zc)
+    T.set_fused_min_batch(256)
+    h, f = out["host"], out["fused"]
+    for key in ("chal", "resp", "coms", "res", "coeffs", "r1", "r2", "r3", "r4"):
+        assert (h[key] == f[key]).all(), key
+    for key in ("ts_p", "ts_v", "ts_b"):                               # 200 state bytes + pos, pos_begin, cur_flags
+        assert (h[key][:, :203] == f[key][:, :203]).all(), key
+    assert h["ok"] and f["ok"] and not f["res"].any()
+    for key in ("r1", "r2", "r3", "r4"):
+        assert f[key][n // 2] == 1 and f[key].sum() == 1, key
+    assert not f["ok_bad"] and not f["ok_ident"] and not f["ok_zc"]
+    assert not h["ok_bad"] and not h["ok_ident"] and not h["ok_zc"]
+
+
+@pytest.mark.parametrize("n", [2, 700])
+def test_dleq_fused_equals_host_route_and_oracle(eng, n):
+    mod, x, A, B, H = _dleq_batch(n, 7)
+    st = mod.statement
+    label = b"DLEQBatch"
+    inst = np.ascontiguousarray(np.stack([A, B, H]))
+    common = np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32).copy()
+    rng = np.random.default_rng(5)
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    got = {}
+    for route, thr in (("host", NEVER), ("fused", 0)):
+        T.set_fused_min_batch(thr)
+        ts = _fresh(label, n)
+        chal, resp, coms = T.prove_batch(eng, st, ts, x, inst, common, entropy)
+        ts2 = _fresh(label, n)
+        res = T.verify_compact_batch(eng, st, ts2, inst, common, chal, resp)
+        ts3 = _fresh(label, n)
+        T.batch_verify(eng, st, ts3, inst, common, coms, resp)
+        got[route] = (chal, resp, coms, ts, res, ts2, ts3)
+    T.set_fused_min_batch(256)
+    for a, b in zip(got["host"], got["fused"]):
+        a, b = (a[:, :203], b[:, :203]) if a.shape[-1] == 208 else (a, b)
+        assert (a == b).all()
+    assert not got["fused"][4].any()
+    cst = C.Statement.from_model(M.dleq_statement())
+    for j in (0, n - 1):
+        pts = np.concatenate([inst[:, j], common])
+        ec, er, ek, _ = C.prove(cst, label, x[j], pts, entropy[j].tobytes())
+        assert got["fused"][0][j].tobytes() == ec.tobytes() and (got["fused"][1][j] == er).all() and (got["fused"][2][j] == ek).all()
+
+
+def test_ragged_transcripts_use_the_host_route(eng):
+    """Transcripts at different STROBE positions cannot share a device program: the toolbox hashes them on the host
+    (same results as proving each one alone); the raw fused entry point refuses them."""
+    n = 300
+    mod, x, A, B, H = _dleq_batch(n, 9)
+    st = mod.statement
+    inst = np.ascontiguousarray(np.stack([A, B, H]))
+    common = np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32).copy()
+    entropy = np.random.default_rng(1).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    states = []
+    for j in range(n):
+        t = T.Transcript(b"ragged")
+        t.append_message(b"m", b"x" * (j % 7))
+        states.append(t.state)
+    T.set_fused_min_batch(0)
+    ts = np.stack(states)
+    chal, resp, coms = T.prove_batch(eng, st, ts, x, inst, common, entropy)
+    T.set_fused_min_batch(NEVER)
+    ts2 = np.stack(states)
+    chal2, resp2, coms2 = T.prove_batch(eng, st, ts2, x, inst, common, entropy)
+    T.set_fused_min_batch(256)
+    assert (chal == chal2).all() and (resp == resp2).all() and (coms == coms2).all() and (ts[:, :203] == ts2[:, :203]).all()
+    ts3 = np.stack(states)
+    res = T.verify_compact_batch(eng, st, ts3, inst, common, chal, resp)
+    assert not res.any()

@@ -1,0 +1,647 @@
+// Fused statement flows: the whole life of a batch of proofs of ONE statement on the device --
+// Merlin transcripts (merlin_prog.h), scalar arithmetic mod l (sc25519.h), operand assembly and the MSMs -- so that
+// the host only uploads the inputs and downloads proofs / verdicts.  Included at the end of zkp_kernels.hip (one
+// translation unit: shares zkp_ctx, the workspace carving and the MSM paths).
+//
+//   zkp_fused_prove           N x { macros.rs:206-258 build_prover ; prover.rs:76-112 prove_impl }
+//   zkp_fused_verify_compact  N x { macros.rs:280-311 build_verifier ; verifier.rs:80-120 }
+//   zkp_fused_batch_verify    macros.rs:336-370 ; batch_verifier.rs:67-235
+#pragma once
+#include "merlin_prog.h"
+
+namespace zkp {
+
+// One lane per proof; the STROBE state lives in an LDS column so that the interpreter can index words dynamically.
+// No cross-lane traffic, hence no barriers.  tail = pos | pos_begin << 8 | cur_flags << 16 after the program.
+__global__ void __launch_bounds__(64)
+k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, uint32_t N, const tr_bufs* __restrict__ bufs,
+                 uint8_t* __restrict__ ts, uint64_t* __restrict__ saved, uint32_t* __restrict__ failed, uint32_t tail) {
+  __shared__ uint64_t S[25 * 64];
+  const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= N) return;
+  uint64_t* col = S + threadIdx.x;
+  uint64_t* blob = reinterpret_cast<uint64_t*>(ts + 208 * (size_t)j);
+#pragma unroll
+  for (int i = 0; i < 25; ++i) col[64 * i] = blob[i];
+  uint32_t f = 0;
+  tr_run_one(prog, n_ops, j, *bufs, col, 64, saved + j, N, &f);
+#pragma unroll
+  for (int i = 0; i < 25; ++i) blob[i] = col[64 * i];
+  blob[25] = tail;
+  if (f) failed[j] = 1;
+}
+
+// Scalar::from_bytes_mod_order_wide over n 64-byte strings
+__global__ void __launch_bounds__(256)
+k_wide_reduce(uint32_t n, const uint8_t* __restrict__ wide, uint8_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sc lo, hi, r;
+  load_vec<2>(lo.v, wide + 64 * (size_t)i);
+  load_vec<2>(hi.v, wide + 64 * (size_t)i + 32);
+  sc_from_wide(r, lo, hi);
+  store_vec<2>(out + 32 * (size_t)i, r.v);
+}
+
+// out[i] = -(in[i] mod l)
+__global__ void __launch_bounds__(256)
+k_neg_reduce(uint32_t n, const uint8_t* in, uint8_t* out) {       // in may equal out
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sc a, r;
+  load_vec<2>(a.v, in + 32 * (size_t)i);
+  sc_reduce(r, a);
+  sc_neg(r, r);
+  store_vec<2>(out + 32 * (size_t)i, r.v);
+}
+
+// The CSR multiscalar job of a batch of proofs of one statement: T terms per proof in nc MSMs.
+//   term t of proof j:  scalar = tsc[t] == ~0 ? special[j] : vals[j][tsc[t]];   point = table index of point id tpt[t]
+// (prover.rs:94-97 with vals = blindings; verifier.rs:97-106 with vals = responses, special = -c)
+__global__ void __launch_bounds__(256)
+k_stmt_terms(uint32_t N, uint32_t T, uint32_t nc, uint32_t ns, uint32_t m, const uint32_t* __restrict__ toff,
+             const uint32_t* __restrict__ tsc, const uint32_t* __restrict__ tpt, const uint8_t* __restrict__ vals,
+             const uint8_t* __restrict__ special, uint32_t* __restrict__ off, uint8_t* __restrict__ scalars,
+             uint32_t* __restrict__ pidx) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < (size_t)N * nc) off[g] = (uint32_t)((g / nc) * T + toff[g % nc]);
+  if (g == 0) off[(size_t)N * nc] = N * T;
+  if (g >= (size_t)N * T) return;
+  const uint32_t j = (uint32_t)(g / T), t = (uint32_t)(g % T);
+  const uint32_t s = tsc[t], p = tpt[t];
+  const uint8_t* src = s == 0xffffffffu ? special + 32 * (size_t)j : vals + 32 * ((size_t)j * m + s);
+  uint32_t w[8];
+  load_vec<2>(w, src);
+  store_vec<2>(scalars + 32 * g, w);
+  pidx[g] = p < ns ? p : ns + (p - ns) * N + j;
+}
+
+// responses  s * c + b  (prover.rs:107-109)
+__global__ void __launch_bounds__(256)
+k_responses(uint32_t N, uint32_t m, const uint8_t* __restrict__ secrets, const uint8_t* __restrict__ chal,
+            const uint8_t* __restrict__ blind, uint8_t* __restrict__ resp) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)N * m) return;
+  sc s, c, b, r;
+  load_vec<2>(s.v, secrets + 32 * g);
+  load_vec<2>(c.v, chal + 32 * (g / m));
+  load_vec<2>(b.v, blind + 32 * g);
+  sc_mul(r, s, c);                      // s may be any 256-bit value (first operand), c and b are canonical
+  sc_add(r, r, b);
+  store_vec<2>(resp + 32 * g, r.v);
+}
+
+// verify_compact verdicts (verifier.rs:87-92, :113-119): 0 = accepted
+__global__ void __launch_bounds__(256)
+k_verify_finish(uint32_t N, uint32_t nc, uint32_t ns, const uint8_t* __restrict__ chal, const uint8_t* __restrict__ claimed,
+                const uint8_t* __restrict__ status8, const uint32_t* __restrict__ failed, const dev_affine* __restrict__ pts,
+                const uint32_t* __restrict__ unref, uint32_t n_unref, uint8_t* __restrict__ results) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  uint32_t bad = failed[j];
+  for (uint32_t k = 0; k < nc; ++k) bad |= status8[(size_t)j * nc + k];
+  for (uint32_t u = 0; u < n_unref; ++u) {
+    const uint32_t p = unref[u];
+    bad |= pts[p < ns ? p : ns + (p - ns) * N + j].valid == 0;
+  }
+  sc a, b;
+  load_vec<2>(a.v, chal + 32 * (size_t)j);
+  load_vec<2>(b.v, claimed + 32 * (size_t)j);
+  sc_reduce(b, b);
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d |= a.v[i] ^ b.v[i];
+  results[j] = (bad || d) ? 1 : 0;
+}
+
+// commitment rows of the batch-verification operand list: rows[k][j] = commitments[j][k]  (batch_verifier.rs:208-212)
+__global__ void __launch_bounds__(256)
+k_transpose_commitments(uint32_t N, uint32_t nc, const uint8_t* __restrict__ coms, uint8_t* __restrict__ rows) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)N * nc) return;
+  const size_t j = g / nc, k = g % nc;
+  uint32_t w[8];
+  load_vec<2>(w, coms + 32 * g);
+  store_vec<2>(rows + 32 * (k * N + j), w);
+}
+
+__global__ void k_any_nonzero(uint32_t n, const uint32_t* __restrict__ flags, uint32_t* __restrict__ any) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) *any = 1;
+}
+
+}  // namespace zkp
+
+namespace {
+using namespace zkp;
+
+struct fused_shape {
+  uint32_t m, ns, ni, nc, np, T;
+  std::vector<uint32_t> inc_off, inc_k, inc_sc;          // per point id: (constraint, secret | ~0)
+  std::vector<uint32_t> unref;                           // point ids no constraint mentions
+};
+
+int parse_shape(const zkp_batch_statement* st, fused_shape& s) {
+  s.m = st->n_secrets; s.ns = st->n_static; s.ni = st->n_instance; s.nc = st->n_constraints; s.np = s.ns + s.ni;
+  if (s.nc && (!st->cons_lhs || !st->cons_off)) return fail(ZKP_ERR_ARG, "statement without constraint arrays");
+  s.T = s.nc ? st->cons_off[s.nc] : 0;
+  if (s.T && (!st->cons_sc || !st->cons_pt)) return fail(ZKP_ERR_ARG, "statement without term arrays");
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> inc(s.np);
+  std::vector<char> used(s.np, 0);
+  for (uint32_t k = 0; k < s.nc; ++k) {
+    if (st->cons_lhs[k] >= s.np) return fail(ZKP_ERR_ARG, "constraint lhs out of range");
+    if (st->cons_off[k + 1] < st->cons_off[k]) return fail(ZKP_ERR_ARG, "cons_off must be non-decreasing");
+    inc[st->cons_lhs[k]].emplace_back(k, 0xffffffffu);
+    used[st->cons_lhs[k]] = 1;
+    for (uint32_t q = st->cons_off[k]; q < st->cons_off[k + 1]; ++q) {
+      if (st->cons_pt[q] >= s.np || st->cons_sc[q] >= s.m) return fail(ZKP_ERR_ARG, "constraint term out of range");
+      inc[st->cons_pt[q]].emplace_back(k, st->cons_sc[q]);
+      used[st->cons_pt[q]] = 1;
+    }
+  }
+  s.inc_off.assign(s.np + 1, 0);
+  for (uint32_t p = 0; p < s.np; ++p) {
+    for (auto& e : inc[p]) { s.inc_k.push_back(e.first); s.inc_sc.push_back(e.second); }
+    s.inc_off[p + 1] = (uint32_t)s.inc_k.size();
+    if (!used[p]) s.unref.push_back(p);
+  }
+  return ZKP_OK;
+}
+
+// batch_verifier.rs:173-206 on device buffers; d_inc = inc_off | inc_k | inc_sc
+void launch_coeff_build(zkp_ctx* c, const fused_shape& s, uint32_t N, const uint32_t* d_inc, const uint8_t* d_mc,
+                        const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_sc, uint32_t* d_part) {
+  const uint32_t* d_inc_off = d_inc;
+  const uint32_t* d_inc_k = d_inc + s.inc_off.size();
+  const uint32_t* d_inc_sc = d_inc_k + s.inc_k.size();
+  const uint32_t nblk = (N + 255) / 256, rows = s.ni + s.nc;
+  if (N && rows)
+    hipLaunchKernelGGL(k_coeff_matrix, dim3(nblk, rows), dim3(256), 0, c->stream, N, s.m, s.ns, s.ni, s.nc, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, d_sc);
+  if (s.ns) {
+    if (N) {
+      hipLaunchKernelGGL(k_coeff_static_partial, dim3(nblk, s.ns), dim3(256), 0, c->stream, N, s.m, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, d_part);
+      hipLaunchKernelGGL(k_coeff_static_final, dim3(s.ns), dim3(64), 0, c->stream, nblk, d_part, d_sc);
+    } else {
+      hipMemsetAsync(d_sc, 0, (size_t)s.ns * 32, c->stream);
+    }
+  }
+}
+int upload_incidence(zkp_ctx* c, const fused_shape& s, uint32_t* d_inc) {
+  HIP_TRY(hipMemcpyAsync(d_inc, s.inc_off.data(), s.inc_off.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if (!s.inc_k.empty()) {
+    HIP_TRY(hipMemcpyAsync(d_inc + s.inc_off.size(), s.inc_k.data(), s.inc_k.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_inc + s.inc_off.size() + s.inc_k.size(), s.inc_sc.data(), s.inc_sc.size() * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  return ZKP_OK;
+}
+size_t optional_ws(uint64_t total) {
+  if (total <= kSmallOptional) return 1024 + (total + 1) * 4 + terms_path_ws((uint32_t)total, (uint32_t)total);
+  switch (pick_c(total)) {
+    case 7: return pip_ws<7>(total);
+    case 10: return pip_ws<10>(total);
+    case 11: return pip_ws<11>(total);
+    default: return pip_ws<16>(total);
+  }
+}
+
+// ---- transcripts ---------------------------------------------------------------------------------------------------
+int check_fused_statement(const zkp_fused_statement* st, fused_shape& s) {
+  if (!st) return fail(ZKP_ERR_ARG, "statement is NULL");
+  int rc = parse_shape(&st->shape, s);
+  if (rc) return rc;
+  if (!st->label || (s.m && !st->secret_labels) || (s.np && (!st->point_labels || !st->alloc_order)))
+    return fail(ZKP_ERR_ARG, "statement labels missing");
+  std::vector<char> seen(s.np, 0);
+  for (uint32_t i = 0; i < s.np; ++i) {
+    if (st->alloc_order[i] >= s.np || seen[st->alloc_order[i]]) return fail(ZKP_ERR_ARG, "alloc_order is not a permutation of the point ids");
+    seen[st->alloc_order[i]] = 1;
+  }
+  return ZKP_OK;
+}
+// all transcripts of a fused call must stand at the same STROBE position (they do whenever they were built by the
+// same sequence of appends with equal lengths); the caller falls back to the host pipeline otherwise
+int common_tail(const uint8_t* ts, uint32_t N, uint8_t tail[3]) {
+  memcpy(tail, ts + 200, 3);
+  for (uint32_t j = 1; j < N; ++j)
+    if (memcmp(ts + 208 * (size_t)j + 200, tail, 3) != 0) return fail(ZKP_ERR_ARG, "transcripts stand at different STROBE positions");
+  if (tail[0] >= 166) return fail(ZKP_ERR_ARG, "corrupt transcript blob");
+  return ZKP_OK;
+}
+enum { SRC_TABLE = 0, SRC_SECRETS = 1, SRC_ENTROPY = 2, SRC_COMS = 3 };
+enum { DST_WIDE = 0, DST_CHAL = 1 };
+
+// Prover::new / Verifier::new + allocate_scalar + allocate_point in allocation order (prover.rs:41-73, verifier.rs:47-77)
+void compile_allocations(TrCompiler& tc, const zkp_fused_statement* st, const fused_shape& s, uint32_t N, const uint8_t* common, bool validate) {
+  tc.domain_sep(st->label);
+  for (uint32_t i = 0; i < s.m; ++i) tc.append_scalar_var(st->secret_labels[i]);
+  for (uint32_t a = 0; a < s.np; ++a) {
+    const uint32_t p = st->alloc_order[a];
+    // every proof of the batch reads the table  common || inst[ni][N]; common points are variables of the program too
+    // (stride 0) so that one compiled program does not depend on their values
+    const tr_ref ref = p < s.ns ? tr_ref{SRC_TABLE, 0, 32ull * p} : tr_ref{SRC_TABLE, 32, 32ull * (s.ns + (uint64_t)(p - s.ns) * N)};
+    tc.append_point_var_var(st->point_labels[p], ref, validate);
+  }
+  (void)common;
+}
+
+struct prog_dev { const tr_op* ops; uint32_t n; uint32_t tail; };
+int upload_program(zkp_ctx* c, const std::vector<tr_op>& prog, const uint8_t tail[3], char* d_where, prog_dev& out) {
+  if (!prog.empty()) HIP_TRY(hipMemcpyAsync(d_where, prog.data(), prog.size() * sizeof(tr_op), hipMemcpyHostToDevice, c->stream));
+  out.ops = reinterpret_cast<const tr_op*>(d_where);
+  out.n = (uint32_t)prog.size();
+  out.tail = tail[0] | (uint32_t)tail[1] << 8 | (uint32_t)tail[2] << 16;
+  return ZKP_OK;
+}
+void run_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs* d_bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed) {
+  hipLaunchKernelGGL(k_transcript_run, dim3((N + 63) / 64), dim3(64), 0, c->stream, p.ops, p.n, N, d_bufs, d_ts, d_saved, d_failed, p.tail);
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkp_batch_check(zkp_ctx* c, const zkp_batch_statement* st, uint32_t N, const uint8_t* minus_c, const uint8_t* responses,
+                    const uint8_t* weights16, const uint8_t* static_points, const uint8_t* instance_points,
+                    const uint8_t* commitments, uint8_t out_point[32], int* status, uint8_t* debug_scalars) {
+  if (!c || !st || !out_point || !status) return fail(ZKP_ERR_ARG, "NULL pointer");
+  fused_shape s;
+  int rc = parse_shape(st, s);
+  if (rc) return rc;
+  const uint32_t m = s.m, ns = s.ns, ni = s.ni, nc = s.nc;
+  if (N && ((!minus_c) || (m && !responses) || (nc && (!weights16 || !commitments)) || (ni && !instance_points)))
+    return fail(ZKP_ERR_ARG, "NULL input pointer");
+  if (ns && !static_points) return fail(ZKP_ERR_ARG, "NULL static points");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t rows = (size_t)ni + nc, total = (size_t)ns + rows * N;
+  if (total > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  const uint32_t nblk = (N + 255) / 256;
+  carve cv;
+  const size_t o_sc = cv.take(total * 32 + 32);
+  const size_t o_pts = cv.take(total * 32 + 32);
+  const size_t o_out = cv.take(32);
+  const size_t o_st = cv.take(4);
+  const size_t o_mc = cv.take((size_t)N * 32);
+  const size_t o_resp = cv.take((size_t)N * m * 32);
+  const size_t o_w = cv.take((size_t)nc * N * 16);
+  const size_t o_coms = cv.take((size_t)nc * N * 32);
+  const size_t o_inc = cv.take((s.inc_off.size() + s.inc_k.size() * 2 + 4) * 4);
+  const size_t o_part = cv.take((size_t)(ns ? ns : 1) * (nblk ? nblk : 1) * 32);
+  const size_t reserved = cv.off;
+  rc = ensure_ws(c, reserved + optional_ws(total));
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  uint8_t* d_sc = reinterpret_cast<uint8_t*>(base + o_sc);
+  uint8_t* d_pts = reinterpret_cast<uint8_t*>(base + o_pts);
+  // operands of batch_verifier.rs:219-228: points = static || instance rows || commitment rows (row = constraint)
+  if (ns) HIP_TRY(hipMemcpyAsync(d_pts, static_points, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
+  if (ni && N) HIP_TRY(hipMemcpyAsync(d_pts + 32 * (size_t)ns, instance_points, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
+  if (nc && N) {
+    HIP_TRY(hipMemcpyAsync(base + o_coms, commitments, (size_t)nc * N * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(base + o_w, weights16, (size_t)nc * N * 16, hipMemcpyHostToDevice, c->stream));
+  }
+  if (N) {
+    HIP_TRY(hipMemcpyAsync(base + o_mc, minus_c, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
+    if (m) HIP_TRY(hipMemcpyAsync(base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
+  }
+  rc = upload_incidence(c, s, reinterpret_cast<uint32_t*>(base + o_inc));
+  if (rc) return rc;
+  prof_begin(c);
+  if (nc && N)
+    hipLaunchKernelGGL(k_transpose_commitments, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, N, nc,
+                       reinterpret_cast<const uint8_t*>(base + o_coms), d_pts + 32 * ((size_t)ns + (size_t)ni * N));
+  launch_coeff_build(c, s, N, reinterpret_cast<uint32_t*>(base + o_inc), reinterpret_cast<uint8_t*>(base + o_mc),
+                     reinterpret_cast<uint8_t*>(base + o_resp), reinterpret_cast<uint8_t*>(base + o_w), d_sc,
+                     reinterpret_cast<uint32_t*>(base + o_part));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, d_sc, total * 32, hipMemcpyDeviceToHost, c->stream));
+  rc = msm_optional_impl(c, total, d_sc, d_pts, reinterpret_cast<uint8_t*>(base + o_out), reinterpret_cast<uint32_t*>(base + o_st), reserved);
+  if (rc) return rc;
+  uint32_t stv = 1;
+  HIP_TRY(hipMemcpyAsync(out_point, static_cast<char*>(c->ws) + o_out, 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&stv, static_cast<char*>(c->ws) + o_st, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *status = (int)stv;
+  return ZKP_OK;
+}
+
+int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
+                    const uint8_t* inst, const uint8_t* common, const uint8_t* entropy, uint8_t* challenges,
+                    uint8_t* responses, uint8_t* commitments, int* invalid_point) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  fused_shape s;
+  int rc = check_fused_statement(st, s);
+  if (rc) return rc;
+  if (N == 0) { if (invalid_point) *invalid_point = 0; return ZKP_OK; }
+  if (!transcripts || !entropy || !challenges || !invalid_point || (s.m && (!secrets || !responses)) || (s.nc && !commitments) ||
+      (s.ni && !inst) || (s.ns && !common))
+    return fail(ZKP_ERR_ARG, "NULL pointer");
+  if ((uint64_t)N * s.T > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  uint8_t tail0[3], tailA[3], tailB[3];
+  rc = common_tail(transcripts, N, tail0);
+  if (rc) return rc;
+  const uint32_t m = s.m, nc = s.nc, T = s.T, n_points = s.ns + s.ni * N;
+  // program A: allocations, then the blinding factors from a clone of the transcript (prover.rs:78-89)
+  TrCompiler ta(tail0[0], tail0[1], tail0[2]);
+  compile_allocations(ta, st, s, N, common, false);
+  ta.save();
+  for (uint32_t i = 0; i < m; ++i) ta.rng_rekey_with_witness_var("", tr_ref{SRC_SECRETS, 32 * m, 32ull * i}, 32);
+  ta.rng_finalize_var(tr_ref{SRC_ENTROPY, 32, 0});
+  for (uint32_t i = 0; i < m; ++i) ta.rng_fill_bytes(tr_ref{DST_WIDE, 64 * m, 64ull * i}, 64);
+  ta.restore();
+  const std::vector<tr_op> progA = ta.finish(tailA);
+  // program B: commitments, challenge (prover.rs:98-106)
+  TrCompiler tb(tailA[0], tailA[1], tailA[2]);
+  for (uint32_t k = 0; k < nc; ++k)
+    tb.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, false);
+  tb.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});
+  const std::vector<tr_op> progB = tb.finish(tailB);
+
+  HIP_TRY(hipSetDevice(c->device));
+  carve cv;
+  const size_t o_ts = cv.take((size_t)N * 208);
+  const size_t o_sec = cv.take((size_t)N * m * 32 + 32);
+  const size_t o_tbl = cv.take((size_t)n_points * 32 + 32);
+  const size_t o_ent = cv.take((size_t)N * 32);
+  const size_t o_pa = cv.take(progA.size() * sizeof(tr_op) + 64);
+  const size_t o_pb = cv.take(progB.size() * sizeof(tr_op) + 64);
+  const size_t o_bufs = cv.take(sizeof(tr_bufs));
+  const size_t o_saved = cv.take((size_t)N * 25 * 8);
+  const size_t o_failed = cv.take((size_t)N * 4);
+  const size_t o_wide = cv.take((size_t)N * m * 64 + 64);
+  const size_t o_blind = cv.take((size_t)N * m * 32 + 32);
+  const size_t o_tarr = cv.take(((size_t)nc + 1 + 2 * (size_t)T + 4) * 4);
+  const size_t o_off = cv.take(((size_t)N * nc + 1) * 4);
+  const size_t o_sc = cv.take((size_t)N * T * 32 + 32);
+  const size_t o_pidx = cv.take((size_t)N * T * 4 + 4);
+  const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
+  const size_t o_st = cv.take((size_t)N * nc + 4);
+  const size_t o_wchal = cv.take((size_t)N * 64);
+  const size_t o_chal = cv.take((size_t)N * 32);
+  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
+  const size_t reserved = cv.off;
+  rc = ensure_ws(c, reserved + terms_path_ws(n_points, N * T));
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  auto u8 = [&](size_t o) { return reinterpret_cast<uint8_t*>(base + o); };
+  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t*>(base + o); };
+  HIP_TRY(hipMemcpyAsync(base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
+  if (m) HIP_TRY(hipMemcpyAsync(base + o_sec, secrets, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
+  if (s.ns) HIP_TRY(hipMemcpyAsync(base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
+  if (s.ni) HIP_TRY(hipMemcpyAsync(base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(base + o_ent, entropy, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
+  prog_dev pa, pb;
+  rc = upload_program(c, progA, tailA, base + o_pa, pa);
+  if (rc) return rc;
+  rc = upload_program(c, progB, tailB, base + o_pb, pb);
+  if (rc) return rc;
+  tr_bufs hb{};
+  hb.src[SRC_TABLE] = u8(o_tbl); hb.src[SRC_SECRETS] = u8(o_sec); hb.src[SRC_ENTROPY] = u8(o_ent); hb.src[SRC_COMS] = u8(o_coms);
+  hb.dst[DST_WIDE] = u8(o_wide); hb.dst[DST_CHAL] = u8(o_wchal);
+  HIP_TRY(hipMemcpyAsync(base + o_bufs, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
+  std::vector<uint32_t> tarr;
+  tarr.insert(tarr.end(), st->shape.cons_off, st->shape.cons_off + nc + (nc ? 1 : 0));
+  if (!nc) tarr.push_back(0);
+  if (T) { tarr.insert(tarr.end(), st->shape.cons_sc, st->shape.cons_sc + T); tarr.insert(tarr.end(), st->shape.cons_pt, st->shape.cons_pt + T); }
+  HIP_TRY(hipMemcpyAsync(base + o_tarr, tarr.data(), tarr.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(base + o_failed, 0, (size_t)N * 4, c->stream));
+  const tr_bufs* d_bufs = reinterpret_cast<const tr_bufs*>(base + o_bufs);
+  uint64_t* d_saved = reinterpret_cast<uint64_t*>(base + o_saved);
+
+  prof_begin(c);
+  run_program(c, pa, N, d_bufs, u8(o_ts), d_saved, u32(o_failed));
+  prof_mark(c, ZKP_K_TRANSCRIPT);
+  if (m) hipLaunchKernelGGL(k_wide_reduce, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N * m, u8(o_wide), u8(o_blind));
+  const size_t lanes = std::max<size_t>((size_t)N * T, (size_t)N * nc) + 1;
+  hipLaunchKernelGGL(k_stmt_terms, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, s.ns, m, u32(o_tarr), u32(o_tarr) + nc + 1,
+                     u32(o_tarr) + nc + 1 + T, u8(o_blind), (const uint8_t*)nullptr, u32(o_off), u8(o_sc), u32(o_pidx));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  if (nc) {
+    rc = msm_terms_path(c, N * nc, u32(o_off), u8(o_sc), u32(o_pidx), u8(o_tbl), n_points, N * T, ZKP_CT, u8(o_coms), u8(o_st), nullptr, reserved);
+    if (rc) return rc;
+  }
+  run_program(c, pb, N, d_bufs, u8(o_ts), d_saved, u32(o_failed));
+  prof_mark(c, ZKP_K_TRANSCRIPT);
+  hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_wchal), u8(o_chal));
+  if (m) hipLaunchKernelGGL(k_responses, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N, m, u8(o_sec), u8(o_chal), u8(o_blind), u8(o_resp));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  std::vector<uint8_t> status((size_t)N * nc);
+  HIP_TRY(hipMemcpyAsync(challenges, base + o_chal, (size_t)N * 32, hipMemcpyDeviceToHost, c->stream));
+  if (m) HIP_TRY(hipMemcpyAsync(responses, base + o_resp, (size_t)N * m * 32, hipMemcpyDeviceToHost, c->stream));
+  if (nc) {
+    HIP_TRY(hipMemcpyAsync(commitments, base + o_coms, (size_t)N * nc * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(status.data(), base + o_st, (size_t)N * nc, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(transcripts, base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *invalid_point = 0;
+  for (uint8_t b : status) if (b) *invalid_point = 1;
+  return ZKP_OK;
+}
+
+int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
+                             const uint8_t* common, const uint8_t* challenges, const uint8_t* responses, uint8_t* results) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  fused_shape s;
+  int rc = check_fused_statement(st, s);
+  if (rc) return rc;
+  if (N == 0) return ZKP_OK;
+  if (!transcripts || !challenges || !results || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
+  const uint32_t m = s.m, nc = s.nc, T1 = s.T + nc, n_points = s.ns + s.ni * N;
+  if ((uint64_t)N * T1 > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  uint8_t tail0[3], tailA[3], tailB[3];
+  rc = common_tail(transcripts, N, tail0);
+  if (rc) return rc;
+  TrCompiler ta(tail0[0], tail0[1], tail0[2]);
+  compile_allocations(ta, st, s, N, common, true);                       // verifier.rs:61-77 validating appends
+  const std::vector<tr_op> progA = ta.finish(tailA);
+  TrCompiler tb(tailA[0], tailA[1], tailA[2]);
+  for (uint32_t k = 0; k < nc; ++k)                                       // verifier.rs:108 (non-validating)
+    tb.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, false);
+  tb.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});
+  const std::vector<tr_op> progB = tb.finish(tailB);
+  // verifier.rs:95-106: per constraint the rhs terms with the responses, then (-c) on the lhs point
+  std::vector<uint32_t> tarr(nc + 1, 0), vsc, vpt;
+  for (uint32_t k = 0; k < nc; ++k) {
+    for (uint32_t q = st->shape.cons_off[k]; q < st->shape.cons_off[k + 1]; ++q) { vsc.push_back(st->shape.cons_sc[q]); vpt.push_back(st->shape.cons_pt[q]); }
+    vsc.push_back(0xffffffffu);
+    vpt.push_back(st->shape.cons_lhs[k]);
+    tarr[k + 1] = (uint32_t)vsc.size();
+  }
+  tarr.insert(tarr.end(), vsc.begin(), vsc.end());
+  tarr.insert(tarr.end(), vpt.begin(), vpt.end());
+  tarr.insert(tarr.end(), s.unref.begin(), s.unref.end());
+
+  HIP_TRY(hipSetDevice(c->device));
+  carve cv;
+  const size_t o_ts = cv.take((size_t)N * 208);
+  const size_t o_tbl = cv.take((size_t)n_points * 32 + 32);
+  const size_t o_claim = cv.take((size_t)N * 32);
+  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
+  const size_t o_pa = cv.take(progA.size() * sizeof(tr_op) + 64);
+  const size_t o_pb = cv.take(progB.size() * sizeof(tr_op) + 64);
+  const size_t o_bufs = cv.take(sizeof(tr_bufs));
+  const size_t o_saved = cv.take(256);
+  const size_t o_failed = cv.take((size_t)N * 4);
+  const size_t o_mc = cv.take((size_t)N * 32);
+  const size_t o_tarr = cv.take(tarr.size() * 4 + 16);
+  const size_t o_off = cv.take(((size_t)N * nc + 1) * 4);
+  const size_t o_sc = cv.take((size_t)N * T1 * 32 + 32);
+  const size_t o_pidx = cv.take((size_t)N * T1 * 4 + 4);
+  const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
+  const size_t o_st = cv.take((size_t)N * nc + 4);
+  const size_t o_wchal = cv.take((size_t)N * 64);
+  const size_t o_chal = cv.take((size_t)N * 32);
+  const size_t o_res = cv.take((size_t)N);
+  const size_t reserved = cv.off;
+  rc = ensure_ws(c, reserved + terms_path_ws(n_points, N * T1));
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  auto u8 = [&](size_t o) { return reinterpret_cast<uint8_t*>(base + o); };
+  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t*>(base + o); };
+  HIP_TRY(hipMemcpyAsync(base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
+  if (s.ns) HIP_TRY(hipMemcpyAsync(base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
+  if (s.ni) HIP_TRY(hipMemcpyAsync(base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(base + o_claim, challenges, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
+  if (m) HIP_TRY(hipMemcpyAsync(base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
+  prog_dev pa, pb;
+  rc = upload_program(c, progA, tailA, base + o_pa, pa);
+  if (rc) return rc;
+  rc = upload_program(c, progB, tailB, base + o_pb, pb);
+  if (rc) return rc;
+  tr_bufs hb{};
+  hb.src[SRC_TABLE] = u8(o_tbl); hb.src[SRC_COMS] = u8(o_coms);
+  hb.dst[DST_CHAL] = u8(o_wchal);
+  HIP_TRY(hipMemcpyAsync(base + o_bufs, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(base + o_tarr, tarr.data(), tarr.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(base + o_failed, 0, (size_t)N * 4, c->stream));
+  const tr_bufs* d_bufs = reinterpret_cast<const tr_bufs*>(base + o_bufs);
+  uint64_t* d_saved = reinterpret_cast<uint64_t*>(base + o_saved);
+
+  prof_begin(c);
+  run_program(c, pa, N, d_bufs, u8(o_ts), d_saved, u32(o_failed));
+  prof_mark(c, ZKP_K_TRANSCRIPT);
+  hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_claim), u8(o_mc));
+  const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
+  hipLaunchKernelGGL(k_stmt_terms, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, s.ns, m, u32(o_tarr), u32(o_tarr) + nc + 1,
+                     u32(o_tarr) + nc + 1 + T1, u8(o_resp), u8(o_mc), u32(o_off), u8(o_sc), u32(o_pidx));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  // with no constraints there is no MSM, but every allocated point must still decode (verifier.rs:87-92)
+  rc = msm_terms_path(c, N * nc, u32(o_off), u8(o_sc), u32(o_pidx), u8(o_tbl), n_points, N * T1, ZKP_VARTIME, u8(o_coms), u8(o_st), nullptr, reserved);
+  if (rc) return rc;
+  run_program(c, pb, N, d_bufs, u8(o_ts), d_saved, u32(o_failed));
+  prof_mark(c, ZKP_K_TRANSCRIPT);
+  hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_wchal), u8(o_chal));
+  hipLaunchKernelGGL(k_verify_finish, grid1(N, 256), dim3(256), 0, c->stream, N, nc, s.ns, u8(o_chal), u8(o_claim), u8(o_st), u32(o_failed),
+                     reinterpret_cast<const dev_affine*>(base + reserved), u32(o_tarr) + nc + 1 + 2 * (size_t)T1, (uint32_t)s.unref.size(), u8(o_res));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(results, base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(transcripts, base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+}
+
+int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
+                           const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
+                           int* verdict, uint8_t* debug_scalars) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  fused_shape s;
+  int rc = check_fused_statement(st, s);
+  if (rc) return rc;
+  if (!verdict) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (N && (!transcripts || (s.nc && (!commitments || !weights16)) || (s.m && !responses) || (s.ni && !inst))) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (s.ns && !common) return fail(ZKP_ERR_ARG, "NULL pointer");
+  const uint32_t m = s.m, nc = s.nc, ns = s.ns, ni = s.ni;
+  const size_t rows = (size_t)ni + nc, total = (size_t)ns + rows * N;
+  if (total > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  uint8_t tail0[3] = {0, 0, 0}, tailA[3] = {0, 0, 0};
+  std::vector<tr_op> prog;
+  if (N) {
+    rc = common_tail(transcripts, N, tail0);
+    if (rc) return rc;
+    TrCompiler ta(tail0[0], tail0[1], tail0[2]);
+    compile_allocations(ta, st, s, N, common, true);                     // batch_verifier.rs:92-94, :105-107, :125-128
+    for (uint32_t k = 0; k < nc; ++k)                                     // :152-160 validating
+      ta.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, true);
+    ta.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});               // :163-167
+    prog = ta.finish(tailA);
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  const uint32_t nblk = (N + 255) / 256;
+  carve cv;
+  const size_t o_sc = cv.take(total * 32 + 32);
+  const size_t o_pts = cv.take(total * 32 + 32);          // static || instance rows || commitment rows  (also the transcripts' point table)
+  const size_t o_out = cv.take(32);
+  const size_t o_st = cv.take(16);                        // MSM status | any transcript failure
+  const size_t o_ts = cv.take((size_t)N * 208);
+  const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
+  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
+  const size_t o_w = cv.take((size_t)nc * N * 16 + 16);
+  const size_t o_prog = cv.take(prog.size() * sizeof(tr_op) + 64);
+  const size_t o_bufs = cv.take(sizeof(tr_bufs));
+  const size_t o_failed = cv.take((size_t)N * 4 + 4);
+  const size_t o_wchal = cv.take((size_t)N * 64 + 64);
+  const size_t o_mc = cv.take((size_t)N * 32 + 32);
+  const size_t o_inc = cv.take((s.inc_off.size() + s.inc_k.size() * 2 + 4) * 4);
+  const size_t o_part = cv.take((size_t)(ns ? ns : 1) * (nblk ? nblk : 1) * 32);
+  const size_t reserved = cv.off;
+  rc = ensure_ws(c, reserved + optional_ws(total));
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  auto u8 = [&](size_t o) { return reinterpret_cast<uint8_t*>(base + o); };
+  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t*>(base + o); };
+  if (ns) HIP_TRY(hipMemcpyAsync(base + o_pts, common, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
+  if (ni && N) HIP_TRY(hipMemcpyAsync(base + o_pts + 32 * (size_t)ns, inst, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(base + o_st, 0, 16, c->stream));
+  if (N) {
+    HIP_TRY(hipMemcpyAsync(base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
+    if (nc) {
+      HIP_TRY(hipMemcpyAsync(base + o_coms, commitments, (size_t)N * nc * 32, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(base + o_w, weights16, (size_t)nc * N * 16, hipMemcpyHostToDevice, c->stream));
+    }
+    if (m) HIP_TRY(hipMemcpyAsync(base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
+    prog_dev pd;
+    rc = upload_program(c, prog, tailA, base + o_prog, pd);
+    if (rc) return rc;
+    tr_bufs hb{};
+    hb.src[SRC_TABLE] = u8(o_pts); hb.src[SRC_COMS] = u8(o_coms);
+    hb.dst[DST_CHAL] = u8(o_wchal);
+    HIP_TRY(hipMemcpyAsync(base + o_bufs, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(base + o_failed, 0, (size_t)N * 4, c->stream));
+    rc = upload_incidence(c, s, u32(o_inc));
+    if (rc) return rc;
+    prof_begin(c);
+    run_program(c, pd, N, reinterpret_cast<const tr_bufs*>(base + o_bufs), u8(o_ts), nullptr, u32(o_failed));
+    prof_mark(c, ZKP_K_TRANSCRIPT);
+    hipLaunchKernelGGL(k_any_nonzero, grid1(N, 256), dim3(256), 0, c->stream, N, u32(o_failed), u32(o_st) + 1);
+    // challenge -> -c, in place through the wide buffer: reduce to 32 bytes, then negate
+    hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_wchal), u8(o_mc));
+    hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_mc), u8(o_mc));
+    if (nc) hipLaunchKernelGGL(k_transpose_commitments, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, N, nc, u8(o_coms), u8(o_pts) + 32 * ((size_t)ns + (size_t)ni * N));
+  } else {
+    rc = upload_incidence(c, s, u32(o_inc));
+    if (rc) return rc;
+    prof_begin(c);
+  }
+  launch_coeff_build(c, s, N, u32(o_inc), u8(o_mc), u8(o_resp), u8(o_w), u8(o_sc), u32(o_part));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, base + o_sc, total * 32, hipMemcpyDeviceToHost, c->stream));
+  rc = msm_optional_impl(c, total, u8(o_sc), u8(o_pts), u8(o_out), u32(o_st), reserved);
+  if (rc) return rc;
+  uint8_t out[32];
+  uint32_t stv[2] = {1, 1};
+  HIP_TRY(hipMemcpyAsync(out, base + o_out, 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(stv, base + o_st, 8, hipMemcpyDeviceToHost, c->stream));
+  if (N) HIP_TRY(hipMemcpyAsync(transcripts, base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  static const uint8_t zero[32] = {0};
+  *verdict = (stv[0] == 0 && stv[1] == 0 && memcmp(out, zero, 32) == 0) ? 0 : 1;   // batch_verifier.rs:230-234
+  return ZKP_OK;
+}
+
+}  // extern "C"

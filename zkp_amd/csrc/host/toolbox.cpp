@@ -186,9 +186,49 @@ std::vector<uint8_t> point_table(const zkp_statement& st, uint32_t N, const uint
   return tbl;
 }
 
+// ---- fused (all-on-device) flows: zkp_mi355x.h (2c) ------------------------------------------------------------
+std::atomic<uint32_t> g_fused_min_batch{256};
+
+struct FusedView {
+  zkp_fused_statement fs{};
+  std::vector<uint32_t> lhs, off, csc, cpt, order;
+  std::vector<const char*> slabels, plabels;
+  explicit FusedView(const zkp_statement& st) {
+    const uint32_t nc = (uint32_t)st.cons.size(), np = (uint32_t)st.points.size();
+    auto pid = [&](uint32_t v) { return st.points[v].common ? st.points[v].rank : st.ns + st.points[v].rank; };
+    lhs.resize(nc);
+    off.assign(nc + 1, 0);
+    for (uint32_t k = 0; k < nc; ++k) {
+      lhs[k] = pid(st.cons[k].lhs);
+      for (const auto& term : st.cons[k].lc) { csc.push_back(term.first); cpt.push_back(pid(term.second)); }
+      off[k + 1] = (uint32_t)csc.size();
+    }
+    plabels.resize(np);
+    for (uint32_t v = 0; v < np; ++v) { order.push_back(pid(v)); plabels[pid(v)] = st.points[v].name.c_str(); }
+    for (const auto& s : st.secrets) slabels.push_back(s.c_str());
+    fs.shape = zkp_batch_statement{(uint32_t)st.secrets.size(), st.ns, st.ni, nc, lhs.data(), off.data(), csc.data(), cpt.data()};
+    fs.label = st.label.c_str();
+    fs.secret_labels = slabels.data();
+    fs.point_labels = plabels.data();
+    fs.alloc_order = order.data();
+  }
+};
+
+// the device transcript programs need all blobs at one STROBE position; small batches stay with the host threads
+// (a lone wavefront needs ~10 us per Keccak permutation, the host ~0.4 us)
+bool use_fused(const uint8_t* ts, uint32_t N) {
+  if (N < g_fused_min_batch.load() || N == 0) return false;
+  for (uint32_t j = 1; j < N; ++j)
+    if (std::memcmp(ts + TB * (size_t)j + 200, ts + 200, 3) != 0) return false;
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
+
+void zkp_toolbox_set_fused_min_batch(uint32_t n) { g_fused_min_batch = n; }
+uint32_t zkp_toolbox_get_fused_min_batch(void) { return g_fused_min_batch.load(); }
 
 // ---- transcripts / scalars -----------------------------------------------------------------------------
 void zkp_transcript_init(uint8_t* t, const uint8_t* label, size_t len) { Transcript(label, len).to_bytes(t); }
@@ -315,6 +355,16 @@ int zkp_prove_batch(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* 
                     uint8_t* responses, uint8_t* commitments) {
   if (!ctx || !st) return ZKP_TB_BAD_STATEMENT;
   if (N == 0) return ZKP_TB_OK;
+  if (ts && use_fused(ts, N)) {
+    std::vector<uint8_t> own_entropy;
+    if (!entropy) { own_entropy.resize(32 * (size_t)N); os_random(own_entropy.data(), own_entropy.size()); entropy = own_entropy.data(); }
+    if (st->ns && N >= 32) { const int rc = zkp_ctx_prepare_fixed_points(ctx, st->ns, common); if (rc) return rc; }
+    FusedView fv(*st);
+    int invalid = 0;
+    const int rc = zkp_fused_prove(ctx, &fv.fs, N, ts, secrets, inst, common, entropy, challenges, responses, commitments, &invalid);
+    if (rc) return rc;
+    return invalid ? ZKP_TB_INVALID_POINT : ZKP_TB_OK;
+  }
   const uint32_t m = (uint32_t)st->secrets.size(), nc = (uint32_t)st->cons.size(), T = st->terms;
   std::vector<uint8_t> blind(32 * (size_t)N * m), scalars(32 * (size_t)N * T), status((size_t)N * nc);
   std::vector<uint32_t> off((size_t)N * nc + 1), pidx((size_t)N * T);
@@ -352,6 +402,11 @@ int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N,
   if (!ctx || !stp || !ts || !results || !challenges || !responses) return ZKP_TB_BAD_STATEMENT;
   if (N == 0) return ZKP_TB_OK;
   const zkp_statement& st = *stp;
+  if (use_fused(ts, N)) {
+    if (st.ns && N >= 32) { const int rc = zkp_ctx_prepare_fixed_points(ctx, st.ns, common); if (rc) return rc; }
+    FusedView fv(st);
+    return zkp_fused_verify_compact(ctx, &fv.fs, N, ts, inst, common, challenges, responses, results);
+  }
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), T1 = st.terms + nc;
   std::memset(results, 0, N);
   build_verifiers(st, N, ts, inst, common, n_threads, results);
@@ -548,6 +603,15 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, 
   if (n_transcripts != N) return ZKP_TB_BATCH_SIZE_MISMATCH;           // batch_verifier.rs:72-74
   const zkp_statement& st = *stp;
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), ni = st.ni, ns = st.ns;
+  if (ts && use_fused(ts, N)) {
+    std::vector<uint8_t> own_w;
+    if (!weights16) { own_w.resize(16 * (size_t)N * nc); os_random(own_w.data(), own_w.size()); weights16 = own_w.data(); }
+    FusedView fv(st);
+    int verdict = 1;
+    const int rc = zkp_fused_batch_verify(ctx, &fv.fs, N, ts, inst, common, commitments, responses, weights16, &verdict, coeffs);
+    if (rc) return rc;
+    return verdict ? ZKP_TB_VERIFICATION_FAILURE : ZKP_TB_OK;
+  }
   std::vector<uint8_t> minus_c(32 * (size_t)N);
   if (N) {
     std::vector<uint8_t> failed(N, 0);

@@ -118,7 +118,7 @@ ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, uint64_t j, const tr_b
 
 }  // namespace zkp
 
-#ifndef __HIP_DEVICE_COMPILE__
+// ---- host side: the compiler (plain C++, also parsed by the device pass of hipcc, never emitted there) ----
 #include <string>
 #include <vector>
 namespace zkp {
@@ -322,4 +322,3 @@ class TrCompiler {
 };
 
 }  // namespace zkp
-#endif

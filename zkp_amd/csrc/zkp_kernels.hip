@@ -687,6 +687,7 @@ static int fail(int code, const std::string& msg) {
                   std::string(#expr) + ": " + hipGetErrorString(e_));                          \
   } while (0)
 
+constexpr int kMaxEvents = 24;     // timing marks per call (a fused flow records more than one per kind)
 struct zkp_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -694,8 +695,8 @@ struct zkp_ctx {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool profiling = false;
-  hipEvent_t ev[ZKP_K_COUNT + 1] = {};
-  int ev_kind[ZKP_K_COUNT + 1] = {};
+  hipEvent_t ev[kMaxEvents] = {};
+  int ev_kind[kMaxEvents] = {};
   int n_ev = 0;
   float kernel_ms[ZKP_K_COUNT] = {};
   float total_ms = 0;
@@ -740,7 +741,7 @@ void prof_begin(zkp_ctx* c) {
   if (c->profiling) { hipEventRecord(c->ev[0], c->stream); c->ev_kind[0] = -1; c->n_ev = 1; }
 }
 void prof_mark(zkp_ctx* c, int kind) {
-  if (c->profiling && c->n_ev <= ZKP_K_COUNT) {
+  if (c->profiling && c->n_ev < kMaxEvents) {
     hipEventRecord(c->ev[c->n_ev], c->stream);
     c->ev_kind[c->n_ev] = kind;
     c->n_ev++;
@@ -1239,109 +1240,6 @@ int zkp_msm_optional(zkp_ctx* c, uint64_t n, const uint8_t* scalars, const uint8
   return ZKP_OK;
 }
 
-int zkp_batch_check(zkp_ctx* c, const zkp_batch_statement* st, uint32_t N, const uint8_t* minus_c, const uint8_t* responses,
-                    const uint8_t* weights16, const uint8_t* static_points, const uint8_t* instance_points,
-                    const uint8_t* commitments, uint8_t out_point[32], int* status, uint8_t* debug_scalars) {
-  if (!c || !st || !out_point || !status) return fail(ZKP_ERR_ARG, "NULL pointer");
-  const uint32_t m = st->n_secrets, ns = st->n_static, ni = st->n_instance, nc = st->n_constraints, np = ns + ni;
-  if (nc && (!st->cons_lhs || !st->cons_off)) return fail(ZKP_ERR_ARG, "statement without constraint arrays");
-  if (N && ((!minus_c) || (m && !responses) || (nc && (!weights16 || !commitments)) || (ni && !instance_points)))
-    return fail(ZKP_ERR_ARG, "NULL input pointer");
-  if (ns && !static_points) return fail(ZKP_ERR_ARG, "NULL static points");
-  // incidence lists per point id: (constraint, secret index | ~0 when the point is the constraint's left-hand side)
-  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> inc(np);
-  for (uint32_t k = 0; k < nc; ++k) {
-    if (st->cons_lhs[k] >= np) return fail(ZKP_ERR_ARG, "constraint lhs out of range");
-    inc[st->cons_lhs[k]].emplace_back(k, 0xffffffffu);
-    for (uint32_t q = st->cons_off[k]; q < st->cons_off[k + 1]; ++q) {
-      if (st->cons_pt[q] >= np || st->cons_sc[q] >= m) return fail(ZKP_ERR_ARG, "constraint term out of range");
-      inc[st->cons_pt[q]].emplace_back(k, st->cons_sc[q]);
-    }
-  }
-  std::vector<uint32_t> inc_off(np + 1, 0), inc_k, inc_sc;
-  for (uint32_t p = 0; p < np; ++p) {
-    for (auto& e : inc[p]) { inc_k.push_back(e.first); inc_sc.push_back(e.second); }
-    inc_off[p + 1] = (uint32_t)inc_k.size();
-  }
-  HIP_TRY(hipSetDevice(c->device));
-  const size_t rows = (size_t)ni + nc, total = (size_t)ns + rows * N;
-  const uint32_t nblk = (N + 255) / 256;
-  carve cv;
-  const size_t o_sc = cv.take(total * 32 + 32);
-  const size_t o_pts = cv.take(total * 32 + 32);
-  const size_t o_out = cv.take(32);
-  const size_t o_st = cv.take(4);
-  const size_t o_mc = cv.take((size_t)N * 32);
-  const size_t o_resp = cv.take((size_t)N * m * 32);
-  const size_t o_w = cv.take((size_t)nc * N * 16);
-  const size_t o_inc = cv.take((inc_off.size() + inc_k.size() * 2 + 4) * 4);
-  const size_t o_part = cv.take((size_t)(ns ? ns : 1) * (nblk ? nblk : 1) * 32);
-  const size_t reserved = cv.off;
-  size_t need = 0;
-  if (total <= kSmallOptional) {
-    need = 1024 + (total + 1) * 4 + terms_path_ws((uint32_t)total, (uint32_t)total);
-  } else {
-    switch (pick_c(total)) {
-      case 7: need = pip_ws<7>(total); break;
-      case 10: need = pip_ws<10>(total); break;
-      case 11: need = pip_ws<11>(total); break;
-      default: need = pip_ws<16>(total); break;
-    }
-  }
-  int rc = ensure_ws(c, reserved + need);
-  if (rc) return rc;
-  char* base = static_cast<char*>(c->ws);
-  uint8_t* d_sc = reinterpret_cast<uint8_t*>(base + o_sc);
-  uint8_t* d_pts = reinterpret_cast<uint8_t*>(base + o_pts);
-  uint32_t* d_inc_off = reinterpret_cast<uint32_t*>(base + o_inc);
-  uint32_t* d_inc_k = d_inc_off + inc_off.size();
-  uint32_t* d_inc_sc = d_inc_k + inc_k.size();
-  // operands of batch_verifier.rs:219-228: points = static || instance rows || commitment rows (row = constraint)
-  if (ns) HIP_TRY(hipMemcpyAsync(d_pts, static_points, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
-  if (ni && N) HIP_TRY(hipMemcpyAsync(d_pts + 32 * (size_t)ns, instance_points, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
-  std::vector<uint8_t> com_rows((size_t)nc * N * 32);
-  for (uint32_t j = 0; j < N; ++j)
-    for (uint32_t k = 0; k < nc; ++k) memcpy(com_rows.data() + 32 * ((size_t)k * N + j), commitments + 32 * ((size_t)j * nc + k), 32);
-  if (nc && N) {
-    HIP_TRY(hipMemcpyAsync(d_pts + 32 * ((size_t)ns + (size_t)ni * N), com_rows.data(), com_rows.size(), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(base + o_w, weights16, (size_t)nc * N * 16, hipMemcpyHostToDevice, c->stream));
-  }
-  if (N) {
-    HIP_TRY(hipMemcpyAsync(base + o_mc, minus_c, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
-    if (m) HIP_TRY(hipMemcpyAsync(base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  }
-  HIP_TRY(hipMemcpyAsync(d_inc_off, inc_off.data(), inc_off.size() * 4, hipMemcpyHostToDevice, c->stream));
-  if (!inc_k.empty()) {
-    HIP_TRY(hipMemcpyAsync(d_inc_k, inc_k.data(), inc_k.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_inc_sc, inc_sc.data(), inc_sc.size() * 4, hipMemcpyHostToDevice, c->stream));
-  }
-  prof_begin(c);
-  const uint8_t* d_mc = reinterpret_cast<uint8_t*>(base + o_mc);
-  const uint8_t* d_resp = reinterpret_cast<uint8_t*>(base + o_resp);
-  const uint8_t* d_w = reinterpret_cast<uint8_t*>(base + o_w);
-  if (N && rows)
-    hipLaunchKernelGGL(k_coeff_matrix, dim3(nblk, (unsigned)rows), dim3(256), 0, c->stream, N, m, ns, ni, nc, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, d_sc);
-  if (ns) {
-    uint32_t* part = reinterpret_cast<uint32_t*>(base + o_part);
-    if (N) {
-      hipLaunchKernelGGL(k_coeff_static_partial, dim3(nblk, ns), dim3(256), 0, c->stream, N, m, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, part);
-      hipLaunchKernelGGL(k_coeff_static_final, dim3(ns), dim3(64), 0, c->stream, nblk, part, d_sc);
-    } else {
-      HIP_TRY(hipMemsetAsync(d_sc, 0, (size_t)ns * 32, c->stream));
-    }
-  }
-  HIP_TRY(hipGetLastError());
-  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, d_sc, total * 32, hipMemcpyDeviceToHost, c->stream));
-  rc = msm_optional_impl(c, total, d_sc, d_pts, reinterpret_cast<uint8_t*>(base + o_out), reinterpret_cast<uint32_t*>(base + o_st), reserved);
-  if (rc) return rc;
-  uint32_t stv = 1;
-  HIP_TRY(hipMemcpyAsync(out_point, static_cast<char*>(c->ws) + o_out, 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(&stv, static_cast<char*>(c->ws) + o_st, 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  *status = (int)stv;
-  return ZKP_OK;
-}
-
 int zkp_decode_check(zkp_ctx* c, uint64_t n, const uint8_t* points, uint8_t* status, uint8_t* xyzt) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   if (n == 0) return ZKP_OK;
@@ -1408,3 +1306,5 @@ int zkp_encode_many(zkp_ctx* c, uint64_t n, const uint8_t* xyzt, uint8_t* out) {
 }
 
 }  // extern "C"
+
+#include "fused_flows.h"

@@ -16,13 +16,13 @@ LIB_PATH = os.path.join(_HERE, "libzkp_mi355x.so")
 
 ZKP_VARTIME = 0
 ZKP_CT = 1
-K_NAMES = ("decode", "terms", "reduce", "sort", "bucket", "combine")
+K_NAMES = ("decode", "terms", "reduce", "sort", "bucket", "combine", "transcript", "scalars")
 
 EXPORTS = (
     "zkp_ctx_create", "zkp_ctx_destroy", "zkp_ctx_set_stream", "zkp_ctx_synchronize", "zkp_last_error",
     "zkp_version", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
-    "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest", "zkp_batch_check",
+    "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest", "zkp_batch_check", "zkp_fused_prove", "zkp_fused_verify_compact", "zkp_fused_batch_verify",
 )
 
 

@@ -119,7 +119,16 @@ def main():
     inst, _ = eng.msm_many(np.arange(13 * n + 12 + 1, dtype=np.uint32), rand_scalars(13 * n + 12), np.zeros(13 * n + 12, np.uint32), base, ZKP_CT)
     d_bv_pts = torch.zeros((n_bv, 32), dtype=torch.uint8, device=dev)
     d_bv_pts[: 12 + 13 * n] = t(inst)
-    d_bv_sc = t(rand_scalars(n_bv))
+    # scalars as batch_verifier.rs:173-206 produces them: static coefficients and instance rows are products/sums mod l
+    # (uniform), the 11 commitment rows are -r mod l for fresh 128-bit r (:179-183)
+    bv_sc = rand_scalars(n_bv)
+    L = 2**252 + 27742317777372353535851937790883648493
+    r128 = rng.integers(0, 256, size=(11 * n, 16), dtype=np.uint8)
+    neg = np.zeros((11 * n, 32), np.uint8)
+    for i in range(11 * n):
+        neg[i] = np.frombuffer((L - int.from_bytes(r128[i].tobytes(), "little")).to_bytes(32, "little"), np.uint8)
+    bv_sc[12 + 13 * n:] = neg
+    d_bv_sc = t(bv_sc)
     d_bv_out = torch.zeros(32, dtype=torch.uint8, device=dev)
     d_bv_st = torch.zeros(1, dtype=torch.int32, device=dev)
     verdict = torch.ones(1, dtype=torch.int32, device=dev)

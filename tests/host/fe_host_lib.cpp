@@ -87,6 +87,7 @@ void t_sc_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 3: sc_reduce(r, x); break;
     case 4: { sc t; sc_to_mont(t, x); sc_mont(r, t, y); break; }
     case 5: sc_from_wide(r, x, y); break;      // a + b * 2^256
+    case 6: { r = x; const uint32_t f = sc_fold_sign(r.v); r.v[7] |= f << 31; break; }   // folded scalar, flag in bit 255
     default: sc_zero(r);
   }
   memcpy(out, r.v, 32);

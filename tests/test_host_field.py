@@ -204,6 +204,16 @@ def test_scalar_arithmetic_mod_l(lib):
         assert out.raw == b32(a % M.L)
         lib.t_sc_op(0, b32(a), b32(7), out)                 # first operand of a product may be non-canonical
         assert out.raw == b32(a * 7 % M.L)
+    half = (M.L - 1) // 2                                    # sign folding: s -> l - s iff half < s <= l
+    for a in [0, 1, half - 1, half, half + 1, M.L - 1, M.L, M.L + 1, (1 << 256) - 1, M.L - (1 << 128) + 5, 1 << 252] + \
+            [rng.randrange(M.L) for _ in range(200)] + [M.L - rng.randrange(1 << 128) for _ in range(50)]:
+        lib.t_sc_op(6, b32(a), b32(0), out)
+        v = int.from_bytes(out.raw, "little")
+        fold = half < a <= M.L                               # l itself folds to 0 (same group element)
+        if a >> 255:
+            assert v == a                                   # never folded (>= l), value untouched
+        else:
+            assert (v >> 255) == int(fold) and (v & ((1 << 255) - 1)) == (M.L - a if fold else a), a
     wide = [0, (1 << 512) - 1, (1 << 256), M.L << 256, (M.L << 256) - 1] + [rng.randrange(1 << 512) for _ in range(300)]
     for x in wide:                                          # Scalar::from_bytes_mod_order_wide
         lib.t_sc_op(5, b32(x & ((1 << 256) - 1)), b32(x >> 256), out)

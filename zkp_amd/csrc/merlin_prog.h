@@ -34,7 +34,22 @@ struct tr_bufs {
   uint8_t* dst[TR_MAX_BUFS];
 };
 
-ZKP_HD uint64_t tr_rotl(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
+// 64-bit rotation by a compile-time amount.  On the GPU: two full-rate v_alignbit_b32 on the 32-bit halves (the
+// compiler's own choice, 64-bit shifts + or, runs at a quarter of that rate).
+template <int N>
+ZKP_HD uint64_t tr_rotl_c(uint64_t v) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  constexpr int n = N & 31;
+  uint32_t rlo, rhi;
+  if (n == 0) { rlo = lo; rhi = hi; }
+  else { rhi = __builtin_amdgcn_alignbit(hi, lo, 32 - n); rlo = __builtin_amdgcn_alignbit(lo, hi, 32 - n); }
+  return (N & 32) ? ((uint64_t)rlo << 32 | rhi) : ((uint64_t)rhi << 32 | rlo);
+#else
+  return (v << N) | (v >> (64 - N));
+#endif
+}
+#define tr_rotl(v, n) tr_rotl_c<n>(v)
 
 // Keccak-f[1600] on a strided column (S[i * stride]), 25 lanes held in registers for the 24 rounds.
 ZKP_HD void keccak_f1600_col(uint64_t* S, int stride) {
@@ -85,8 +100,11 @@ ZKP_HD uint64_t tr_bytemask(uint32_t nb) { return nb >= 8 ? ~0ULL : ((1ULL << (8
 // (saved[i * saved_stride]); *failed is set when a checked encoding is all zero (mod.rs:191, :215).
 ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, uint64_t j, const tr_bufs& bufs, uint64_t* S, int stride,
                        uint64_t* saved, size_t saved_stride, uint32_t* failed) {
+  if (n_ops == 0) return;
+  tr_op next = prog[0];
   for (uint32_t q = 0; q < n_ops; ++q) {
-    const tr_op op = prog[q];
+    const tr_op op = next;
+    if (q + 1 < n_ops) next = prog[q + 1];    // fetched while this operation runs
     if (op.flags & TR_RESTORE)
       for (int i = 0; i < 25; ++i) S[i * stride] = saved[i * saved_stride];
     if (op.flags & TR_CHECK_NONZERO) {

@@ -22,6 +22,10 @@ ZKP_HD uint32_t sc_rr(int i) {
 ZKP_HD uint32_t sc_r1(int i) {
   return i == 0 ? 0x8d98951du : i == 1 ? 0xd6ec3174u : i == 2 ? 0x737dcf70u : i == 3 ? 0xc6ef5bf4u : i == 4 ? 0xfffffffeu : i == 5 ? 0xffffffffu : i == 6 ? 0xffffffffu : 0x0fffffffu;
 }
+// (l - 1) / 2
+ZKP_HD uint32_t sc_half(int i) {
+  return i == 0 ? 0x2e7ae9f6u : i == 1 ? 0x2c09318du : i == 2 ? 0x517bce6bu : i == 3 ? 0x0a6f7cefu : i == 7 ? 0x08000000u : 0u;
+}
 constexpr uint32_t SC_N0INV = 0x12547e1bu;      // -l^-1 mod 2^32
 
 ZKP_HD void sc_zero(sc& r) {
@@ -124,6 +128,27 @@ ZKP_HD void sc_reduce(sc& r, const sc& a) {
   sc t;
   sc_to_mont(t, a);          // a R mod l   (a may be >= l: sc_mont allows it in the first operand)
   sc_mont(r, t, one);        // a
+}
+
+// Sign folding for multiscalar multiplication: s * P = (l - s) * (-P).  If (l-1)/2 < s <= l, replaces s by l - s and
+// returns 1 (the caller negates the point or the digits); otherwise leaves s alone (also when s > l: non-canonical
+// scalars keep their value).  The folded scalar is < 2^252, and the negated 128-bit weights of the batch verifier
+// (batch_verifier.rs:183: l - r) come out as r: 128 bits instead of 253, with none of the all-ones digit runs.
+ZKP_HD uint32_t sc_fold_sign(uint32_t s[8]) {
+  uint32_t d[8];
+  uint64_t b1 = 0, b2 = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t t1 = (uint64_t)sc_half(i) - s[i] - b1;      // borrow out  <=>  s > half
+    b1 = (t1 >> 63) & 1u;
+    const uint64_t t2 = (uint64_t)sc_l(i) - s[i] - b2;         // l - s, borrow out  <=>  s > l
+    d[i] = (uint32_t)t2;
+    b2 = (t2 >> 63) & 1u;
+  }
+  const bool fold = b1 && !b2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = fold ? d[i] : s[i];
+  return fold ? 1u : 0u;
 }
 
 // 512-bit little-endian value (lo + hi * 2^256) -> canonical scalar: Scalar::from_bytes_mod_order_wide

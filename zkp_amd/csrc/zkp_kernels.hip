@@ -222,6 +222,7 @@ k_pip_prepare(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __
   }
   uint32_t s[8], e[10];
   load_vec<2>(s, scalars + 32 * (size_t)i);
+  const uint32_t flip = sc_fold_sign(s);      // s * P = (l - s) * (-P): the point's sign moves into the digits
   {
     uint64_t c = 0;
 #pragma unroll
@@ -246,7 +247,7 @@ k_pip_prepare(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __
       neg = 0;
       mag = v;
     }
-    digits[(size_t)w * n + i] = mag | (neg << 31);
+    digits[(size_t)w * n + i] = mag | ((neg ^ flip) << 31);
   }
 }
 

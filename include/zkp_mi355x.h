@@ -150,6 +150,26 @@ int zkp_fused_batch_verify(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t
                            const uint8_t* inst, const uint8_t* common, const uint8_t* commitments,
                            const uint8_t* responses, const uint8_t* weights16, int* verdict, uint8_t* debug_scalars);
 
+/*     Device-resident variants: every buffer is a device pointer (16-byte aligned), nothing is copied and the call
+ *     returns as soon as the work is queued on the context's stream (zkp_ctx_synchronize to wait).  strobe_pos =
+ *     pos | pos_begin << 8 | cur_flags << 16, the three trailing bytes every one of the N transcript blobs holds.
+ *     d_table = common points followed by the instance rows: [n_static + n_instance * N][32].
+ *     zkp_fused_prove_dev: d_status [N * n_constraints] bytes, non-zero where an input point failed to decode.
+ *     zkp_fused_batch_verify_dev: d_points [n_static + (n_instance + n_constraints) * N][32] with the static points
+ *     and instance rows filled in (the commitment rows are written by the call); d_status [2] words: decode failure
+ *     in the MSM | a point or commitment rejected by the transcript protocol (identity encoding); the batch verifies
+ *     iff both are 0 and d_out_point holds 32 zero bytes. */
+int zkp_fused_prove_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos, uint8_t* d_transcripts,
+                        const uint8_t* d_secrets, const uint8_t* d_table, const uint8_t* d_entropy, uint8_t* d_challenges,
+                        uint8_t* d_responses, uint8_t* d_commitments, uint8_t* d_status);
+int zkp_fused_verify_compact_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos,
+                                 uint8_t* d_transcripts, const uint8_t* d_table, const uint8_t* d_challenges,
+                                 const uint8_t* d_responses, uint8_t* d_results);
+int zkp_fused_batch_verify_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos,
+                               uint8_t* d_transcripts, uint8_t* d_points, const uint8_t* d_commitments,
+                               const uint8_t* d_responses, const uint8_t* d_weights16, uint8_t* d_out_point,
+                               uint32_t* d_status);
+
 /* (3) Stand-alone decode / validity check, batched.  Replaces the
  *     `.map(|pt| pt.decompress()).collect::<Option<Vec<_>>>()` of verifier.rs:87-92.
  *     status[i] = 0 valid | 1 decompress() would return None.  If xyzt != NULL it receives the

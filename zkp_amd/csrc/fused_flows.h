@@ -14,7 +14,7 @@ namespace zkp {
 // One lane per proof; the STROBE state lives in an LDS column so that the interpreter can index words dynamically.
 // No cross-lane traffic, hence no barriers.  tail = pos | pos_begin << 8 | cur_flags << 16 after the program.
 __global__ void __launch_bounds__(64)
-k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, uint32_t N, const tr_bufs* __restrict__ bufs,
+k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, uint32_t N, const tr_bufs bufs,
                  uint8_t* __restrict__ ts, uint64_t* __restrict__ saved, uint32_t* __restrict__ failed, uint32_t tail) {
   __shared__ uint64_t S[25 * 64];
   const uint32_t j = blockIdx.x * 64 + threadIdx.x;
@@ -24,7 +24,7 @@ k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, uint32_t N, con
 #pragma unroll
   for (int i = 0; i < 25; ++i) col[64 * i] = blob[i];
   uint32_t f = 0;
-  tr_run_one(prog, n_ops, j, *bufs, col, 64, saved + j, N, &f);
+  tr_run_one(prog, n_ops, j, bufs, col, 64, saved + j, N, &f);
 #pragma unroll
   for (int i = 0; i < 25; ++i) blob[i] = col[64 * i];
   blob[25] = tail;
@@ -167,6 +167,12 @@ int parse_shape(const zkp_batch_statement* st, fused_shape& s) {
   }
   return ZKP_OK;
 }
+std::vector<uint32_t> incidence_words(const fused_shape& s) {
+  std::vector<uint32_t> w(s.inc_off);
+  w.insert(w.end(), s.inc_k.begin(), s.inc_k.end());
+  w.insert(w.end(), s.inc_sc.begin(), s.inc_sc.end());
+  return w;
+}
 
 // batch_verifier.rs:173-206 on device buffers; d_inc = inc_off | inc_k | inc_sc
 void launch_coeff_build(zkp_ctx* c, const fused_shape& s, uint32_t N, const uint32_t* d_inc, const uint8_t* d_mc,
@@ -186,14 +192,6 @@ void launch_coeff_build(zkp_ctx* c, const fused_shape& s, uint32_t N, const uint
     }
   }
 }
-int upload_incidence(zkp_ctx* c, const fused_shape& s, uint32_t* d_inc) {
-  HIP_TRY(hipMemcpyAsync(d_inc, s.inc_off.data(), s.inc_off.size() * 4, hipMemcpyHostToDevice, c->stream));
-  if (!s.inc_k.empty()) {
-    HIP_TRY(hipMemcpyAsync(d_inc + s.inc_off.size(), s.inc_k.data(), s.inc_k.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_inc + s.inc_off.size() + s.inc_k.size(), s.inc_sc.data(), s.inc_sc.size() * 4, hipMemcpyHostToDevice, c->stream));
-  }
-  return ZKP_OK;
-}
 size_t optional_ws(uint64_t total) {
   if (total <= kSmallOptional) return 1024 + (total + 1) * 4 + terms_path_ws((uint32_t)total, (uint32_t)total);
   switch (pick_c(total)) {
@@ -204,7 +202,21 @@ size_t optional_ws(uint64_t total) {
   }
 }
 
-// ---- transcripts ---------------------------------------------------------------------------------------------------
+// ---- plans: everything about (flow, statement, N, STROBE position) that does not depend on the data -----------------
+enum { SRC_TABLE = 0, SRC_SECRETS = 1, SRC_ENTROPY = 2, SRC_COMS = 3 };
+enum { DST_WIDE = 0, DST_CHAL = 1 };
+enum fused_flow : char { FLOW_PROVE = 'P', FLOW_VERIFY = 'V', FLOW_BATCH = 'B' };
+
+struct prog_dev { const tr_op* ops = nullptr; uint32_t n = 0; uint32_t tail = 0; };
+struct fused_plan {
+  fused_shape s;
+  uint32_t N = 0, T1 = 0;          // T1 = terms per proof of the flow's CSR job
+  char* d_block = nullptr;         // one allocation: programs | term arrays | incidence
+  prog_dev a, b;
+  const uint32_t* d_tarr = nullptr;   // toff[nc + 1] | tsc[T1] | tpt[T1] | unref[]
+  const uint32_t* d_inc = nullptr;
+};
+
 int check_fused_statement(const zkp_fused_statement* st, fused_shape& s) {
   if (!st) return fail(ZKP_ERR_ARG, "statement is NULL");
   int rc = parse_shape(&st->shape, s);
@@ -220,43 +232,286 @@ int check_fused_statement(const zkp_fused_statement* st, fused_shape& s) {
 }
 // all transcripts of a fused call must stand at the same STROBE position (they do whenever they were built by the
 // same sequence of appends with equal lengths); the caller falls back to the host pipeline otherwise
-int common_tail(const uint8_t* ts, uint32_t N, uint8_t tail[3]) {
-  memcpy(tail, ts + 200, 3);
+int common_tail(const uint8_t* ts, uint32_t N, uint32_t* pos) {
   for (uint32_t j = 1; j < N; ++j)
-    if (memcmp(ts + 208 * (size_t)j + 200, tail, 3) != 0) return fail(ZKP_ERR_ARG, "transcripts stand at different STROBE positions");
-  if (tail[0] >= 166) return fail(ZKP_ERR_ARG, "corrupt transcript blob");
+    if (memcmp(ts + 208 * (size_t)j + 200, ts + 200, 3) != 0) return fail(ZKP_ERR_ARG, "transcripts stand at different STROBE positions");
+  *pos = ts[200] | (uint32_t)ts[201] << 8 | (uint32_t)ts[202] << 16;
   return ZKP_OK;
 }
-enum { SRC_TABLE = 0, SRC_SECRETS = 1, SRC_ENTROPY = 2, SRC_COMS = 3 };
-enum { DST_WIDE = 0, DST_CHAL = 1 };
 
-// Prover::new / Verifier::new + allocate_scalar + allocate_point in allocation order (prover.rs:41-73, verifier.rs:47-77)
-void compile_allocations(TrCompiler& tc, const zkp_fused_statement* st, const fused_shape& s, uint32_t N, const uint8_t* common, bool validate) {
+// Prover::new / Verifier::new + allocate_scalar + allocate_point in allocation order (prover.rs:41-73, verifier.rs:47-77).
+// Every proof reads the table  common || inst[ni][N]; common points are variables of the program too (stride 0), so a
+// compiled program does not depend on any value.
+void compile_allocations(TrCompiler& tc, const zkp_fused_statement* st, const fused_shape& s, uint32_t N, bool validate) {
   tc.domain_sep(st->label);
   for (uint32_t i = 0; i < s.m; ++i) tc.append_scalar_var(st->secret_labels[i]);
   for (uint32_t a = 0; a < s.np; ++a) {
     const uint32_t p = st->alloc_order[a];
-    // every proof of the batch reads the table  common || inst[ni][N]; common points are variables of the program too
-    // (stride 0) so that one compiled program does not depend on their values
-    const tr_ref ref = p < s.ns ? tr_ref{SRC_TABLE, 0, 32ull * p} : tr_ref{SRC_TABLE, 32, 32ull * (s.ns + (uint64_t)(p - s.ns) * N)};
+    tr_ref ref;
+    if (p < s.ns) ref = tr_ref{SRC_TABLE, 0, 32ull * p};
+    else ref = tr_ref{SRC_TABLE, 32, 32ull * (s.ns + (uint64_t)(p - s.ns) * N)};
     tc.append_point_var_var(st->point_labels[p], ref, validate);
   }
-  (void)common;
 }
 
-struct prog_dev { const tr_op* ops; uint32_t n; uint32_t tail; };
-int upload_program(zkp_ctx* c, const std::vector<tr_op>& prog, const uint8_t tail[3], char* d_where, prog_dev& out) {
-  if (!prog.empty()) HIP_TRY(hipMemcpyAsync(d_where, prog.data(), prog.size() * sizeof(tr_op), hipMemcpyHostToDevice, c->stream));
-  out.ops = reinterpret_cast<const tr_op*>(d_where);
-  out.n = (uint32_t)prog.size();
-  out.tail = tail[0] | (uint32_t)tail[1] << 8 | (uint32_t)tail[2] << 16;
+std::string plan_key(char flow, const zkp_fused_statement* st, const fused_shape& s, uint32_t N, uint32_t pos) {
+  std::string k(1, flow);
+  auto u32 = [&](uint32_t v) { k.append(reinterpret_cast<const char*>(&v), 4); };
+  auto str = [&](const char* p) { u32((uint32_t)strlen(p)); k.append(p); };
+  u32(N); u32(pos); u32(s.m); u32(s.ns); u32(s.ni); u32(s.nc);
+  str(st->label);
+  for (uint32_t i = 0; i < s.m; ++i) str(st->secret_labels[i]);
+  for (uint32_t i = 0; i < s.np; ++i) { str(st->point_labels[i]); u32(st->alloc_order[i]); }
+  for (uint32_t i = 0; i < s.nc; ++i) { u32(st->shape.cons_lhs[i]); u32(st->shape.cons_off[i + 1]); }
+  for (uint32_t i = 0; i < s.T; ++i) { u32(st->shape.cons_sc[i]); u32(st->shape.cons_pt[i]); }
+  return k;
+}
+
+int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, uint32_t pos, fused_plan** out) {
+  fused_shape s;
+  int rc = check_fused_statement(st, s);
+  if (rc) return rc;
+  if ((pos & 0xff) >= 166) return fail(ZKP_ERR_ARG, "corrupt transcript blob (STROBE position out of range)");
+  const std::string key = plan_key(flow, st, s, N, pos);
+  auto it = c->fused_plans.find(key);
+  if (it != c->fused_plans.end()) { *out = static_cast<fused_plan*>(it->second); return ZKP_OK; }
+  std::unique_ptr<fused_plan> pl(new fused_plan());
+  pl->s = s;
+  pl->N = N;
+  const uint32_t m = s.m, nc = s.nc;
+  uint8_t tailA[3], tailB[3];
+  std::vector<tr_op> pa, pb;
+  std::vector<uint32_t> tarr;
+  TrCompiler ta((uint8_t)pos, (uint8_t)(pos >> 8), (uint8_t)(pos >> 16));
+  if (flow == FLOW_PROVE) {
+    // program A: allocations, then the blinding factors from a clone of the transcript (prover.rs:78-89)
+    compile_allocations(ta, st, s, N, false);
+    ta.save();
+    for (uint32_t i = 0; i < m; ++i) ta.rng_rekey_with_witness_var("", tr_ref{SRC_SECRETS, 32 * m, 32ull * i}, 32);
+    ta.rng_finalize_var(tr_ref{SRC_ENTROPY, 32, 0});
+    for (uint32_t i = 0; i < m; ++i) ta.rng_fill_bytes(tr_ref{DST_WIDE, 64 * m, 64ull * i}, 64);
+    ta.restore();
+    pa = ta.finish(tailA);
+    // program B: commitments, challenge (prover.rs:98-106)
+    TrCompiler tb(tailA[0], tailA[1], tailA[2]);
+    for (uint32_t k = 0; k < nc; ++k)
+      tb.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, false);
+    tb.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});
+    pb = tb.finish(tailB);
+    // prover.rs:94-97 operand lists
+    tarr.assign(nc + 1, 0);
+    for (uint32_t k = 0; k < nc; ++k) tarr[k + 1] = st->shape.cons_off[k + 1];
+    if (s.T) { tarr.insert(tarr.end(), st->shape.cons_sc, st->shape.cons_sc + s.T); tarr.insert(tarr.end(), st->shape.cons_pt, st->shape.cons_pt + s.T); }
+    pl->T1 = s.T;
+  } else if (flow == FLOW_VERIFY) {
+    compile_allocations(ta, st, s, N, true);                            // verifier.rs:61-77 validating appends
+    pa = ta.finish(tailA);
+    TrCompiler tb(tailA[0], tailA[1], tailA[2]);
+    for (uint32_t k = 0; k < nc; ++k)                                    // verifier.rs:108 (non-validating)
+      tb.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, false);
+    tb.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});
+    pb = tb.finish(tailB);
+    // verifier.rs:95-106: per constraint the rhs terms with the responses, then (-c) on the lhs point
+    std::vector<uint32_t> vsc, vpt;
+    tarr.assign(nc + 1, 0);
+    for (uint32_t k = 0; k < nc; ++k) {
+      for (uint32_t q = st->shape.cons_off[k]; q < st->shape.cons_off[k + 1]; ++q) { vsc.push_back(st->shape.cons_sc[q]); vpt.push_back(st->shape.cons_pt[q]); }
+      vsc.push_back(0xffffffffu);
+      vpt.push_back(st->shape.cons_lhs[k]);
+      tarr[k + 1] = (uint32_t)vsc.size();
+    }
+    pl->T1 = (uint32_t)vsc.size();
+    tarr.insert(tarr.end(), vsc.begin(), vsc.end());
+    tarr.insert(tarr.end(), vpt.begin(), vpt.end());
+    tarr.insert(tarr.end(), s.unref.begin(), s.unref.end());
+  } else {
+    compile_allocations(ta, st, s, N, true);                            // batch_verifier.rs:92-94, :105-107, :125-128
+    for (uint32_t k = 0; k < nc; ++k)                                    // :152-160 validating
+      ta.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, true);
+    ta.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});              // :163-167
+    pa = ta.finish(tailA);
+  }
+  const std::vector<uint32_t> inc = incidence_words(s);
+  carve cv;
+  const size_t o_a = cv.take(pa.size() * sizeof(tr_op) + 64);
+  const size_t o_b = cv.take(pb.size() * sizeof(tr_op) + 64);
+  const size_t o_t = cv.take(tarr.size() * 4 + 64);
+  const size_t o_i = cv.take(inc.size() * 4 + 64);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_block), cv.off));
+  auto put = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpy(pl->d_block + o, src, bytes, hipMemcpyHostToDevice) : hipSuccess; };
+  hipError_t e = put(o_a, pa.data(), pa.size() * sizeof(tr_op));
+  if (e == hipSuccess) e = put(o_b, pb.data(), pb.size() * sizeof(tr_op));
+  if (e == hipSuccess) e = put(o_t, tarr.data(), tarr.size() * 4);
+  if (e == hipSuccess) e = put(o_i, inc.data(), inc.size() * 4);
+  if (e != hipSuccess) { hipFree(pl->d_block); return fail(ZKP_ERR_HIP, std::string("plan upload: ") + hipGetErrorString(e)); }
+  pl->a = prog_dev{reinterpret_cast<const tr_op*>(pl->d_block + o_a), (uint32_t)pa.size(), tailA[0] | (uint32_t)tailA[1] << 8 | (uint32_t)tailA[2] << 16};
+  pl->b = prog_dev{reinterpret_cast<const tr_op*>(pl->d_block + o_b), (uint32_t)pb.size(), tailB[0] | (uint32_t)tailB[1] << 8 | (uint32_t)tailB[2] << 16};
+  pl->d_tarr = reinterpret_cast<const uint32_t*>(pl->d_block + o_t);
+  pl->d_inc = reinterpret_cast<const uint32_t*>(pl->d_block + o_i);
+  if (c->fused_plans.size() >= 64) free_fused_plans(c);        // a bound on what a long-lived context keeps
+  *out = pl.get();
+  c->fused_plans[key] = pl.release();
   return ZKP_OK;
 }
-void run_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs* d_bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed) {
-  hipLaunchKernelGGL(k_transcript_run, dim3((N + 63) / 64), dim3(64), 0, c->stream, p.ops, p.n, N, d_bufs, d_ts, d_saved, d_failed, p.tail);
+
+void run_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed) {
+  if (p.n) hipLaunchKernelGGL(k_transcript_run, dim3((N + 63) / 64), dim3(64), 0, c->stream, p.ops, p.n, N, bufs, d_ts, d_saved, d_failed, p.tail);
+}
+
+// ---- the flows on device buffers (asynchronous on the context's stream) ----------------------------------------------
+struct ws_view {
+  char* base;
+  uint8_t* u8(size_t o) const { return reinterpret_cast<uint8_t*>(base + o); }
+  uint32_t* u32(size_t o) const { return reinterpret_cast<uint32_t*>(base + o); }
+};
+
+struct prove_inter { size_t saved, failed, wide, blind, off, sc, pidx, wchal, end; };
+prove_inter prove_carve(const fused_plan& pl, size_t start) {
+  const size_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T = pl.T1;
+  carve cv;
+  cv.off = start;
+  prove_inter o;
+  o.saved = cv.take(N * 25 * 8);
+  o.failed = cv.take(N * 4 + 4);
+  o.wide = cv.take(N * m * 64 + 64);
+  o.blind = cv.take(N * m * 32 + 32);
+  o.off = cv.take((N * nc + 1) * 4);
+  o.sc = cv.take(N * T * 32 + 32);
+  o.pidx = cv.take(N * T * 4 + 4);
+  o.wchal = cv.take(N * 64 + 64);
+  o.end = cv.off;
+  return o;
+}
+int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* d_ts, const uint8_t* d_sec, const uint8_t* d_tbl,
+               const uint8_t* d_ent, uint8_t* d_chal, uint8_t* d_resp, uint8_t* d_coms, uint8_t* d_st8) {
+  const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
+  const ws_view w{static_cast<char*>(c->ws)};
+  tr_bufs hb{};
+  hb.src[SRC_TABLE] = d_tbl; hb.src[SRC_SECRETS] = d_sec; hb.src[SRC_ENTROPY] = d_ent; hb.src[SRC_COMS] = d_coms;
+  hb.dst[DST_WIDE] = w.u8(o.wide); hb.dst[DST_CHAL] = w.u8(o.wchal);
+  uint64_t* d_saved = reinterpret_cast<uint64_t*>(w.base + o.saved);
+  prof_begin(c);
+  run_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed));
+  prof_mark(c, ZKP_K_TRANSCRIPT);
+  if (m) hipLaunchKernelGGL(k_wide_reduce, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N * m, w.u8(o.wide), w.u8(o.blind));
+  const size_t lanes = std::max<size_t>((size_t)N * T, (size_t)N * nc) + 1;
+  hipLaunchKernelGGL(k_stmt_terms, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, pl.s.ns, m, pl.d_tarr, pl.d_tarr + nc + 1,
+                     pl.d_tarr + nc + 1 + T, w.u8(o.blind), (const uint8_t*)nullptr, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  if (nc) {
+    const int rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end);
+    if (rc) return rc;
+  }
+  run_program(c, pl.b, N, hb, d_ts, d_saved, w.u32(o.failed));
+  prof_mark(c, ZKP_K_TRANSCRIPT);
+  hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), d_chal);
+  if (m) hipLaunchKernelGGL(k_responses, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N, m, d_sec, d_chal, w.u8(o.blind), d_resp);
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  return ZKP_OK;
+}
+
+struct verify_inter { size_t failed, mc, off, sc, pidx, coms, st8, wchal, chal, end; };
+verify_inter verify_carve(const fused_plan& pl, size_t start) {
+  const size_t N = pl.N, nc = pl.s.nc, T1 = pl.T1;
+  carve cv;
+  cv.off = start;
+  verify_inter o;
+  o.failed = cv.take(N * 4 + 4);
+  o.mc = cv.take(N * 32 + 32);
+  o.off = cv.take((N * nc + 1) * 4);
+  o.sc = cv.take(N * T1 * 32 + 32);
+  o.pidx = cv.take(N * T1 * 4 + 4);
+  o.coms = cv.take(N * nc * 32 + 32);
+  o.st8 = cv.take(N * nc + 4);
+  o.wchal = cv.take(N * 64 + 64);
+  o.chal = cv.take(N * 32 + 32);
+  o.end = cv.off;
+  return o;
+}
+int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_claim,
+                const uint8_t* d_resp, uint8_t* d_results) {
+  const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T1 = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
+  const ws_view w{static_cast<char*>(c->ws)};
+  tr_bufs hb{};
+  hb.src[SRC_TABLE] = d_tbl; hb.src[SRC_COMS] = w.u8(o.coms);
+  hb.dst[DST_CHAL] = w.u8(o.wchal);
+  HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
+  prof_begin(c);
+  run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed));
+  prof_mark(c, ZKP_K_TRANSCRIPT);
+  hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, d_claim, w.u8(o.mc));
+  const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
+  hipLaunchKernelGGL(k_stmt_terms, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, pl.s.ns, m, pl.d_tarr, pl.d_tarr + nc + 1,
+                     pl.d_tarr + nc + 1 + T1, d_resp, w.u8(o.mc), w.u32(o.off), w.u8(o.sc), w.u32(o.pidx));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  // with no constraints there is no MSM, but every allocated point must still decode (verifier.rs:87-92)
+  const int rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end);
+  if (rc) return rc;
+  run_program(c, pl.b, N, hb, d_ts, nullptr, w.u32(o.failed));
+  prof_mark(c, ZKP_K_TRANSCRIPT);
+  hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.chal));
+  // the decoded point table is the first thing msm_terms_path carves after its reserved prefix
+  hipLaunchKernelGGL(k_verify_finish, grid1(N, 256), dim3(256), 0, c->stream, N, nc, pl.s.ns, w.u8(o.chal), d_claim, w.u8(o.st8), w.u32(o.failed),
+                     reinterpret_cast<const dev_affine*>(w.base + o.end), pl.d_tarr + nc + 1 + 2 * (size_t)T1, (uint32_t)pl.s.unref.size(), d_results);
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  return ZKP_OK;
+}
+
+// d_pts = [ns + (ni + nc) N][32] with static || instance rows filled in by the caller; the commitment rows are written here
+struct batch_inter { size_t sc, failed, wchal, mc, part, end; };
+batch_inter batch_carve(const fused_plan& pl, size_t start) {
+  const size_t N = pl.N, ns = pl.s.ns, total = ns + ((size_t)pl.s.ni + pl.s.nc) * N, nblk = (N + 255) / 256;
+  carve cv;
+  cv.off = start;
+  batch_inter o;
+  o.sc = cv.take(total * 32 + 32);
+  o.failed = cv.take(N * 4 + 4);
+  o.wchal = cv.take(N * 64 + 64);
+  o.mc = cv.take(N * 32 + 32);
+  o.part = cv.take((ns ? ns : 1) * (nblk ? nblk : 1) * 32);
+  o.end = cv.off;
+  return o;
+}
+int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* d_ts, uint8_t* d_pts, const uint8_t* d_coms,
+               const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_out, uint32_t* d_status /*[2]: MSM decode failure | transcript rejection*/) {
+  const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni;
+  const size_t total = (size_t)ns + ((size_t)ni + nc) * N;
+  const ws_view w{static_cast<char*>(c->ws)};
+  HIP_TRY(hipMemsetAsync(d_status, 0, 8, c->stream));
+  prof_begin(c);
+  if (N) {
+    tr_bufs hb{};
+    hb.src[SRC_TABLE] = d_pts; hb.src[SRC_COMS] = d_coms;
+    hb.dst[DST_CHAL] = w.u8(o.wchal);
+    HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
+    run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed));
+    prof_mark(c, ZKP_K_TRANSCRIPT);
+    hipLaunchKernelGGL(k_any_nonzero, grid1(N, 256), dim3(256), 0, c->stream, N, w.u32(o.failed), d_status + 1);
+    hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.mc));
+    hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.mc), w.u8(o.mc));
+    if (nc) hipLaunchKernelGGL(k_transpose_commitments, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, N, nc, d_coms, d_pts + 32 * ((size_t)ns + (size_t)ni * N));
+  }
+  launch_coeff_build(c, pl.s, N, pl.d_inc, w.u8(o.mc), d_resp, d_w, w.u8(o.sc), w.u32(o.part));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  return msm_optional_impl(c, total, w.u8(o.sc), d_pts, d_out, d_status, o.end);
 }
 
 }  // namespace
+
+void free_fused_plans(zkp_ctx* c) {
+  for (auto& kv : c->fused_plans) {
+    fused_plan* pl = static_cast<fused_plan*>(kv.second);
+    if (pl->d_block) hipFree(pl->d_block);
+    delete pl;
+  }
+  c->fused_plans.clear();
+}
 
 extern "C" {
 
@@ -275,6 +530,7 @@ int zkp_batch_check(zkp_ctx* c, const zkp_batch_statement* st, uint32_t N, const
   const size_t rows = (size_t)ni + nc, total = (size_t)ns + rows * N;
   if (total > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const uint32_t nblk = (N + 255) / 256;
+  const std::vector<uint32_t> inc = incidence_words(s);
   carve cv;
   const size_t o_sc = cv.take(total * 32 + 32);
   const size_t o_pts = cv.take(total * 32 + 32);
@@ -284,7 +540,7 @@ int zkp_batch_check(zkp_ctx* c, const zkp_batch_statement* st, uint32_t N, const
   const size_t o_resp = cv.take((size_t)N * m * 32);
   const size_t o_w = cv.take((size_t)nc * N * 16);
   const size_t o_coms = cv.take((size_t)nc * N * 32);
-  const size_t o_inc = cv.take((s.inc_off.size() + s.inc_k.size() * 2 + 4) * 4);
+  const size_t o_inc = cv.take(inc.size() * 4 + 16);
   const size_t o_part = cv.take((size_t)(ns ? ns : 1) * (nblk ? nblk : 1) * 32);
   const size_t reserved = cv.off;
   rc = ensure_ws(c, reserved + optional_ws(total));
@@ -303,8 +559,7 @@ int zkp_batch_check(zkp_ctx* c, const zkp_batch_statement* st, uint32_t N, const
     HIP_TRY(hipMemcpyAsync(base + o_mc, minus_c, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
     if (m) HIP_TRY(hipMemcpyAsync(base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
   }
-  rc = upload_incidence(c, s, reinterpret_cast<uint32_t*>(base + o_inc));
-  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(base + o_inc, inc.data(), inc.size() * 4, hipMemcpyHostToDevice, c->stream));
   prof_begin(c);
   if (nc && N)
     hipLaunchKernelGGL(k_transpose_commitments, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, N, nc,
@@ -325,319 +580,204 @@ int zkp_batch_check(zkp_ctx* c, const zkp_batch_statement* st, uint32_t N, const
   return ZKP_OK;
 }
 
+// ---- prove ---------------------------------------------------------------------------------------------------------
+int zkp_fused_prove_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos, uint8_t* d_transcripts,
+                        const uint8_t* d_secrets, const uint8_t* d_table, const uint8_t* d_entropy, uint8_t* d_challenges,
+                        uint8_t* d_responses, uint8_t* d_commitments, uint8_t* d_status) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (N == 0) return ZKP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  fused_plan* pl = nullptr;
+  int rc = get_plan(c, FLOW_PROVE, st, N, strobe_pos, &pl);
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if (!d_transcripts || !d_entropy || !d_challenges || (s.m && (!d_secrets || !d_responses)) || (s.nc && (!d_commitments || !d_status)) || (s.np && !d_table))
+    return fail(ZKP_ERR_ARG, "NULL device pointer");
+  if ((uint64_t)N * s.T > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  const prove_inter o = prove_carve(*pl, 0);
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T));
+  if (rc) return rc;
+  return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status);
+}
+
 int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
                     const uint8_t* inst, const uint8_t* common, const uint8_t* entropy, uint8_t* challenges,
                     uint8_t* responses, uint8_t* commitments, int* invalid_point) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
-  fused_shape s;
-  int rc = check_fused_statement(st, s);
-  if (rc) return rc;
   if (N == 0) { if (invalid_point) *invalid_point = 0; return ZKP_OK; }
-  if (!transcripts || !entropy || !challenges || !invalid_point || (s.m && (!secrets || !responses)) || (s.nc && !commitments) ||
-      (s.ni && !inst) || (s.ns && !common))
+  if (!transcripts) return fail(ZKP_ERR_ARG, "NULL pointer");
+  uint32_t pos = 0;
+  int rc = common_tail(transcripts, N, &pos);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  fused_plan* pl = nullptr;
+  rc = get_plan(c, FLOW_PROVE, st, N, pos, &pl);
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if (!entropy || !challenges || !invalid_point || (s.m && (!secrets || !responses)) || (s.nc && !commitments) || (s.ni && !inst) || (s.ns && !common))
     return fail(ZKP_ERR_ARG, "NULL pointer");
   if ((uint64_t)N * s.T > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
-  uint8_t tail0[3], tailA[3], tailB[3];
-  rc = common_tail(transcripts, N, tail0);
-  if (rc) return rc;
-  const uint32_t m = s.m, nc = s.nc, T = s.T, n_points = s.ns + s.ni * N;
-  // program A: allocations, then the blinding factors from a clone of the transcript (prover.rs:78-89)
-  TrCompiler ta(tail0[0], tail0[1], tail0[2]);
-  compile_allocations(ta, st, s, N, common, false);
-  ta.save();
-  for (uint32_t i = 0; i < m; ++i) ta.rng_rekey_with_witness_var("", tr_ref{SRC_SECRETS, 32 * m, 32ull * i}, 32);
-  ta.rng_finalize_var(tr_ref{SRC_ENTROPY, 32, 0});
-  for (uint32_t i = 0; i < m; ++i) ta.rng_fill_bytes(tr_ref{DST_WIDE, 64 * m, 64ull * i}, 64);
-  ta.restore();
-  const std::vector<tr_op> progA = ta.finish(tailA);
-  // program B: commitments, challenge (prover.rs:98-106)
-  TrCompiler tb(tailA[0], tailA[1], tailA[2]);
-  for (uint32_t k = 0; k < nc; ++k)
-    tb.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, false);
-  tb.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});
-  const std::vector<tr_op> progB = tb.finish(tailB);
-
-  HIP_TRY(hipSetDevice(c->device));
+  const uint32_t m = s.m, nc = s.nc, n_points = s.ns + s.ni * N;
   carve cv;
   const size_t o_ts = cv.take((size_t)N * 208);
   const size_t o_sec = cv.take((size_t)N * m * 32 + 32);
   const size_t o_tbl = cv.take((size_t)n_points * 32 + 32);
   const size_t o_ent = cv.take((size_t)N * 32);
-  const size_t o_pa = cv.take(progA.size() * sizeof(tr_op) + 64);
-  const size_t o_pb = cv.take(progB.size() * sizeof(tr_op) + 64);
-  const size_t o_bufs = cv.take(sizeof(tr_bufs));
-  const size_t o_saved = cv.take((size_t)N * 25 * 8);
-  const size_t o_failed = cv.take((size_t)N * 4);
-  const size_t o_wide = cv.take((size_t)N * m * 64 + 64);
-  const size_t o_blind = cv.take((size_t)N * m * 32 + 32);
-  const size_t o_tarr = cv.take(((size_t)nc + 1 + 2 * (size_t)T + 4) * 4);
-  const size_t o_off = cv.take(((size_t)N * nc + 1) * 4);
-  const size_t o_sc = cv.take((size_t)N * T * 32 + 32);
-  const size_t o_pidx = cv.take((size_t)N * T * 4 + 4);
   const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
   const size_t o_st = cv.take((size_t)N * nc + 4);
-  const size_t o_wchal = cv.take((size_t)N * 64);
   const size_t o_chal = cv.take((size_t)N * 32);
   const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
-  const size_t reserved = cv.off;
-  rc = ensure_ws(c, reserved + terms_path_ws(n_points, N * T));
+  const prove_inter o = prove_carve(*pl, cv.off);
+  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T));
   if (rc) return rc;
-  char* base = static_cast<char*>(c->ws);
-  auto u8 = [&](size_t o) { return reinterpret_cast<uint8_t*>(base + o); };
-  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t*>(base + o); };
-  HIP_TRY(hipMemcpyAsync(base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
-  if (m) HIP_TRY(hipMemcpyAsync(base + o_sec, secrets, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  if (s.ns) HIP_TRY(hipMemcpyAsync(base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
-  if (s.ni) HIP_TRY(hipMemcpyAsync(base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(base + o_ent, entropy, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
-  prog_dev pa, pb;
-  rc = upload_program(c, progA, tailA, base + o_pa, pa);
+  const ws_view w{static_cast<char*>(c->ws)};
+  HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
+  if (m) HIP_TRY(hipMemcpyAsync(w.base + o_sec, secrets, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
+  if (s.ns) HIP_TRY(hipMemcpyAsync(w.base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
+  if (s.ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(w.base + o_ent, entropy, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
+  rc = prove_core(c, *pl, o, w.u8(o_ts), w.u8(o_sec), w.u8(o_tbl), w.u8(o_ent), w.u8(o_chal), w.u8(o_resp), w.u8(o_coms), w.u8(o_st));
   if (rc) return rc;
-  rc = upload_program(c, progB, tailB, base + o_pb, pb);
-  if (rc) return rc;
-  tr_bufs hb{};
-  hb.src[SRC_TABLE] = u8(o_tbl); hb.src[SRC_SECRETS] = u8(o_sec); hb.src[SRC_ENTROPY] = u8(o_ent); hb.src[SRC_COMS] = u8(o_coms);
-  hb.dst[DST_WIDE] = u8(o_wide); hb.dst[DST_CHAL] = u8(o_wchal);
-  HIP_TRY(hipMemcpyAsync(base + o_bufs, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
-  std::vector<uint32_t> tarr;
-  tarr.insert(tarr.end(), st->shape.cons_off, st->shape.cons_off + nc + (nc ? 1 : 0));
-  if (!nc) tarr.push_back(0);
-  if (T) { tarr.insert(tarr.end(), st->shape.cons_sc, st->shape.cons_sc + T); tarr.insert(tarr.end(), st->shape.cons_pt, st->shape.cons_pt + T); }
-  HIP_TRY(hipMemcpyAsync(base + o_tarr, tarr.data(), tarr.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemsetAsync(base + o_failed, 0, (size_t)N * 4, c->stream));
-  const tr_bufs* d_bufs = reinterpret_cast<const tr_bufs*>(base + o_bufs);
-  uint64_t* d_saved = reinterpret_cast<uint64_t*>(base + o_saved);
-
-  prof_begin(c);
-  run_program(c, pa, N, d_bufs, u8(o_ts), d_saved, u32(o_failed));
-  prof_mark(c, ZKP_K_TRANSCRIPT);
-  if (m) hipLaunchKernelGGL(k_wide_reduce, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N * m, u8(o_wide), u8(o_blind));
-  const size_t lanes = std::max<size_t>((size_t)N * T, (size_t)N * nc) + 1;
-  hipLaunchKernelGGL(k_stmt_terms, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, s.ns, m, u32(o_tarr), u32(o_tarr) + nc + 1,
-                     u32(o_tarr) + nc + 1 + T, u8(o_blind), (const uint8_t*)nullptr, u32(o_off), u8(o_sc), u32(o_pidx));
-  prof_mark(c, ZKP_K_SCALARS);
-  HIP_TRY(hipGetLastError());
-  if (nc) {
-    rc = msm_terms_path(c, N * nc, u32(o_off), u8(o_sc), u32(o_pidx), u8(o_tbl), n_points, N * T, ZKP_CT, u8(o_coms), u8(o_st), nullptr, reserved);
-    if (rc) return rc;
-  }
-  run_program(c, pb, N, d_bufs, u8(o_ts), d_saved, u32(o_failed));
-  prof_mark(c, ZKP_K_TRANSCRIPT);
-  hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_wchal), u8(o_chal));
-  if (m) hipLaunchKernelGGL(k_responses, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N, m, u8(o_sec), u8(o_chal), u8(o_blind), u8(o_resp));
-  prof_mark(c, ZKP_K_SCALARS);
-  HIP_TRY(hipGetLastError());
   std::vector<uint8_t> status((size_t)N * nc);
-  HIP_TRY(hipMemcpyAsync(challenges, base + o_chal, (size_t)N * 32, hipMemcpyDeviceToHost, c->stream));
-  if (m) HIP_TRY(hipMemcpyAsync(responses, base + o_resp, (size_t)N * m * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(challenges, w.base + o_chal, (size_t)N * 32, hipMemcpyDeviceToHost, c->stream));
+  if (m) HIP_TRY(hipMemcpyAsync(responses, w.base + o_resp, (size_t)N * m * 32, hipMemcpyDeviceToHost, c->stream));
   if (nc) {
-    HIP_TRY(hipMemcpyAsync(commitments, base + o_coms, (size_t)N * nc * 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(status.data(), base + o_st, (size_t)N * nc, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(commitments, w.base + o_coms, (size_t)N * nc * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(status.data(), w.base + o_st, (size_t)N * nc, hipMemcpyDeviceToHost, c->stream));
   }
-  HIP_TRY(hipMemcpyAsync(transcripts, base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *invalid_point = 0;
   for (uint8_t b : status) if (b) *invalid_point = 1;
   return ZKP_OK;
 }
 
+// ---- verify_compact --------------------------------------------------------------------------------------------------
+int zkp_fused_verify_compact_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos, uint8_t* d_transcripts,
+                                 const uint8_t* d_table, const uint8_t* d_challenges, const uint8_t* d_responses, uint8_t* d_results) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (N == 0) return ZKP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  fused_plan* pl = nullptr;
+  int rc = get_plan(c, FLOW_VERIFY, st, N, strobe_pos, &pl);
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if (!d_transcripts || !d_challenges || !d_results || (s.m && !d_responses) || (s.np && !d_table)) return fail(ZKP_ERR_ARG, "NULL device pointer");
+  if ((uint64_t)N * pl->T1 > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  const verify_inter o = verify_carve(*pl, 0);
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1));
+  if (rc) return rc;
+  return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results);
+}
+
 int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
                              const uint8_t* common, const uint8_t* challenges, const uint8_t* responses, uint8_t* results) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
-  fused_shape s;
-  int rc = check_fused_statement(st, s);
-  if (rc) return rc;
   if (N == 0) return ZKP_OK;
-  if (!transcripts || !challenges || !results || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
-  const uint32_t m = s.m, nc = s.nc, T1 = s.T + nc, n_points = s.ns + s.ni * N;
-  if ((uint64_t)N * T1 > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
-  uint8_t tail0[3], tailA[3], tailB[3];
-  rc = common_tail(transcripts, N, tail0);
+  if (!transcripts) return fail(ZKP_ERR_ARG, "NULL pointer");
+  uint32_t pos = 0;
+  int rc = common_tail(transcripts, N, &pos);
   if (rc) return rc;
-  TrCompiler ta(tail0[0], tail0[1], tail0[2]);
-  compile_allocations(ta, st, s, N, common, true);                       // verifier.rs:61-77 validating appends
-  const std::vector<tr_op> progA = ta.finish(tailA);
-  TrCompiler tb(tailA[0], tailA[1], tailA[2]);
-  for (uint32_t k = 0; k < nc; ++k)                                       // verifier.rs:108 (non-validating)
-    tb.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, false);
-  tb.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});
-  const std::vector<tr_op> progB = tb.finish(tailB);
-  // verifier.rs:95-106: per constraint the rhs terms with the responses, then (-c) on the lhs point
-  std::vector<uint32_t> tarr(nc + 1, 0), vsc, vpt;
-  for (uint32_t k = 0; k < nc; ++k) {
-    for (uint32_t q = st->shape.cons_off[k]; q < st->shape.cons_off[k + 1]; ++q) { vsc.push_back(st->shape.cons_sc[q]); vpt.push_back(st->shape.cons_pt[q]); }
-    vsc.push_back(0xffffffffu);
-    vpt.push_back(st->shape.cons_lhs[k]);
-    tarr[k + 1] = (uint32_t)vsc.size();
-  }
-  tarr.insert(tarr.end(), vsc.begin(), vsc.end());
-  tarr.insert(tarr.end(), vpt.begin(), vpt.end());
-  tarr.insert(tarr.end(), s.unref.begin(), s.unref.end());
-
   HIP_TRY(hipSetDevice(c->device));
+  fused_plan* pl = nullptr;
+  rc = get_plan(c, FLOW_VERIFY, st, N, pos, &pl);
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if (!challenges || !results || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
+  const uint32_t m = s.m, n_points = s.ns + s.ni * N;
+  if ((uint64_t)N * pl->T1 > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   carve cv;
   const size_t o_ts = cv.take((size_t)N * 208);
   const size_t o_tbl = cv.take((size_t)n_points * 32 + 32);
   const size_t o_claim = cv.take((size_t)N * 32);
   const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
-  const size_t o_pa = cv.take(progA.size() * sizeof(tr_op) + 64);
-  const size_t o_pb = cv.take(progB.size() * sizeof(tr_op) + 64);
-  const size_t o_bufs = cv.take(sizeof(tr_bufs));
-  const size_t o_saved = cv.take(256);
-  const size_t o_failed = cv.take((size_t)N * 4);
-  const size_t o_mc = cv.take((size_t)N * 32);
-  const size_t o_tarr = cv.take(tarr.size() * 4 + 16);
-  const size_t o_off = cv.take(((size_t)N * nc + 1) * 4);
-  const size_t o_sc = cv.take((size_t)N * T1 * 32 + 32);
-  const size_t o_pidx = cv.take((size_t)N * T1 * 4 + 4);
-  const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
-  const size_t o_st = cv.take((size_t)N * nc + 4);
-  const size_t o_wchal = cv.take((size_t)N * 64);
-  const size_t o_chal = cv.take((size_t)N * 32);
   const size_t o_res = cv.take((size_t)N);
-  const size_t reserved = cv.off;
-  rc = ensure_ws(c, reserved + terms_path_ws(n_points, N * T1));
+  const verify_inter o = verify_carve(*pl, cv.off);
+  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * pl->T1));
   if (rc) return rc;
-  char* base = static_cast<char*>(c->ws);
-  auto u8 = [&](size_t o) { return reinterpret_cast<uint8_t*>(base + o); };
-  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t*>(base + o); };
-  HIP_TRY(hipMemcpyAsync(base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
-  if (s.ns) HIP_TRY(hipMemcpyAsync(base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
-  if (s.ni) HIP_TRY(hipMemcpyAsync(base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(base + o_claim, challenges, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
-  if (m) HIP_TRY(hipMemcpyAsync(base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  prog_dev pa, pb;
-  rc = upload_program(c, progA, tailA, base + o_pa, pa);
+  const ws_view w{static_cast<char*>(c->ws)};
+  HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
+  if (s.ns) HIP_TRY(hipMemcpyAsync(w.base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
+  if (s.ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(w.base + o_claim, challenges, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
+  if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
+  rc = verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res));
   if (rc) return rc;
-  rc = upload_program(c, progB, tailB, base + o_pb, pb);
-  if (rc) return rc;
-  tr_bufs hb{};
-  hb.src[SRC_TABLE] = u8(o_tbl); hb.src[SRC_COMS] = u8(o_coms);
-  hb.dst[DST_CHAL] = u8(o_wchal);
-  HIP_TRY(hipMemcpyAsync(base + o_bufs, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(base + o_tarr, tarr.data(), tarr.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemsetAsync(base + o_failed, 0, (size_t)N * 4, c->stream));
-  const tr_bufs* d_bufs = reinterpret_cast<const tr_bufs*>(base + o_bufs);
-  uint64_t* d_saved = reinterpret_cast<uint64_t*>(base + o_saved);
-
-  prof_begin(c);
-  run_program(c, pa, N, d_bufs, u8(o_ts), d_saved, u32(o_failed));
-  prof_mark(c, ZKP_K_TRANSCRIPT);
-  hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_claim), u8(o_mc));
-  const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
-  hipLaunchKernelGGL(k_stmt_terms, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, s.ns, m, u32(o_tarr), u32(o_tarr) + nc + 1,
-                     u32(o_tarr) + nc + 1 + T1, u8(o_resp), u8(o_mc), u32(o_off), u8(o_sc), u32(o_pidx));
-  prof_mark(c, ZKP_K_SCALARS);
-  HIP_TRY(hipGetLastError());
-  // with no constraints there is no MSM, but every allocated point must still decode (verifier.rs:87-92)
-  rc = msm_terms_path(c, N * nc, u32(o_off), u8(o_sc), u32(o_pidx), u8(o_tbl), n_points, N * T1, ZKP_VARTIME, u8(o_coms), u8(o_st), nullptr, reserved);
-  if (rc) return rc;
-  run_program(c, pb, N, d_bufs, u8(o_ts), d_saved, u32(o_failed));
-  prof_mark(c, ZKP_K_TRANSCRIPT);
-  hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_wchal), u8(o_chal));
-  hipLaunchKernelGGL(k_verify_finish, grid1(N, 256), dim3(256), 0, c->stream, N, nc, s.ns, u8(o_chal), u8(o_claim), u8(o_st), u32(o_failed),
-                     reinterpret_cast<const dev_affine*>(base + reserved), u32(o_tarr) + nc + 1 + 2 * (size_t)T1, (uint32_t)s.unref.size(), u8(o_res));
-  prof_mark(c, ZKP_K_SCALARS);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(results, base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(transcripts, base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(results, w.base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ZKP_OK;
+}
+
+// ---- batch verification ----------------------------------------------------------------------------------------------
+int zkp_fused_batch_verify_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos, uint8_t* d_transcripts,
+                               uint8_t* d_points, const uint8_t* d_commitments, const uint8_t* d_responses, const uint8_t* d_weights16,
+                               uint8_t* d_out_point, uint32_t* d_status) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  fused_plan* pl = nullptr;
+  int rc = get_plan(c, FLOW_BATCH, st, N, N ? strobe_pos : 0, &pl);
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if (!d_out_point || !d_status || (N && (!d_transcripts || (s.nc && (!d_commitments || !d_weights16)) || (s.m && !d_responses))) ||
+      ((s.ns || (N && (s.ni || s.nc))) && !d_points))
+    return fail(ZKP_ERR_ARG, "NULL device pointer");
+  const size_t total = (size_t)s.ns + ((size_t)s.ni + s.nc) * N;
+  if (total > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  const batch_inter o = batch_carve(*pl, 0);
+  rc = ensure_ws(c, o.end + optional_ws(total));
+  if (rc) return rc;
+  return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_point, d_status);
 }
 
 int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
                            const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
                            int* verdict, uint8_t* debug_scalars) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
-  fused_shape s;
-  int rc = check_fused_statement(st, s);
+  if (!verdict || (N && !transcripts)) return fail(ZKP_ERR_ARG, "NULL pointer");
+  uint32_t pos = 0;
+  int rc = N ? common_tail(transcripts, N, &pos) : ZKP_OK;
   if (rc) return rc;
-  if (!verdict) return fail(ZKP_ERR_ARG, "NULL pointer");
-  if (N && (!transcripts || (s.nc && (!commitments || !weights16)) || (s.m && !responses) || (s.ni && !inst))) return fail(ZKP_ERR_ARG, "NULL pointer");
+  HIP_TRY(hipSetDevice(c->device));
+  fused_plan* pl = nullptr;
+  rc = get_plan(c, FLOW_BATCH, st, N, pos, &pl);
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if (N && ((s.nc && (!commitments || !weights16)) || (s.m && !responses) || (s.ni && !inst))) return fail(ZKP_ERR_ARG, "NULL pointer");
   if (s.ns && !common) return fail(ZKP_ERR_ARG, "NULL pointer");
   const uint32_t m = s.m, nc = s.nc, ns = s.ns, ni = s.ni;
-  const size_t rows = (size_t)ni + nc, total = (size_t)ns + rows * N;
+  const size_t total = (size_t)ns + ((size_t)ni + nc) * N;
   if (total > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
-  uint8_t tail0[3] = {0, 0, 0}, tailA[3] = {0, 0, 0};
-  std::vector<tr_op> prog;
-  if (N) {
-    rc = common_tail(transcripts, N, tail0);
-    if (rc) return rc;
-    TrCompiler ta(tail0[0], tail0[1], tail0[2]);
-    compile_allocations(ta, st, s, N, common, true);                     // batch_verifier.rs:92-94, :105-107, :125-128
-    for (uint32_t k = 0; k < nc; ++k)                                     // :152-160 validating
-      ta.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, true);
-    ta.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});               // :163-167
-    prog = ta.finish(tailA);
-  }
-  HIP_TRY(hipSetDevice(c->device));
-  const uint32_t nblk = (N + 255) / 256;
   carve cv;
-  const size_t o_sc = cv.take(total * 32 + 32);
-  const size_t o_pts = cv.take(total * 32 + 32);          // static || instance rows || commitment rows  (also the transcripts' point table)
+  const size_t o_pts = cv.take(total * 32 + 32);
   const size_t o_out = cv.take(32);
-  const size_t o_st = cv.take(16);                        // MSM status | any transcript failure
+  const size_t o_st = cv.take(16);
   const size_t o_ts = cv.take((size_t)N * 208);
   const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
   const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
   const size_t o_w = cv.take((size_t)nc * N * 16 + 16);
-  const size_t o_prog = cv.take(prog.size() * sizeof(tr_op) + 64);
-  const size_t o_bufs = cv.take(sizeof(tr_bufs));
-  const size_t o_failed = cv.take((size_t)N * 4 + 4);
-  const size_t o_wchal = cv.take((size_t)N * 64 + 64);
-  const size_t o_mc = cv.take((size_t)N * 32 + 32);
-  const size_t o_inc = cv.take((s.inc_off.size() + s.inc_k.size() * 2 + 4) * 4);
-  const size_t o_part = cv.take((size_t)(ns ? ns : 1) * (nblk ? nblk : 1) * 32);
-  const size_t reserved = cv.off;
-  rc = ensure_ws(c, reserved + optional_ws(total));
+  const batch_inter o = batch_carve(*pl, cv.off);
+  rc = ensure_ws(c, o.end + optional_ws(total));
   if (rc) return rc;
-  char* base = static_cast<char*>(c->ws);
-  auto u8 = [&](size_t o) { return reinterpret_cast<uint8_t*>(base + o); };
-  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t*>(base + o); };
-  if (ns) HIP_TRY(hipMemcpyAsync(base + o_pts, common, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
-  if (ni && N) HIP_TRY(hipMemcpyAsync(base + o_pts + 32 * (size_t)ns, inst, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemsetAsync(base + o_st, 0, 16, c->stream));
+  const ws_view w{static_cast<char*>(c->ws)};
+  if (ns) HIP_TRY(hipMemcpyAsync(w.base + o_pts, common, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
   if (N) {
-    HIP_TRY(hipMemcpyAsync(base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
+    if (ni) HIP_TRY(hipMemcpyAsync(w.base + o_pts + 32 * (size_t)ns, inst, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
     if (nc) {
-      HIP_TRY(hipMemcpyAsync(base + o_coms, commitments, (size_t)N * nc * 32, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hipMemcpyAsync(base + o_w, weights16, (size_t)nc * N * 16, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(w.base + o_coms, commitments, (size_t)N * nc * 32, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(w.base + o_w, weights16, (size_t)nc * N * 16, hipMemcpyHostToDevice, c->stream));
     }
-    if (m) HIP_TRY(hipMemcpyAsync(base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-    prog_dev pd;
-    rc = upload_program(c, prog, tailA, base + o_prog, pd);
-    if (rc) return rc;
-    tr_bufs hb{};
-    hb.src[SRC_TABLE] = u8(o_pts); hb.src[SRC_COMS] = u8(o_coms);
-    hb.dst[DST_CHAL] = u8(o_wchal);
-    HIP_TRY(hipMemcpyAsync(base + o_bufs, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(base + o_failed, 0, (size_t)N * 4, c->stream));
-    rc = upload_incidence(c, s, u32(o_inc));
-    if (rc) return rc;
-    prof_begin(c);
-    run_program(c, pd, N, reinterpret_cast<const tr_bufs*>(base + o_bufs), u8(o_ts), nullptr, u32(o_failed));
-    prof_mark(c, ZKP_K_TRANSCRIPT);
-    hipLaunchKernelGGL(k_any_nonzero, grid1(N, 256), dim3(256), 0, c->stream, N, u32(o_failed), u32(o_st) + 1);
-    // challenge -> -c, in place through the wide buffer: reduce to 32 bytes, then negate
-    hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_wchal), u8(o_mc));
-    hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, u8(o_mc), u8(o_mc));
-    if (nc) hipLaunchKernelGGL(k_transpose_commitments, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, N, nc, u8(o_coms), u8(o_pts) + 32 * ((size_t)ns + (size_t)ni * N));
-  } else {
-    rc = upload_incidence(c, s, u32(o_inc));
-    if (rc) return rc;
-    prof_begin(c);
+    if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
   }
-  launch_coeff_build(c, s, N, u32(o_inc), u8(o_mc), u8(o_resp), u8(o_w), u8(o_sc), u32(o_part));
-  prof_mark(c, ZKP_K_SCALARS);
-  HIP_TRY(hipGetLastError());
-  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, base + o_sc, total * 32, hipMemcpyDeviceToHost, c->stream));
-  rc = msm_optional_impl(c, total, u8(o_sc), u8(o_pts), u8(o_out), u32(o_st), reserved);
+  rc = batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st));
   if (rc) return rc;
   uint8_t out[32];
   uint32_t stv[2] = {1, 1};
-  HIP_TRY(hipMemcpyAsync(out, base + o_out, 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(stv, base + o_st, 8, hipMemcpyDeviceToHost, c->stream));
-  if (N) HIP_TRY(hipMemcpyAsync(transcripts, base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
+  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, w.base + o.sc, total * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(out, w.base + o_out, 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(stv, w.base + o_st, 8, hipMemcpyDeviceToHost, c->stream));
+  if (N) HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   static const uint8_t zero[32] = {0};
   *verdict = (stv[0] == 0 && stv[1] == 0 && memcmp(out, zero, 32) == 0) ? 0 : 1;   // batch_verifier.rs:230-234

@@ -17,7 +17,7 @@
 
 namespace zkp {
 
-constexpr int TR_MAX_BUFS = 8;
+constexpr int TR_MAX_BUFS = 4;
 constexpr uint8_t TR_PERMUTE = 1, TR_SAVE = 2, TR_RESTORE = 4, TR_CHECK_NONZERO = 8;
 
 struct tr_op {                      // 48 bytes
@@ -94,6 +94,21 @@ ZKP_HD void keccak_f1600_col(uint64_t* S, int stride) {
   S[20 * stride] = a04; S[21 * stride] = a14; S[22 * stride] = a24; S[23 * stride] = a34; S[24 * stride] = a44;
 }
 
+// bufs.src[i] / bufs.dst[i] for a run-time (wave-uniform) i: a select chain, so that the table can be a by-value kernel
+// argument without being copied to scratch for indexing
+ZKP_HD const uint8_t* tr_src_ptr(const tr_bufs& b, uint32_t i) {
+  const uint8_t* p = b.src[0];
+#pragma unroll
+  for (int k = 1; k < TR_MAX_BUFS; ++k) p = (i == (uint32_t)k) ? b.src[k] : p;
+  return p;
+}
+ZKP_HD uint8_t* tr_dst_ptr(const tr_bufs& b, uint32_t i) {
+  uint8_t* p = b.dst[0];
+#pragma unroll
+  for (int k = 1; k < TR_MAX_BUFS; ++k) p = (i == (uint32_t)k) ? b.dst[k] : p;
+  return p;
+}
+
 ZKP_HD uint64_t tr_bytemask(uint32_t nb) { return nb >= 8 ? ~0ULL : ((1ULL << (8 * nb)) - 1); }
 
 // Runs the program for proof j on the state column S (stride in words).  `saved` = this proof's clone slot
@@ -108,13 +123,13 @@ ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, uint64_t j, const tr_b
     if (op.flags & TR_RESTORE)
       for (int i = 0; i < 25; ++i) S[i * stride] = saved[i * saved_stride];
     if (op.flags & TR_CHECK_NONZERO) {
-      const uint64_t* p = reinterpret_cast<const uint64_t*>(bufs.src[op.src_buf - 1] + j * op.src_stride + op.src_off);
+      const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + j * op.src_stride + op.src_off);
       if ((p[0] | p[1] | p[2] | p[3]) == 0) *failed = 1;
       continue;
     }
     uint64_t v = S[op.w * stride];
     if (op.dst_buf) {
-      uint8_t* d = bufs.dst[op.dst_buf - 1] + j * op.dst_stride + op.dst_off;
+      uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + j * op.dst_stride + op.dst_off;
       const uint64_t e = v >> (8 * op.dlb);
       for (uint32_t i = 0; i < op.dnb; ++i) d[i] = (uint8_t)(e >> (8 * i));
     }
@@ -122,7 +137,7 @@ ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, uint64_t j, const tr_b
     if (op.src_buf) {
       const uint64_t addr = j * op.src_stride + op.src_off;
       const uint32_t sh = (uint32_t)(addr & 7);
-      const uint64_t* p = reinterpret_cast<const uint64_t*>(bufs.src[op.src_buf - 1] + (addr - sh));
+      const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
       x = p[0] >> (8 * sh);
       if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
       x = (x & tr_bytemask(op.nb)) << (8 * op.lb);

@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <map>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/zkp_mi355x.h"
@@ -710,7 +712,10 @@ struct zkp_ctx {
   uint64_t hot_used[HOT_SLOTS] = {};
   uint64_t hot_tick = 0;
   uint32_t hot_nreg = 0;
+  // fused flows (fused_flows.h): compiled transcript programs and operand templates per (flow, statement, N, position)
+  std::map<std::string, void*> fused_plans;
 };
+void free_fused_plans(zkp_ctx* c);
 
 namespace {
 
@@ -972,6 +977,7 @@ void zkp_ctx_destroy(zkp_ctx* c) {
   if (c->hot_reg_words) hipFree(c->hot_reg_words);
   if (c->hot_reg_slot) hipFree(c->hot_reg_slot);
   if (c->hot_scratch) hipFree(c->hot_scratch);
+  free_fused_plans(c);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;

@@ -23,6 +23,7 @@ EXPORTS = (
     "zkp_version", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
     "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest", "zkp_batch_check", "zkp_fused_prove", "zkp_fused_verify_compact", "zkp_fused_batch_verify",
+    "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_batch_verify_dev",
 )
 
 
@@ -173,6 +174,22 @@ class Engine:
     def msm_optional_dev(self, n, d_scalars, d_points, d_out, d_status) -> None:
         _check(self._lib.zkp_msm_optional_dev(self._h, n, d_scalars, d_points, d_out, d_status), "zkp_msm_optional_dev")
 
+    # ---- fused statement flows on device-resident buffers (include/zkp_mi355x.h section 2c) -------------
+    def fused_prove_dev(self, fst: "FusedStatement", n, strobe_pos, d_ts, d_secrets, d_table, d_entropy, d_chal, d_resp, d_coms, d_status) -> None:
+        _check(self._lib.zkp_fused_prove_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ctypes.c_uint32(strobe_pos),
+                                             *[ctypes.c_void_p(x) for x in (d_ts, d_secrets, d_table, d_entropy, d_chal, d_resp, d_coms, d_status)]),
+               "zkp_fused_prove_dev")
+
+    def fused_verify_compact_dev(self, fst: "FusedStatement", n, strobe_pos, d_ts, d_table, d_chal, d_resp, d_results) -> None:
+        _check(self._lib.zkp_fused_verify_compact_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ctypes.c_uint32(strobe_pos),
+                                                      *[ctypes.c_void_p(x) for x in (d_ts, d_table, d_chal, d_resp, d_results)]),
+               "zkp_fused_verify_compact_dev")
+
+    def fused_batch_verify_dev(self, fst: "FusedStatement", n, strobe_pos, d_ts, d_points, d_coms, d_resp, d_w, d_out, d_status) -> None:
+        _check(self._lib.zkp_fused_batch_verify_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ctypes.c_uint32(strobe_pos),
+                                                    *[ctypes.c_void_p(x) for x in (d_ts, d_points, d_coms, d_resp, d_w, d_out, d_status)]),
+               "zkp_fused_batch_verify_dev")
+
     def set_profiling(self, enabled: bool) -> None:
         _check(self._lib.zkp_ctx_set_profiling(self._h, int(enabled)), "zkp_ctx_set_profiling")
 
@@ -183,3 +200,49 @@ class Engine:
         if rc < 0:
             _check(rc, "zkp_ctx_last_timing")
         return {k: float(arr[i]) for i, k in enumerate(K_NAMES)}, float(tot.value)
+
+
+class _BatchStatementC(ctypes.Structure):
+    _fields_ = [("n_secrets", ctypes.c_uint32), ("n_static", ctypes.c_uint32), ("n_instance", ctypes.c_uint32),
+                ("n_constraints", ctypes.c_uint32), ("cons_lhs", ctypes.c_void_p), ("cons_off", ctypes.c_void_p),
+                ("cons_sc", ctypes.c_void_p), ("cons_pt", ctypes.c_void_p)]
+
+
+class _FusedStatementC(ctypes.Structure):
+    _fields_ = [("shape", _BatchStatementC), ("label", ctypes.c_char_p), ("secret_labels", ctypes.POINTER(ctypes.c_char_p)),
+                ("point_labels", ctypes.POINTER(ctypes.c_char_p)), ("alloc_order", ctypes.c_void_p)]
+
+
+class FusedStatement:
+    """zkp_fused_statement (include/zkp_mi355x.h): the statement in point-id form (static ids first, then instance ids)
+    with its transcript labels.  points = [(label, is_common)] in allocation order; constraints = [(lhs, [(secret, point)])]
+    with indices into `secrets` / `points`, exactly as Prover/Verifier::constrain receives them."""
+
+    def __init__(self, proof_label: bytes, secrets, points, constraints):
+        ns = sum(1 for _, c in points if c)
+        rank, k_c, k_i = [], 0, 0
+        for _, c in points:
+            if c:
+                rank.append(k_c); k_c += 1
+            else:
+                rank.append(ns + k_i); k_i += 1
+        self.n_static, self.n_instance = k_c, k_i
+        self._lhs = np.array([rank[l] for l, _ in constraints], np.uint32)
+        off, sc, pt = [0], [], []
+        for _, lc in constraints:
+            for s_, p_ in lc:
+                sc.append(s_); pt.append(rank[p_])
+            off.append(len(sc))
+        self._off = np.array(off, np.uint32)
+        self._sc = np.array(sc, np.uint32)
+        self._pt = np.array(pt, np.uint32)
+        self._order = np.array(rank, np.uint32)
+        plabels = [None] * len(points)
+        for (name, _), r in zip(points, rank):
+            plabels[r] = bytes(name)
+        self._sl = (ctypes.c_char_p * max(1, len(secrets)))(*[bytes(x) for x in secrets])
+        self._pl = (ctypes.c_char_p * max(1, len(points)))(*plabels)
+        self._label = bytes(proof_label)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self.c = _FusedStatementC(_BatchStatementC(len(secrets), k_c, k_i, len(constraints), vp(self._lhs), vp(self._off), vp(self._sc), vp(self._pt)),
+                                  self._label, self._sl, self._pl, vp(self._order))

@@ -37,6 +37,32 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
 LABEL = b"Benchmark"
 
 
+def cmz_shape(n):
+    """CSR shape of the prover's commitment MSMs for n CMZ proofs (benches/zkp.rs:27-46) over the stand-alone point table
+    [0..11) common X_1..X_10, A ; then per proof j: P_j = 11 + 2j, Q_j = 12 + 2j (used by the full-size MSM tests and
+    tools/large_batch_bench.py).  Scalar order per proof follows the constraints: (m_i, z_i) x 10, then m_1..m_10, minus_z_Q."""
+    import numpy as np
+    per = []
+    for i in range(10):
+        per += [("P", None), ("A", None)]
+    per += [("X", i) for i in range(10)] + [("Q", None)]
+    off_one = np.array([2 * i for i in range(11)] + [31], dtype=np.uint32)      # 10 x 2 terms, 1 x 11 terms
+    pidx = np.zeros((n, 31), dtype=np.uint32)
+    j = np.arange(n, dtype=np.uint32)
+    for t, (kind, i) in enumerate(per):
+        if kind == "P":
+            pidx[:, t] = 11 + 2 * j
+        elif kind == "Q":
+            pidx[:, t] = 12 + 2 * j
+        elif kind == "A":
+            pidx[:, t] = 10
+        else:
+            pidx[:, t] = i
+    off = (off_one[None, :-1] + 31 * j[:, None]).reshape(-1)
+    off = np.concatenate([off, np.array([31 * n], dtype=np.uint32)]).astype(np.uint32)
+    return off, pidx.reshape(-1), 11 + 2 * n
+
+
 def cmz_statement():
     """cred_show_10 (benches/zkp.rs:27-46) in the argument form of zkp_amd.engine.FusedStatement."""
     secrets = [b"m_%d" % i for i in range(1, 11)] + [b"z_%d" % i for i in range(1, 11)] + [b"minus_z_Q"]

@@ -78,7 +78,7 @@ extern "C" int t_tr_selftest(uint32_t seed, uint32_t N, uint32_t m, uint32_t np,
     uint64_t S[25], saved[25];
     memcpy(S, &blobs[208 * (size_t)j], 200);
     uint32_t failed = 0;
-    tr_run_one(prog.data(), (uint32_t)prog.size(), j, bufs, S, 1, saved, 1, &failed);
+    tr_run_one(prog.data(), (uint32_t)prog.size(), c.tables().data(), j, bufs, S, 1, saved, 1, &failed);
     if (memcmp(S, &want_blobs[208 * (size_t)j], 200) != 0) bad |= 1;
     if (tail[0] != want_blobs[208 * (size_t)j + 200] || tail[1] != want_blobs[208 * (size_t)j + 201] || tail[2] != want_blobs[208 * (size_t)j + 202]) bad |= 2;
     if ((failed != 0) != (want_fail[j] != 0)) bad |= 4;

@@ -11,24 +11,124 @@
 
 namespace zkp {
 
-// One lane per proof; the STROBE state lives in an LDS column so that the interpreter can index words dynamically.
-// No cross-lane traffic, hence no barriers.  tail = pos | pos_begin << 8 | cur_flags << 16 after the program.
-__global__ void __launch_bounds__(64)
-k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, uint32_t N, const tr_bufs bufs,
-                 uint8_t* __restrict__ ts, uint64_t* __restrict__ saved, uint32_t* __restrict__ failed, uint32_t tail) {
-  __shared__ uint64_t S[25 * 64];
-  const uint32_t j = blockIdx.x * 64 + threadIdx.x;
-  if (j >= N) return;
-  uint64_t* col = S + threadIdx.x;
-  uint64_t* blob = reinterpret_cast<uint64_t*>(ts + 208 * (size_t)j);
+// ---- the transcript interpreter on the GPU ---------------------------------------------------------------------------
+// A lone wavefront issues one VALU instruction every 4 cycles, and a batch of a few thousand proofs is only a few dozen
+// wavefronts: the kernel is latency-bound, so each proof is spread over a PAIR of lanes.  Lane h of the pair holds the
+// h-th 32-bit half of every 64-bit STROBE word (LDS columns of uint32: dynamic word index without scratch).  XOR / AND /
+// NOT are half-local; a 64-bit rotation takes the partner's half with one DPP quad_perm move and one v_alignbit_b32:
+// ~160 full-rate VALU operations per Keccak round per lane instead of 264.  Semantics = tr_run_one (merlin_prog.h).
+__device__ __forceinline__ uint32_t pair_swap(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+}
+// half of rotl64 by R that this lane keeps (mine / partner = this lane's and the other lane's half of the word)
+__device__ __forceinline__ uint32_t rotl_half(uint32_t mine, uint32_t partner, int R) {
+  const int n = R & 31;
+  if (R & 32) return n ? __builtin_amdgcn_alignbit(partner, mine, 32 - n) : partner;
+  return n ? __builtin_amdgcn_alignbit(mine, partner, 32 - n) : mine;
+}
+__device__ __forceinline__ uint32_t half_of(uint64_t v, uint32_t h) { return h ? (uint32_t)(v >> 32) : (uint32_t)v; }
+
+__device__ __forceinline__ void keccak_f1600_split(uint32_t a[25], uint32_t h) {
+  static const uint64_t RC[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+      0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+      0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+      0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};   // [x + 5 y]
+#pragma unroll 1
+  for (int round = 0; round < 24; ++round) {
+    uint32_t c[5], b[25];
 #pragma unroll
-  for (int i = 0; i < 25; ++i) col[64 * i] = blob[i];
-  uint32_t f = 0;
-  tr_run_one(prog, n_ops, j, bufs, col, 64, saved + j, N, &f);
+    for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
 #pragma unroll
-  for (int i = 0; i < 25; ++i) blob[i] = col[64 * i];
-  blob[25] = tail;
-  if (f) failed[j] = 1;
+    for (int x = 0; x < 5; ++x) {                       // theta: D[x] = C[x-1] ^ rotl(C[x+1], 1)
+      const uint32_t cn = c[(x + 1) % 5];
+      const uint32_t d = c[(x + 4) % 5] ^ rotl_half(cn, pair_swap(cn), 1);
+#pragma unroll
+      for (int y = 0; y < 5; ++y) a[x + 5 * y] ^= d;
+    }
+#pragma unroll
+    for (int y = 0; y < 5; ++y)                         // rho + pi: B[y][2x+3y] = rotl(A[x][y], r[x][y])
+#pragma unroll
+      for (int x = 0; x < 5; ++x) {
+        const uint32_t v = a[x + 5 * y];
+        b[y + 5 * ((2 * x + 3 * y) % 5)] = RHO[x + 5 * y] ? rotl_half(v, pair_swap(v), RHO[x + 5 * y]) : v;
+      }
+#pragma unroll
+    for (int y = 0; y < 5; ++y)                         // chi
+#pragma unroll
+      for (int x = 0; x < 5; ++x) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+    a[0] ^= half_of(RC[round], h);                      // iota
+  }
+}
+
+constexpr int TR_BLOCK = 64;       // lanes per workgroup = 32 proofs
+__global__ void __launch_bounds__(TR_BLOCK)
+k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t* __restrict__ tables, uint32_t N, const tr_bufs bufs,
+                 uint8_t* __restrict__ ts, uint32_t* __restrict__ saved /*[25][2N]*/, uint32_t* __restrict__ failed, uint32_t tail) {
+  __shared__ uint32_t S[25 * TR_BLOCK];
+  const uint32_t lane = threadIdx.x, h = lane & 1;
+  const uint32_t j = blockIdx.x * (TR_BLOCK / 2) + (lane >> 1);
+  if (j >= N) return;                                   // both lanes of a pair leave together
+  uint32_t* col = S + lane;
+  uint32_t* blob = reinterpret_cast<uint32_t*>(ts + 208 * (size_t)j);
+#pragma unroll
+  for (int i = 0; i < 25; ++i) col[TR_BLOCK * i] = blob[2 * i + h];
+  uint32_t* sv = saved + 2 * (size_t)j + h;
+  const size_t sv_stride = 2 * (size_t)N;
+  uint32_t bad = 0;
+  if (n_ops == 0) return;
+  tr_op next = prog[0];
+  for (uint32_t q = 0; q < n_ops; ++q) {
+    const tr_op op = next;
+    if (q + 1 < n_ops) next = prog[q + 1];              // fetched while this operation runs
+    if (op.flags & TR_RESTORE) {
+#pragma unroll
+      for (int i = 0; i < 25; ++i) col[TR_BLOCK * i] = sv[i * sv_stride];
+    }
+    if (op.flags & TR_CHECK_NONZERO) {
+      const uint4* p = reinterpret_cast<const uint4*>(tr_src_ptr(bufs, op.src_buf - 1u) + (size_t)j * op.src_stride + op.src_off);
+      const uint4 lo = p[0], hi = p[1];
+      if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) bad = 1;
+    }
+    if (op.dst_buf) {                                   // PRF output: the bytes of word w that live in this half
+      uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + (size_t)j * op.dst_stride + op.dst_off;
+      const uint32_t v = col[TR_BLOCK * op.w];
+      for (uint32_t i = 0; i < op.dnb; ++i) {
+        const uint32_t b = op.dlb + i;
+        if ((b >> 2) == h) d[i] = (uint8_t)(v >> (8 * (b & 3)));
+      }
+    }
+    if (op.src_buf && !(op.flags & TR_CHECK_NONZERO)) {
+      const uint64_t addr = (uint64_t)j * op.src_stride + op.src_off;
+      const uint32_t sh = (uint32_t)(addr & 7);
+      const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
+      uint64_t x = p[0] >> (8 * sh);
+      if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
+      x = (x & tr_bytemask(op.nb)) << (8 * op.lb);
+      col[TR_BLOCK * op.w] = (col[TR_BLOCK * op.w] & half_of(op.keep, h)) ^ half_of(x, h);
+    }
+    if (op.flags & TR_APPLY) {
+      const uint64_t* tbl = tables + (size_t)TR_TABLE_WORDS * op.src_off;
+      uint32_t a[25];
+#pragma unroll
+      for (int i = 0; i < 25; ++i) a[i] = col[TR_BLOCK * i];
+#pragma unroll
+      for (int i = 0; i < 21; ++i) a[i] = (a[i] & half_of(tbl[i], h)) ^ half_of(tbl[21 + i], h);
+      if (op.flags & TR_PERMUTE) keccak_f1600_split(a, h);
+#pragma unroll
+      for (int i = 0; i < 25; ++i) col[TR_BLOCK * i] = a[i];
+    }
+    if (op.flags & TR_SAVE) {
+#pragma unroll
+      for (int i = 0; i < 25; ++i) sv[i * sv_stride] = col[TR_BLOCK * i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 25; ++i) blob[2 * i + h] = col[TR_BLOCK * i];
+  if (h == 0) { blob[50] = tail; blob[51] = 0; }
+  if (bad && h == 0) failed[j] = 1;
 }
 
 // Scalar::from_bytes_mod_order_wide over n 64-byte strings
@@ -207,7 +307,7 @@ enum { SRC_TABLE = 0, SRC_SECRETS = 1, SRC_ENTROPY = 2, SRC_COMS = 3 };
 enum { DST_WIDE = 0, DST_CHAL = 1 };
 enum fused_flow : char { FLOW_PROVE = 'P', FLOW_VERIFY = 'V', FLOW_BATCH = 'B' };
 
-struct prog_dev { const tr_op* ops = nullptr; uint32_t n = 0; uint32_t tail = 0; };
+struct prog_dev { const tr_op* ops = nullptr; uint32_t n = 0; uint32_t tail = 0; const uint64_t* tables = nullptr; };
 struct fused_plan {
   fused_shape s;
   uint32_t N = 0, T1 = 0;          // T1 = terms per proof of the flow's CSR job
@@ -281,6 +381,7 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   const uint32_t m = s.m, nc = s.nc;
   uint8_t tailA[3], tailB[3];
   std::vector<tr_op> pa, pb;
+  std::vector<uint64_t> tbl_a, tbl_b;
   std::vector<uint32_t> tarr;
   TrCompiler ta((uint8_t)pos, (uint8_t)(pos >> 8), (uint8_t)(pos >> 16));
   if (flow == FLOW_PROVE) {
@@ -292,12 +393,14 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
     for (uint32_t i = 0; i < m; ++i) ta.rng_fill_bytes(tr_ref{DST_WIDE, 64 * m, 64ull * i}, 64);
     ta.restore();
     pa = ta.finish(tailA);
+    tbl_a = ta.tables();
     // program B: commitments, challenge (prover.rs:98-106)
     TrCompiler tb(tailA[0], tailA[1], tailA[2]);
     for (uint32_t k = 0; k < nc; ++k)
       tb.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, false);
     tb.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});
     pb = tb.finish(tailB);
+    tbl_b = tb.tables();
     // prover.rs:94-97 operand lists
     tarr.assign(nc + 1, 0);
     for (uint32_t k = 0; k < nc; ++k) tarr[k + 1] = st->shape.cons_off[k + 1];
@@ -306,11 +409,13 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   } else if (flow == FLOW_VERIFY) {
     compile_allocations(ta, st, s, N, true);                            // verifier.rs:61-77 validating appends
     pa = ta.finish(tailA);
+    tbl_a = ta.tables();
     TrCompiler tb(tailA[0], tailA[1], tailA[2]);
     for (uint32_t k = 0; k < nc; ++k)                                    // verifier.rs:108 (non-validating)
       tb.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, false);
     tb.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});
     pb = tb.finish(tailB);
+    tbl_b = tb.tables();
     // verifier.rs:95-106: per constraint the rhs terms with the responses, then (-c) on the lhs point
     std::vector<uint32_t> vsc, vpt;
     tarr.assign(nc + 1, 0);
@@ -330,11 +435,14 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
       ta.append_blinding_commitment_var(st->point_labels[st->shape.cons_lhs[k]], tr_ref{SRC_COMS, 32 * nc, 32ull * k}, true);
     ta.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});              // :163-167
     pa = ta.finish(tailA);
+    tbl_a = ta.tables();
   }
   const std::vector<uint32_t> inc = incidence_words(s);
   carve cv;
   const size_t o_a = cv.take(pa.size() * sizeof(tr_op) + 64);
   const size_t o_b = cv.take(pb.size() * sizeof(tr_op) + 64);
+  const size_t o_ta = cv.take(tbl_a.size() * 8 + 64);
+  const size_t o_tb = cv.take(tbl_b.size() * 8 + 64);
   const size_t o_t = cv.take(tarr.size() * 4 + 64);
   const size_t o_i = cv.take(inc.size() * 4 + 64);
   HIP_TRY(hipSetDevice(c->device));
@@ -342,11 +450,15 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   auto put = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpy(pl->d_block + o, src, bytes, hipMemcpyHostToDevice) : hipSuccess; };
   hipError_t e = put(o_a, pa.data(), pa.size() * sizeof(tr_op));
   if (e == hipSuccess) e = put(o_b, pb.data(), pb.size() * sizeof(tr_op));
+  if (e == hipSuccess) e = put(o_ta, tbl_a.data(), tbl_a.size() * 8);
+  if (e == hipSuccess) e = put(o_tb, tbl_b.data(), tbl_b.size() * 8);
   if (e == hipSuccess) e = put(o_t, tarr.data(), tarr.size() * 4);
   if (e == hipSuccess) e = put(o_i, inc.data(), inc.size() * 4);
   if (e != hipSuccess) { hipFree(pl->d_block); return fail(ZKP_ERR_HIP, std::string("plan upload: ") + hipGetErrorString(e)); }
-  pl->a = prog_dev{reinterpret_cast<const tr_op*>(pl->d_block + o_a), (uint32_t)pa.size(), tailA[0] | (uint32_t)tailA[1] << 8 | (uint32_t)tailA[2] << 16};
-  pl->b = prog_dev{reinterpret_cast<const tr_op*>(pl->d_block + o_b), (uint32_t)pb.size(), tailB[0] | (uint32_t)tailB[1] << 8 | (uint32_t)tailB[2] << 16};
+  pl->a = prog_dev{reinterpret_cast<const tr_op*>(pl->d_block + o_a), (uint32_t)pa.size(), tailA[0] | (uint32_t)tailA[1] << 8 | (uint32_t)tailA[2] << 16,
+                    reinterpret_cast<const uint64_t*>(pl->d_block + o_ta)};
+  pl->b = prog_dev{reinterpret_cast<const tr_op*>(pl->d_block + o_b), (uint32_t)pb.size(), tailB[0] | (uint32_t)tailB[1] << 8 | (uint32_t)tailB[2] << 16,
+                    reinterpret_cast<const uint64_t*>(pl->d_block + o_tb)};
   pl->d_tarr = reinterpret_cast<const uint32_t*>(pl->d_block + o_t);
   pl->d_inc = reinterpret_cast<const uint32_t*>(pl->d_block + o_i);
   if (c->fused_plans.size() >= 64) free_fused_plans(c);        // a bound on what a long-lived context keeps
@@ -356,7 +468,9 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
 }
 
 void run_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed) {
-  if (p.n) hipLaunchKernelGGL(k_transcript_run, dim3((N + 63) / 64), dim3(64), 0, c->stream, p.ops, p.n, N, bufs, d_ts, d_saved, d_failed, p.tail);
+  constexpr uint32_t per_block = TR_BLOCK / 2;
+  if (p.n) hipLaunchKernelGGL(k_transcript_run, dim3((N + per_block - 1) / per_block), dim3(TR_BLOCK), 0, c->stream, p.ops, p.n, p.tables, N, bufs, d_ts,
+                              reinterpret_cast<uint32_t*>(d_saved), d_failed, p.tail);
 }
 
 // ---- the flows on device buffers (asynchronous on the context's stream) ----------------------------------------------

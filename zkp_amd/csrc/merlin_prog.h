@@ -2,11 +2,13 @@
 //
 // Every proof of one batch call runs the SAME sequence of transcript operations (same labels, same lengths); only
 // the 32-byte values differ.  STROBE's byte position is therefore known on the host, and a transcript "program" can
-// be compiled once per call: per Keccak block, a handful of 64-bit word operations
-//        state[w] = (state[w] & keep) ^ cx ^ (bytes from this proof's inputs << 8*lb)        [+ emit bytes of state[w]]
-// followed by the permutation.  Constants (labels, length prefixes, STROBE framing and padding, common points) are
-// folded into keep/cx at compile time; the GPU interprets the word list with one lane per proof, the state in an
-// LDS column (dynamic word index without scratch), and no divergence.
+// be compiled once per (statement, batch size): per Keccak block
+//   * word operations that move this proof's bytes:  emit bytes of state[w] (PRF output), or
+//        state[w] = (state[w] & keep) ^ (bytes from this proof's inputs << 8*lb)             (absorb / key)
+//   * one APPLY operation: state[w] = (state[w] & KEEP[w]) ^ CX[w] for the 21 rate words, with everything constant
+//     (labels, length prefixes, STROBE framing and padding, zeroing of squeezed bytes) folded into one 336-byte table,
+//     then the permutation.
+// The GPU interprets the list with the state in LDS columns (dynamic word index without scratch), no divergence.
 //
 // TrCompiler mirrors the host classes in host/merlin.hpp method for method; tests/test_host_field.py runs compiled
 // programs through tr_run_one on the CPU and compares with the host Merlin byte for byte.
@@ -18,7 +20,8 @@
 namespace zkp {
 
 constexpr int TR_MAX_BUFS = 4;
-constexpr uint8_t TR_PERMUTE = 1, TR_SAVE = 2, TR_RESTORE = 4, TR_CHECK_NONZERO = 8;
+constexpr uint8_t TR_PERMUTE = 1, TR_SAVE = 2, TR_RESTORE = 4, TR_CHECK_NONZERO = 8, TR_APPLY = 16;
+constexpr int TR_TABLE_WORDS = 42;   // per block: keep[21] | cx[21] over the 168 rate + padding bytes
 
 struct tr_op {                      // 48 bytes
   uint64_t keep, cx;
@@ -51,8 +54,9 @@ ZKP_HD uint64_t tr_rotl_c(uint64_t v) {
 }
 #define tr_rotl(v, n) tr_rotl_c<n>(v)
 
-// Keccak-f[1600] on a strided column (S[i * stride]), 25 lanes held in registers for the 24 rounds.
-ZKP_HD void keccak_f1600_col(uint64_t* S, int stride) {
+// The APPLY operation on a strided column (S[i * stride]): the block's constant table, then (permute) Keccak-f[1600]
+// with the 25 lanes held in registers for the 24 rounds.
+ZKP_HD void tr_apply_block(uint64_t* S, int stride, const uint64_t* tbl, bool permute) {
   const uint64_t RC[24] = {
       0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
       0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
@@ -64,8 +68,13 @@ ZKP_HD void keccak_f1600_col(uint64_t* S, int stride) {
   uint64_t a02 = S[10 * stride], a12 = S[11 * stride], a22 = S[12 * stride], a32 = S[13 * stride], a42 = S[14 * stride];
   uint64_t a03 = S[15 * stride], a13 = S[16 * stride], a23 = S[17 * stride], a33 = S[18 * stride], a43 = S[19 * stride];
   uint64_t a04 = S[20 * stride], a14 = S[21 * stride], a24 = S[22 * stride], a34 = S[23 * stride], a44 = S[24 * stride];
+#define TR_T(v, i) v = (v & tbl[i]) ^ tbl[21 + i]
+  TR_T(a00, 0); TR_T(a10, 1); TR_T(a20, 2); TR_T(a30, 3); TR_T(a40, 4); TR_T(a01, 5); TR_T(a11, 6);
+  TR_T(a21, 7); TR_T(a31, 8); TR_T(a41, 9); TR_T(a02, 10); TR_T(a12, 11); TR_T(a22, 12); TR_T(a32, 13);
+  TR_T(a42, 14); TR_T(a03, 15); TR_T(a13, 16); TR_T(a23, 17); TR_T(a33, 18); TR_T(a43, 19); TR_T(a04, 20);
+#undef TR_T
 #pragma unroll 1
-  for (int round = 0; round < 24; ++round) {
+  for (int round = 0; round < (permute ? 24 : 0); ++round) {
     const uint64_t c0 = a00 ^ a01 ^ a02 ^ a03 ^ a04, c1 = a10 ^ a11 ^ a12 ^ a13 ^ a14, c2 = a20 ^ a21 ^ a22 ^ a23 ^ a24,
                    c3 = a30 ^ a31 ^ a32 ^ a33 ^ a34, c4 = a40 ^ a41 ^ a42 ^ a43 ^ a44;
     const uint64_t d0 = c4 ^ tr_rotl(c1, 1), d1 = c0 ^ tr_rotl(c2, 1), d2 = c1 ^ tr_rotl(c3, 1), d3 = c2 ^ tr_rotl(c4, 1),
@@ -113,37 +122,33 @@ ZKP_HD uint64_t tr_bytemask(uint32_t nb) { return nb >= 8 ? ~0ULL : ((1ULL << (8
 
 // Runs the program for proof j on the state column S (stride in words).  `saved` = this proof's clone slot
 // (saved[i * saved_stride]); *failed is set when a checked encoding is all zero (mod.rs:191, :215).
-ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, uint64_t j, const tr_bufs& bufs, uint64_t* S, int stride,
-                       uint64_t* saved, size_t saved_stride, uint32_t* failed) {
-  if (n_ops == 0) return;
-  tr_op next = prog[0];
+// This is the reference semantics of a program (and what the host tests run); the GPU kernel k_transcript_run in
+// fused_flows.h implements the same operations on 32-bit half-words split across lane pairs.
+ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, const uint64_t* tables, uint64_t j, const tr_bufs& bufs, uint64_t* S,
+                       int stride, uint64_t* saved, size_t saved_stride, uint32_t* failed) {
   for (uint32_t q = 0; q < n_ops; ++q) {
-    const tr_op op = next;
-    if (q + 1 < n_ops) next = prog[q + 1];    // fetched while this operation runs
+    const tr_op op = prog[q];
     if (op.flags & TR_RESTORE)
       for (int i = 0; i < 25; ++i) S[i * stride] = saved[i * saved_stride];
     if (op.flags & TR_CHECK_NONZERO) {
       const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + j * op.src_stride + op.src_off);
       if ((p[0] | p[1] | p[2] | p[3]) == 0) *failed = 1;
-      continue;
     }
-    uint64_t v = S[op.w * stride];
     if (op.dst_buf) {
       uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + j * op.dst_stride + op.dst_off;
-      const uint64_t e = v >> (8 * op.dlb);
+      const uint64_t e = S[op.w * stride] >> (8 * op.dlb);
       for (uint32_t i = 0; i < op.dnb; ++i) d[i] = (uint8_t)(e >> (8 * i));
     }
-    uint64_t x = 0;
-    if (op.src_buf) {
+    if (op.src_buf && !(op.flags & TR_CHECK_NONZERO)) {
       const uint64_t addr = j * op.src_stride + op.src_off;
       const uint32_t sh = (uint32_t)(addr & 7);
       const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
-      x = p[0] >> (8 * sh);
+      uint64_t x = p[0] >> (8 * sh);
       if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
       x = (x & tr_bytemask(op.nb)) << (8 * op.lb);
+      S[op.w * stride] = (S[op.w * stride] & op.keep) ^ x;
     }
-    S[op.w * stride] = (v & op.keep) ^ op.cx ^ x;
-    if (op.flags & TR_PERMUTE) keccak_f1600_col(S, stride);
+    if (op.flags & TR_APPLY) tr_apply_block(S, stride, tables + (size_t)TR_TABLE_WORDS * op.src_off, (op.flags & TR_PERMUTE) != 0);
     if (op.flags & TR_SAVE)
       for (int i = 0; i < 25; ++i) saved[i * saved_stride] = S[i * stride];
   }
@@ -238,6 +243,7 @@ class TrCompiler {
     tail[0] = pos_; tail[1] = pos_begin_; tail[2] = cur_flags_;
     return ops_;
   }
+  const std::vector<uint64_t>& tables() const { return tables_; }    // TR_TABLE_WORDS words per APPLY operation
   size_t permutations() const { return n_perm_; }
 
  private:
@@ -289,12 +295,20 @@ class TrCompiler {
     op.flags = flag;
     ops_.push_back(op);
   }
-  // emit the pending byte effects as word operations; permute = the block ends here
+  // emit the pending byte effects: word operations for the bytes that move, one APPLY with the block's constant
+  // table for everything else; permute = the block ends here
   void flush(bool permute) {
     if (!dirty_ && !permute) return;
-    const size_t first = ops_.size();
+    uint64_t keep[21], cx[21];
     for (unsigned w = 0; w < 21; ++w) {
       const ByteEff* e = &eff_[8 * w];
+      keep[w] = 0; cx[w] = 0;
+      for (unsigned b = 0; b < 8; ++b) {
+        // bytes overwritten from a per-proof source are cleared by their own operation, not by the table
+        const uint8_t k = e[b].has_src ? 0xff : e[b].keep;
+        keep[w] |= (uint64_t)k << (8 * b);
+        cx[w] |= (uint64_t)e[b].cx << (8 * b);
+      }
       // bytes leaving the state (squeeze), grouped into runs with contiguous destinations
       for (unsigned b = 0; b < 8;) {
         if (!e[b].has_dst) { ++b; continue; }
@@ -311,23 +325,16 @@ class TrCompiler {
         ops_.push_back(op);
         b += n;
       }
-      uint64_t keep = 0, cx = 0;
-      for (unsigned b = 0; b < 8; ++b) { keep |= (uint64_t)e[b].keep << (8 * b); cx |= (uint64_t)e[b].cx << (8 * b); }
-      if (keep != ~0ULL || cx != 0) {
-        tr_op op{};
-        op.keep = keep;
-        op.cx = cx;
-        op.w = (uint8_t)w;
-        ops_.push_back(op);
-      }
       for (unsigned b = 0; b < 8;) {
         if (!e[b].has_src) { ++b; continue; }
         unsigned n = 1;
-        // a run must stay inside one 32-byte source item so that the two aligned loads of tr_run_one do too
+        // a run must stay inside one 32-byte source item so that the two aligned loads of the interpreter do too,
+        // and must be all-absorb or all-overwrite
         while (b + n < 8 && e[b + n].has_src && e[b + n].src.buf == e[b].src.buf && e[b + n].src.off == e[b].src.off + n &&
-               ((e[b].src.off + n) & 31) != 0) ++n;
+               e[b + n].keep == e[b].keep && ((e[b].src.off + n) & 31) != 0) ++n;
         tr_op op{};
-        op.keep = ~0ULL;
+        const uint64_t mask = (n >= 8 ? ~0ULL : ((1ULL << (8 * n)) - 1)) << (8 * b);
+        op.keep = e[b].keep ? ~0ULL : ~mask;
         op.w = (uint8_t)w;
         op.src_buf = (uint8_t)(e[b].src.buf + 1);
         op.src_stride = e[b].src.stride;
@@ -338,15 +345,19 @@ class TrCompiler {
         b += n;
       }
     }
-    if (permute) {
-      if (ops_.size() == first) marker(0);
-      ops_.back().flags |= TR_PERMUTE;
-      ++n_perm_;
-    }
+    tr_op ap{};
+    ap.keep = ~0ULL;
+    ap.flags = (uint8_t)(TR_APPLY | (permute ? TR_PERMUTE : 0));
+    ap.src_off = tables_.size() / TR_TABLE_WORDS;
+    tables_.insert(tables_.end(), keep, keep + 21);
+    tables_.insert(tables_.end(), cx, cx + 21);
+    ops_.push_back(ap);
+    if (permute) ++n_perm_;
     reset_block();
   }
 
   std::vector<tr_op> ops_;
+  std::vector<uint64_t> tables_;
   ByteEff eff_[168];
   bool dirty_ = false;
   uint8_t pos_, pos_begin_, cur_flags_;

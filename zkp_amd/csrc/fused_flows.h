@@ -63,14 +63,18 @@ __device__ __forceinline__ void keccak_f1600_split(uint32_t a[25], uint32_t h) {
   }
 }
 
-constexpr int TR_BLOCK = 64;       // lanes per workgroup = 32 proofs
+constexpr int TR_BLOCK = 64;       // lanes per workgroup (one wavefront) = 32 proofs
+// The operation list is fetched 64 operations at a time: lane i loads operation base + i (one coalesced 1 KiB load), and
+// the wavefront then walks them with v_readlane -- no scalar-memory latency inside the loop (an s_load per operation
+// would be waited for at every LDS access, since both count on lgkmcnt).
 __global__ void __launch_bounds__(TR_BLOCK)
 k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t* __restrict__ tables, uint32_t N, const tr_bufs bufs,
                  uint8_t* __restrict__ ts, uint32_t* __restrict__ saved /*[25][2N]*/, uint32_t* __restrict__ failed, uint32_t tail) {
   __shared__ uint32_t S[25 * TR_BLOCK];
   const uint32_t lane = threadIdx.x, h = lane & 1;
-  const uint32_t j = blockIdx.x * (TR_BLOCK / 2) + (lane >> 1);
-  if (j >= N) return;                                   // both lanes of a pair leave together
+  const uint32_t j_raw = blockIdx.x * (TR_BLOCK / 2) + (lane >> 1);
+  const bool live = j_raw < N;                          // lanes past the end shadow the last proof (they must stay in the
+  const uint32_t j = live ? j_raw : N - 1;              // wavefront: they carry operations for v_readlane) and store nothing
   uint32_t* col = S + lane;
   uint32_t* blob = reinterpret_cast<uint32_t*>(ts + 208 * (size_t)j);
 #pragma unroll
@@ -78,53 +82,59 @@ k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t*
   uint32_t* sv = saved + 2 * (size_t)j + h;
   const size_t sv_stride = 2 * (size_t)N;
   uint32_t bad = 0;
-  if (n_ops == 0) return;
-  tr_op next = prog[0];
-  for (uint32_t q = 0; q < n_ops; ++q) {
-    const tr_op op = next;
-    if (q + 1 < n_ops) next = prog[q + 1];              // fetched while this operation runs
-    if (op.flags & TR_RESTORE) {
+  for (uint32_t base = 0; base < n_ops; base += TR_BLOCK) {
+    const uint32_t cnt = n_ops - base < TR_BLOCK ? n_ops - base : TR_BLOCK;
+    uint4 mine = make_uint4(0, 0, 0, 0);
+    if (lane < cnt) mine = reinterpret_cast<const uint4*>(prog)[base + lane];
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t o_ctl = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)i);
+      const uint32_t o_stride = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)i);
+      const uint64_t o_off = (uint32_t)__builtin_amdgcn_readlane((int)mine.z, (int)i) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mine.w, (int)i) << 32;
+      const tr_fields op = tr_unpack(o_ctl, o_stride, o_off);
+      if (op.flags & TR_RESTORE) {
 #pragma unroll
-      for (int i = 0; i < 25; ++i) col[TR_BLOCK * i] = sv[i * sv_stride];
-    }
-    if (op.flags & TR_CHECK_NONZERO) {
-      const uint4* p = reinterpret_cast<const uint4*>(tr_src_ptr(bufs, op.src_buf - 1u) + (size_t)j * op.src_stride + op.src_off);
-      const uint4 lo = p[0], hi = p[1];
-      if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) bad = 1;
-    }
-    if (op.dst_buf) {                                   // PRF output: the bytes of word w that live in this half
-      uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + (size_t)j * op.dst_stride + op.dst_off;
-      const uint32_t v = col[TR_BLOCK * op.w];
-      for (uint32_t i = 0; i < op.dnb; ++i) {
-        const uint32_t b = op.dlb + i;
-        if ((b >> 2) == h) d[i] = (uint8_t)(v >> (8 * (b & 3)));
+        for (int k = 0; k < 25; ++k) col[TR_BLOCK * k] = sv[k * sv_stride];
+      }
+      if (op.flags & TR_CHECK_NONZERO) {
+        const uint4* p = reinterpret_cast<const uint4*>(tr_src_ptr(bufs, op.src_buf - 1u) + (size_t)j * op.stride + op.off);
+        const uint4 lo = p[0], hi = p[1];
+        if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) bad = 1;
+      }
+      if (op.dst_buf) {                                 // PRF output: the bytes of word w that live in this half
+        uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + (size_t)j * op.stride + op.off;
+        const uint32_t v = col[TR_BLOCK * op.w];
+        for (uint32_t k = 0; k < op.dnb; ++k) {
+          const uint32_t b = op.dlb + k;
+          if ((b >> 2) == h && live) d[k] = (uint8_t)(v >> (8 * (b & 3)));
+        }
+      }
+      if (op.src_buf && !(op.flags & TR_CHECK_NONZERO)) {
+        const uint64_t addr = (uint64_t)j * op.stride + op.off;
+        const uint32_t sh = (uint32_t)(addr & 7);
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
+        uint64_t x = p[0] >> (8 * sh);
+        if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
+        x = (x & tr_bytemask(op.nb)) << (8 * op.lb);
+        col[TR_BLOCK * op.w] = (col[TR_BLOCK * op.w] & half_of(op.keep, h)) ^ half_of(x, h);
+      }
+      if (op.flags & TR_APPLY) {
+        const uint64_t* tbl = tables + (size_t)TR_TABLE_WORDS * op.off;
+        uint32_t a[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) a[k] = col[TR_BLOCK * k];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) a[k] = (a[k] & half_of(tbl[k], h)) ^ half_of(tbl[21 + k], h);
+        if (op.flags & TR_PERMUTE) keccak_f1600_split(a, h);
+#pragma unroll
+        for (int k = 0; k < 25; ++k) col[TR_BLOCK * k] = a[k];
+      }
+      if ((op.flags & TR_SAVE) && live) {
+#pragma unroll
+        for (int k = 0; k < 25; ++k) sv[k * sv_stride] = col[TR_BLOCK * k];
       }
     }
-    if (op.src_buf && !(op.flags & TR_CHECK_NONZERO)) {
-      const uint64_t addr = (uint64_t)j * op.src_stride + op.src_off;
-      const uint32_t sh = (uint32_t)(addr & 7);
-      const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
-      uint64_t x = p[0] >> (8 * sh);
-      if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
-      x = (x & tr_bytemask(op.nb)) << (8 * op.lb);
-      col[TR_BLOCK * op.w] = (col[TR_BLOCK * op.w] & half_of(op.keep, h)) ^ half_of(x, h);
-    }
-    if (op.flags & TR_APPLY) {
-      const uint64_t* tbl = tables + (size_t)TR_TABLE_WORDS * op.src_off;
-      uint32_t a[25];
-#pragma unroll
-      for (int i = 0; i < 25; ++i) a[i] = col[TR_BLOCK * i];
-#pragma unroll
-      for (int i = 0; i < 21; ++i) a[i] = (a[i] & half_of(tbl[i], h)) ^ half_of(tbl[21 + i], h);
-      if (op.flags & TR_PERMUTE) keccak_f1600_split(a, h);
-#pragma unroll
-      for (int i = 0; i < 25; ++i) col[TR_BLOCK * i] = a[i];
-    }
-    if (op.flags & TR_SAVE) {
-#pragma unroll
-      for (int i = 0; i < 25; ++i) sv[i * sv_stride] = col[TR_BLOCK * i];
-    }
   }
+  if (!live) return;
 #pragma unroll
   for (int i = 0; i < 25; ++i) blob[2 * i + h] = col[TR_BLOCK * i];
   if (h == 0) { blob[50] = tail; blob[51] = 0; }
@@ -436,6 +446,16 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
     ta.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});              // :163-167
     pa = ta.finish(tailA);
     tbl_a = ta.tables();
+  }
+  if (const char* dbg = getenv("ZKP_TR_DEBUG")) {          // TIMING EXPERIMENTS ONLY (results are wrong)
+    for (auto* pr : {&pa, &pb})
+      for (auto& op : *pr) {
+        const bool check = (op.ctl & TR_CHECK_NONZERO) != 0;
+        if (strstr(dbg, "noperm")) op.ctl &= ~(uint32_t)TR_PERMUTE;
+        if (strstr(dbg, "nosrc") && !check) op.ctl &= ~(7u << 25);
+        if (strstr(dbg, "nodst")) op.ctl &= ~(7u << 28);
+        if (strstr(dbg, "nocheck") && check) op.ctl &= ~((uint32_t)TR_CHECK_NONZERO | 7u << 25);
+      }
   }
   const std::vector<uint32_t> inc = incidence_words(s);
   carve cv;

@@ -23,14 +23,44 @@ constexpr int TR_MAX_BUFS = 4;
 constexpr uint8_t TR_PERMUTE = 1, TR_SAVE = 2, TR_RESTORE = 4, TR_CHECK_NONZERO = 8, TR_APPLY = 16;
 constexpr int TR_TABLE_WORDS = 42;   // per block: keep[21] | cx[21] over the 168 rate + padding bytes
 
-struct tr_op {                      // 48 bytes
-  uint64_t keep, cx;
-  uint64_t src_off, dst_off;        // byte offsets inside buffer (before + j * stride)
-  uint32_t src_stride, dst_stride;  // bytes per proof
-  uint8_t w, nb, lb, src_buf;       // src_buf / dst_buf: 0 = none, else 1 + index into tr_bufs
-  uint8_t dst_buf, flags, dnb, dlb; // dnb/dlb: byte count / position of the emitted bytes
+constexpr uint8_t TR_OVERWRITE = 32;  // (word operation) the source bytes replace the state bytes instead of XORing into them
+
+// One operation as the interpreters read it: 16 bytes, so that a wavefront fetches 64 of them with one coalesced load.
+//   ctl = flags[5:0] | w[10:6] | nb[14:11] | lb[17:15] | dnb[21:18] | dlb[24:22] | src_buf[27:25] | dst_buf[30:28]
+//   stride / off: bytes per proof and byte offset of the source or destination (an operation has at most one of them);
+//   for TR_APPLY, off = index of the block's constant table.
+struct tr_op { uint32_t ctl, stride; uint64_t off; };
+static_assert(sizeof(tr_op) == 16, "tr_op layout");
+struct tr_fields {
+  uint32_t flags, w, nb, lb, dnb, dlb, src_buf, dst_buf;   // src_buf / dst_buf: 0 = none, else 1 + index into tr_bufs
+  uint32_t stride;
+  uint64_t off, keep;
 };
-static_assert(sizeof(tr_op) == 48, "tr_op layout");
+ZKP_HD tr_fields tr_unpack(uint32_t ctl, uint32_t stride, uint64_t off) {
+  tr_fields f;
+  f.flags = ctl & 63u; f.w = (ctl >> 6) & 31u; f.nb = (ctl >> 11) & 15u; f.lb = (ctl >> 15) & 7u;
+  f.dnb = (ctl >> 18) & 15u; f.dlb = (ctl >> 22) & 7u; f.src_buf = (ctl >> 25) & 7u; f.dst_buf = (ctl >> 28) & 7u;
+  f.stride = stride;
+  f.off = off;
+  const uint64_t mask = (f.nb >= 8 ? ~0ULL : ((1ULL << (8 * f.nb)) - 1)) << (8 * f.lb);
+  f.keep = (f.flags & TR_OVERWRITE) ? ~mask : ~0ULL;
+  return f;
+}
+// the compiler's working form
+struct tr_op_wide {
+  uint64_t keep = ~0ULL;
+  uint64_t src_off = 0, dst_off = 0;
+  uint32_t src_stride = 0, dst_stride = 0;
+  uint8_t w = 0, nb = 0, lb = 0, src_buf = 0, dst_buf = 0, flags = 0, dnb = 0, dlb = 0;
+};
+inline tr_op tr_pack(const tr_op_wide& o) {
+  tr_op p;
+  p.ctl = (uint32_t)o.flags | (uint32_t)o.w << 6 | (uint32_t)o.nb << 11 | (uint32_t)o.lb << 15 | (uint32_t)o.dnb << 18 |
+          (uint32_t)o.dlb << 22 | (uint32_t)o.src_buf << 25 | (uint32_t)o.dst_buf << 28;
+  p.stride = o.dst_buf ? o.dst_stride : o.src_stride;
+  p.off = o.dst_buf ? o.dst_off : o.src_off;
+  return p;
+}
 
 struct tr_bufs {
   const uint8_t* src[TR_MAX_BUFS];
@@ -127,20 +157,20 @@ ZKP_HD uint64_t tr_bytemask(uint32_t nb) { return nb >= 8 ? ~0ULL : ((1ULL << (8
 ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, const uint64_t* tables, uint64_t j, const tr_bufs& bufs, uint64_t* S,
                        int stride, uint64_t* saved, size_t saved_stride, uint32_t* failed) {
   for (uint32_t q = 0; q < n_ops; ++q) {
-    const tr_op op = prog[q];
+    const tr_fields op = tr_unpack(prog[q].ctl, prog[q].stride, prog[q].off);
     if (op.flags & TR_RESTORE)
       for (int i = 0; i < 25; ++i) S[i * stride] = saved[i * saved_stride];
     if (op.flags & TR_CHECK_NONZERO) {
-      const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + j * op.src_stride + op.src_off);
+      const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + j * op.stride + op.off);
       if ((p[0] | p[1] | p[2] | p[3]) == 0) *failed = 1;
     }
     if (op.dst_buf) {
-      uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + j * op.dst_stride + op.dst_off;
+      uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + j * op.stride + op.off;
       const uint64_t e = S[op.w * stride] >> (8 * op.dlb);
       for (uint32_t i = 0; i < op.dnb; ++i) d[i] = (uint8_t)(e >> (8 * i));
     }
     if (op.src_buf && !(op.flags & TR_CHECK_NONZERO)) {
-      const uint64_t addr = j * op.src_stride + op.src_off;
+      const uint64_t addr = j * op.stride + op.off;
       const uint32_t sh = (uint32_t)(addr & 7);
       const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
       uint64_t x = p[0] >> (8 * sh);
@@ -148,7 +178,7 @@ ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, const uint64_t* tables
       x = (x & tr_bytemask(op.nb)) << (8 * op.lb);
       S[op.w * stride] = (S[op.w * stride] & op.keep) ^ x;
     }
-    if (op.flags & TR_APPLY) tr_apply_block(S, stride, tables + (size_t)TR_TABLE_WORDS * op.src_off, (op.flags & TR_PERMUTE) != 0);
+    if (op.flags & TR_APPLY) tr_apply_block(S, stride, tables + (size_t)TR_TABLE_WORDS * op.off, (op.flags & TR_PERMUTE) != 0);
     if (op.flags & TR_SAVE)
       for (int i = 0; i < 25; ++i) saved[i * saved_stride] = S[i * stride];
   }
@@ -229,7 +259,7 @@ class TrCompiler {
 
   void check_nonzero(tr_ref src) {
     flush(false);
-    tr_op op{};
+    tr_op_wide op{};
     op.keep = ~0ULL;
     op.flags = TR_CHECK_NONZERO;
     op.src_buf = (uint8_t)(src.buf + 1);
@@ -241,7 +271,9 @@ class TrCompiler {
   std::vector<tr_op> finish(uint8_t tail[3]) {
     flush(false);
     tail[0] = pos_; tail[1] = pos_begin_; tail[2] = cur_flags_;
-    return ops_;
+    std::vector<tr_op> packed;
+    for (const auto& o : ops_) packed.push_back(tr_pack(o));
+    return packed;
   }
   const std::vector<uint64_t>& tables() const { return tables_; }    // TR_TABLE_WORDS words per APPLY operation
   size_t permutations() const { return n_perm_; }
@@ -290,7 +322,7 @@ class TrCompiler {
     if ((flags & (kC | kK)) && pos_ != 0) run_f();
   }
   void marker(uint8_t flag) {
-    tr_op op{};
+    tr_op_wide op{};
     op.keep = ~0ULL;
     op.flags = flag;
     ops_.push_back(op);
@@ -314,7 +346,7 @@ class TrCompiler {
         if (!e[b].has_dst) { ++b; continue; }
         unsigned n = 1;
         while (b + n < 8 && e[b + n].has_dst && e[b + n].dst.buf == e[b].dst.buf && e[b + n].dst.off == e[b].dst.off + n) ++n;
-        tr_op op{};
+        tr_op_wide op{};
         op.keep = ~0ULL;
         op.w = (uint8_t)w;
         op.dst_buf = (uint8_t)(e[b].dst.buf + 1);
@@ -332,9 +364,10 @@ class TrCompiler {
         // and must be all-absorb or all-overwrite
         while (b + n < 8 && e[b + n].has_src && e[b + n].src.buf == e[b].src.buf && e[b + n].src.off == e[b].src.off + n &&
                e[b + n].keep == e[b].keep && ((e[b].src.off + n) & 31) != 0) ++n;
-        tr_op op{};
+        tr_op_wide op{};
         const uint64_t mask = (n >= 8 ? ~0ULL : ((1ULL << (8 * n)) - 1)) << (8 * b);
         op.keep = e[b].keep ? ~0ULL : ~mask;
+        if (!e[b].keep) op.flags |= TR_OVERWRITE;
         op.w = (uint8_t)w;
         op.src_buf = (uint8_t)(e[b].src.buf + 1);
         op.src_stride = e[b].src.stride;
@@ -345,7 +378,7 @@ class TrCompiler {
         b += n;
       }
     }
-    tr_op ap{};
+    tr_op_wide ap{};
     ap.keep = ~0ULL;
     ap.flags = (uint8_t)(TR_APPLY | (permute ? TR_PERMUTE : 0));
     ap.src_off = tables_.size() / TR_TABLE_WORDS;
@@ -356,7 +389,7 @@ class TrCompiler {
     reset_block();
   }
 
-  std::vector<tr_op> ops_;
+  std::vector<tr_op_wide> ops_;
   std::vector<uint64_t> tables_;
   ByteEff eff_[168];
   bool dirty_ = false;

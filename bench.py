@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU per step (BASELINE configs[1]: 4096)")
-    ap.add_argument("--streams", type=int, default=8, help="independent batches in flight, each on its own HIP stream / engine context")
+    ap.add_argument("--streams", type=int, default=16, help="independent batches in flight, each on its own HIP stream / engine context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,7 +129,7 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per stream (default is 4)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(args.streams, 24))))      # one hardware queue per stream (default is 4)
     import numpy as np
     import torch
     from zkp_amd.engine import Engine, FusedStatement

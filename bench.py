@@ -280,12 +280,15 @@ def main():
     mads = n * (11 * mads_comb_term + 20 * mads_fixed_term)
     valu = mads / t_terms if t_terms > 0 else 0.0
     traffic = None
+    step_valu = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")       # rocprofv3 --pmc passes of this same command
     if os.path.exists(pmc) and n == 4096:
         try:
-            traffic = json.load(open(pmc))["k_terms_split<true>"]["hbm_bytes_per_launch"]
+            pj = json.load(open(pmc))
+            traffic = pj["k_terms_split<true>"]["hbm_bytes_per_launch"]
+            step_valu = pj["_step_totals"]["valu_wave_instructions_per_step"]
         except Exception:
-            traffic = None
+            pass
     msm_only = lambda d: sum(d.get(k, 0.0) for k in ("decode", "terms", "reduce", "sort", "bucket", "combine"))
     out = {
         "metric": METRIC, "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -305,6 +308,13 @@ def main():
                      "valu_achieved_mads_per_s": valu, "valu_peak_mads_per_s": VALU_PEAK_MADS, "valu_frac": valu / VALU_PEAK_MADS,
                      "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": k_prove["terms"]},
     }
+    if step_valu:
+        # every VALU instruction of one step (PMC SQ_INSTS_VALU, all kernels) against the measured 4-cycle-class issue peak:
+        # how close the pipelined step as a whole runs to the integer-VALU roofline
+        lane_instr = step_valu * 64.0
+        out["step_valu"] = {"wave_instructions_per_step": step_valu, "lane_instructions_per_s": lane_instr / (ms_per_step * 1e-3) * world / world,
+                            "peak_lane_instructions_per_s": VALU_PEAK_MADS, "frac": lane_instr / (ms_per_step * 1e-3) / VALU_PEAK_MADS,
+                            "note": "simple 32-bit adds / fma issue at twice this class's rate, so frac slightly understates the headroom"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, secrets, inst, common, d_ent.cpu().numpy(), d_w.cpu().numpy())
     print(json.dumps(out))

@@ -29,6 +29,14 @@ def main():
             row["hbm_bytes_per_launch"] = (2.0 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024.0
         res[k] = row
         print("%-34s %s" % (k[-34:], "  ".join("%s=%.4g" % (c, v) for c, v in sorted(row.items()))))
+    # whole-step totals: one k_terms_split<true> launch per bench step (set-up launches of other kernels excluded by
+    # scaling every kernel's per-launch average with launches / steps, capped at what a step can contain)
+    steps = res.get("k_terms_split<true>", {}).get("launches")
+    if steps:
+        tot = sum(v["SQ_INSTS_VALU"] * v["launches"] for k, v in res.items() if "SQ_INSTS_VALU" in v and "k_hot_" not in k) / steps
+        res["_step_totals"] = {"steps": steps, "valu_wave_instructions_per_step": tot,
+                               "note": "sum over kernels of SQ_INSTS_VALU x launches / steps (fixed-base table set-up kernels excluded)"}
+        print("%-34s valu wave-instructions per bench step = %.4g" % ("_step_totals", tot))
     json.dump(res, open(out, "w"), indent=1)
 
 

@@ -583,7 +583,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
   // with no constraints there is no MSM, but every allocated point must still decode (verifier.rs:87-92)
-  const int rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end);
+  const int rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true);
   if (rc) return rc;
   run_program(c, pl.b, N, hb, d_ts, nullptr, w.u32(o.failed));
   prof_mark(c, ZKP_K_TRANSCRIPT);

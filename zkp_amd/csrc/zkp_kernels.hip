@@ -66,9 +66,12 @@ __device__ __forceinline__ uint32_t sel8(const uint32_t w[8], int j) {
 // (A) small-MSM path
 // =============================================================================================
 __global__ void __launch_bounds__(256, 2)
-k_decode_affine(uint32_t n, const uint8_t* __restrict__ enc, dev_affine* __restrict__ out) {
+k_decode_affine(uint32_t n, const uint8_t* __restrict__ enc, dev_affine* __restrict__ out, const uint32_t* __restrict__ only) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  // `only` (optional): decode just the points some term multiplies through their coordinates.  The others are either
+  // on a fixed-base table (registered points decoded successfully, hot_tables.h) or referenced by no term of this call.
+  if (only && !only[i]) { out[i].valid = 1; return; }
   uint32_t w[8];
   load_vec<2>(w, enc + 32 * (size_t)i);
   ge_p3 p;
@@ -759,7 +762,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint8_t* d_scalars,
                    const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms, int flags,
-                   uint8_t* d_out, uint8_t* d_status8, uint32_t* d_status32, size_t ws_reserved) {
+                   uint8_t* d_out, uint8_t* d_status8, uint32_t* d_status32, size_t ws_reserved, bool decode_all = false) {
   carve cv;
   cv.off = ws_reserved;
   const size_t o_pts = cv.take((size_t)n_points * sizeof(dev_affine));
@@ -774,8 +777,6 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
   char* base = static_cast<char*>(c->ws);
   dev_affine* pts = reinterpret_cast<dev_affine*>(base + o_pts);
   dev_ext* part = reinterpret_cast<dev_ext*>(base + o_part);
-  if (n_points) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts);
-  prof_mark(c, ZKP_K_DECODE);
   if (n_terms >= 1024) {
     // split the terms: those on a registered fixed-base point (grouped by table) / the rest, which go through per-point
     // comb tables built here for exactly the points they reference
@@ -792,6 +793,11 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     else
       HIP_TRY(hipMemsetAsync(hotmap, 0xff, (size_t)n_points * 4, c->stream));
     hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, class_cnt, needs);
+    prof_mark(c, ZKP_K_SORT);
+    // decode: every point when the caller's semantics ask for it (a verifier rejects any allocated point that does not
+    // decompress, verifier.rs:87-92), otherwise only the points whose coordinates this call uses
+    hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, decode_all ? (const uint32_t*)nullptr : needs);
+    prof_mark(c, ZKP_K_DECODE);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor);
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, cursor, list);
     hipLaunchKernelGGL(k_comb_tables, grid1((size_t)n_points * 4, 256), dim3(256), 0, c->stream, n_points, needs, pts, comb);
@@ -801,8 +807,10 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
       hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, part);
     else
       hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, part);
-  } else if (n_terms) {
-    hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part);
+  } else {
+    if (n_points) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, (const uint32_t*)nullptr);
+    prof_mark(c, ZKP_K_DECODE);
+    if (n_terms) hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part);
   }
   prof_mark(c, ZKP_K_TERMS);
   if (n_msm) {
@@ -1048,7 +1056,7 @@ int zkp_ctx_prepare_fixed_points(zkp_ctx* c, uint32_t n, const uint8_t* encoding
     std::vector<uint8_t> h_enc(32 * (size_t)nh);
     for (uint32_t i = 0; i < nh; ++i) memcpy(h_enc.data() + 32 * (size_t)i, fresh[i].data(), 32);
     HIP_TRY(hipMemcpyAsync(d_enc, h_enc.data(), h_enc.size(), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_decode_affine, grid1(nh, 256), dim3(256), 0, c->stream, nh, d_enc, d_aff);
+    hipLaunchKernelGGL(k_decode_affine, grid1(nh, 256), dim3(256), 0, c->stream, nh, d_enc, d_aff, (const uint32_t*)nullptr);
     std::vector<dev_affine> h_aff(nh);
     HIP_TRY(hipMemcpyAsync(h_aff.data(), d_aff, sizeof(dev_affine) * nh, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -158,3 +158,126 @@ def test_ragged_transcripts_use_the_host_route(eng):
     ts3 = np.stack(states)
     res = T.verify_compact_batch(eng, st, ts3, inst, common, chal, resp)
     assert not res.any()
+
+
+def _random_points(k, rng):
+    base = np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32)
+    s = rng.integers(0, 256, size=(k, 32), dtype=np.uint8)
+    s[:, 31] &= 0x0f
+    pts, st = C.msm_many(np.arange(k + 1, dtype=np.uint32), s, np.zeros(k, np.uint32), base, 0)
+    assert not st.any()
+    return pts, s
+
+
+@pytest.mark.parametrize("n", [3, 400])
+def test_constraint_api_allocation_order_fused(eng, n):
+    """benches/dleq.rs:188-241: the static points G, H are allocated BEFORE the instance points A, B, so their
+    encodings enter the transcript first; the fused route takes the order from alloc_order.  Proofs must equal the
+    oracle's (same allocation order) byte for byte."""
+    rng = np.random.default_rng(77)
+    label = b"DLEQBatchTest"
+    cst = C.Statement(b"DLEQProof", ["x"], [("G", True), ("H", True), ("A", False), ("B", False)],
+                      [("A", [("x", "G")]), ("B", [("x", "H")])])
+    st = T.Statement(b"DLEQProof")
+    x = st.add_secret(b"x")
+    g, h = st.add_point(b"G", True), st.add_point(b"H", True)
+    a, b = st.add_point(b"A", False), st.add_point(b"B", False)
+    st.constrain(a, [(x, g)])
+    st.constrain(b, [(x, h)])
+    gh, _ = _random_points(2, rng)
+    xs = rng.integers(0, 256, size=(n, 1, 32), dtype=np.uint8)
+    xs[:, :, 31] &= 0x0f
+    A, _ = C.msm_many(np.arange(n + 1, dtype=np.uint32), xs[:, 0], np.zeros(n, np.uint32), gh[0:1], 0)
+    B, _ = C.msm_many(np.arange(n + 1, dtype=np.uint32), xs[:, 0], np.zeros(n, np.uint32), gh[1:2], 0)
+    inst = np.ascontiguousarray(np.stack([A, B]))
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    T.set_fused_min_batch(0)
+    try:
+        ts = _fresh(label, n)
+        chal, resp, coms = T.prove_batch(eng, st, ts, xs, inst, gh, entropy)
+        for j in sorted(set([0, n // 2, n - 1])):
+            ec, er, ek, _ = C.prove(cst, label, xs[j], np.stack([gh[0], gh[1], A[j], B[j]]), entropy[j].tobytes())
+            assert chal[j].tobytes() == ec.tobytes() and (resp[j] == er).all() and (coms[j] == ek).all()
+        ts = _fresh(label, n)
+        assert not T.verify_compact_batch(eng, st, ts, inst, gh, chal, resp).any()
+        ts = _fresh(label, n)
+        T.batch_verify(eng, st, ts, inst, gh, coms, resp)
+        swapped = np.ascontiguousarray(inst[::-1])                      # A and B exchanged: every proof fails
+        ts = _fresh(label, n)
+        assert T.verify_compact_batch(eng, st, ts, swapped, gh, chal, resp).all()
+        ts = _fresh(label, n)
+        with pytest.raises(T.VerificationFailure):
+            T.batch_verify(eng, st, ts, swapped, gh, coms, resp)
+    finally:
+        T.set_fused_min_batch(256)
+
+
+def test_w64_statement_fused_equals_host_route(eng):
+    """BASELINE config 5's wide statement Q = sum_{i<64} x_i G_i: 64 secrets, 64 common points, one 64-term constraint
+    (the transcript program has 64 rekeys + 64 fills: 150+ Keccak permutations per proof)."""
+    n = 300
+    rng = np.random.default_rng(64)
+    names = [f"x_{i}" for i in range(64)]
+    gens = [f"G_{i}" for i in range(64)]
+    mod = T.define_proof("w64", b"W64", names, ["Q"], gens, [("Q", [(names[i], gens[i]) for i in range(64)])])
+    st = mod.statement
+    G, _ = _random_points(64, rng)
+    xs = rng.integers(0, 256, size=(n, 64, 32), dtype=np.uint8)
+    xs[:, :, 31] &= 0x0f
+    off = (np.arange(n + 1, dtype=np.uint64) * 64).astype(np.uint32)
+    Q, stq = C.msm_many(off, xs.reshape(-1, 32), np.tile(np.arange(64, dtype=np.uint32), n), G, 0)
+    assert not stq.any()
+    inst = np.ascontiguousarray(Q[None])
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    w = rng.integers(0, 256, size=(1, n, 16), dtype=np.uint8)
+    out = {}
+    for route, thr in (("host", NEVER), ("fused", 0)):
+        T.set_fused_min_batch(thr)
+        ts = _fresh(b"wide", n)
+        chal, resp, coms = T.prove_batch(eng, st, ts, xs, inst, G, entropy)
+        ts2 = _fresh(b"wide", n)
+        res = T.verify_compact_batch(eng, st, ts2, inst, G, chal, resp)
+        ts3 = _fresh(b"wide", n)
+        ok, coeffs = T.batch_verify_coeffs(eng, st, ts3, inst, G, coms, resp, w)
+        out[route] = (chal, resp, coms, ts[:, :203], res, ts2[:, :203], coeffs, ts3[:, :203])
+        assert ok and not res.any()
+    T.set_fused_min_batch(256)
+    for a, b in zip(out["host"], out["fused"]):
+        assert (a == b).all()
+
+
+def test_fused_entry_points_reject_bad_arguments(eng):
+    """The raw C entry points fail closed: negative return code, message in zkp_last_error, nothing marked verified."""
+    import ctypes
+    from zkp_amd.engine import FusedStatement, load_library
+    lib = load_library()
+    fst = FusedStatement(b"DLEQ proof", [b"x"], [(b"A", False), (b"B", False), (b"H", False), (b"G", True)],
+                         [(0, [(0, 3)]), (1, [(0, 2)])])
+    n = 4
+    ts = np.stack([T.Transcript(b"t").state] * n)
+    z = lambda *s: np.zeros(s, np.uint8)
+    verdict = ctypes.c_int(0)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    # NULL inputs
+    rc = lib.zkp_fused_batch_verify(eng._h, ctypes.byref(fst.c), ctypes.c_uint32(n), vp(ts), None, None, None, None, None, ctypes.byref(verdict), None)
+    assert rc < 0 and b"NULL" in lib.zkp_last_error()
+    # transcripts at different STROBE positions
+    t2 = T.Transcript(b"t")
+    t2.append_message(b"m", b"xyz")
+    ragged = ts.copy()
+    ragged[2] = t2.state
+    res = z(n)
+    rc = lib.zkp_fused_verify_compact(eng._h, ctypes.byref(fst.c), ctypes.c_uint32(n), vp(ragged), vp(z(3, n, 32)), vp(z(1, 32)), vp(z(n, 32)),
+                                      vp(z(n, 1, 32)), vp(res))
+    assert rc < 0 and b"STROBE" in lib.zkp_last_error()
+    # a statement whose constraint names a point that does not exist
+    bad = FusedStatement(b"DLEQ proof", [b"x"], [(b"A", False), (b"G", True)], [(0, [(0, 1)])])
+    bad._pt[0] = 7
+    rc = lib.zkp_fused_verify_compact(eng._h, ctypes.byref(bad.c), ctypes.c_uint32(n), vp(ts), vp(z(1, n, 32)), vp(z(1, 32)), vp(z(n, 32)),
+                                      vp(z(n, 1, 32)), vp(res))
+    assert rc < 0 and b"out of range" in lib.zkp_last_error()
+    # all-zero (identity) encodings everywhere: the call works and every proof is rejected
+    res[:] = 0
+    rc = lib.zkp_fused_verify_compact(eng._h, ctypes.byref(fst.c), ctypes.c_uint32(n), vp(ts.copy()), vp(z(3, n, 32)), vp(z(1, 32)), vp(z(n, 32)),
+                                      vp(z(n, 1, 32)), vp(res))
+    assert rc == 0 and res.all()

@@ -150,6 +150,13 @@ int zkp_fused_batch_verify(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t
                            const uint8_t* inst, const uint8_t* common, const uint8_t* commitments,
                            const uint8_t* responses, const uint8_t* weights16, int* verdict, uint8_t* debug_scalars);
 
+/* N x { build_verifier ; Verifier::verify_batchable (verifier.rs:123-173) }: one MSM of (points + commitments) terms per
+ * proof, folded with the 128-bit weights16 [N][n_constraints][16] (verifier.rs:153).  results[j]: 0 = accepted.  This is
+ * the per-proof check that localises a bad proof after a failed batch verification. */
+int zkp_fused_verify_batchable(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts,
+                               const uint8_t* inst, const uint8_t* common, const uint8_t* commitments,
+                               const uint8_t* responses, const uint8_t* weights16, uint8_t* results);
+
 /*     Device-resident variants: every buffer is a device pointer (16-byte aligned), nothing is copied and the call
  *     returns as soon as the work is queued on the context's stream (zkp_ctx_synchronize to wait).  strobe_pos =
  *     pos | pos_begin << 8 | cur_flags << 16, the three trailing bytes every one of the N transcript blobs holds.

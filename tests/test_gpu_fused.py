@@ -66,6 +66,10 @@ def test_cmz_fused_equals_host_route(eng, n):
         ts = _fresh(label, n, b"some context")
         ok, coeffs = T.batch_verify_coeffs(eng, st, ts, inst, common, coms, resp, w)
         ts_b = ts.copy()
+        w_each = np.ascontiguousarray(w.transpose(1, 0, 2))                  # verifier.rs:153 draws per proof: [N][nc][16]
+        ts = _fresh(label, n, b"some context")
+        e0 = T.verify_batchable_each(eng, st, ts, inst, common, coms, resp, w_each)
+        ts_e = ts.copy()
         # a wrong response, a wrong challenge, an identity instance point, an undecodable instance point
         k = n // 2
         bad_resp = resp.copy(); bad_resp[k, 3, 0] ^= 1
@@ -87,13 +91,28 @@ def test_cmz_fused_equals_host_route(eng, n):
         zc = coms.copy(); zc[k, 0] = 0
         ts = _fresh(label, n, b"some context")
         ok_zc, _ = T.batch_verify_coeffs(eng, st, ts, inst, common, zc, resp, w)
+        ts = _fresh(label, n, b"some context")
+        e1 = T.verify_batchable_each(eng, st, ts, inst, common, coms, bad_resp, w_each)
+        ts = _fresh(label, n, b"some context")
+        e2 = T.verify_batchable_each(eng, st, ts, ident, common, coms, resp, w_each)
+        ts = _fresh(label, n, b"some context")
+        e3 = T.verify_batchable_each(eng, st, ts, junk, common, coms, resp, w_each)
+        ts = _fresh(label, n, b"some context")
+        e4 = T.verify_batchable_each(eng, st, ts, inst, common, zc, resp, w_each)
+        badc = common.copy(); badc[11] = np.frombuffer(bytes([1] + [0] * 31), np.uint8)    # `B`: in no constraint, must still decode
+        ts = _fresh(label, n, b"some context")
+        e5 = T.verify_batchable_each(eng, st, ts, inst, badc, coms, resp, w_each)
         out[route] = dict(chal=chal, resp=resp, coms=coms, ts_p=ts_p, res=res, ts_v=ts_v, ok=ok, coeffs=coeffs, ts_b=ts_b,
-                          r1=r1, r2=r2, r3=r3, r4=r4, ok_bad=ok_bad, ok_ident=ok_ident, ok_zc=ok_zc)
+                          r1=r1, r2=r2, r3=r3, r4=r4, ok_bad=ok_bad, ok_ident=ok_ident, ok_zc=ok_zc,
+                          e0=e0, e1=e1, e2=e2, e3=e3, e4=e4, e5=e5, ts_e=ts_e)
     T.set_fused_min_batch(256)
     h, f = out["host"], out["fused"]
-    for key in ("chal", "resp", "coms", "res", "coeffs", "r1", "r2", "r3", "r4"):
+    for key in ("chal", "resp", "coms", "res", "coeffs", "r1", "r2", "r3", "r4", "e0", "e1", "e2", "e3", "e4", "e5"):
         assert (h[key] == f[key]).all(), key
-    for key in ("ts_p", "ts_v", "ts_b"):                               # 200 state bytes + pos, pos_begin, cur_flags
+    assert not f["e0"].any() and f["e5"].all()
+    for key in ("e1", "e2", "e3", "e4"):
+        assert f[key][n // 2] == 1 and f[key].sum() == 1, key
+    for key in ("ts_p", "ts_v", "ts_b", "ts_e"):                               # 200 state bytes + pos, pos_begin, cur_flags
         assert (h[key][:, :203] == f[key][:, :203]).all(), key
     assert h["ok"] and f["ok"] and not f["res"].any()
     for key in ("r1", "r2", "r3", "r4"):

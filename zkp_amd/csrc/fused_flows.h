@@ -235,6 +235,46 @@ k_transpose_commitments(uint32_t N, uint32_t nc, const uint8_t* __restrict__ com
   store_vec<2>(rows + 32 * (k * N + j), w);
 }
 
+// verify_batchable (verifier.rs:144-166), one MSM of K = np + nc terms per proof over  points || commitments:
+//   coeffs[np + k] = -r_k ;  coeffs[lhs_k] += r_k * (-c) ;  coeffs[pt] += r_k * resp[sc]        (weights16 [N][nc][16], :153)
+// Operand i of proof j: point id i for i < np (static ids first), commitment i - np after that.
+__global__ void __launch_bounds__(256)
+k_each_coeffs(uint32_t N, uint32_t m, uint32_t ns, uint32_t ni, uint32_t nc, const uint32_t* __restrict__ inc_off,
+              const uint32_t* __restrict__ inc_k, const uint32_t* __restrict__ inc_sc, const uint8_t* __restrict__ minus_c,
+              const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16, uint32_t* __restrict__ off,
+              uint8_t* __restrict__ scalars, uint32_t* __restrict__ pidx) {
+  const uint32_t np = ns + ni, K = np + nc;
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= N) off[g] = (uint32_t)(g * K);
+  if (g >= (size_t)N * K) return;
+  const uint32_t j = (uint32_t)(g / K), i = (uint32_t)(g % K);
+  sc acc;
+  if (i < np) {
+    coeff_of_point(acc, i, j, N, m, inc_off, inc_k, inc_sc, minus_c, responses, weights16, 1, nc);
+  } else {
+    sc r;
+    sc_zero(r);
+    load_vec<1>(r.v, weights16 + 16 * ((size_t)j * nc + (i - np)));
+    sc_neg(acc, r);                                                // verifier.rs:154
+  }
+  store_vec<2>(scalars + 32 * g, acc.v);
+  pidx[g] = i < ns ? i : (i < np ? ns + (i - ns) * N + j : ns + ni * N + j * nc + (i - np));
+}
+// verdicts of verify_batchable: accepted iff no rejection by the transcript protocol, every point decoded and the MSM
+// is the identity (verifier.rs:134-140, :162-172)
+__global__ void __launch_bounds__(256)
+k_each_finish(uint32_t N, const uint8_t* __restrict__ out, const uint8_t* __restrict__ status8, const uint32_t* __restrict__ failed,
+              uint8_t* __restrict__ results) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  uint32_t w[8];
+  load_vec<2>(w, out + 32 * (size_t)j);
+  uint32_t d = failed[j] | status8[j];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d |= w[i];
+  results[j] = d ? 1 : 0;
+}
+
 __global__ void k_any_nonzero(uint32_t n, const uint32_t* __restrict__ flags, uint32_t* __restrict__ any) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && flags[i]) *any = 1;
@@ -636,6 +676,53 @@ int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* 
   return msm_optional_impl(c, total, w.u8(o.sc), d_pts, d_out, d_status, o.end);
 }
 
+// d_tbl = [ns + ni N + N nc][32]: common || instance rows || commitments [N][nc] (the last part doubles as the
+// transcripts' commitment source)
+struct each_inter { size_t failed, wchal, mc, off, sc, pidx, out, st8, end; };
+each_inter each_carve(const fused_plan& pl, size_t start) {
+  const size_t N = pl.N, K = (size_t)pl.s.np + pl.s.nc;
+  carve cv;
+  cv.off = start;
+  each_inter o;
+  o.failed = cv.take(N * 4 + 4);
+  o.wchal = cv.take(N * 64 + 64);
+  o.mc = cv.take(N * 32 + 32);
+  o.off = cv.take((N + 1) * 4);
+  o.sc = cv.take(N * K * 32 + 32);
+  o.pidx = cv.take(N * K * 4 + 4);
+  o.out = cv.take(N * 32 + 32);
+  o.st8 = cv.take(N + 4);
+  o.end = cv.off;
+  return o;
+}
+int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_resp,
+              const uint8_t* d_w, uint8_t* d_results) {
+  const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni, K = pl.s.np + nc;
+  const uint32_t n_points = ns + ni * N + N * nc;
+  const ws_view w{static_cast<char*>(c->ws)};
+  const uint8_t* d_coms = d_tbl + 32 * ((size_t)ns + (size_t)ni * N);
+  tr_bufs hb{};
+  hb.src[SRC_TABLE] = d_tbl; hb.src[SRC_COMS] = d_coms;
+  hb.dst[DST_CHAL] = w.u8(o.wchal);
+  HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
+  prof_begin(c);
+  run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed));
+  prof_mark(c, ZKP_K_TRANSCRIPT);
+  hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.mc));
+  hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.mc), w.u8(o.mc));
+  const uint32_t* d_inc_k = pl.d_inc + pl.s.inc_off.size();
+  hipLaunchKernelGGL(k_each_coeffs, grid1(std::max<size_t>((size_t)N * K, N) + 1, 256), dim3(256), 0, c->stream, N, pl.s.m, ns, ni, nc, pl.d_inc, d_inc_k,
+                     d_inc_k + pl.s.inc_k.size(), w.u8(o.mc), d_resp, d_w, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx));
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  const int rc = msm_terms_path(c, N, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * K, ZKP_VARTIME, w.u8(o.out), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_each_finish, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.out), w.u8(o.st8), w.u32(o.failed), d_results);
+  prof_mark(c, ZKP_K_SCALARS);
+  HIP_TRY(hipGetLastError());
+  return ZKP_OK;
+}
+
 }  // namespace
 
 void free_fused_plans(zkp_ctx* c) {
@@ -915,6 +1002,51 @@ int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N
   HIP_TRY(hipStreamSynchronize(c->stream));
   static const uint8_t zero[32] = {0};
   *verdict = (stv[0] == 0 && stv[1] == 0 && memcmp(out, zero, 32) == 0) ? 0 : 1;   // batch_verifier.rs:230-234
+  return ZKP_OK;
+}
+
+// ---- verify_batchable, one verdict per proof -----------------------------------------------------------------------------
+int zkp_fused_verify_batchable(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
+                               const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
+                               uint8_t* results) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (N == 0) return ZKP_OK;
+  if (!transcripts || !results) return fail(ZKP_ERR_ARG, "NULL pointer");
+  uint32_t pos = 0;
+  int rc = common_tail(transcripts, N, &pos);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  fused_plan* pl = nullptr;
+  rc = get_plan(c, FLOW_BATCH, st, N, pos, &pl);          // same transcript program as the batch verifier (:134-142 = :152-167)
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if ((s.nc && (!commitments || !weights16)) || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
+  const uint32_t m = s.m, nc = s.nc, ns = s.ns, ni = s.ni;
+  const size_t n_points = (size_t)ns + (size_t)ni * N + (size_t)N * nc, K = (size_t)s.np + nc;
+  if (n_points > 0x7fffffffull || (size_t)N * K > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  carve cv;
+  const size_t o_ts = cv.take((size_t)N * 208);
+  const size_t o_tbl = cv.take(n_points * 32 + 32);
+  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
+  const size_t o_w = cv.take((size_t)N * nc * 16 + 16);
+  const size_t o_res = cv.take((size_t)N + 4);
+  const each_inter o = each_carve(*pl, cv.off);
+  rc = ensure_ws(c, o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K)));
+  if (rc) return rc;
+  const ws_view w{static_cast<char*>(c->ws)};
+  HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
+  if (ns) HIP_TRY(hipMemcpyAsync(w.base + o_tbl, common, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
+  if (ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)ns, inst, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
+  if (nc) {
+    HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * ((size_t)ns + (size_t)ni * N), commitments, (size_t)N * nc * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(w.base + o_w, weights16, (size_t)N * nc * 16, hipMemcpyHostToDevice, c->stream));
+  }
+  if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
+  rc = each_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_resp), w.u8(o_w), w.u8(o_res));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(results, w.base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return ZKP_OK;
 }
 

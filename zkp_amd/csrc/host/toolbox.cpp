@@ -480,10 +480,15 @@ int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N
   if (N == 0) return ZKP_TB_OK;
   const zkp_statement& st = *stp;
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), np = (uint32_t)st.points.size();
-  std::memset(results, 0, N);
-  build_verifiers(st, N, ts, inst, common, n_threads, results);
   std::vector<uint8_t> own_w;
   if (!weights16) { own_w.resize(16 * (size_t)N * nc); os_random(own_w.data(), own_w.size()); weights16 = own_w.data(); }
+  if (use_fused(ts, N)) {
+    if (st.ns && N >= 32) { const int rc = zkp_ctx_prepare_fixed_points(ctx, st.ns, common); if (rc) return rc; }
+    FusedView fv(st);
+    return zkp_fused_verify_batchable(ctx, &fv.fs, N, ts, inst, common, commitments, responses, weights16, results);
+  }
+  std::memset(results, 0, N);
+  build_verifiers(st, N, ts, inst, common, n_threads, results);
   // one (np + nc)-term MSM per proof over  points || commitments   (verifier.rs:144-166)
   const uint32_t K = np + nc;
   std::vector<uint8_t> scalars(32 * (size_t)N * K), out(32 * (size_t)N), status(N);

@@ -567,13 +567,15 @@ k_debug_quad(uint32_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ 
 __device__ __forceinline__ void coeff_of_point(sc& acc, uint32_t p, uint32_t j, uint32_t N, uint32_t m,
                                                const uint32_t* __restrict__ inc_off, const uint32_t* __restrict__ inc_k,
                                                const uint32_t* __restrict__ inc_sc, const uint8_t* __restrict__ minus_c,
-                                               const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16) {
+                                               const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16,
+                                               size_t wk = 0, size_t wj = 1) {
+  if (wk == 0) wk = N;                                             // default layout [n_constraints][N][16] (batch_verifier.rs:179)
   sc_zero(acc);
   for (uint32_t e = inc_off[p]; e < inc_off[p + 1]; ++e) {
     const uint32_t k = inc_k[e], svar = inc_sc[e];
     sc r, rm, x, t;
     sc_zero(r);
-    load_vec<1>(r.v, weights16 + 16 * ((size_t)k * N + j));        // Scalar::from(u128)
+    load_vec<1>(r.v, weights16 + 16 * ((size_t)k * wk + (size_t)j * wj));   // Scalar::from(u128)
     sc_to_mont(rm, r);
     const uint8_t* src = svar == 0xffffffffu ? minus_c + 32 * (size_t)j : responses + 32 * ((size_t)j * m + svar);
     load_vec<2>(x.v, src);

@@ -487,16 +487,6 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
     pa = ta.finish(tailA);
     tbl_a = ta.tables();
   }
-  if (const char* dbg = getenv("ZKP_TR_DEBUG")) {          // TIMING EXPERIMENTS ONLY (results are wrong)
-    for (auto* pr : {&pa, &pb})
-      for (auto& op : *pr) {
-        const bool check = (op.ctl & TR_CHECK_NONZERO) != 0;
-        if (strstr(dbg, "noperm")) op.ctl &= ~(uint32_t)TR_PERMUTE;
-        if (strstr(dbg, "nosrc") && !check) op.ctl &= ~(7u << 25);
-        if (strstr(dbg, "nodst")) op.ctl &= ~(7u << 28);
-        if (strstr(dbg, "nocheck") && check) op.ctl &= ~((uint32_t)TR_CHECK_NONZERO | 7u << 25);
-      }
-  }
   const std::vector<uint32_t> inc = incidence_words(s);
   carve cv;
   const size_t o_a = cv.take(pa.size() * sizeof(tr_op) + 64);

@@ -300,3 +300,58 @@ def test_fused_entry_points_reject_bad_arguments(eng):
     rc = lib.zkp_fused_verify_compact(eng._h, ctypes.byref(fst.c), ctypes.c_uint32(n), vp(ts.copy()), vp(z(3, n, 32)), vp(z(1, 32)), vp(z(n, 32)),
                                       vp(z(n, 1, 32)), vp(res))
     assert rc == 0 and res.all()
+
+
+@pytest.mark.parametrize("shape", ["no_constraints", "lhs_only", "shared_secret_many_points"])
+def test_degenerate_statements_fused_equals_host_route(eng, shape):
+    """Statements at the edges of what the constraint API accepts: points but no constraints (nothing to prove, the
+    transcript still binds the points); a constraint with an empty right-hand side (a false statement: must be rejected
+    by every verifier); one secret over many points."""
+    n = 70
+    rng = np.random.default_rng(5)
+    pts, _ = _random_points(6, rng)
+    st = T.Statement(b"edge")
+    if shape == "no_constraints":
+        st.add_secret(b"x")
+        st.add_point(b"P", False)
+        st.add_point(b"G", True)
+        inst, common = np.ascontiguousarray(np.repeat(pts[0:1][None], n, 1)), pts[1:2].copy()
+        secrets = rng.integers(0, 256, size=(n, 1, 32), dtype=np.uint8); secrets[:, :, 31] &= 0x0f
+    elif shape == "lhs_only":
+        p = st.add_point(b"P", False)
+        st.constrain(p, [])
+        inst, common = np.ascontiguousarray(np.repeat(pts[0:1][None], n, 1)), np.zeros((0, 32), np.uint8)
+        secrets = np.zeros((n, 0, 32), np.uint8)
+    else:
+        x = st.add_secret(b"x")
+        gs = [st.add_point(b"G%d" % i, True) for i in range(5)]
+        q = st.add_point(b"Q", False)
+        st.constrain(q, [(x, g) for g in gs])
+        secrets = rng.integers(0, 256, size=(n, 1, 32), dtype=np.uint8); secrets[:, :, 31] &= 0x0f
+        common = pts[:5].copy()
+        off = (np.arange(n + 1, dtype=np.uint64) * 5).astype(np.uint32)
+        Q, _ = C.msm_many(off, np.repeat(secrets[:, 0], 5, axis=0), np.tile(np.arange(5, dtype=np.uint32), n), common, 0)
+        inst = np.ascontiguousarray(Q[None])
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    out = {}
+    for route, thr in (("host", NEVER), ("fused", 0)):
+        T.set_fused_min_batch(thr)
+        ts = _fresh(b"edge-case", n)
+        chal, resp, coms = T.prove_batch(eng, st, ts, secrets, inst, common, entropy)
+        ts2 = _fresh(b"edge-case", n)
+        res = T.verify_compact_batch(eng, st, ts2, inst, common, chal, resp)
+        w = rng.integers(0, 256, size=(max(st.nc, 1), n, 16), dtype=np.uint8)[: st.nc]
+        ts3 = _fresh(b"edge-case", n)
+        try:
+            T.batch_verify(eng, st, ts3, inst, common, coms, resp, np.ascontiguousarray(w))
+            ok = True
+        except T.VerificationFailure:
+            ok = False
+        out[route] = (chal, resp, coms, ts[:, :203], res, ts2[:, :203], np.array([ok]))
+    T.set_fused_min_batch(256)
+    for a, b in zip(out["host"], out["fused"]):
+        assert a.shape == b.shape and (a == b).all()
+    # "P = (empty sum)" is a false statement for P != identity (and an identity P is refused by the verifier's transcript):
+    # the prover's commitment is the identity, the verifier recomputes (-c) P; every route must reject
+    assert out["fused"][4].all() if shape == "lhs_only" else not out["fused"][4].any()
+    assert out["fused"][6][0] == (shape != "lhs_only")

@@ -287,7 +287,9 @@ uint32_t zkp_statement_num_terms(const zkp_statement* st) { return st ? st->term
 int zkp_prove_phase_a(const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* secrets, const uint8_t* inst,
                       const uint8_t* common, const uint8_t* entropy, int n_threads, uint8_t* blindings, uint32_t* off,
                       uint8_t* scalars, uint32_t* pidx) {
-  if (!stp || !ts || !blindings || !off || !scalars || !pidx || (!secrets && !stp->secrets.empty())) return ZKP_TB_BAD_STATEMENT;
+  if (!stp || !ts || !off) return ZKP_TB_BAD_STATEMENT;
+  // empty parts of a statement come with empty (possibly NULL) buffers
+  if ((!stp->secrets.empty() && (!secrets || !blindings)) || (stp->terms && (!scalars || !pidx))) return ZKP_TB_BAD_STATEMENT;
   const zkp_statement& st = *stp;
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), T = st.terms;
   apply_prefix(st, N, ts, n_threads);                                  // prover.rs:42, :54
@@ -329,7 +331,7 @@ int zkp_prove_phase_a(const zkp_statement* stp, uint32_t N, uint8_t* ts, const u
 
 int zkp_prove_phase_b(const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* secrets, const uint8_t* blindings,
                       const uint8_t* commitments, int n_threads, uint8_t* challenges, uint8_t* responses) {
-  if (!stp || !ts || !commitments || !challenges || !responses) return ZKP_TB_BAD_STATEMENT;
+  if (!stp || !ts || !challenges || (!stp->cons.empty() && !commitments) || (!stp->secrets.empty() && !responses)) return ZKP_TB_BAD_STATEMENT;
   const zkp_statement& st = *stp;
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size();
   parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
@@ -399,7 +401,7 @@ static void build_verifiers(const zkp_statement& st, uint32_t N, uint8_t* ts, co
 int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* inst,
                              const uint8_t* common, const uint8_t* challenges, const uint8_t* responses, int n_threads,
                              uint8_t* results) {
-  if (!ctx || !stp || !ts || !results || !challenges || !responses) return ZKP_TB_BAD_STATEMENT;
+  if (!ctx || !stp || !ts || !results || !challenges || (!stp->secrets.empty() && !responses)) return ZKP_TB_BAD_STATEMENT;
   if (N == 0) return ZKP_TB_OK;
   const zkp_statement& st = *stp;
   if (use_fused(ts, N)) {
@@ -476,7 +478,7 @@ int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N,
 int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* inst,
                               const uint8_t* common, const uint8_t* commitments, const uint8_t* responses,
                               const uint8_t* weights16, int n_threads, uint8_t* results) {
-  if (!ctx || !stp || !ts || !results || !commitments || !responses) return ZKP_TB_BAD_STATEMENT;
+  if (!ctx || !stp || !ts || !results || (!stp->cons.empty() && !commitments) || (!stp->secrets.empty() && !responses)) return ZKP_TB_BAD_STATEMENT;
   if (N == 0) return ZKP_TB_OK;
   const zkp_statement& st = *stp;
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), np = (uint32_t)st.points.size();

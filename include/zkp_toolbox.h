@@ -108,6 +108,11 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, u
 void zkp_toolbox_set_fused_min_batch(uint32_t n);
 uint32_t zkp_toolbox_get_fused_min_batch(void);
 
+/* The ChaCha20 block function (RFC 8439 section 2.3; state words 12-13 = counter, 14-15 = nonce) behind the default
+ * entropy / weights of the calls above (`entropy == NULL`, `weights16 == NULL`): like the reference's `thread_rng()`, a
+ * ChaCha stream keyed from the operating system.  Exposed for the known-answer test. */
+void zkp_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t nonce, uint8_t out[64]);
+
 /* ---- host-only halves, exposed so the host logic can be tested without a GPU ----------------------- */
 /* Everything of zkp_batch_verify up to (not including) the MSM: writes the exact operand sequence of
  * batch_verifier.rs:219-228, ns + (ni + nc) * N scalars and encodings.  Returns 0 or the error the

@@ -218,3 +218,15 @@ def test_proof_wire_format_roundtrip_and_rejects():
         T.CompactProof.from_bytes(noncanon)
     with pytest.raises(ValueError):
         T.BatchableProof.from_bytes(T.BatchableProof([], [((1 << 256) - 1).to_bytes(32, "little")]).to_bytes())
+
+
+def test_chacha20_block_rfc8439_vector():
+    """RFC 8439 section 2.3.2: the generator behind the toolbox's default entropy / batch weights."""
+    import ctypes
+    key = bytes(range(32))
+    out = ctypes.create_string_buffer(64)
+    # IETF layout: counter = 1, nonce = 00:00:00:09:00:00:00:4a:00:00:00:00 -> words 13, 14, 15 = 0x09000000, 0x4a000000, 0
+    T.lib().zkp_chacha20_block(key, ctypes.c_uint64(1 | (0x09000000 << 32)), ctypes.c_uint64(0x4a000000), out)
+    want = bytes.fromhex("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                         "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    assert out.raw == want

@@ -117,12 +117,49 @@ void parallel_for(uint32_t n, int n_threads, F&& body) {
   });
 }
 
-void os_random(uint8_t* out, size_t len) {
+void os_entropy(uint8_t* out, size_t len) {
   size_t got = 0;
   while (got < len) {
     const ssize_t r = getrandom(out + got, len - got, 0);
     if (r > 0) got += (size_t)r;
   }
+}
+
+// ChaCha20 block function (RFC 8439 section 2.3), used as the stream generator below
+inline uint32_t rotl32(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+void chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint8_t out[64]) {
+  uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                     (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)nonce, (uint32_t)(nonce >> 32)};
+  uint32_t x[16];
+  std::memcpy(x, st, sizeof(x));
+#define ZKP_QR(a, b, c, d) x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12); \
+                           x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+  for (int r = 0; r < 10; ++r) {
+    ZKP_QR(0, 4, 8, 12) ZKP_QR(1, 5, 9, 13) ZKP_QR(2, 6, 10, 14) ZKP_QR(3, 7, 11, 15)
+    ZKP_QR(0, 5, 10, 15) ZKP_QR(1, 6, 11, 12) ZKP_QR(2, 7, 8, 13) ZKP_QR(3, 4, 9, 14)
+  }
+#undef ZKP_QR
+  for (int i = 0; i < 16; ++i) { const uint32_t v = x[i] + st[i]; std::memcpy(out + 4 * i, &v, 4); }
+}
+
+// What `thread_rng()` is to the reference (prover.rs:82, verifier.rs:153, batch_verifier.rs:179): a ChaCha stream keyed
+// with 32 bytes from the operating system for every call -- getrandom() itself delivers only a few hundred MB/s, which
+// for the batch verifier's 16 bytes per (constraint, proof) would cost more than the whole GPU side of the call.
+void os_random(uint8_t* out, size_t len) {
+  if (len <= 256) { os_entropy(out, len); return; }
+  uint32_t key[8];
+  uint64_t nonce;
+  os_entropy(reinterpret_cast<uint8_t*>(key), sizeof(key));
+  os_entropy(reinterpret_cast<uint8_t*>(&nonce), sizeof(nonce));
+  const uint64_t blocks = (len + 63) / 64;
+  parallel_for((uint32_t)std::min<uint64_t>(blocks, 0xffffffffu), 0, [&](uint32_t lo, uint32_t hi) {
+    uint8_t tmp[64];
+    for (uint64_t b = lo; b < hi; ++b) {
+      const size_t o = (size_t)b * 64;
+      if (o + 64 <= len) chacha20_block(key, b, nonce, out + o);
+      else { chacha20_block(key, b, nonce, tmp); std::memcpy(out + o, tmp, len - o); }
+    }
+  });
 }
 
 // encoding of point variable p for proof j
@@ -227,6 +264,11 @@ bool use_fused(const uint8_t* ts, uint32_t N) {
 
 extern "C" {
 
+void zkp_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t nonce, uint8_t out[64]) {
+  uint32_t k[8];
+  std::memcpy(k, key, 32);
+  chacha20_block(k, counter, nonce, out);
+}
 void zkp_toolbox_set_fused_min_batch(uint32_t n) { g_fused_min_batch = n; }
 uint32_t zkp_toolbox_get_fused_min_batch(void) { return g_fused_min_batch.load(); }
 

@@ -37,7 +37,7 @@ EXPORTS = (
     "zkp_statement_add_point", "zkp_statement_constrain", "zkp_statement_num_secrets", "zkp_statement_num_instance",
     "zkp_statement_num_common", "zkp_statement_num_constraints", "zkp_statement_num_terms", "zkp_prove_batch",
     "zkp_verify_compact_batch", "zkp_verify_batchable_each", "zkp_batch_verify", "zkp_batch_verify_coeffs", "zkp_batch_verify_build",
-    "zkp_prove_phase_a", "zkp_prove_phase_b", "zkp_toolbox_set_fused_min_batch", "zkp_toolbox_get_fused_min_batch",
+    "zkp_prove_phase_a", "zkp_prove_phase_b", "zkp_toolbox_set_fused_min_batch", "zkp_toolbox_get_fused_min_batch", "zkp_chacha20_block",
 )
 
 

@@ -25,12 +25,12 @@ __device__ __forceinline__ void q_store_cached(dev_ext* dst, const qcached& c, i
 }
 
 __global__ void __launch_bounds__(256, 2)
-k_comb_tables(uint32_t n_points, const uint32_t* __restrict__ needs, const dev_affine* __restrict__ pts,
+k_comb_tables(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t comb_min, const dev_affine* __restrict__ pts,
               dev_ext* __restrict__ comb) {
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t pi = gt >> 2;
   const int q = (int)(gt & 3u);
-  if (pi >= n_points || !needs[pi]) return;            // uniform within the quad
+  if (pi >= n_points || uses[pi] < comb_min) return;    // uniform within the quad
   qpt base;
   {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(pts + pi);      // x[9] y[9] t[9] valid

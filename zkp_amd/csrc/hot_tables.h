@@ -18,7 +18,8 @@ namespace zkp {
 constexpr int HOT_WINDOWS = 65;
 constexpr int HOT_ENTRIES = 8;
 constexpr int HOT_SLOTS = 64;
-constexpr int HOT_CLASSES = HOT_SLOTS + 1;                       // class 64 = generic ("cold") terms
+constexpr int HOT_CLASSES = HOT_SLOTS + 2;                       // class 64 = "cold" terms through a comb table, 65 = cold terms on a ladder
+constexpr int CLASS_COMB = HOT_SLOTS, CLASS_LADDER = HOT_SLOTS + 1;
 constexpr size_t HOT_SLOT_NIELS = (size_t)HOT_WINDOWS * HOT_ENTRIES;
 
 // ---- table construction ---------------------------------------------------------------------------------------------
@@ -102,29 +103,39 @@ k_hot_match(uint32_t n_points, const uint8_t* __restrict__ points, uint32_t nreg
   if (slot >= 0) *any_hot = 1u;
 }
 
-// ---- term classification: class = table slot (0..63) or 64 for the generic path; terms grouped by class ---------------
-__device__ __forceinline__ uint32_t term_class(uint32_t t, const uint32_t* pidx, uint32_t n_points, const int32_t* hotmap) {
+// ---- term classification: class = table slot (0..63), 64 = per-point comb table, 65 = plain ladder; terms grouped by class --
+// uses[p] = number of terms of this call on point p that are not on a fixed-base table.  A comb table costs about as
+// much as 1.3 ladders and makes every term on its point 2.8x cheaper, so it pays from the second use on; a point used
+// once (a constraint's left-hand side in verify_compact, verifier.rs:101-105) goes to the ladder when comb_min = 2.
+// Constant-time calls keep comb_min = 1: every cold term has the same schedule.
+__global__ void __launch_bounds__(256)
+k_use_count(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_points, const int32_t* __restrict__ hotmap,
+            uint32_t* __restrict__ uses) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
   const uint32_t pi = pidx[t];
-  const int32_t s = pi < n_points ? hotmap[pi] : -1;
-  return s >= 0 ? (uint32_t)s : (uint32_t)HOT_SLOTS;
+  if (pi < n_points && hotmap[pi] < 0) atomicAdd(&uses[pi], 1u);
+}
+__device__ __forceinline__ uint32_t term_class(uint32_t t, const uint32_t* pidx, uint32_t n_points, const int32_t* hotmap,
+                                               const uint32_t* uses, uint32_t comb_min) {
+  const uint32_t pi = pidx[t];
+  if (pi >= n_points) return (uint32_t)CLASS_COMB;                  // out of range: flagged by k_reduce_encode
+  const int32_t s = hotmap[pi];
+  if (s >= 0) return (uint32_t)s;
+  return uses[pi] >= comb_min ? (uint32_t)CLASS_COMB : (uint32_t)CLASS_LADDER;
 }
 __global__ void __launch_bounds__(256)
 k_class_count(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_points, const int32_t* __restrict__ hotmap,
-              uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ needs_comb) {
+              const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t* __restrict__ class_cnt) {
   __shared__ uint32_t h[HOT_CLASSES];
   if (threadIdx.x < HOT_CLASSES) h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n_terms) {
-    const uint32_t c = term_class(t, pidx, n_points, hotmap);
-    atomicAdd(&h[c], 1u);
-    const uint32_t pi = pidx[t];
-    if (c == (uint32_t)HOT_SLOTS && pi < n_points) needs_comb[pi] = 1u;      // this point gets a comb table (comb_tables.h)
-  }
+  if (t < n_terms) atomicAdd(&h[term_class(t, pidx, n_points, hotmap, uses, comb_min)], 1u);
   __syncthreads();
   if (threadIdx.x < HOT_CLASSES && h[threadIdx.x]) atomicAdd(&class_cnt[threadIdx.x], h[threadIdx.x]);
 }
-// class_start[c] = first list position of class c; class_start[65] = n_terms; cursor = copy
+// class_start[c] = first list position of class c; class_start[HOT_CLASSES] = n_terms; cursor = copy
 __global__ void k_class_scan(const uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_start, uint32_t* __restrict__ cursor) {
   if (threadIdx.x != 0) return;
   uint32_t run = 0;
@@ -133,14 +144,14 @@ __global__ void k_class_scan(const uint32_t* __restrict__ class_cnt, uint32_t* _
 }
 __global__ void __launch_bounds__(256)
 k_class_scatter(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_points, const int32_t* __restrict__ hotmap,
-                uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
+                const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
   __shared__ uint32_t h[HOT_CLASSES];
   __shared__ uint32_t base[HOT_CLASSES];
   if (threadIdx.x < HOT_CLASSES) h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t c = 0, rank = 0;
-  if (t < n_terms) { c = term_class(t, pidx, n_points, hotmap); rank = atomicAdd(&h[c], 1u); }
+  if (t < n_terms) { c = term_class(t, pidx, n_points, hotmap, uses, comb_min); rank = atomicAdd(&h[c], 1u); }
   __syncthreads();
   if (threadIdx.x < HOT_CLASSES && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
   __syncthreads();

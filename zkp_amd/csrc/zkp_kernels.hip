@@ -128,24 +128,33 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
   if (t < n_terms) term_generic(t, scalars, pidx, n_points, pts, partial);
 }
 
-// Classified terms in ONE launch: the first blocks take the terms on per-proof points (comb tables: 128 point operations
-// per lane), the remaining blocks the fixed-base terms (65 mixed additions), which fill the SIMDs the former leave idle.
+// Classified terms in ONE launch, longest first: ladder terms (single-use points of a variable-time call: 384 point
+// operations per lane), terms on per-proof points with a comb table (128 point operations), and the fixed-base terms
+// (65 mixed additions), which fill the SIMDs the others leave idle.
 template <bool CT>
 __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ list,
-              const int32_t* __restrict__ hotmap, const dev_niels* __restrict__ tables, dev_ext* __restrict__ partial) {
-  const uint32_t n_hot = class_start[HOT_SLOTS], n_cold = class_start[HOT_CLASSES] - n_hot;
-  const uint32_t cold_blocks = (n_cold + blockDim.x - 1) / blockDim.x;
-  if (blockIdx.x < cold_blocks) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_cold) {
+              const int32_t* __restrict__ hotmap, const dev_niels* __restrict__ tables, const dev_affine* __restrict__ pts,
+              dev_ext* __restrict__ partial) {
+  const uint32_t n_hot = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - n_hot;
+  const uint32_t n_ladder = CT ? 0u : class_start[HOT_CLASSES] - class_start[CLASS_LADDER];
+  const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
+  const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
+  if (!CT && blockIdx.x < ladder_blocks) {
+    if constexpr (!CT) {
+      const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+      if (i < n_ladder) term_generic(list[n_hot + n_comb + i], scalars, pidx, n_points, pts, partial);
+    }
+  } else if (blockIdx.x < ladder_blocks + comb_blocks) {
+    const uint32_t i = (blockIdx.x - ladder_blocks) * blockDim.x + threadIdx.x;
+    if (i < n_comb) {
       const uint32_t t = list[n_hot + i];
       const uint32_t pi = pidx[t];
       if (pi < n_points) term_comb<CT>(t, scalars, comb + (size_t)pi * COMB_ENTRIES, partial);   // (out of range: flagged by k_reduce_encode)
     }
   } else {
-    const uint32_t i = (blockIdx.x - cold_blocks) * blockDim.x + threadIdx.x;
+    const uint32_t i = (blockIdx.x - ladder_blocks - comb_blocks) * blockDim.x + threadIdx.x;
     if (i < n_hot) {
       const uint32_t t = list[i];
       term_fixed_base<CT>(t, scalars, tables + (size_t)hotmap[pidx[t]] * HOT_SLOT_NIELS, partial);
@@ -783,7 +792,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     // split the terms: those on a registered fixed-base point (grouped by table) / the rest, which go through per-point
     // comb tables built here for exactly the points they reference
     int32_t* hotmap = reinterpret_cast<int32_t*>(base + o_hot);
-    uint32_t* cls = reinterpret_cast<uint32_t*>(base + o_cls);     // cnt[65] | start[66] | cursor[65] | any
+    uint32_t* cls = reinterpret_cast<uint32_t*>(base + o_cls);     // cnt[66] | start[67] | cursor[66] | any
     uint32_t* class_cnt = cls, *class_start = cls + 80, *cursor = cls + 160, *any_hot = cls + 240;
     uint32_t* list = reinterpret_cast<uint32_t*>(base + o_list);
     uint32_t* needs = reinterpret_cast<uint32_t*>(base + o_needs);
@@ -794,21 +803,24 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
       hipLaunchKernelGGL(k_hot_match, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, c->hot_nreg, c->hot_reg_words, c->hot_reg_slot, hotmap, any_hot);
     else
       HIP_TRY(hipMemsetAsync(hotmap, 0xff, (size_t)n_points * 4, c->stream));
-    hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, class_cnt, needs);
+    // a comb table from the second use of a point on (variable-time calls); constant-time calls: every cold term alike
+    const uint32_t comb_min = flags == ZKP_CT ? 1u : 2u;
+    hipLaunchKernelGGL(k_use_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs);
+    hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, class_cnt);
     prof_mark(c, ZKP_K_SORT);
     // decode: every point when the caller's semantics ask for it (a verifier rejects any allocated point that does not
     // decompress, verifier.rs:87-92), otherwise only the points whose coordinates this call uses
     hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, decode_all ? (const uint32_t*)nullptr : needs);
     prof_mark(c, ZKP_K_DECODE);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor);
-    hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, cursor, list);
-    hipLaunchKernelGGL(k_comb_tables, grid1((size_t)n_points * 4, 256), dim3(256), 0, c->stream, n_points, needs, pts, comb);
+    hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, cursor, list);
+    hipLaunchKernelGGL(k_comb_tables, grid1((size_t)n_points * 4, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, pts, comb);
     prof_mark(c, ZKP_K_SORT);          // path A: term classification + comb-table construction
-    const dim3 grid((unsigned)((n_terms + 255) / 256 + 1));
+    const dim3 grid((unsigned)((n_terms + 255) / 256 + 2));
     if (flags == ZKP_CT)
-      hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, part);
+      hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, part);
     else
-      hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, part);
+      hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, part);
   } else {
     if (n_points) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, (const uint32_t*)nullptr);
     prof_mark(c, ZKP_K_DECODE);

@@ -116,7 +116,7 @@ def cmz_instance(eng, n, rng):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU per step (BASELINE configs[1]: 4096)")
     ap.add_argument("--streams", type=int, default=16, help="independent batches in flight, each on its own HIP stream / engine context")

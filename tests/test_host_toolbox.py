@@ -230,3 +230,14 @@ def test_chacha20_block_rfc8439_vector():
     want = bytes.fromhex("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
                          "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
     assert out.raw == want
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: both headers must compile as C99 (what bindgen / cgo / a C caller would parse) and as
+    C++11, warning-free with -pedantic."""
+    import subprocess
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "zkp_mi355x.h"\n#include "zkp_toolbox.h"\nint main(void) { return (int)sizeof(zkp_fused_statement) * 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src), "-o", str(tmp_path / "a.o")])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")])

@@ -168,22 +168,27 @@ k_neg_reduce(uint32_t n, const uint8_t* in, uint8_t* out) {       // in may equa
 // The CSR multiscalar job of a batch of proofs of one statement: T terms per proof in nc MSMs.
 //   term t of proof j:  scalar = tsc[t] == ~0 ? special[j] : vals[j][tsc[t]];   point = table index of point id tpt[t]
 // (prover.rs:94-97 with vals = blindings; verifier.rs:97-106 with vals = responses, special = -c)
+// (two kernels: the index half depends on the statement only and runs with the point phase, next to the transcripts)
 __global__ void __launch_bounds__(256)
-k_stmt_terms(uint32_t N, uint32_t T, uint32_t nc, uint32_t ns, uint32_t m, const uint32_t* __restrict__ toff,
-             const uint32_t* __restrict__ tsc, const uint32_t* __restrict__ tpt, const uint8_t* __restrict__ vals,
-             const uint8_t* __restrict__ special, uint32_t* __restrict__ off, uint8_t* __restrict__ scalars,
-             uint32_t* __restrict__ pidx) {
+k_stmt_index(uint32_t N, uint32_t T, uint32_t nc, uint32_t ns, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ tpt,
+             uint32_t* __restrict__ off, uint32_t* __restrict__ pidx) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < (size_t)N * nc) off[g] = (uint32_t)((g / nc) * T + toff[g % nc]);
   if (g == 0) off[(size_t)N * nc] = N * T;
   if (g >= (size_t)N * T) return;
-  const uint32_t j = (uint32_t)(g / T), t = (uint32_t)(g % T);
-  const uint32_t s = tsc[t], p = tpt[t];
+  const uint32_t j = (uint32_t)(g / T), p = tpt[g % T];
+  pidx[g] = p < ns ? p : ns + (p - ns) * N + j;
+}
+__global__ void __launch_bounds__(256)
+k_stmt_scalars(uint32_t N, uint32_t T, uint32_t m, const uint32_t* __restrict__ tsc, const uint8_t* __restrict__ vals,
+               const uint8_t* __restrict__ special, uint8_t* __restrict__ scalars) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)N * T) return;
+  const uint32_t j = (uint32_t)(g / T), s = tsc[g % T];
   const uint8_t* src = s == 0xffffffffu ? special + 32 * (size_t)j : vals + 32 * ((size_t)j * m + s);
   uint32_t w[8];
   load_vec<2>(w, src);
   store_vec<2>(scalars + 32 * g, w);
-  pidx[g] = p < ns ? p : ns + (p - ns) * N + j;
 }
 
 // responses  s * c + b  (prover.rs:107-109)
@@ -523,6 +528,37 @@ void run_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs,
                               reinterpret_cast<uint32_t*>(d_saved), d_failed, p.tail);
 }
 
+// ---- side stream: the scalar-independent half of path A runs next to the transcripts -------------------------------------
+// overlap = false: the same work stays on the context's stream.  The synchronous host-pointer entry points overlap (one
+// call in flight per context: latency matters, prove 1.71 -> 1.45 ms per 4096 CMZ proofs); the asynchronous _dev entry
+// points do not (their callers pipeline many contexts, and cross-stream events between 2 x 16 streams cost more
+// throughput than the overlap returns: 0.99 -> 1.9 ms per step).
+int side_begin(zkp_ctx* c, hipStream_t* main_out, bool overlap) {
+  *main_out = c->stream;
+  if (!overlap) return ZKP_OK;
+  if (!c->side_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventRecord(c->ev_fork, c->stream));            // inputs (and everything queued before) are ready
+  HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+  c->stream = c->side_stream;
+  c->prof_suspended = true;
+  return ZKP_OK;
+}
+int side_end(zkp_ctx* c, hipStream_t main, bool overlap) {
+  if (!overlap) return ZKP_OK;
+  c->prof_suspended = false;
+  c->stream = main;
+  HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
+  return ZKP_OK;
+}
+int side_join(zkp_ctx* c, bool overlap) {
+  if (overlap) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  return ZKP_OK;
+}
+
 // ---- the flows on device buffers (asynchronous on the context's stream) ----------------------------------------------
 struct ws_view {
   char* base;
@@ -548,7 +584,7 @@ prove_inter prove_carve(const fused_plan& pl, size_t start) {
   return o;
 }
 int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* d_ts, const uint8_t* d_sec, const uint8_t* d_tbl,
-               const uint8_t* d_ent, uint8_t* d_chal, uint8_t* d_resp, uint8_t* d_coms, uint8_t* d_st8) {
+               const uint8_t* d_ent, uint8_t* d_chal, uint8_t* d_resp, uint8_t* d_coms, uint8_t* d_st8, bool overlap) {
   const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
   const ws_view w{static_cast<char*>(c->ws)};
   tr_bufs hb{};
@@ -556,16 +592,26 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   hb.dst[DST_WIDE] = w.u8(o.wide); hb.dst[DST_CHAL] = w.u8(o.wchal);
   uint64_t* d_saved = reinterpret_cast<uint64_t*>(w.base + o.saved);
   prof_begin(c);
+  const size_t lanes = std::max<size_t>((size_t)N * T, (size_t)N * nc) + 1;
+  {   // side stream: operand indices, decode, classification, comb tables (nothing here depends on the blindings)
+    hipStream_t main;
+    int rc = side_begin(c, &main, overlap);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T, w.u32(o.off), w.u32(o.pidx));
+    if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_POINTS);
+    const int rc2 = side_end(c, main, overlap);
+    if (rc || rc2) return rc ? rc : rc2;
+  }
   run_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed));
   prof_mark(c, ZKP_K_TRANSCRIPT);
   if (m) hipLaunchKernelGGL(k_wide_reduce, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N * m, w.u8(o.wide), w.u8(o.blind));
-  const size_t lanes = std::max<size_t>((size_t)N * T, (size_t)N * nc) + 1;
-  hipLaunchKernelGGL(k_stmt_terms, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, pl.s.ns, m, pl.d_tarr, pl.d_tarr + nc + 1,
-                     pl.d_tarr + nc + 1 + T, w.u8(o.blind), (const uint8_t*)nullptr, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx));
+  if (T) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T, 256), dim3(256), 0, c->stream, N, T, m, pl.d_tarr + nc + 1, w.u8(o.blind), (const uint8_t*)nullptr, w.u8(o.sc));
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
-  if (nc) {
-    const int rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end);
+  {
+    int rc = side_join(c, overlap);
+    if (rc) return rc;
+    if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_SCALARS);
     if (rc) return rc;
   }
   run_program(c, pl.b, N, hb, d_ts, d_saved, w.u32(o.failed));
@@ -596,7 +642,7 @@ verify_inter verify_carve(const fused_plan& pl, size_t start) {
   return o;
 }
 int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_claim,
-                const uint8_t* d_resp, uint8_t* d_results) {
+                const uint8_t* d_resp, uint8_t* d_results, bool overlap) {
   const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T1 = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
   const ws_view w{static_cast<char*>(c->ws)};
   tr_bufs hb{};
@@ -604,16 +650,26 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   hb.dst[DST_CHAL] = w.u8(o.wchal);
   HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
   prof_begin(c);
+  const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
+  {   // side stream: operand indices and the point phase.  With no constraints there is no MSM, but every allocated
+      // point must still decode (verifier.rs:87-92)
+    hipStream_t main;
+    int rc = side_begin(c, &main, overlap);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T1, w.u32(o.off), w.u32(o.pidx));
+    rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_POINTS);
+    const int rc2 = side_end(c, main, overlap);
+    if (rc || rc2) return rc ? rc : rc2;
+  }
   run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed));
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, d_claim, w.u8(o.mc));
-  const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
-  hipLaunchKernelGGL(k_stmt_terms, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, pl.s.ns, m, pl.d_tarr, pl.d_tarr + nc + 1,
-                     pl.d_tarr + nc + 1 + T1, d_resp, w.u8(o.mc), w.u32(o.off), w.u8(o.sc), w.u32(o.pidx));
+  if (T1) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T1, 256), dim3(256), 0, c->stream, N, T1, m, pl.d_tarr + nc + 1, d_resp, w.u8(o.mc), w.u8(o.sc));
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
-  // with no constraints there is no MSM, but every allocated point must still decode (verifier.rs:87-92)
-  const int rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true);
+  int rc = side_join(c, overlap);
+  if (rc) return rc;
+  rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_SCALARS);
   if (rc) return rc;
   run_program(c, pl.b, N, hb, d_ts, nullptr, w.u32(o.failed));
   prof_mark(c, ZKP_K_TRANSCRIPT);
@@ -808,7 +864,7 @@ int zkp_fused_prove_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, u
   const prove_inter o = prove_carve(*pl, 0);
   rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T));
   if (rc) return rc;
-  return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status);
+  return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status, /*overlap=*/false);
 }
 
 int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
@@ -847,7 +903,7 @@ int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8
   if (s.ns) HIP_TRY(hipMemcpyAsync(w.base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
   if (s.ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(w.base + o_ent, entropy, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
-  rc = prove_core(c, *pl, o, w.u8(o_ts), w.u8(o_sec), w.u8(o_tbl), w.u8(o_ent), w.u8(o_chal), w.u8(o_resp), w.u8(o_coms), w.u8(o_st));
+  rc = prove_core(c, *pl, o, w.u8(o_ts), w.u8(o_sec), w.u8(o_tbl), w.u8(o_ent), w.u8(o_chal), w.u8(o_resp), w.u8(o_coms), w.u8(o_st), /*overlap=*/true);
   if (rc) return rc;
   std::vector<uint8_t> status((size_t)N * nc);
   HIP_TRY(hipMemcpyAsync(challenges, w.base + o_chal, (size_t)N * 32, hipMemcpyDeviceToHost, c->stream));
@@ -878,7 +934,7 @@ int zkp_fused_verify_compact_dev(zkp_ctx* c, const zkp_fused_statement* st, uint
   const verify_inter o = verify_carve(*pl, 0);
   rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1));
   if (rc) return rc;
-  return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results);
+  return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results, /*overlap=*/false);
 }
 
 int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
@@ -912,7 +968,7 @@ int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t
   if (s.ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(w.base + o_claim, challenges, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
   if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  rc = verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res));
+  rc = verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res), /*overlap=*/true);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(results, w.base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));

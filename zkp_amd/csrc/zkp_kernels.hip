@@ -709,6 +709,9 @@ struct zkp_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t side_stream = nullptr;       // fused flows: point phase of the MSM next to the transcripts
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool prof_suspended = false;
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool profiling = false;
@@ -761,7 +764,7 @@ void prof_begin(zkp_ctx* c) {
   if (c->profiling) { hipEventRecord(c->ev[0], c->stream); c->ev_kind[0] = -1; c->n_ev = 1; }
 }
 void prof_mark(zkp_ctx* c, int kind) {
-  if (c->profiling && c->n_ev < kMaxEvents) {
+  if (c->profiling && !c->prof_suspended && c->n_ev < kMaxEvents) {
     hipEventRecord(c->ev[c->n_ev], c->stream);
     c->ev_kind[c->n_ev] = kind;
     c->n_ev++;
@@ -771,9 +774,13 @@ void prof_mark(zkp_ctx* c, int kind) {
 inline dim3 grid1(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// phase: everything (default), or only the part that does not look at the scalars (decode, classification, comb tables:
+// the fused flows run it on the context's side stream next to the transcripts that produce the scalars), or the rest.
+enum : int { PH_POINTS = 1, PH_SCALARS = 2, PH_ALL = 3 };
 int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint8_t* d_scalars,
                    const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms, int flags,
-                   uint8_t* d_out, uint8_t* d_status8, uint32_t* d_status32, size_t ws_reserved, bool decode_all = false) {
+                   uint8_t* d_out, uint8_t* d_status8, uint32_t* d_status32, size_t ws_reserved, bool decode_all = false,
+                   int phase = PH_ALL) {
   carve cv;
   cv.off = ws_reserved;
   const size_t o_pts = cv.take((size_t)n_points * sizeof(dev_affine));
@@ -797,6 +804,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     uint32_t* list = reinterpret_cast<uint32_t*>(base + o_list);
     uint32_t* needs = reinterpret_cast<uint32_t*>(base + o_needs);
     dev_ext* comb = reinterpret_cast<dev_ext*>(base + o_comb);
+    if (phase & PH_POINTS) {
     HIP_TRY(hipMemsetAsync(cls, 0, 256 * 4, c->stream));
     HIP_TRY(hipMemsetAsync(needs, 0, (size_t)n_points * 4, c->stream));
     if (c->hot_nreg)
@@ -816,16 +824,19 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, cursor, list);
     hipLaunchKernelGGL(k_comb_tables, grid1((size_t)n_points * 4, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, pts, comb);
     prof_mark(c, ZKP_K_SORT);          // path A: term classification + comb-table construction
+    }
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 2));
-    if (flags == ZKP_CT)
+    if (!(phase & PH_SCALARS)) {
+    } else if (flags == ZKP_CT)
       hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, part);
     else
       hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, part);
   } else {
-    if (n_points) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, (const uint32_t*)nullptr);
+    if (n_points && (phase & PH_POINTS)) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, (const uint32_t*)nullptr);
     prof_mark(c, ZKP_K_DECODE);
-    if (n_terms) hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part);
+    if (n_terms && (phase & PH_SCALARS)) hipLaunchKernelGGL(k_terms_r4, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_pidx, n_points, pts, part);
   }
+  if (!(phase & PH_SCALARS)) { HIP_TRY(hipGetLastError()); return ZKP_OK; }
   prof_mark(c, ZKP_K_TERMS);
   if (n_msm) {
     if (d_status8)
@@ -1000,6 +1011,9 @@ void zkp_ctx_destroy(zkp_ctx* c) {
   if (c->hot_reg_slot) hipFree(c->hot_reg_slot);
   if (c->hot_scratch) hipFree(c->hot_scratch);
   free_fused_plans(c);
+  if (c->side_stream) hipStreamDestroy(c->side_stream);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;

@@ -8,3 +8,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # tests/test_gpu_device_entry.py keeps its device buffers in torch tensors.  torch ships its own HIP runtime; when both
+    # it and libzkp_mi355x.so (linked against /opt/rocm) live in one process, torch's must initialise FIRST (the other
+    # order leaves the later one without devices), exactly as bench.py does -- so for `-m gpu` sessions on a GPU box it
+    # is initialised here, before any test module is imported.
+    expr = config.getoption("markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr and os.path.exists("/dev/kfd"):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass

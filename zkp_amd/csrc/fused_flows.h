@@ -598,7 +598,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
     int rc = side_begin(c, &main, overlap);
     if (rc) return rc;
     hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T, w.u32(o.off), w.u32(o.pidx));
-    if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_POINTS);
+    if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_POINTS, /*lane_tables=*/!overlap);
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) return rc ? rc : rc2;
   }
@@ -657,7 +657,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
     int rc = side_begin(c, &main, overlap);
     if (rc) return rc;
     hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T1, w.u32(o.off), w.u32(o.pidx));
-    rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_POINTS);
+    rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_POINTS, /*lane_tables=*/!overlap);
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) return rc ? rc : rc2;
   }

@@ -780,7 +780,7 @@ enum : int { PH_POINTS = 1, PH_SCALARS = 2, PH_ALL = 3 };
 int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint8_t* d_scalars,
                    const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms, int flags,
                    uint8_t* d_out, uint8_t* d_status8, uint32_t* d_status32, size_t ws_reserved, bool decode_all = false,
-                   int phase = PH_ALL) {
+                   int phase = PH_ALL, bool lane_tables = false) {
   carve cv;
   cv.off = ws_reserved;
   const size_t o_pts = cv.take((size_t)n_points * sizeof(dev_affine));
@@ -822,7 +822,10 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     prof_mark(c, ZKP_K_DECODE);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor);
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, cursor, list);
-    hipLaunchKernelGGL(k_comb_tables, grid1((size_t)n_points * 4, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, pts, comb);
+    if (lane_tables)
+      hipLaunchKernelGGL(k_comb_tables_lane, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, pts, comb);
+    else
+      hipLaunchKernelGGL(k_comb_tables, grid1((size_t)n_points * 4, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, pts, comb);
     prof_mark(c, ZKP_K_SORT);          // path A: term classification + comb-table construction
     }
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 2));
@@ -1150,7 +1153,7 @@ int zkp_msm_many_dev(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const ui
   const int rc = ensure_ws(c, terms_path_ws(n_points, n_terms));
   if (rc) return rc;
   prof_begin(c);
-  return msm_terms_path(c, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms, flags, d_out, d_status, nullptr, 0);
+  return msm_terms_path(c, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms, flags, d_out, d_status, nullptr, 0, false, PH_ALL, /*lane_tables=*/true);
 }
 
 int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t* scalars, const uint32_t* pidx,

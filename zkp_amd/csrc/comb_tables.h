@@ -170,4 +170,58 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
   store_ext(partial + t, acc);
 }
 
+// partial[t] = scalars[t] * P for a point that no other term of a variable-time call uses (a constraint's left-hand side
+// in verify_compact): signed radix-16 ladder over P's own eight multiples, 256 doublings + 65 additions instead of the
+// radix-4 ladder's 256 + 128.  The multiples live in the point's (otherwise unused) comb-table slot.  Addresses depend on
+// the scalar: variable-time callers only.
+__device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restrict__ scalars, const dev_affine* __restrict__ pt,
+                                              dev_ext* __restrict__ tbl, dev_ext* __restrict__ partial) {
+  uint32_t s[8], e[8], top;
+  load_vec<2>(s, scalars + 32 * (size_t)t);
+  sc_add_pattern(e, top, s, 0x88888888u);                       // signed radix-16 digits: nibble - 8 in [-8, 7]
+  ge_p3 acc;
+  {
+    ge_p3 P, m2, m3, m4, m;
+    ge_cached c1, c;
+    load_affine(P, pt);
+    ge_to_cached(c1, P);
+    store_comb_entry(tbl + 0, c1);
+    ge_double<true>(m2, P);
+    ge_to_cached(c, m2); store_comb_entry(tbl + 1, c);
+    ge_add_cached(m3, m2, c1);
+    ge_to_cached(c, m3); store_comb_entry(tbl + 2, c);
+    ge_double<true>(m4, m2);
+    ge_to_cached(c, m4); store_comb_entry(tbl + 3, c);
+    ge_add_cached(m, m4, c1);
+    ge_to_cached(c, m); store_comb_entry(tbl + 4, c);
+    ge_double<true>(m, m3);
+    ge_to_cached(c, m); store_comb_entry(tbl + 5, c);
+    ge_add_cached(m, m, c1);
+    ge_to_cached(c, m); store_comb_entry(tbl + 6, c);
+    ge_double<true>(m, m4);
+    ge_to_cached(c, m); store_comb_entry(tbl + 7, c);
+    ge_cached sel;                                              // carry out of bit 255: one more P at the top
+    ge_cached_identity(sel);
+    ge_cached_cmov(sel, c1, top);
+    ge_identity(acc);
+    ge_add_cached(acc, acc, sel);
+  }
+#pragma unroll 1
+  for (int w = 63; w >= 0; --w) {
+    ge_double<false>(acc, acc);
+    ge_double<false>(acc, acc);
+    ge_double<false>(acc, acc);
+    ge_double<true>(acc, acc);
+    const uint32_t nib = (sel8(e, w >> 3) >> (4 * (w & 7))) & 15u;
+    const uint32_t neg = (uint32_t)(nib < 8u);
+    const uint32_t mag = neg ? 8u - nib : nib - 8u;             // 0..8
+    ge_cached sel;
+    ge_cached_identity(sel);
+    if (mag) load_comb_entry(sel, tbl + (mag - 1));
+    ge_cached_cneg(sel, neg);
+    ge_add_cached(acc, acc, sel);
+  }
+  store_ext(partial + t, acc);
+}
+
 }  // namespace zkp

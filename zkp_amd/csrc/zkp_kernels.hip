@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ list,
               const int32_t* __restrict__ hotmap, const dev_niels* __restrict__ tables, const dev_affine* __restrict__ pts,
-              dev_ext* __restrict__ partial) {
+              dev_ext* __restrict__ comb_rw, dev_ext* __restrict__ partial) {
   const uint32_t n_hot = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - n_hot;
   const uint32_t n_ladder = CT ? 0u : class_start[HOT_CLASSES] - class_start[CLASS_LADDER];
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
@@ -144,7 +144,11 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   if (!CT && blockIdx.x < ladder_blocks) {
     if constexpr (!CT) {
       const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-      if (i < n_ladder) term_generic(list[n_hot + n_comb + i], scalars, pidx, n_points, pts, partial);
+      if (i < n_ladder) {
+        const uint32_t t = list[n_hot + n_comb + i];
+        const uint32_t pi = pidx[t];                              // < n_points (out-of-range indices are classed with the comb terms)
+        term_ladder16(t, scalars, pts + pi, comb_rw + (size_t)pi * COMB_ENTRIES, partial);
+      }
     }
   } else if (blockIdx.x < ladder_blocks + comb_blocks) {
     const uint32_t i = (blockIdx.x - ladder_blocks) * blockDim.x + threadIdx.x;
@@ -831,9 +835,9 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 2));
     if (!(phase & PH_SCALARS)) {
     } else if (flags == ZKP_CT)
-      hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, part);
+      hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, comb, part);
     else
-      hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, part);
+      hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, comb, part);
   } else {
     if (n_points && (phase & PH_POINTS)) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, (const uint32_t*)nullptr);
     prof_mark(c, ZKP_K_DECODE);

@@ -103,7 +103,7 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, u
 
 /* Batches of at least this many proofs whose transcripts stand at one STROBE position run entirely on the device
  * (zkp_mi355x.h section 2c: transcripts, scalars and MSMs); smaller or ragged batches hash their transcripts on the
- * host threads and use the GPU for the group arithmetic only.  Both routes produce the same bytes.  Default 256;
+ * host threads and use the GPU for the group arithmetic only.  Both routes produce the same bytes.  Default 32 (the measured crossover for the CMZ statement);
  * 0 = always fused, UINT32_MAX = never. */
 void zkp_toolbox_set_fused_min_batch(uint32_t n);
 uint32_t zkp_toolbox_get_fused_min_batch(void);

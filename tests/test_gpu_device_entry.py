@@ -82,7 +82,7 @@ def test_fused_dev_flows_equal_host_pointer_flows(eng, n):
         ok, coeffs = T.batch_verify_coeffs(eng, st, ts, inst, common, coms, resp, w)
         assert ok
     finally:
-        T.set_fused_min_batch(256)
+        T.set_fused_min_batch(32)
     eng.prepare_fixed_points(common)
     table = np.concatenate([common, inst.reshape(-1, 32)])
     d_ts, d_sec, d_tbl, d_ent = _dev(ts0), _dev(secrets), _dev(table), _dev(entropy)

@@ -21,7 +21,7 @@ def eng():
     e = Engine(0)
     yield e
     e.close()
-    T.set_fused_min_batch(256)
+    T.set_fused_min_batch(32)
 
 
 def _fresh(label, n, extra=None):
@@ -105,7 +105,7 @@ def test_cmz_fused_equals_host_route(eng, n):
         out[route] = dict(chal=chal, resp=resp, coms=coms, ts_p=ts_p, res=res, ts_v=ts_v, ok=ok, coeffs=coeffs, ts_b=ts_b,
                           r1=r1, r2=r2, r3=r3, r4=r4, ok_bad=ok_bad, ok_ident=ok_ident, ok_zc=ok_zc,
                           e0=e0, e1=e1, e2=e2, e3=e3, e4=e4, e5=e5, ts_e=ts_e)
-    T.set_fused_min_batch(256)
+    T.set_fused_min_batch(32)
     h, f = out["host"], out["fused"]
     for key in ("chal", "resp", "coms", "res", "coeffs", "r1", "r2", "r3", "r4", "e0", "e1", "e2", "e3", "e4", "e5"):
         assert (h[key] == f[key]).all(), key
@@ -140,7 +140,7 @@ def test_dleq_fused_equals_host_route_and_oracle(eng, n):
         ts3 = _fresh(label, n)
         T.batch_verify(eng, st, ts3, inst, common, coms, resp)
         got[route] = (chal, resp, coms, ts, res, ts2, ts3)
-    T.set_fused_min_batch(256)
+    T.set_fused_min_batch(32)
     for a, b in zip(got["host"], got["fused"]):
         a, b = (a[:, :203], b[:, :203]) if a.shape[-1] == 208 else (a, b)
         assert (a == b).all()
@@ -172,7 +172,7 @@ def test_ragged_transcripts_use_the_host_route(eng):
     T.set_fused_min_batch(NEVER)
     ts2 = np.stack(states)
     chal2, resp2, coms2 = T.prove_batch(eng, st, ts2, x, inst, common, entropy)
-    T.set_fused_min_batch(256)
+    T.set_fused_min_batch(32)
     assert (chal == chal2).all() and (resp == resp2).all() and (coms == coms2).all() and (ts[:, :203] == ts2[:, :203]).all()
     ts3 = np.stack(states)
     res = T.verify_compact_batch(eng, st, ts3, inst, common, chal, resp)
@@ -228,7 +228,7 @@ def test_constraint_api_allocation_order_fused(eng, n):
         with pytest.raises(T.VerificationFailure):
             T.batch_verify(eng, st, ts, swapped, gh, coms, resp)
     finally:
-        T.set_fused_min_batch(256)
+        T.set_fused_min_batch(32)
 
 
 def test_w64_statement_fused_equals_host_route(eng):
@@ -260,7 +260,7 @@ def test_w64_statement_fused_equals_host_route(eng):
         ok, coeffs = T.batch_verify_coeffs(eng, st, ts3, inst, G, coms, resp, w)
         out[route] = (chal, resp, coms, ts[:, :203], res, ts2[:, :203], coeffs, ts3[:, :203])
         assert ok and not res.any()
-    T.set_fused_min_batch(256)
+    T.set_fused_min_batch(32)
     for a, b in zip(out["host"], out["fused"]):
         assert (a == b).all()
 
@@ -348,7 +348,7 @@ def test_degenerate_statements_fused_equals_host_route(eng, shape):
         except T.VerificationFailure:
             ok = False
         out[route] = (chal, resp, coms, ts[:, :203], res, ts2[:, :203], np.array([ok]))
-    T.set_fused_min_batch(256)
+    T.set_fused_min_batch(32)
     for a, b in zip(out["host"], out["fused"]):
         assert a.shape == b.shape and (a == b).all()
     # "P = (empty sum)" is a false statement for P != identity (and an identity P is refused by the verifier's transcript):

@@ -43,4 +43,4 @@ for n in sizes:
         if route == "fused":
             for k, (d, tot) in km.items():
                 print("           device %-14s %7.3f ms: " % (k, tot) + ", ".join("%s %.3f" % (a, b) for a, b in d.items() if b > 0))
-T.set_fused_min_batch(256)
+T.set_fused_min_batch(32)

@@ -224,7 +224,7 @@ std::vector<uint8_t> point_table(const zkp_statement& st, uint32_t N, const uint
 }
 
 // ---- fused (all-on-device) flows: zkp_mi355x.h (2c) ------------------------------------------------------------
-std::atomic<uint32_t> g_fused_min_batch{256};
+std::atomic<uint32_t> g_fused_min_batch{32};
 
 struct FusedView {
   zkp_fused_statement fs{};

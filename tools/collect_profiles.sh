@@ -6,7 +6,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
-python bench.py --steps 20 --warmup 3 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o kt -- $B > $O/${TAG}_kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_prof -o fetch -- $B > $O/${TAG}_fetch.log 2>&1

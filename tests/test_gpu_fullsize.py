@@ -181,3 +181,39 @@ def test_config4_share_complete_flows_524288(eng):
     ts = np.repeat(t0[None], n, axis=0)
     res = T.verify_compact_batch(eng, st, ts, inst, common, chal, resp)
     assert res[k] == 1 and int(res.sum()) == 1
+
+
+def test_config3_complete_flows_dleq_2p20(eng):
+    """Config 3 through the complete flows: 2^20 DLEQ proofs (benches/zkp.rs:49: A = x G, B = x H with a per-proof H)
+    proven and batch-verified on the device (the batch MSM has 1 + 5 N = 5,242,881 terms); a flipped bit fails the
+    batch; sampled proofs equal the C oracle's byte for byte."""
+    from zkp_amd import toolbox as T
+    n = 1 << 20
+    rng = np.random.default_rng(33)
+    base = np.frombuffer(bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"), np.uint8).reshape(1, 32)
+    eng.prepare_fixed_points(base)
+    x = rand_scalars(rng, n)
+    iota = np.arange(n + 1, dtype=np.uint32)
+    H, s1 = eng.msm_many(iota, rand_scalars(rng, n), np.zeros(n, np.uint32), base, 1)
+    A, s2 = eng.msm_many(iota, x, np.zeros(n, np.uint32), base, 1)
+    B, s3 = eng.msm_many(iota, x, np.arange(n, dtype=np.uint32), H, 1)
+    assert not (s1.any() or s2.any() or s3.any())
+    inst = np.ascontiguousarray(np.stack([A, B, H]))
+    mod = T.dleq_module()
+    st = mod.statement
+    label = b"config-3"
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    t0 = T.Transcript(label).state
+    ts = np.repeat(t0[None], n, axis=0)
+    secrets = np.ascontiguousarray(x.reshape(n, 1, 32))
+    chal, resp, coms = T.prove_batch(eng, st, ts, secrets, inst, base.copy(), entropy)
+    cst = C.Statement.from_model(M.dleq_statement())
+    for j in (0, 77777, n - 1):
+        ec, er, ek, _ = C.prove(cst, label, secrets[j], np.concatenate([inst[:, j], base]), entropy[j].tobytes())
+        assert chal[j].tobytes() == ec.tobytes() and (resp[j] == er).all() and (coms[j] == ek).all(), j
+    ts = np.repeat(t0[None], n, axis=0)
+    T.batch_verify(eng, st, ts, inst, base.copy(), coms, resp)
+    coms[n // 3, 1, 5] ^= 0x40                      # most likely no longer a valid encoding -> failure either way
+    ts = np.repeat(t0[None], n, axis=0)
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify(eng, st, ts, inst, base.copy(), coms, resp)

@@ -217,3 +217,41 @@ def test_config3_complete_flows_dleq_2p20(eng):
     ts = np.repeat(t0[None], n, axis=0)
     with pytest.raises(T.VerificationFailure):
         T.batch_verify(eng, st, ts, inst, base.copy(), coms, resp)
+
+
+def test_config5_share_complete_flows_w64_32768(eng):
+    """Per-GPU share of config 5 through the complete flows: the wide statement Q = sum_{i<64} x_i G_i, 32,768 proofs
+    proven, verified one by one and batch-verified on the device; sampled proofs equal the C oracle's."""
+    from zkp_amd import toolbox as T
+    n = 32768
+    rng = np.random.default_rng(55)
+    gens, _ = make_points(eng, rng, 64)
+    eng.prepare_fixed_points(gens)
+    names = [f"x_{i}" for i in range(64)]
+    gnames = [f"G_{i}" for i in range(64)]
+    cons = [("Q", [(names[i], gnames[i]) for i in range(64)])]
+    mod = T.define_proof("w64", b"W64", names, ["Q"], gnames, cons)
+    st = mod.statement
+    xs = rand_scalars(rng, 64 * n)
+    off = (np.arange(n + 1, dtype=np.uint64) * 64).astype(np.uint32)
+    Q, sq = eng.msm_many(off, xs, np.tile(np.arange(64, dtype=np.uint32), n), gens, 1)
+    assert not sq.any()
+    inst = np.ascontiguousarray(Q[None])
+    secrets = np.ascontiguousarray(xs.reshape(n, 64, 32))
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    label = b"config-5"
+    t0 = T.Transcript(label).state
+    ts = np.repeat(t0[None], n, axis=0)
+    chal, resp, coms = T.prove_batch(eng, st, ts, secrets, inst, gens, entropy)
+    cst = C.Statement.from_model(M.Statement(b"W64", names, ["Q"], gnames, cons))
+    for j in (0, n - 1):
+        ec, er, ek, _ = C.prove(cst, label, secrets[j], np.concatenate([inst[:, j], gens]), entropy[j].tobytes())
+        assert chal[j].tobytes() == ec.tobytes() and (resp[j] == er).all() and (coms[j] == ek).all(), j
+    ts = np.repeat(t0[None], n, axis=0)
+    assert not T.verify_compact_batch(eng, st, ts, inst, gens, chal, resp).any()
+    ts = np.repeat(t0[None], n, axis=0)
+    T.batch_verify(eng, st, ts, inst, gens, coms, resp)
+    resp[n - 5, 63, 0] ^= 2
+    ts = np.repeat(t0[None], n, axis=0)
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify(eng, st, ts, inst, gens, coms, resp)

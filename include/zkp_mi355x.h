@@ -55,6 +55,15 @@ const char* zkp_last_error(void);
 /* Library / build identification, e.g. "zkp-mi355x 0.1 gfx950". */
 const char* zkp_version(void);
 
+/* Tuning knobs (results never depend on them).
+ *   ZKP_OPT_BATCH_ENCODE_MIN: calls of zkp_msm_many / the fused flows with at least this many outputs encode them as
+ *     2 * H with H = sum (s_i / 2) P_i, which needs one field inversion per 65,536 outputs instead of an inverse square
+ *     root per output (the identity behind curve25519-dalek's double_and_compress_batch): 10 x fewer instructions in the
+ *     encoding step, three short kernels instead of one (default 65536: below that the extra latency outweighs the
+ *     instructions saved; 0 = always, UINT64_MAX = never). */
+enum { ZKP_OPT_BATCH_ENCODE_MIN = 1 };
+int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
+
 /* Performance hint, never changes a result: declare points that very many terms of later zkp_msm_many calls
  * will reference -- in the reference's vocabulary the statement's COMMON variables (define_proof!,
  * macros.rs:84,236-242) / BatchVerifier's static points (batch_verifier.rs:100-112), e.g. the issuer

@@ -64,6 +64,21 @@ int t_point_op(int op, const uint8_t* pe, const uint8_t* qe, uint8_t* out) {
   enc(out, r);
   return ok;
 }
+// out = encode(2 P) through the inversion-only path (ristretto_dc_*), the point optionally rescaled by z first;
+// returns 2 if x = e g f h was zero (no output), else the decode flag
+int t_double_compress(const uint8_t* pe, const uint8_t* z, uint8_t* out) {
+  ge_p3 p; const int ok = dec(p, pe);
+  fe zz; load(zz, z);
+  fe_mul(p.X, p.X, zz); fe_mul(p.Y, p.Y, zz); fe_mul(p.Z, p.Z, zz); fe_mul(p.T, p.T, zz);
+  ristretto_dc_state s; fe x, inv;
+  ristretto_dc_prepare(s, x, p);
+  if (fe_iszero(x)) return 2;
+  fe_invert(inv, x);
+  uint32_t w[8];
+  ristretto_dc_finish(w, s, inv);
+  memcpy(out, w, 32);
+  return ok;
+}
 // plain double-and-add scalar multiplication with the device formulas (long dependent chains)
 int t_scalarmult(const uint8_t* s, const uint8_t* pe, uint8_t* out) {
   ge_p3 p, acc; int ok = dec(p, pe);
@@ -88,6 +103,7 @@ void t_sc_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 4: { sc t; sc_to_mont(t, x); sc_mont(r, t, y); break; }
     case 5: sc_from_wide(r, x, y); break;      // a + b * 2^256
     case 6: { r = x; const uint32_t f = sc_fold_sign(r.v); r.v[7] |= f << 31; break; }   // folded scalar, flag in bit 255
+    case 7: sc_halve(r, x); break;             // a / 2 mod l
     default: sc_zero(r);
   }
   memcpy(out, r.v, 32);

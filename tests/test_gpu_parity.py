@@ -234,3 +234,54 @@ def test_quad_cooperative_point_ops(eng, base_points):
         exp = [M.pt_double(P), M.pt_add(P, Q), M.pt_add(P, Q), M.pt_add(P, M.pt_neg(Q))]
         for k in range(4):
             assert out[i, k].tobytes() == M.ristretto_encode(exp[k]), (i, k)
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_batched_encoder_equals_per_output_encoder(base_points, flags):
+    """ZKP_OPT_BATCH_ENCODE_MIN: outputs encoded as 2 * sum (s/2) P with one shared inversion (ristretto_dc_*, the identity
+    behind dalek's double_and_compress_batch) must be the bytes of the per-output encoder -- including empty MSMs and MSMs
+    that cancel to the identity (x = 0 in the batch: general encoder), non-canonical scalars, invalid points (zeroed output,
+    status 1), with block sizes that leave the last product-tree block partly empty."""
+    from zkp_amd.engine import Engine, ZKP_OPT_BATCH_ENCODE_MIN
+    rng = random.Random(99 + flags)
+    logs, encs = base_points
+    special = [0, 1, 2, M.L - 1, M.L, M.L + 1, (1 << 256) - 1, 1 << 255, (1 << 252) + 7]
+    for n_msm in (300, 513, 1400):
+        off, scalars, pidx = [0], [], []
+        for m in range(n_msm):
+            kind = m % 9
+            if kind == 0:
+                pass                                                    # empty MSM -> identity
+            elif kind == 1:
+                p = rng.randrange(40); s = rng.randrange(1, M.L)        # s P + (l - s) P = identity
+                scalars += [s, M.L - s]; pidx += [p, p]
+            elif kind == 2:
+                scalars += [0, 0, 0]; pidx += [rng.randrange(40) for _ in range(3)]
+            else:
+                for _ in range([1, 2, 11, 5][m % 4]):
+                    scalars.append(special[rng.randrange(len(special))] if rng.random() < 0.25 else rng.randrange(1 << 256))
+                    pidx.append(rng.randrange(40))
+            off.append(len(scalars))
+        while len(scalars) < 1100:                                      # the classified path needs >= 1024 terms
+            scalars.append(rng.randrange(1 << 256)); pidx.append(rng.randrange(40)); off[-1] += 1
+        sc_arr = np.stack([sc(s) for s in scalars])
+        pts = enc_arr(encs[:40])
+        pts_bad = pts.copy()
+        pts_bad[7] = np.frombuffer(bytes.fromhex("01" + "00" * 31), np.uint8)
+        results = {}
+        for mode, thr in (("per-output", 0xFFFFFFFFFFFFFFFF), ("batched", 0)):
+            e = Engine(0)
+            e.set_option(ZKP_OPT_BATCH_ENCODE_MIN, thr)
+            e.prepare_fixed_points(enc_arr(encs[:9]))
+            results[mode] = [e.msm_many(off, sc_arr, pidx, pts, flags), e.msm_many(off, sc_arr, pidx, pts_bad, flags)]
+            e.close()
+        for (o1, s1), (o2, s2) in zip(results["per-output"], results["batched"]):
+            assert (s1 == s2).all() and (o1 == o2).all()
+        out, st = results["batched"][0]
+        assert not st.any()
+        for m in range(0, n_msm, 9):
+            assert out[m].tobytes() == bytes(32) and out[m + 1].tobytes() == bytes(32) if m + 1 < n_msm else True
+        for m in range(3, n_msm, 41):                                   # and against the big-integer definition
+            dlog = sum(scalars[t] * logs[pidx[t]] for t in range(off[m], off[m + 1])) % M.L
+            assert out[m].tobytes() == M.ristretto_encode(M.pt_mul(dlog, M.BASEPOINT))
+        assert results["batched"][1][1].any()

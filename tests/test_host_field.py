@@ -214,7 +214,27 @@ def test_scalar_arithmetic_mod_l(lib):
             assert v == a                                   # never folded (>= l), value untouched
         else:
             assert (v >> 255) == int(fold) and (v & ((1 << 255) - 1)) == (M.L - a if fold else a), a
+    inv2 = (M.L + 1) // 2
+    for a in [0, 1, 2, 3, M.L - 1, M.L, M.L + 1, (1 << 256) - 1] + [rng.randrange(1 << 256) for _ in range(100)]:
+        lib.t_sc_op(7, b32(a), b32(0), out)                 # halving (the MSM kernels emit encode(2 * sum (s/2) P))
+        assert out.raw == b32(a * inv2 % M.L)
     wide = [0, (1 << 512) - 1, (1 << 256), M.L << 256, (M.L << 256) - 1] + [rng.randrange(1 << 512) for _ in range(300)]
     for x in wide:                                          # Scalar::from_bytes_mod_order_wide
         lib.t_sc_op(5, b32(x & ((1 << 256) - 1)), b32(x >> 256), out)
         assert out.raw == b32(x % M.L)
+
+
+def test_double_and_compress_without_square_root(lib):
+    """ristretto_dc_prepare / _finish (ge25519.h): encode(2 P) from one inversion -- the identity behind
+    curve25519-dalek's double_and_compress_batch -- against the model's encode(double(P)), for random points in random
+    projective scalings (and, in the bound-tracked build, with every lazy add/sub chain checked)."""
+    rng = random.Random(77)
+    out = ctypes.create_string_buffer(32)
+    B = M.ristretto_decode(bytes.fromhex(GENERATOR_MULTIPLES[1]))
+    for i in range(120):
+        k = rng.randrange(1, M.L)
+        Pt = M.pt_mul(k, B)
+        z = rng.randrange(1, M.P) if i % 3 else 1
+        rc = lib.t_double_compress(M.ristretto_encode(Pt), z.to_bytes(32, "little"), out)
+        assert rc == 1 and out.raw == M.ristretto_encode(M.pt_double(Pt)), i
+    assert lib.t_double_compress(bytes(32), (1).to_bytes(32, "little"), out) == 2       # identity: x = 0, caller falls back

@@ -348,7 +348,7 @@ void launch_coeff_build(zkp_ctx* c, const fused_shape& s, uint32_t N, const uint
   }
 }
 size_t optional_ws(uint64_t total) {
-  if (total <= kSmallOptional) return 1024 + (total + 1) * 4 + terms_path_ws((uint32_t)total, (uint32_t)total);
+  if (total <= kSmallOptional) return 1024 + (total + 1) * 4 + terms_path_ws((uint32_t)total, (uint32_t)total, 1);
   switch (pick_c(total)) {
     case 7: return pip_ws<7>(total);
     case 10: return pip_ws<10>(total);
@@ -862,7 +862,7 @@ int zkp_fused_prove_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, u
     return fail(ZKP_ERR_ARG, "NULL device pointer");
   if ((uint64_t)N * s.T > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const prove_inter o = prove_carve(*pl, 0);
-  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T));
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T, N * s.nc));
   if (rc) return rc;
   return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status, /*overlap=*/false);
 }
@@ -895,7 +895,7 @@ int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8
   const size_t o_chal = cv.take((size_t)N * 32);
   const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
   const prove_inter o = prove_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T));
+  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T, N * s.nc));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
@@ -932,7 +932,7 @@ int zkp_fused_verify_compact_dev(zkp_ctx* c, const zkp_fused_statement* st, uint
   if (!d_transcripts || !d_challenges || !d_results || (s.m && !d_responses) || (s.np && !d_table)) return fail(ZKP_ERR_ARG, "NULL device pointer");
   if ((uint64_t)N * pl->T1 > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const verify_inter o = verify_carve(*pl, 0);
-  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1));
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1, N * s.nc));
   if (rc) return rc;
   return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results, /*overlap=*/false);
 }
@@ -960,7 +960,7 @@ int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t
   const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
   const size_t o_res = cv.take((size_t)N);
   const verify_inter o = verify_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * pl->T1));
+  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * pl->T1, N * s.nc));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
@@ -1077,7 +1077,7 @@ int zkp_fused_verify_batchable(zkp_ctx* c, const zkp_fused_statement* st, uint32
   const size_t o_w = cv.take((size_t)N * nc * 16 + 16);
   const size_t o_res = cv.take((size_t)N + 4);
   const each_inter o = each_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K)));
+  rc = ensure_ws(c, o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));

@@ -307,4 +307,67 @@ ZKP_HD void ristretto_encode(uint32_t w[8], const ge_p3& p) {
   fe_towords(w, t);
 }
 
+// ---- encode(2 P) with a plain inversion instead of an inverse square root ---------------------------------------------------
+// The encoding of a DOUBLED point needs no square root: with e = 2XY, f = Z^2 + dT^2, g = Y^2 + X^2, h = Z^2 - dT^2 (the
+// numerators / denominators of the doubling) everything reduces to 1 / (e g f h), and inversions batch (Montgomery's
+// trick) where inverse square roots do not.  curve25519-dalek uses the same identity in
+// RistrettoPoint::double_and_compress_batch.  The MSM kernels therefore compute H = sum (s_i / 2) P_i and emit encode(2 H):
+// ~25 field multiplications per output instead of ~265.
+//   ristretto_dc_prepare : state of P and x = e g f h   (x = 0 iff 2P is in the identity coset: caller falls back)
+//   ristretto_dc_finish  : the 32 bytes from the state and 1 / x
+struct ristretto_dc_state { fe e, f, g, h, eg, fh; };
+
+ZKP_HD void ristretto_dc_prepare(ristretto_dc_state& s, fe& x, const ge_p3& p) {
+  fe xx, yy, zz, dtt, t, d;
+  fe_sq(xx, p.X);
+  fe_sq(yy, p.Y);
+  fe_sq(zz, p.Z);
+  fe_sq(t, p.T);
+  fe_from_const(d, FE_D);
+  fe_mul(dtt, t, d);
+  fe_add(t, p.Y, p.Y);
+  fe_mul(s.e, p.X, t);           // 2 X Y
+  fe_add(t, zz, dtt);
+  fe_carry(s.f, t);              // Z^2 + d T^2
+  fe_add(t, yy, xx);
+  fe_carry(s.g, t);              // Y^2 - a X^2
+  fe_sub(t, zz, dtt);
+  fe_carry(s.h, t);              // Z^2 - d T^2
+  fe_mul(s.eg, s.e, s.g);
+  fe_mul(s.fh, s.f, s.h);
+  fe_mul(x, s.eg, s.fh);
+}
+
+ZKP_HD void ristretto_dc_finish(uint32_t w[8], const ristretto_dc_state& s, const fe& inv) {
+  fe zinv, tinv, magic, sqrt_m1, t, e, g, h, me, fs, mg;
+  fe_mul(zinv, s.eg, inv);       // 1 / (f h)
+  fe_mul(tinv, s.fh, inv);       // 1 / (e g)
+  fe_mul(t, s.eg, zinv);
+  const uint32_t rotate = fe_isnegative(t);
+  e = s.e;
+  g = s.g;
+  h = s.h;
+  fe_neg(t, s.e);
+  fe_carry(me, t);
+  fe_from_const(sqrt_m1, FE_SQRT_M1);
+  fe_mul(fs, s.f, sqrt_m1);
+  fe_from_const(magic, FE_INVSQRT_A_MINUS_D);
+  fe_cmov(e, s.g, rotate);
+  fe_cmov(g, me, rotate);
+  fe_cmov(h, fs, rotate);
+  fe_cmov(magic, sqrt_m1, rotate);
+  fe_mul(t, h, e);
+  fe_mul(t, t, zinv);
+  const uint32_t neg_g = fe_isnegative(t);
+  fe_neg(t, g);
+  fe_carry(t, t);
+  fe_cmov(g, t, neg_g);
+  fe_mul(mg, g, tinv);
+  fe_mul(mg, magic, mg);
+  fe_sub(t, h, g);
+  fe_mul(t, t, mg);
+  fe_abs(t, t);
+  fe_towords(w, t);
+}
+
 }  // namespace zkp

@@ -195,6 +195,189 @@ k_reduce_encode(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t
   status[i] = (STATUS_T)bad;
 }
 
+// ---- batched encoding: H = sum (s_i / 2) P_i per MSM, output encode(2 H) from ONE field inversion per 65,536 outputs ----
+// (ristretto_dc_* in ge25519.h; Montgomery's trick as a product tree: level 1 = blocks of 256 outputs in LDS, level 2 = the
+// block products.)  k_reduce_encode, which pays an inverse square root per output, remains for calls below 1,024 terms.
+__global__ void __launch_bounds__(256)
+k_halve_scalars(uint32_t n, const uint8_t* __restrict__ in, uint8_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sc a, r;
+  load_vec<2>(a.v, in + 32 * (size_t)i);
+  sc_halve(r, a);
+  store_vec<2>(out + 32 * (size_t)i, r.v);
+}
+
+constexpr int ENC_BLOCK = 256;
+struct enc_tree { uint32_t node[2 * ENC_BLOCK][9]; };        // heap layout: node 1 = root, leaves ENC_BLOCK .. 2 ENC_BLOCK - 1
+__device__ __forceinline__ void tree_get(fe& r, const enc_tree& t, int n) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = t.node[n][i];
+  FE_TRACK(fe_set_ub_tight(r));
+}
+__device__ __forceinline__ void tree_put(enc_tree& t, int n, const fe& a) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t.node[n][i] = a.v[i];
+}
+// node = product of its children, up to the root
+__device__ __forceinline__ void tree_up(enc_tree& t, int tid) {
+  for (int w = ENC_BLOCK / 2; w >= 1; w >>= 1) {
+    if (tid < w) {
+      fe a, b, c;
+      tree_get(a, t, 2 * (w + tid));
+      tree_get(b, t, 2 * (w + tid) + 1);
+      fe_mul(c, a, b);
+      tree_put(t, w + tid, c);
+    }
+    __syncthreads();
+  }
+}
+// node 1 holds the inverse of the root product; afterwards every leaf holds the inverse of its value
+__device__ __forceinline__ void tree_down(enc_tree& t, int tid) {
+  for (int w = 1; w <= ENC_BLOCK / 2; w <<= 1) {
+    if (tid < w) {
+      fe p, a, b, ia, ib;
+      tree_get(p, t, w + tid);
+      tree_get(a, t, 2 * (w + tid));
+      tree_get(b, t, 2 * (w + tid) + 1);
+      fe_mul(ia, p, b);
+      fe_mul(ib, p, a);
+      tree_put(t, 2 * (w + tid), ia);
+      tree_put(t, 2 * (w + tid) + 1, ib);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ uint32_t msm_sum(ge_p3& acc, uint32_t i, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pidx,
+                                            uint32_t n_points, const dev_affine* __restrict__ pts, const dev_ext* __restrict__ partial) {
+  const uint32_t b = off[i], e = off[i + 1];
+  ge_identity(acc);
+  uint32_t bad = 0;
+#pragma unroll 1
+  for (uint32_t t = b; t < e; ++t) {
+    ge_p3 q;
+    load_ext(q, partial + t);
+    ge_add_p3(acc, acc, q);
+    const uint32_t pi = pidx[t];
+    bad |= pi < n_points ? (pts[pi].valid ^ 1u) : 1u;
+  }
+  return bad;
+}
+
+// pass 1: per MSM the sum of its partials, the decode status, the encoding state; per block the product of the x's
+template <typename STATUS_T>
+__global__ void __launch_bounds__(ENC_BLOCK, 2)
+k_encode_prepare(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pidx, uint32_t n_points,
+                 const dev_affine* __restrict__ pts, const dev_ext* __restrict__ partial, uint32_t* __restrict__ states /*[n][6][9]*/,
+                 uint32_t* __restrict__ xs /*[n][9]*/, uint32_t* __restrict__ bprod /*[blocks][9]*/, uint8_t* __restrict__ zflag,
+                 STATUS_T* __restrict__ status) {
+  __shared__ enc_tree tree;
+  const int tid = threadIdx.x;
+  const uint32_t i = blockIdx.x * ENC_BLOCK + tid;
+  fe x;
+  fe_1(x);
+  if (i < n_msm) {
+    ge_p3 acc;
+    const uint32_t bad = msm_sum(acc, i, off, pidx, n_points, pts, partial);
+    status[i] = (STATUS_T)bad;
+    ristretto_dc_state s;
+    ristretto_dc_prepare(s, x, acc);
+    const uint32_t zero = fe_iszero(x);
+    zflag[i] = (uint8_t)zero;
+    if (zero) fe_1(x);
+    uint32_t* st = states + (size_t)i * 54;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      st[k] = s.e.v[k]; st[9 + k] = s.f.v[k]; st[18 + k] = s.g.v[k]; st[27 + k] = s.h.v[k]; st[36 + k] = s.eg.v[k]; st[45 + k] = s.fh.v[k];
+      xs[(size_t)i * 9 + k] = x.v[k];
+    }
+  }
+  tree_put(tree, ENC_BLOCK + tid, x);
+  __syncthreads();
+  tree_up(tree, tid);
+  if (tid < 9) bprod[(size_t)blockIdx.x * 9 + tid] = tree.node[1][tid];
+}
+
+// pass 2: inverses of up to 256 block products per block (one field inversion each)
+__global__ void __launch_bounds__(ENC_BLOCK)
+k_encode_invert(uint32_t n_blocks, const uint32_t* __restrict__ bprod, uint32_t* __restrict__ binv) {
+  __shared__ enc_tree tree;
+  const int tid = threadIdx.x;
+  const uint32_t b = blockIdx.x * ENC_BLOCK + tid;
+  fe x;
+  fe_1(x);
+  if (b < n_blocks) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x.v[k] = bprod[(size_t)b * 9 + k];
+    FE_TRACK(fe_set_ub_tight(x));
+  }
+  tree_put(tree, ENC_BLOCK + tid, x);
+  __syncthreads();
+  tree_up(tree, tid);
+  if (tid == 0) {
+    fe r, inv;
+    tree_get(r, tree, 1);
+    fe_invert(inv, r);
+    tree_put(tree, 1, inv);
+  }
+  __syncthreads();
+  tree_down(tree, tid);
+  if (b < n_blocks) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) binv[(size_t)b * 9 + k] = tree.node[ENC_BLOCK + tid][k];
+  }
+}
+
+// pass 3: per-output inverses from the block inverse, then the 32 bytes
+__global__ void __launch_bounds__(ENC_BLOCK, 2)
+k_encode_finish(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pidx, uint32_t n_points,
+                const dev_affine* __restrict__ pts, const dev_ext* __restrict__ partial, const uint32_t* __restrict__ states,
+                const uint32_t* __restrict__ xs, const uint32_t* __restrict__ binv, const uint8_t* __restrict__ zflag,
+                const uint8_t* __restrict__ status8, const uint32_t* __restrict__ status32, uint8_t* __restrict__ out) {
+  __shared__ enc_tree tree;
+  const int tid = threadIdx.x;
+  const uint32_t i = blockIdx.x * ENC_BLOCK + tid;
+  fe x;
+  fe_1(x);
+  if (i < n_msm) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x.v[k] = xs[(size_t)i * 9 + k];
+    FE_TRACK(fe_set_ub_tight(x));
+  }
+  tree_put(tree, ENC_BLOCK + tid, x);
+  __syncthreads();
+  tree_up(tree, tid);
+  if (tid < 9) tree.node[1][tid] = binv[(size_t)blockIdx.x * 9 + tid];
+  __syncthreads();
+  tree_down(tree, tid);
+  if (i >= n_msm) return;
+  uint32_t w[8];
+  if (zflag[i]) {
+    // 2 H lies in the identity coset (or H is one of the few points where e g f h = 0): the general encoder
+    ge_p3 acc;
+    msm_sum(acc, i, off, pidx, n_points, pts, partial);
+    ge_double<true>(acc, acc);
+    ristretto_encode(w, acc);
+  } else {
+    ristretto_dc_state s;
+    const uint32_t* st = states + (size_t)i * 54;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      s.e.v[k] = st[k]; s.f.v[k] = st[9 + k]; s.g.v[k] = st[18 + k]; s.h.v[k] = st[27 + k]; s.eg.v[k] = st[36 + k]; s.fh.v[k] = st[45 + k];
+    }
+    fe inv;
+    tree_get(inv, tree, ENC_BLOCK + tid);
+    ristretto_dc_finish(w, s, inv);
+  }
+  const uint32_t bad = status8 ? (uint32_t)status8[i] : status32[i];
+  if (bad) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = 0;
+  }
+  store_vec<2>(out + 32 * (size_t)i, w);
+}
+
 __global__ void k_iota_single_msm(uint32_t n, uint32_t* __restrict__ pidx, uint32_t* __restrict__ off) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) pidx[i] = i;
@@ -716,6 +899,7 @@ struct zkp_ctx {
   hipStream_t side_stream = nullptr;       // fused flows: point phase of the MSM next to the transcripts
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool prof_suspended = false;
+  uint64_t batch_encode_min = 65536;       // ZKP_OPT_BATCH_ENCODE_MIN
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool profiling = false;
@@ -794,6 +978,13 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
   const size_t o_list = cv.take((size_t)n_terms * 4);
   const size_t o_needs = cv.take((size_t)n_points * 4);
   const size_t o_comb = cv.take(n_terms >= 1024 ? (size_t)n_points * COMB_ENTRIES * sizeof(dev_ext) : 0);
+  const bool batched_encode = n_terms >= 1024 && (uint64_t)n_msm >= c->batch_encode_min;
+  const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
+  const size_t o_half = cv.take(batched_encode ? (size_t)n_terms * 32 : 0);
+  const size_t o_states = cv.take(batched_encode ? (size_t)n_msm * 54 * 4 : 0);
+  const size_t o_xs = cv.take(batched_encode ? (size_t)n_msm * 9 * 4 : 0);
+  const size_t o_bprod = cv.take(batched_encode ? (size_t)enc_blocks * 9 * 4 * 2 : 0);
+  const size_t o_zflag = cv.take(batched_encode ? (size_t)n_msm : 0);
   // ensure_ws was done by the caller for ws_reserved + this much; recompute defensively
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
   char* base = static_cast<char*>(c->ws);
@@ -833,6 +1024,12 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     prof_mark(c, ZKP_K_SORT);          // path A: term classification + comb-table construction
     }
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 2));
+    // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l
+    if (batched_encode) {
+      uint8_t* d_half = reinterpret_cast<uint8_t*>(base + o_half);
+      if (phase & PH_SCALARS) hipLaunchKernelGGL(k_halve_scalars, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_half);
+      d_scalars = d_half;
+    }
     if (!(phase & PH_SCALARS)) {
     } else if (flags == ZKP_CT)
       hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, comb, part);
@@ -845,7 +1042,20 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
   }
   if (!(phase & PH_SCALARS)) { HIP_TRY(hipGetLastError()); return ZKP_OK; }
   prof_mark(c, ZKP_K_TERMS);
-  if (n_msm) {
+  if (n_msm && batched_encode) {
+    uint32_t* states = reinterpret_cast<uint32_t*>(base + o_states);
+    uint32_t* xs = reinterpret_cast<uint32_t*>(base + o_xs);
+    uint32_t* bprod = reinterpret_cast<uint32_t*>(base + o_bprod);
+    uint32_t* binv = bprod + (size_t)enc_blocks * 9;
+    uint8_t* zflag = reinterpret_cast<uint8_t*>(base + o_zflag);
+    if (d_status8)
+      hipLaunchKernelGGL(k_encode_prepare<uint8_t>, dim3(enc_blocks), dim3(ENC_BLOCK), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, states, xs, bprod, zflag, d_status8);
+    else
+      hipLaunchKernelGGL(k_encode_prepare<uint32_t>, dim3(enc_blocks), dim3(ENC_BLOCK), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, states, xs, bprod, zflag, d_status32);
+    hipLaunchKernelGGL(k_encode_invert, dim3((enc_blocks + ENC_BLOCK - 1) / ENC_BLOCK), dim3(ENC_BLOCK), 0, c->stream, enc_blocks, bprod, binv);
+    hipLaunchKernelGGL(k_encode_finish, dim3(enc_blocks), dim3(ENC_BLOCK), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, states, xs, binv, zflag,
+                       (const uint8_t*)d_status8, (const uint32_t*)d_status32, d_out);
+  } else if (n_msm) {
     if (d_status8)
       hipLaunchKernelGGL(k_reduce_encode<uint8_t>, grid1(n_msm, 256), dim3(256), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status8);
     else
@@ -855,7 +1065,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
   HIP_TRY(hipGetLastError());
   return ZKP_OK;
 }
-size_t terms_path_ws(uint32_t n_points, uint32_t n_terms) {
+size_t terms_path_ws(uint32_t n_points, uint32_t n_terms, uint32_t n_msm) {
   carve cv;
   cv.take((size_t)n_points * sizeof(dev_affine));
   cv.take((size_t)n_terms * sizeof(dev_ext));
@@ -864,6 +1074,13 @@ size_t terms_path_ws(uint32_t n_points, uint32_t n_terms) {
   cv.take((size_t)n_terms * 4);
   cv.take((size_t)n_points * 4);
   cv.take(n_terms >= 1024 ? (size_t)n_points * COMB_ENTRIES * sizeof(dev_ext) : 0);
+  const bool batched_encode = n_terms >= 1024;
+  const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
+  cv.take(batched_encode ? (size_t)n_terms * 32 : 0);
+  cv.take(batched_encode ? (size_t)n_msm * 54 * 4 : 0);
+  cv.take(batched_encode ? (size_t)n_msm * 9 * 4 : 0);
+  cv.take(batched_encode ? (size_t)enc_blocks * 9 * 4 * 2 : 0);
+  cv.take(batched_encode ? (size_t)n_msm : 0);
   return cv.off;
 }
 
@@ -1031,6 +1248,13 @@ int zkp_ctx_set_stream(zkp_ctx* c, void* s) {
   c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
   return ZKP_OK;
 }
+int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  switch (option) {
+    case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; return ZKP_OK;
+    default: return fail(ZKP_ERR_ARG, "unknown option");
+  }
+}
 int zkp_ctx_synchronize(zkp_ctx* c) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1154,7 +1378,7 @@ int zkp_msm_many_dev(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const ui
   if (n_terms && (!d_scalars || !d_pidx || !d_points || n_points == 0)) return fail(ZKP_ERR_ARG, "terms without scalars/points");
   if (!aligned16(d_scalars) || !aligned16(d_points) || !aligned16(d_out)) return fail(ZKP_ERR_ARG, "device buffers must be 16-byte aligned");
   HIP_TRY(hipSetDevice(c->device));
-  const int rc = ensure_ws(c, terms_path_ws(n_points, n_terms));
+  const int rc = ensure_ws(c, terms_path_ws(n_points, n_terms, n_msm));
   if (rc) return rc;
   prof_begin(c);
   return msm_terms_path(c, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms, flags, d_out, d_status, nullptr, 0, false, PH_ALL, /*lane_tables=*/true);
@@ -1182,7 +1406,7 @@ int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t*
   const size_t o_out = cv.take((size_t)n_msm * 32);
   const size_t o_st = cv.take((size_t)n_msm);
   const size_t reserved = cv.off;
-  int rc = ensure_ws(c, reserved + terms_path_ws(n_points, n_terms));
+  int rc = ensure_ws(c, reserved + terms_path_ws(n_points, n_terms, n_msm));
   if (rc) return rc;
   char* base = static_cast<char*>(c->ws);
   HIP_TRY(hipMemcpyAsync(base + o_off, off, (size_t)(n_msm + 1) * 4, hipMemcpyHostToDevice, c->stream));
@@ -1210,7 +1434,7 @@ static int msm_optional_impl(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, c
     const size_t o_pidx = cv.take((size_t)(n + 1) * 4);
     const size_t o_off = cv.take(256);
     const size_t inner = cv.off;
-    int rc = ensure_ws(c, inner + terms_path_ws((uint32_t)n, (uint32_t)n));
+    int rc = ensure_ws(c, inner + terms_path_ws((uint32_t)n, (uint32_t)n, 1));
     if (rc) return rc;
     char* base = static_cast<char*>(c->ws);
     uint32_t* pidx = reinterpret_cast<uint32_t*>(base + o_pidx);
@@ -1262,7 +1486,7 @@ int zkp_msm_optional(zkp_ctx* c, uint64_t n, const uint8_t* scalars, const uint8
   // size the workspace once, up front (inputs are copied before the kernels are enqueued)
   size_t need = 0;
   if (n <= kSmallOptional) {
-    need = 1024 + (n + 1) * 4 + terms_path_ws((uint32_t)n, (uint32_t)n);
+    need = 1024 + (n + 1) * 4 + terms_path_ws((uint32_t)n, (uint32_t)n, 1);
   } else {
     switch (pick_c(n)) {
       case 7: need = pip_ws<7>(n); break;

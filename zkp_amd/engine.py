@@ -16,11 +16,12 @@ LIB_PATH = os.path.join(_HERE, "libzkp_mi355x.so")
 
 ZKP_VARTIME = 0
 ZKP_CT = 1
+ZKP_OPT_BATCH_ENCODE_MIN = 1
 K_NAMES = ("decode", "terms", "reduce", "sort", "bucket", "combine", "transcript", "scalars")
 
 EXPORTS = (
     "zkp_ctx_create", "zkp_ctx_destroy", "zkp_ctx_set_stream", "zkp_ctx_synchronize", "zkp_last_error",
-    "zkp_version", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
+    "zkp_version", "zkp_ctx_set_option", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
     "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest", "zkp_batch_check", "zkp_fused_prove", "zkp_fused_verify_compact", "zkp_fused_batch_verify",
     "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_batch_verify_dev",
@@ -189,6 +190,10 @@ class Engine:
         _check(self._lib.zkp_fused_batch_verify_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ctypes.c_uint32(strobe_pos),
                                                     *[ctypes.c_void_p(x) for x in (d_ts, d_points, d_coms, d_resp, d_w, d_out, d_status)]),
                "zkp_fused_batch_verify_dev")
+
+    def set_option(self, option: int, value: int) -> None:
+        """Tuning knobs of include/zkp_mi355x.h (ZKP_OPT_*); results never depend on them."""
+        _check(self._lib.zkp_ctx_set_option(self._h, ctypes.c_int(option), ctypes.c_uint64(value)), "zkp_ctx_set_option")
 
     def set_profiling(self, enabled: bool) -> None:
         _check(self._lib.zkp_ctx_set_profiling(self._h, int(enabled)), "zkp_ctx_set_profiling")

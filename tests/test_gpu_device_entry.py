@@ -19,10 +19,15 @@ def eng():
     e.close()
 
 
-def _dev(a):
+def _torch():
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("torch cannot see the GPU in this process (its HIP runtime must initialise before libzkp_mi355x.so: use -m gpu)")
+        pytest.skip("torch cannot see the GPU in this process (its HIP runtime must initialise before libzkp_mi355x.so: run with -m gpu)")
+    return torch
+
+
+def _dev(a):
+    torch = _torch()
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
@@ -34,7 +39,7 @@ def _cmz_fused_statement():
 
 @pytest.mark.parametrize("flags", [0, 1])
 def test_msm_many_dev_equals_host_entry_and_oracle(eng, flags):
-    import torch
+    torch = _torch()
     rng = np.random.default_rng(3)
     n = 300
     mod, secrets, inst, common = _cmz_batch(n, 5)
@@ -62,7 +67,7 @@ def test_msm_many_dev_equals_host_entry_and_oracle(eng, flags):
 @pytest.mark.parametrize("n", [40, 1500])
 def test_fused_dev_flows_equal_host_pointer_flows(eng, n):
     """zkp_fused_prove_dev / _verify_compact_dev / _batch_verify_dev against zkp_fused_prove / ... (through the toolbox)."""
-    import torch
+    torch = _torch()
     mod, secrets, inst, common = _cmz_batch(n, 17)
     st = mod.statement
     fst = _cmz_fused_statement()

@@ -102,10 +102,18 @@ k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t*
       }
       if (op.dst_buf) {                                 // PRF output: the bytes of word w that live in this half
         uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + (size_t)j * op.stride + op.off;
-        const uint32_t v = col[TR_BLOCK * op.w];
-        for (uint32_t k = 0; k < op.dnb; ++k) {
-          const uint32_t b = op.dlb + k;
-          if ((b >> 2) == h && live) d[k] = (uint8_t)(v >> (8 * (b & 3)));
+        // this half holds bytes [4h, 4h + 4) of the word; its share of [dlb, dlb + dnb) is one run: a whole half goes
+        // out as one (possibly unaligned) 32-bit store
+        const uint32_t lo = op.dlb > 4 * h ? op.dlb : 4 * h;
+        const uint32_t hi = op.dlb + op.dnb < 4 * h + 4 ? op.dlb + op.dnb : 4 * h + 4;
+        if (hi > lo && live) {
+          const uint32_t v = col[TR_BLOCK * op.w] >> (8 * (lo - 4 * h));
+          uint8_t* dp = d + (lo - op.dlb);
+          if (hi - lo == 4) {
+            __builtin_memcpy(dp, &v, 4);
+          } else {
+            for (uint32_t k = 0; k < hi - lo; ++k) dp[k] = (uint8_t)(v >> (8 * k));
+          }
         }
       }
       if (op.src_buf && !(op.flags & TR_CHECK_NONZERO)) {

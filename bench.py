@@ -315,7 +315,7 @@ def main():
         out["step_valu"] = {"wave_instructions_per_step": step_valu, "lane_instructions_per_s": lane_instr / (ms_per_step * 1e-3) * world / world,
                             "peak_lane_instructions_per_s": VALU_PEAK_MADS, "frac": lane_instr / (ms_per_step * 1e-3) / VALU_PEAK_MADS,
                             "note": "simple 32-bit adds / fma issue at twice this class's rate, so frac slightly understates the headroom"}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(n, secrets, inst, common, d_ent.cpu().numpy(), d_w.cpu().numpy())
         out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
     print(json.dumps(out))

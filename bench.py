@@ -143,8 +143,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("ZKP_BENCH_DRYRUN_ONE_GPU"):
+            # dry run of the multi-rank logic on a box with a single GPU (all ranks on cuda:0, gloo instead of RCCL):
+            # exercises the barriers, the MAX over ranks and the verdict reduction -- not a measurement
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     n_streams = max(1, args.streams)

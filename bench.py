@@ -287,11 +287,13 @@ def main():
     valu = mads / t_terms if t_terms > 0 else 0.0
     traffic = None
     step_valu = None
+    kernel_valu = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")       # rocprofv3 --pmc passes of this same command
     if os.path.exists(pmc) and n == 4096:
         try:
             pj = json.load(open(pmc))
             traffic = pj["k_terms_split<true>"]["hbm_bytes_per_launch"]
+            kernel_valu = pj["k_terms_split<true>"]["SQ_INSTS_VALU"]
             step_valu = pj["_step_totals"]["valu_wave_instructions_per_step"]
         except Exception:
             pass
@@ -314,6 +316,11 @@ def main():
                      "valu_achieved_mads_per_s": valu, "valu_peak_mads_per_s": VALU_PEAK_MADS, "valu_frac": valu / VALU_PEAK_MADS,
                      "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": k_prove["terms"]},
     }
+    if kernel_valu:
+        # every VALU instruction of the dominant kernel (PMC SQ_INSTS_VALU: multiplications, carries, constant-time selects ...)
+        # per second of its launch, against the same issue peak
+        out["roofline"]["valu_issue_lane_instr_per_s"] = kernel_valu * 64.0 / t_terms
+        out["roofline"]["valu_issue_frac"] = kernel_valu * 64.0 / t_terms / VALU_PEAK_MADS
     if step_valu:
         # every VALU instruction of one step (PMC SQ_INSTS_VALU, all kernels) against the measured 4-cycle-class issue peak:
         # how close the pipelined step as a whole runs to the integer-VALU roofline

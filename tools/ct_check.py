@@ -1,0 +1,74 @@
+"""Evidence for the constant-time claim of the ZKP_CT schedule (prover.rs:94 promises a constant-time multiscalar_mul):
+run the SAME CMZ prover job (45,056 MSMs / 126,976 terms) with very different scalar sets and let rocprofv3 count the
+executed instructions of every kernel.  If instruction counts and memory-instruction counts are identical, no branch and
+no load/store was taken or skipped because of a scalar.
+
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES \\
+              --output-format csv -d OUT -o ct -- python tools/ct_check.py
+    python tools/ct_check.py --summarise OUT/ct_counter_collection.csv"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+PATTERNS = ["zero", "one", "l-1", "all-ones-252", "random-a", "random-b"]
+
+
+def scalars(kind, n, rng):
+    L = 2**252 + 27742317777372353535851937790883648493
+    if kind == "zero":
+        v = 0
+    elif kind == "one":
+        v = 1
+    elif kind == "l-1":
+        v = L - 1
+    elif kind == "all-ones-252":
+        v = (1 << 252) - 1
+    else:
+        s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        s[:, 31] &= 0x0f
+        return s
+    return np.tile(np.frombuffer(v.to_bytes(32, "little"), np.uint8), (n, 1))
+
+
+def run():
+    import bench
+    from zkp_amd.engine import Engine, ZKP_CT
+    eng = Engine(0)
+    n = 4096
+    rng = np.random.default_rng(5)
+    off, pidx, n_pts = bench.cmz_shape(n)
+    base = np.frombuffer(bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"), np.uint8).reshape(1, 32)
+    ks = rng.integers(0, 256, size=(n_pts, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x0f
+    pts, st = eng.msm_many(np.arange(n_pts + 1, dtype=np.uint32), ks, np.zeros(n_pts, np.uint32), base, ZKP_CT)
+    eng.prepare_fixed_points(pts[:11])
+    for kind in PATTERNS:                       # one msm_many(ZKP_CT) call per pattern, in this order
+        out, st = eng.msm_many(off, scalars(kind, 31 * n, rng), pidx, pts, ZKP_CT)
+        assert not st.any()
+    eng.close()
+
+
+def summarise(path):
+    import csv, collections
+    rows = list(csv.DictReader(open(path)))
+    per = collections.defaultdict(lambda: collections.defaultdict(list))      # kernel -> counter -> values in dispatch order
+    for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
+        per[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print("# kernels of the ZKP_CT path: executed-instruction counters of the last %d launches (one per scalar pattern: %s)" % (len(PATTERNS), ", ".join(PATTERNS)))
+    ok = True
+    for k in ("k_terms_split<true>", "k_reduce_encode<unsigned char>", "zkp::k_comb_tables", "k_decode_affine"):
+        if k not in per:
+            continue
+        for c, v in sorted(per[k].items()):
+            tail = v[-len(PATTERNS):]
+            same = len(set(tail)) == 1
+            ok &= same
+            print("%-34s %-18s %s  %s" % (k, c, "IDENTICAL" if same else "DIFFERENT", " ".join("%.0f" % x for x in tail)))
+    print("# verdict:", "every counter identical across scalar patterns" if ok else "counters differ")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
+        summarise(sys.argv[2])
+    else:
+        run()

@@ -355,3 +355,89 @@ def test_degenerate_statements_fused_equals_host_route(eng, shape):
     # the prover's commitment is the identity, the verifier recomputes (-c) P; every route must reject
     assert out["fused"][4].all() if shape == "lhs_only" else not out["fused"][4].any()
     assert out["fused"][6][0] == (shape != "lhs_only")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_statements_fused_equals_host_route_and_oracle(eng, seed):
+    """Randomly shaped statements through both routes and the oracle: 1-6 secrets, 0-4 common points, free and derived
+    instance points ALLOCATED IN SHUFFLED ORDER (common and instance interleaved, like the constraint API allows),
+    1-4 constraints with 1-5 terms each, secrets and points reused across constraints, a point that no constraint uses."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(33, 120))
+    m = int(rng.integers(1, 7))
+    n_common = int(rng.integers(0, 5))
+    n_free = int(rng.integers(1, 4))                # instance points that are given (random per proof)
+    nc = int(rng.integers(1, 5))
+    if n_common + n_free == 0:
+        n_free = 1
+    names = [("K%d" % i, True) for i in range(n_common)] + [("F%d" % i, False) for i in range(n_free)] + [("L%d" % k, False) for k in range(nc)]
+    names.append(("U", bool(rng.integers(0, 2))))   # used by no constraint, must still decode
+    order = rng.permutation(len(names))
+    rhs_pool = list(range(n_common + n_free))
+    cons = []
+    for k in range(nc):
+        terms = [(int(rng.integers(0, m)), int(rng.choice(rhs_pool))) for _ in range(int(rng.integers(1, 6)))]
+        cons.append((n_common + n_free + k, terms))
+    # values
+    secrets = rng.integers(0, 256, size=(n, m, 32), dtype=np.uint8)
+    secrets[:, :, 31] &= 0x0f
+    commonv, _ = _random_points(n_common + 1, rng)                       # + U if common
+    freev = [_random_points(n, rng)[0] for _ in range(n_free + 1)]       # per-proof values (+ U if instance)
+    val = {}                                                             # name index -> [n][32] or [32]
+    for i in range(n_common):
+        val[i] = commonv[i]
+    for i in range(n_free):
+        val[n_common + i] = freev[i]
+    for k, (lhs, terms) in enumerate(cons):
+        table = np.concatenate([commonv[:n_common]] + [freev[i] for i in range(n_free)])      # common, then free rows [n_free][n]
+        off = (np.arange(n + 1, dtype=np.uint64) * len(terms)).astype(np.uint32)
+        sc = np.stack([secrets[:, s] for s, _ in terms], axis=1).reshape(n * len(terms), 32)
+        pidx = np.array([[p if p < n_common else n_common + (p - n_common) * n + j for _, p in terms] for j in range(n)], np.uint32).reshape(-1)
+        L, st_ = C.msm_many(off, sc, pidx, table, 0)
+        assert not st_.any()
+        val[lhs] = L
+    u_idx = len(names) - 1
+    val[u_idx] = commonv[n_common] if names[u_idx][1] else freev[n_free]
+    # statements in the shuffled allocation order
+    st = T.Statement(b"random statement %d" % seed)
+    svars = [st.add_secret(b"s%d" % i) for i in range(m)]
+    pvar = {}
+    for a in order:
+        pvar[int(a)] = st.add_point(names[a][0].encode(), names[a][1])
+    for lhs, terms in cons:
+        st.constrain(pvar[lhs], [(svars[s], pvar[p]) for s, p in terms])
+    cst = C.Statement(b"random statement %d" % seed, ["s%d" % i for i in range(m)], [names[a] for a in order],
+                      [(names[lhs][0], [("s%d" % s, names[p][0]) for s, p in terms]) for lhs, terms in cons])
+    inst_rows = [val[int(a)] for a in order if not names[a][1]]
+    common_rows = [val[int(a)] for a in order if names[a][1]]
+    inst = np.ascontiguousarray(np.stack(inst_rows))
+    common = np.ascontiguousarray(np.stack(common_rows)) if common_rows else np.zeros((0, 32), np.uint8)
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    w = rng.integers(0, 256, size=(nc, n, 16), dtype=np.uint8)
+    label = b"fuzz"
+    out = {}
+    for route, thr in (("host", NEVER), ("fused", 0)):
+        T.set_fused_min_batch(thr)
+        ts = _fresh(label, n)
+        chal, resp, coms = T.prove_batch(eng, st, ts, secrets, inst, common, entropy)
+        ts2 = _fresh(label, n)
+        res = T.verify_compact_batch(eng, st, ts2, inst, common, chal, resp)
+        ts3 = _fresh(label, n)
+        ok, coeffs = T.batch_verify_coeffs(eng, st, ts3, inst, common, coms, resp, w)
+        ts4 = _fresh(label, n)
+        each = T.verify_batchable_each(eng, st, ts4, inst, common, coms, resp, np.ascontiguousarray(w.transpose(1, 0, 2)))
+        bad = resp.copy()
+        bad[n // 2, 0, 0] ^= 1
+        ts5 = _fresh(label, n)
+        res_bad = T.verify_compact_batch(eng, st, ts5, inst, common, chal, bad)
+        out[route] = (chal, resp, coms, ts[:, :203], res, ts2[:, :203], coeffs, ts3[:, :203], each, res_bad)
+        assert ok and not res.any() and not each.any()
+        assert res_bad[n // 2] == 1 and res_bad.sum() == 1
+    T.set_fused_min_batch(32)
+    for a, b in zip(out["host"], out["fused"]):
+        assert (a == b).all()
+    # the oracle, in the same allocation order (its point list is the allocation order)
+    for j in (0, n - 1):
+        pts_j = np.stack([val[int(a)] if names[a][1] else val[int(a)][j] for a in order])
+        ec, er, ek, _ = C.prove(cst, label, secrets[j], pts_j, entropy[j].tobytes())
+        assert out["fused"][0][j].tobytes() == ec.tobytes() and (out["fused"][1][j] == er).all() and (out["fused"][2][j] == ek).all()

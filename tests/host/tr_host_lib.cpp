@@ -18,10 +18,11 @@ extern "C" int t_tr_selftest(uint32_t seed, uint32_t N, uint32_t m, uint32_t np,
     for (auto& ch : s) ch = (char)('a' + rng() % 26);
     return s;
   };
-  const std::string tlabel = rand_label(40), plabel = rand_label(30);
+  const bool long_labels = seed >= 1000;                  // labels longer than a STROBE block (166 bytes)
+  const std::string tlabel = rand_label(40), plabel = rand_label(long_labels ? 500 : 30);
   std::vector<std::string> sl(m), pl(np);
-  for (auto& s : sl) s = rand_label(12);
-  for (auto& s : pl) s = rand_label(12);
+  for (auto& s : sl) s = rand_label(long_labels ? 300 : 12);
+  for (auto& s : pl) s = rand_label(long_labels ? 300 : 12);
   const std::string pre = rand_label(200);                 // a message appended before the proof: varies pos
   std::vector<uint8_t> secrets(32 * (size_t)N * m), pts(32 * (size_t)np * N), ent(32 * (size_t)N), coms(32 * (size_t)N * nc), msg(32 * (size_t)N);
   for (auto* v : {&secrets, &pts, &ent, &coms, &msg}) for (auto& b : *v) b = (uint8_t)rng();

@@ -29,7 +29,8 @@ def lib():
     (4, 4, 1, 0, 0, 9),         # no points, no constraints
     (5, 3, 64, 65, 1, 1),       # W64 shape
     (6, 7, 3, 3, 2, 6),         # DLEQ-like
-] + [(100 + s, 2, 1 + s % 5, 1 + s % 7, 1 + s % 3, s % 3) for s in range(24)])   # positions sweep the 166-byte rate
+] + [(100 + s, 2, 1 + s % 5, 1 + s % 7, 1 + s % 3, s % 3) for s in range(24)]     # positions sweep the 166-byte rate
+  + [(1000 + s, 3, 2 + s, 3 + s, 2, 1) for s in range(4)])                        # labels of several STROBE blocks
 def test_compiled_program_equals_host_merlin(lib, args):
     rc = lib.t_tr_selftest(*args)
     assert rc > 0, f"mismatch bits {-rc}"

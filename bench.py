@@ -113,14 +113,27 @@ def cmz_instance(eng, n, rng):
     return secrets, inst, np.ascontiguousarray(common)
 
 
+def pick_streams(steps):
+    """Batches in flight.  A batch is a chain of ~70 kernels, several of them only a few dozen wavefronts wide, so the chip
+    is filled by running independent batches side by side.  With K timed steps over S streams the last round of batches
+    runs with K mod S streams busy; pick S in 12..24 that leaves the fewest idle slots (ties: more streams)."""
+    if steps <= 24:
+        return max(1, steps)
+    best = min(range(12, 25), key=lambda s: ((-steps) % s, -s))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU per step (BASELINE configs[1]: 4096)")
-    ap.add_argument("--streams", type=int, default=16, help="independent batches in flight, each on its own HIP stream / engine context")
+    ap.add_argument("--streams", type=int, default=0, help="independent batches in flight, each on its own HIP stream / engine context "
+                                                            "(0 = automatic: 12..24, the count that splits --steps most evenly)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
+                    help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -129,6 +142,8 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    if args.streams <= 0:
+        args.streams = pick_streams(args.steps)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(args.streams, 24))))      # one hardware queue per stream (default is 4)
     import numpy as np
     import torch
@@ -158,6 +173,8 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     for e_, s_ in zip(engines, streams):
         e_.set_stream(s_.cuda_stream)          # engine work and the torch copies of one batch share one HIP stream
+        for kv in args.engine_opt:
+            e_.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     eng = engines[0]
 
     n = args.batch

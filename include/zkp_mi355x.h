@@ -60,8 +60,15 @@ const char* zkp_version(void);
  *     2 * H with H = sum (s_i / 2) P_i, which needs one field inversion per 65,536 outputs instead of an inverse square
  *     root per output (the identity behind curve25519-dalek's double_and_compress_batch): 10 x fewer instructions in the
  *     encoding step, three short kernels instead of one (default 65536: below that the extra latency outweighs the
- *     instructions saved; 0 = always, UINT64_MAX = never). */
-enum { ZKP_OPT_BATCH_ENCODE_MIN = 1 };
+ *     instructions saved; 0 = always, UINT64_MAX = never).  Unless the option is set, the asynchronous _dev
+ *     entry points, whose callers keep many calls in flight, use 2048.
+ *   ZKP_OPT_COMB_TEETH: comb-table shape zkp_msm_many_dev uses for points that two or more terms of a call multiply
+ *     (4 or 16; default 4).  16 suits calls whose shared points carry about six or more terms each (16 instead of 64
+ *     doublings per term, a 4 x larger table per point).  Every other entry point derives the shape from its inputs.
+ *   ZKP_OPT_CT_SINGLE_USE_TABLES: whether ZKP_CT calls build a comb table also for a point that a single term multiplies
+ *     (1, default) or walk a constant-time radix-16 ladder over the point's own eight multiples (0: ~25 % fewer
+ *     instructions for that term, but a 321-operation dependent chain inside the term kernel). */
+enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* Performance hint, never changes a result: declare points that very many terms of later zkp_msm_many calls
@@ -143,6 +150,10 @@ typedef struct {
   const char* const* secret_labels;   /* [n_secrets]                                                                      */
   const char* const* point_labels;    /* [n_static + n_instance], indexed by point id                                     */
   const uint32_t* alloc_order;        /* [n_static + n_instance] point ids in allocation (= transcript) order             */
+  const uint32_t* alloc_seq;          /* NULL: every secret is allocated before the first point (define_proof!'s order,   */
+                                      /* macros.rs:215-242).  Otherwise [n_secrets + n_static + n_instance] entries, the  */
+                                      /* caller's allocate_scalar / allocate_point calls in order: 0x80000000 | secret     */
+                                      /* index, or a point id (the points must come in alloc_order's order).              */
 } zkp_fused_statement;
 /* N x { build_prover (macros.rs:206-258) ; Prover::prove_impl (prover.rs:76-112) }.  *invalid_point = 1 if some input
  * encoding did not decode (the reference prover holds decoded points, so this is a caller bug there). */

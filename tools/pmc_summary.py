@@ -31,7 +31,7 @@ def main():
         print("%-34s %s" % (k[-34:], "  ".join("%s=%.4g" % (c, v) for c, v in sorted(row.items()))))
     # whole-step totals: one k_terms_split<true> launch per bench step (set-up launches of other kernels excluded by
     # scaling every kernel's per-launch average with launches / steps, capped at what a step can contain)
-    steps = res.get("k_terms_split<true>", {}).get("launches")
+    steps = max([v.get("launches", 0) for k, v in res.items() if k.startswith("k_terms_split<true")] or [0])
     if steps:
         tot = sum(v["SQ_INSTS_VALU"] * v["launches"] for k, v in res.items() if "SQ_INSTS_VALU" in v and "k_hot_" not in k) / steps
         res["_step_totals"] = {"steps": steps, "valu_wave_instructions_per_step": tot,

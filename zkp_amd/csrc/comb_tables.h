@@ -1,22 +1,40 @@
 // Comb tables for the points that do NOT have a fixed-base table (per-proof points such as P, Q of the CMZ statement).
 //
 // A generic term s*P costs 256 doublings + 128 additions in the radix-4 ladder (term_generic).  Splitting the scalar
-// into four 64-bit chunks, s = s0 + 2^64 s1 + 2^128 s2 + 2^192 s3, and tabulating  k * 2^(64 j) * P  (j < 4, k = 1..8)
-// once per DISTINCT point turns it into a 4-way interleaved radix-16 walk: 16 windows x (4 doublings + 4 additions)
-// = 64 doublings + 64 additions per term.  Building the table costs ~256 doublings per point, i.e. what ONE term used
-// to cost -- and in the reference's statements a per-proof point is typically shared by many terms (CMZ: P appears in
-// 10 of the 11 constraints of a proof, benches/zkp.rs:34-43), so the doublings are amortised.  Even a point used once
-// breaks even (more doublings up front, half the additions).
+// into TEETH chunks of 256/TEETH bits, s = sum_j 2^(BITS j) s_j, and tabulating  k * 2^(BITS j) * P  (j < TEETH,
+// k = 1..8) once per DISTINCT point turns it into a TEETH-way interleaved radix-16 walk: BITS/4 windows x (4 doublings +
+// TEETH additions) = BITS doublings + 64 additions per term.  Building the table costs 256 doublings + 7 TEETH point
+// operations per point -- and in the reference's statements a per-proof point is typically shared by many terms (CMZ: P
+// appears in 10 of the 11 constraints of a proof, benches/zkp.rs:34-43), so it is amortised.  Point operations per
+// point with u terms:   256 + 7 TEETH + u (256 / TEETH + 64),   minimal at TEETH ~ sqrt(256 u / 7):
+//     TEETH = 4  (64 doublings per term, 33-entry table, 4.75 KB)   for points with a few uses,
+//     TEETH = 16 (16 doublings per term, 129-entry table, 18.6 KB)  from about 6 uses per point on (CMZ's P: 1564 -> 1168).
+// The first window's four doublings act on the identity and are skipped (12 doublings per term at TEETH = 16).
+// Each row of the TEETH = 16 table is read by exactly one window of a term, so the constant-time scans stream the table
+// once per term instead of cycling 4 rows 16 times through a cache they do not fit (round 1: 556 MB of fabric traffic
+// per launch for 9.6 MB of algorithmic bytes).
 //
-// The table is built by a QUAD of lanes per point (quad.h), because it is a 260-long dependent chain.
-// Layout per point: 33 entries of 144 B in the quad-cached order (Y-X, Y+X, 2Z, 2dT):
-//     entry 8 j + (k-1) = k * 2^(64 j) * P   (j = 0..3, k = 1..8),      entry 32 = 2^256 * P  (carry window)
+// Only points with at least two cold uses get a table; tables are addressed through a compact slot index (slot_of[]),
+// so the workspace holds  #table points x entries  rather than  #points x entries.  Single-use points go to a signed
+// radix-16 ladder over their own eight multiples (term_ladder16: 256 doublings + 65 additions, against 256 + 7 TEETH +
+// BITS + 65 for table + walk), constant-time (masked scans) or variable-time.
+//
+// Layout per table: 8 TEETH + 1 entries of 144 B in the quad-cached order (Y-X, Y+X, 2Z, 2dT):
+//     entry 8 j + (k-1) = k * 2^(BITS j) * P   (j < TEETH, k = 1..8),      entry 8 TEETH = 2^256 * P  (carry window)
 #pragma once
 #include "quad.h"
 
 namespace zkp {
 
-constexpr int COMB_ENTRIES = 33;
+template <int TEETH>
+struct comb_cfg {
+  static_assert(TEETH == 4 || TEETH == 8 || TEETH == 16 || TEETH == 32, "teeth");
+  static constexpr int BITS = 256 / TEETH;          // scalar bits per tooth
+  static constexpr int WINDOWS = BITS / 4;          // radix-16 windows per tooth
+  static constexpr int ENTRIES = 8 * TEETH + 1;
+};
+constexpr int comb_entries(int teeth) { return 8 * teeth + 1; }
+constexpr int LADDER_ENTRIES = 8;                   // per ladder term: 1 P .. 8 P
 
 __device__ __forceinline__ void q_store_cached(dev_ext* dst, const qcached& c, int q) {
   uint32_t* w = reinterpret_cast<uint32_t*>(dst) + 9 * q;
@@ -24,13 +42,40 @@ __device__ __forceinline__ void q_store_cached(dev_ext* dst, const qcached& c, i
   for (int i = 0; i < 9; ++i) w[i] = c.c.v[i];
 }
 
+// slot_of[p] = compact table index of every point with >= comb_min cold uses (wave-aggregated counter: one device-scope
+// atomic per wavefront); slot_pt[slot] = p.  The order of the slots is irrelevant to the results.
+__global__ void __launch_bounds__(256)
+k_comb_slots(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t max_tables,
+             uint32_t* __restrict__ counter, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ slot_pt) {
+  const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool want = pi < n_points && uses[pi] >= comb_min;
+  const uint64_t mask = __ballot(want);
+  if (!mask) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = (uint32_t)__shfl((int)base, leader);
+  if (want) {
+    const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    // max_tables is an upper bound by construction (every table point has >= 2 of the call's terms); a slot beyond it
+    // would be a bug in the caller's bound: the point then keeps no table and its terms are flagged (k_reduce_encode)
+    slot_of[pi] = slot < max_tables ? slot : 0xffffffffu;
+    if (slot < max_tables) slot_pt[slot] = pi;
+  }
+}
+
+template <int TEETH>
 __global__ void __launch_bounds__(256, 2)
-k_comb_tables(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t comb_min, const dev_affine* __restrict__ pts,
-              dev_ext* __restrict__ comb) {
+k_comb_tables(const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
+              const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
+  using cfg = comb_cfg<TEETH>;
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t pi = gt >> 2;
+  const uint32_t slot = gt >> 2;
   const int q = (int)(gt & 3u);
-  if (pi >= n_points || uses[pi] < comb_min) return;    // uniform within the quad
+  const uint32_t ns = min(*n_slots, max_tables);
+  if (slot >= ns) return;                                 // uniform within the quad
+  const uint32_t pi = slot_pt[slot];
   qpt base;
   {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(pts + pi);      // x[9] y[9] t[9] valid
@@ -39,9 +84,9 @@ k_comb_tables(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t com
 #pragma unroll
     for (int i = 0; i < 9; ++i) base.c.v[i] = q == 0 ? w[i] : (q == 1 ? w[9 + i] : (q == 3 ? w[18 + i] : one.v[i]));
   }
-  dev_ext* tbl = comb + (size_t)pi * COMB_ENTRIES;
+  dev_ext* tbl = comb + (size_t)slot * cfg::ENTRIES;
 #pragma unroll 1
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < TEETH; ++j) {
     qpt m2, m3, m4, m;
     qcached c1, c;
     q_to_cached(c1, base, q);
@@ -61,11 +106,11 @@ k_comb_tables(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t com
     q_double(base, m4, q);                                                 // 8
     q_to_cached(c, base, q); q_store_cached(tbl + 8 * j + 7, c, q);
 #pragma unroll 1
-    for (int d = 0; d < 61; ++d) q_double(base, base, q);                  // 8 * 2^61 = 2^64
+    for (int d = 0; d < cfg::BITS - 3; ++d) q_double(base, base, q);       // 8 * 2^(BITS-3) = 2^BITS
   }
   qcached c;
   q_to_cached(c, base, q);                                                 // 2^256 * P
-  q_store_cached(tbl + 32, c, q);
+  q_store_cached(tbl + 8 * TEETH, c, q);
 }
 
 // The same table built by ONE lane per point: about half the instructions of the quad version (no DPP exchanges, no
@@ -76,16 +121,19 @@ __device__ __forceinline__ void store_comb_entry(dev_ext* dst, const ge_cached& 
   fe_get(w, c.YmX); fe_get(w + 9, c.YpX); fe_get(w + 18, c.Z2); fe_get(w + 27, c.T2d);
   store_vec<9>(dst, w);
 }
+template <int TEETH>
 __global__ void __launch_bounds__(256, 2)
-k_comb_tables_lane(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t comb_min, const dev_affine* __restrict__ pts,
-                   dev_ext* __restrict__ comb) {
-  const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= n_points || uses[pi] < comb_min) return;
+k_comb_tables_lane(const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
+                   const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
+  using cfg = comb_cfg<TEETH>;
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ns = min(*n_slots, max_tables);
+  if (slot >= ns) return;
   ge_p3 base;
-  load_affine(base, pts + pi);
-  dev_ext* tbl = comb + (size_t)pi * COMB_ENTRIES;
+  load_affine(base, pts + slot_pt[slot]);
+  dev_ext* tbl = comb + (size_t)slot * cfg::ENTRIES;
 #pragma unroll 1
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < TEETH; ++j) {
     ge_p3 m2, m3, m4, m;
     ge_cached c1, c;
     ge_to_cached(c1, base);
@@ -105,12 +153,12 @@ k_comb_tables_lane(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_
     ge_double<true>(base, m4);                                             // 8
     ge_to_cached(c, base); store_comb_entry(tbl + 8 * j + 7, c);
 #pragma unroll 1
-    for (int d = 0; d < 60; ++d) ge_double<false>(base, base);
-    ge_double<true>(base, base);                                           // 8 * 2^61 = 2^64
+    for (int d = 0; d < cfg::BITS - 4; ++d) ge_double<false>(base, base);
+    ge_double<true>(base, base);                                           // 8 * 2^(BITS-3) = 2^BITS
   }
   ge_cached c;
   ge_to_cached(c, base);                                                   // 2^256 * P
-  store_comb_entry(tbl + 32, c);
+  store_comb_entry(tbl + 8 * TEETH, c);
 }
 
 __device__ __forceinline__ void load_comb_entry(ge_cached& c, const dev_ext* src) {
@@ -119,43 +167,51 @@ __device__ __forceinline__ void load_comb_entry(ge_cached& c, const dev_ext* src
   fe_set(c.YmX, w); fe_set(c.YpX, w + 9); fe_set(c.Z2, w + 18); fe_set(c.T2d, w + 27);
 }
 
-// partial[t] = scalars[t] * P through P's comb table.  CT: every window reads all 8 entries of each chunk row and
-// picks with masks; the instruction stream and the addresses do not depend on the scalar.
+// sel = (mag ? row[mag - 1] : identity) for mag in 0..8.  CT: all 8 entries of the row are read and the entry is picked
+// with masks, two entries (18 independent 16-byte loads) in flight at a time.
 template <bool CT>
+__device__ __forceinline__ void comb_select(ge_cached& sel, const dev_ext* __restrict__ row, uint32_t mag) {
+  ge_cached_identity(sel);
+  if (CT) {
+#pragma unroll 1
+    for (uint32_t h = 0; h < 4; ++h) {
+      ge_cached c0, c1;
+      load_comb_entry(c0, row + 2 * h + 0);
+      load_comb_entry(c1, row + 2 * h + 1);
+      ge_cached_cmov(sel, c0, (uint32_t)(mag == 2 * h + 1));
+      ge_cached_cmov(sel, c1, (uint32_t)(mag == 2 * h + 2));
+    }
+  } else if (mag) {
+    load_comb_entry(sel, row + (mag - 1));
+  }
+}
+
+// partial[t] = scalars[t] * P through P's comb table.  CT: no branch or address depends on the scalar.
+template <bool CT, int TEETH>
 __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict__ scalars, const dev_ext* __restrict__ tbl,
                                           dev_ext* __restrict__ partial) {
+  using cfg = comb_cfg<TEETH>;
   uint32_t s[8], e[8], top;
   load_vec<2>(s, scalars + 32 * (size_t)t);
   sc_add_pattern(e, top, s, 0x88888888u);                       // signed radix-16 digits: nibble - 8 in [-8, 7]
   ge_p3 acc;
   ge_identity(acc);
 #pragma unroll 1
-  for (int w = 15; w >= 0; --w) {
-    ge_double<false>(acc, acc);
-    ge_double<false>(acc, acc);
-    ge_double<false>(acc, acc);
-    ge_double<true>(acc, acc);
+  for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
+    if (w != cfg::WINDOWS - 1) {                                // (the accumulator is still the identity in the first window)
+      ge_double<false>(acc, acc);
+      ge_double<false>(acc, acc);
+      ge_double<false>(acc, acc);
+      ge_double<true>(acc, acc);
+    }
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t nib = (sel8(e, 2 * j + (w >> 3)) >> (4 * (w & 7))) & 15u;
+    for (int j = 0; j < TEETH; ++j) {
+      const int nidx = j * cfg::WINDOWS + w;                    // nibble number of tooth j, window w
+      const uint32_t nib = (sel8(e, nidx >> 3) >> (4 * (nidx & 7))) & 15u;
       const uint32_t neg = (uint32_t)(nib < 8u);
       const uint32_t mag = neg ? 8u - nib : nib - 8u;           // 0..8
-      const dev_ext* row = tbl + 8 * j;
       ge_cached sel;
-      ge_cached_identity(sel);
-      if (CT) {
-        // masked scan of the 8-entry row, two entries (18 independent 16-byte loads) in flight at a time
-#pragma unroll 1
-        for (uint32_t h = 0; h < 4; ++h) {
-          ge_cached c0, c1;
-          load_comb_entry(c0, row + 2 * h + 0);
-          load_comb_entry(c1, row + 2 * h + 1);
-          ge_cached_cmov(sel, c0, (uint32_t)(mag == 2 * h + 1));
-          ge_cached_cmov(sel, c1, (uint32_t)(mag == 2 * h + 2));
-        }
-      } else if (mag) {
-        load_comb_entry(sel, row + (mag - 1));
-      }
+      comb_select<CT>(sel, tbl + 8 * j, mag);
       ge_cached_cneg(sel, neg);
       ge_add_cached(acc, acc, sel);
     }
@@ -163,17 +219,18 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
   {
     ge_cached sel, c;
     ge_cached_identity(sel);
-    load_comb_entry(c, tbl + 32);
+    load_comb_entry(c, tbl + 8 * TEETH);
     ge_cached_cmov(sel, c, top);
     ge_add_cached(acc, acc, sel);
   }
   store_ext(partial + t, acc);
 }
 
-// partial[t] = scalars[t] * P for a point that no other term of a variable-time call uses (a constraint's left-hand side
-// in verify_compact): signed radix-16 ladder over P's own eight multiples, 256 doublings + 65 additions instead of the
-// radix-4 ladder's 256 + 128.  The multiples live in the point's (otherwise unused) comb-table slot.  Addresses depend on
-// the scalar: variable-time callers only.
+// partial[t] = scalars[t] * P for a point that no other cold term of the call uses (a constraint's left-hand side in
+// verify_compact; CMZ's Q in the prover): signed radix-16 ladder over P's own eight multiples, 256 doublings + 65
+// additions instead of the radix-4 ladder's 256 + 128.  The multiples live in the term's slot of the ladder scratch.
+// CT: the eight multiples are scanned with masks (prover.rs:94 semantics); otherwise the entry is loaded directly.
+template <bool CT>
 __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restrict__ scalars, const dev_affine* __restrict__ pt,
                                               dev_ext* __restrict__ tbl, dev_ext* __restrict__ partial) {
   uint32_t s[8], e[8], top;
@@ -207,19 +264,23 @@ __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restr
     ge_add_cached(acc, acc, sel);
   }
 #pragma unroll 1
-  for (int w = 63; w >= 0; --w) {
-    ge_double<false>(acc, acc);
-    ge_double<false>(acc, acc);
-    ge_double<false>(acc, acc);
-    ge_double<true>(acc, acc);
-    const uint32_t nib = (sel8(e, w >> 3) >> (4 * (w & 7))) & 15u;
-    const uint32_t neg = (uint32_t)(nib < 8u);
-    const uint32_t mag = neg ? 8u - nib : nib - 8u;             // 0..8
-    ge_cached sel;
-    ge_cached_identity(sel);
-    if (mag) load_comb_entry(sel, tbl + (mag - 1));
-    ge_cached_cneg(sel, neg);
-    ge_add_cached(acc, acc, sel);
+  for (int j = 7; j >= 0; --j) {
+    uint32_t cur = sel8(e, j);                                  // (the compiler keeps e[] in 32 B of scratch and loads the word: one dword per 8 windows)
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+      ge_double<false>(acc, acc);
+      ge_double<false>(acc, acc);
+      ge_double<false>(acc, acc);
+      ge_double<true>(acc, acc);
+      const uint32_t nib = cur >> 28;
+      cur <<= 4;
+      const uint32_t neg = (uint32_t)(nib < 8u);
+      const uint32_t mag = neg ? 8u - nib : nib - 8u;           // 0..8
+      ge_cached sel;
+      comb_select<CT>(sel, tbl, mag);
+      ge_cached_cneg(sel, neg);
+      ge_add_cached(acc, acc, sel);
+    }
   }
   store_ext(partial + t, acc);
 }

@@ -378,7 +378,27 @@ struct fused_plan {
   prog_dev a, b;
   const uint32_t* d_tarr = nullptr;   // toff[nc + 1] | tsc[T1] | tpt[T1] | unref[]
   const uint32_t* d_inc = nullptr;
+  std::vector<uint32_t> tpt;       // host copy of tpt[]: comb-table shape and table / ladder bounds of the flow's CSR job
 };
+
+// Table / ladder bounds and comb shape of a CSR job whose proofs all multiply the point ids tpt[] (ids < ns: common to the
+// batch; the others: one point per proof).  A common point that is registered for a fixed-base table leaves the cold
+// classes at run time, which only lowers the counts.
+terms_cfg cfg_from_terms(const uint32_t* tpt, uint32_t T1, uint32_t ns, uint32_t np, uint32_t N, uint32_t comb_min) {
+  std::vector<uint64_t> u(np, 0);
+  for (uint32_t i = 0; i < T1; ++i) ++u[tpt[i]];
+  uint64_t n_tab = 0, n_lad = 0, tab_terms = 0;
+  for (uint32_t p = 0; p < np; ++p) {
+    const uint64_t mult = p < ns ? 1 : N, uses = p < ns ? u[p] * N : u[p];
+    if (uses >= comb_min && uses) { n_tab += mult; tab_terms += uses * mult; } else if (uses == 1) n_lad += mult;
+  }
+  terms_cfg k;
+  k.comb_min = comb_min;
+  k.max_tables = (uint32_t)std::min<uint64_t>(n_tab, 0xffffffffu);
+  k.max_ladder = (uint32_t)std::min<uint64_t>(n_lad, 0xffffffffu);
+  k.teeth = pick_teeth(n_tab, tab_terms);
+  return k;
+}
 
 int check_fused_statement(const zkp_fused_statement* st, fused_shape& s) {
   if (!st) return fail(ZKP_ERR_ARG, "statement is NULL");
@@ -390,6 +410,21 @@ int check_fused_statement(const zkp_fused_statement* st, fused_shape& s) {
   for (uint32_t i = 0; i < s.np; ++i) {
     if (st->alloc_order[i] >= s.np || seen[st->alloc_order[i]]) return fail(ZKP_ERR_ARG, "alloc_order is not a permutation of the point ids");
     seen[st->alloc_order[i]] = 1;
+  }
+  if (st->alloc_seq) {                  // every secret once, the points in alloc_order's order
+    std::vector<char> sec_seen(s.m, 0);
+    uint32_t next_pt = 0;
+    for (uint32_t a = 0; a < s.m + s.np; ++a) {
+      const uint32_t e = st->alloc_seq[a];
+      if (e & 0x80000000u) {
+        const uint32_t i = e & 0x7fffffffu;
+        if (i >= s.m || sec_seen[i]) return fail(ZKP_ERR_ARG, "alloc_seq: secret index out of range or repeated");
+        sec_seen[i] = 1;
+      } else {
+        if (next_pt >= s.np || st->alloc_order[next_pt] != e) return fail(ZKP_ERR_ARG, "alloc_seq: points must follow alloc_order");
+        ++next_pt;
+      }
+    }
   }
   return ZKP_OK;
 }
@@ -407,14 +442,22 @@ int common_tail(const uint8_t* ts, uint32_t N, uint32_t* pos) {
 // compiled program does not depend on any value.
 void compile_allocations(TrCompiler& tc, const zkp_fused_statement* st, const fused_shape& s, uint32_t N, bool validate) {
   tc.domain_sep(st->label);
-  for (uint32_t i = 0; i < s.m; ++i) tc.append_scalar_var(st->secret_labels[i]);
-  for (uint32_t a = 0; a < s.np; ++a) {
-    const uint32_t p = st->alloc_order[a];
+  auto point = [&](uint32_t p) {
     tr_ref ref;
     if (p < s.ns) ref = tr_ref{SRC_TABLE, 0, 32ull * p};
     else ref = tr_ref{SRC_TABLE, 32, 32ull * (s.ns + (uint64_t)(p - s.ns) * N)};
     tc.append_point_var_var(st->point_labels[p], ref, validate);
+  };
+  if (st->alloc_seq) {                                   // the caller's interleaving of scalar and point allocations
+    for (uint32_t a = 0; a < s.m + s.np; ++a) {
+      const uint32_t e = st->alloc_seq[a];
+      if (e & 0x80000000u) tc.append_scalar_var(st->secret_labels[e & 0x7fffffffu]);
+      else point(e);
+    }
+    return;
   }
+  for (uint32_t i = 0; i < s.m; ++i) tc.append_scalar_var(st->secret_labels[i]);
+  for (uint32_t a = 0; a < s.np; ++a) point(st->alloc_order[a]);
 }
 
 std::string plan_key(char flow, const zkp_fused_statement* st, const fused_shape& s, uint32_t N, uint32_t pos) {
@@ -427,6 +470,7 @@ std::string plan_key(char flow, const zkp_fused_statement* st, const fused_shape
   for (uint32_t i = 0; i < s.np; ++i) { str(st->point_labels[i]); u32(st->alloc_order[i]); }
   for (uint32_t i = 0; i < s.nc; ++i) { u32(st->shape.cons_lhs[i]); u32(st->shape.cons_off[i + 1]); }
   for (uint32_t i = 0; i < s.T; ++i) { u32(st->shape.cons_sc[i]); u32(st->shape.cons_pt[i]); }
+  if (st->alloc_seq) for (uint32_t a = 0; a < s.m + s.np; ++a) u32(st->alloc_seq[a]);
   return k;
 }
 
@@ -469,6 +513,7 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
     for (uint32_t k = 0; k < nc; ++k) tarr[k + 1] = st->shape.cons_off[k + 1];
     if (s.T) { tarr.insert(tarr.end(), st->shape.cons_sc, st->shape.cons_sc + s.T); tarr.insert(tarr.end(), st->shape.cons_pt, st->shape.cons_pt + s.T); }
     pl->T1 = s.T;
+    pl->tpt.assign(st->shape.cons_pt, st->shape.cons_pt + s.T);
   } else if (flow == FLOW_VERIFY) {
     compile_allocations(ta, st, s, N, true);                            // verifier.rs:61-77 validating appends
     pa = ta.finish(tailA);
@@ -489,6 +534,7 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
       tarr[k + 1] = (uint32_t)vsc.size();
     }
     pl->T1 = (uint32_t)vsc.size();
+    pl->tpt = vpt;
     tarr.insert(tarr.end(), vsc.begin(), vsc.end());
     tarr.insert(tarr.end(), vpt.begin(), vpt.end());
     tarr.insert(tarr.end(), s.unref.begin(), s.unref.end());
@@ -601,12 +647,14 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   uint64_t* d_saved = reinterpret_cast<uint64_t*>(w.base + o.saved);
   prof_begin(c);
   const size_t lanes = std::max<size_t>((size_t)N * T, (size_t)N * nc) + 1;
+  terms_cfg tk = cfg_from_terms(pl.tpt.data(), T, pl.s.ns, pl.s.np, N, c->ct_comb_min);
+  tk.throughput = !overlap;
   {   // side stream: operand indices, decode, classification, comb tables (nothing here depends on the blindings)
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
     if (rc) return rc;
     hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T, w.u32(o.off), w.u32(o.pidx));
-    if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_POINTS, /*lane_tables=*/!overlap);
+    if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_POINTS, tk);
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) return rc ? rc : rc2;
   }
@@ -619,7 +667,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   {
     int rc = side_join(c, overlap);
     if (rc) return rc;
-    if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_SCALARS);
+    if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_SCALARS, tk);
     if (rc) return rc;
   }
   run_program(c, pl.b, N, hb, d_ts, d_saved, w.u32(o.failed));
@@ -659,13 +707,15 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
   prof_begin(c);
   const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
+  terms_cfg tk = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2);
+  tk.throughput = !overlap;
   {   // side stream: operand indices and the point phase.  With no constraints there is no MSM, but every allocated
       // point must still decode (verifier.rs:87-92)
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
     if (rc) return rc;
     hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T1, w.u32(o.off), w.u32(o.pidx));
-    rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_POINTS, /*lane_tables=*/!overlap);
+    rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_POINTS, tk);
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) return rc ? rc : rc2;
   }
@@ -677,7 +727,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   HIP_TRY(hipGetLastError());
   int rc = side_join(c, overlap);
   if (rc) return rc;
-  rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_SCALARS);
+  rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_SCALARS, tk);
   if (rc) return rc;
   run_program(c, pl.b, N, hb, d_ts, nullptr, w.u32(o.failed));
   prof_mark(c, ZKP_K_TRANSCRIPT);
@@ -749,6 +799,15 @@ each_inter each_carve(const fused_plan& pl, size_t start) {
   o.end = cv.off;
   return o;
 }
+// verify_batchable's MSM multiplies every point of a proof exactly once: per-proof points are single-use (ladder), a
+// common point without a fixed-base table is shared by the N proofs (comb table)
+terms_cfg each_terms_cfg(const fused_plan& pl) {
+  terms_cfg k;
+  k.max_tables = pl.N >= 2 ? pl.s.ns : 0;
+  k.max_ladder = (uint32_t)std::min<uint64_t>(((uint64_t)pl.s.ni + pl.s.nc) * pl.N + pl.s.ns, 0xffffffffu);
+  k.teeth = pl.N >= 6 ? 16 : 4;
+  return k;
+}
 int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_resp,
               const uint8_t* d_w, uint8_t* d_results) {
   const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni, K = pl.s.np + nc;
@@ -769,7 +828,8 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
                      d_inc_k + pl.s.inc_k.size(), w.u8(o.mc), d_resp, d_w, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx));
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
-  const int rc = msm_terms_path(c, N, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * K, ZKP_VARTIME, w.u8(o.out), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true);
+  const int rc = msm_terms_path(c, N, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * K, ZKP_VARTIME, w.u8(o.out), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true,
+                                PH_ALL, each_terms_cfg(pl));
   if (rc) return rc;
   hipLaunchKernelGGL(k_each_finish, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.out), w.u8(o.st8), w.u32(o.failed), d_results);
   prof_mark(c, ZKP_K_SCALARS);
@@ -870,7 +930,7 @@ int zkp_fused_prove_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, u
     return fail(ZKP_ERR_ARG, "NULL device pointer");
   if ((uint64_t)N * s.T > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const prove_inter o = prove_carve(*pl, 0);
-  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T, N * s.nc));
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min)));
   if (rc) return rc;
   return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status, /*overlap=*/false);
 }
@@ -903,7 +963,7 @@ int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8
   const size_t o_chal = cv.take((size_t)N * 32);
   const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
   const prove_inter o = prove_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T, N * s.nc));
+  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min)));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
@@ -940,7 +1000,7 @@ int zkp_fused_verify_compact_dev(zkp_ctx* c, const zkp_fused_statement* st, uint
   if (!d_transcripts || !d_challenges || !d_results || (s.m && !d_responses) || (s.np && !d_table)) return fail(ZKP_ERR_ARG, "NULL device pointer");
   if ((uint64_t)N * pl->T1 > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const verify_inter o = verify_carve(*pl, 0);
-  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1, N * s.nc));
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1, N * s.nc, cfg_from_terms(pl->tpt.data(), pl->T1, s.ns, s.np, N, 2)));
   if (rc) return rc;
   return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results, /*overlap=*/false);
 }
@@ -968,7 +1028,7 @@ int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t
   const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
   const size_t o_res = cv.take((size_t)N);
   const verify_inter o = verify_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * pl->T1, N * s.nc));
+  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * pl->T1, N * s.nc, cfg_from_terms(pl->tpt.data(), pl->T1, s.ns, s.np, N, 2)));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
@@ -1085,7 +1145,7 @@ int zkp_fused_verify_batchable(zkp_ctx* c, const zkp_fused_statement* st, uint32
   const size_t o_w = cv.take((size_t)N * nc * 16 + 16);
   const size_t o_res = cv.take((size_t)N + 4);
   const each_inter o = each_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N));
+  rc = ensure_ws(c, o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N, each_terms_cfg(*pl)));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));

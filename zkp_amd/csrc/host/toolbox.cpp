@@ -34,6 +34,16 @@ struct zkp_statement {
   struct Constraint { uint32_t lhs; std::vector<std::pair<uint32_t, uint32_t>> lc; };
   std::vector<Constraint> cons;
   uint32_t terms = 0;
+  // The allocation sequence IS part of the statement: every allocate_scalar / allocate_point call appends to the
+  // transcript when it is made (prover.rs:52-73, verifier.rs:57-77), in whatever order the caller makes them.
+  struct Alloc { bool is_point; uint32_t idx; };
+  std::vector<Alloc> alloc;
+  // number of leading scalar allocations (hashed once for a batch that starts from equal transcripts)
+  uint32_t scalar_prefix() const {
+    uint32_t n = 0;
+    while (n < alloc.size() && !alloc[n].is_point) ++n;
+    return n;
+  }
 };
 
 namespace {
@@ -180,12 +190,13 @@ bool all_transcripts_equal(const uint8_t* ts, uint32_t N) {
   return true;
 }
 
-// Prover::new + allocate_scalar for every secret (prover.rs:41-57) / the same on the verifier side.  When
-// all N incoming transcripts are equal (the usual case) this prefix is hashed once and cloned.
+// Prover::new + the allocate_scalar calls that precede the first point (prover.rs:41-57) / the same on the verifier
+// side.  When all N incoming transcripts are equal (the usual case) this prefix is hashed once and cloned.
 void apply_prefix(const zkp_statement& st, uint32_t N, uint8_t* ts, int n_threads) {
+  const uint32_t lead = st.scalar_prefix();
   auto prefix = [&](Transcript& t) {
     t.domain_sep(st.label.c_str());
-    for (const auto& s : st.secrets) t.append_scalar_var(s.c_str());
+    for (uint32_t a = 0; a < lead; ++a) t.append_scalar_var(st.secrets[st.alloc[a].idx].c_str());
   };
   if (N > 1 && all_transcripts_equal(ts, N)) {
     Transcript t = Transcript::from_bytes(ts);
@@ -200,6 +211,21 @@ void apply_prefix(const zkp_statement& st, uint32_t N, uint8_t* ts, int n_thread
       t.to_bytes(ts + TB * (size_t)j);
     }
   });
+}
+
+// The allocations after the scalar prefix, in the caller's order (points and any scalar allocated after a point).
+// validate = the verifier-side appends, which reject the identity encoding (mod.rs:186-196); false on rejection.
+bool replay_allocations(const zkp_statement& st, Transcript& t, uint32_t j, uint32_t N, const uint8_t* inst, const uint8_t* common,
+                        bool validate) {
+  for (uint32_t a = st.scalar_prefix(); a < st.alloc.size(); ++a) {
+    const auto& al = st.alloc[a];
+    if (!al.is_point) { t.append_scalar_var(st.secrets[al.idx].c_str()); continue; }
+    const char* name = st.points[al.idx].name.c_str();
+    const uint8_t* enc = point_enc(st, al.idx, j, N, inst, common);
+    if (!validate) t.append_point_var(name, enc);
+    else if (!t.validate_and_append_point_var(name, enc)) return false;
+  }
+  return true;
 }
 
 // point variables no constraint mentions (e.g. `B` of the CMZ statement, benches/zkp.rs:32): verify_compact
@@ -228,7 +254,7 @@ std::atomic<uint32_t> g_fused_min_batch{32};
 
 struct FusedView {
   zkp_fused_statement fs{};
-  std::vector<uint32_t> lhs, off, csc, cpt, order;
+  std::vector<uint32_t> lhs, off, csc, cpt, order, seq;
   std::vector<const char*> slabels, plabels;
   explicit FusedView(const zkp_statement& st) {
     const uint32_t nc = (uint32_t)st.cons.size(), np = (uint32_t)st.points.size();
@@ -243,6 +269,8 @@ struct FusedView {
     plabels.resize(np);
     for (uint32_t v = 0; v < np; ++v) { order.push_back(pid(v)); plabels[pid(v)] = st.points[v].name.c_str(); }
     for (const auto& s : st.secrets) slabels.push_back(s.c_str());
+    for (const auto& al : st.alloc) seq.push_back(al.is_point ? pid(al.idx) : (0x80000000u | al.idx));
+    fs.alloc_seq = seq.data();
     fs.shape = zkp_batch_statement{(uint32_t)st.secrets.size(), st.ns, st.ni, nc, lhs.data(), off.data(), csc.data(), cpt.data()};
     fs.label = st.label.c_str();
     fs.secret_labels = slabels.data();
@@ -300,11 +328,13 @@ void zkp_statement_free(zkp_statement* st) { delete st; }
 int zkp_statement_add_secret(zkp_statement* st, const char* name) {
   if (!st || !name) return ZKP_TB_BAD_STATEMENT;
   st->secrets.emplace_back(name);
+  st->alloc.push_back({false, (uint32_t)st->secrets.size() - 1});
   return (int)st->secrets.size() - 1;
 }
 int zkp_statement_add_point(zkp_statement* st, const char* name, int is_common) {
   if (!st || !name) return ZKP_TB_BAD_STATEMENT;
   st->points.push_back({name, is_common != 0, is_common ? st->ns++ : st->ni++});
+  st->alloc.push_back({true, (uint32_t)st->points.size() - 1});
   return (int)st->points.size() - 1;
 }
 int zkp_statement_constrain(zkp_statement* st, uint32_t lhs, uint32_t n_terms, const uint32_t* secrets, const uint32_t* points) {
@@ -344,8 +374,7 @@ int zkp_prove_phase_a(const zkp_statement* stp, uint32_t N, uint8_t* ts, const u
   parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
     for (uint32_t j = lo; j < hi; ++j) {
       Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
-      for (uint32_t p = 0; p < st.points.size(); ++p)                  // prover.rs:69 (encodings are supplied)
-        t.append_point_var(st.points[p].name.c_str(), point_enc(st, p, j, N, inst, common));
+      replay_allocations(st, t, j, N, inst, common, false);            // prover.rs:52-73 (encodings are supplied)
       zkp::host::TranscriptRng rng = t.build_rng();                    // prover.rs:78-82
       for (uint32_t i = 0; i < m; ++i) rng.rekey_with_witness_bytes("", secrets + 32 * ((size_t)j * m + i), 32);
       rng.finalize(entropy + 32 * (size_t)j);
@@ -433,8 +462,7 @@ static void build_verifiers(const zkp_statement& st, uint32_t N, uint8_t* ts, co
   parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
     for (uint32_t j = lo; j < hi; ++j) {
       Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
-      for (uint32_t p = 0; p < st.points.size() && !failed[j]; ++p)
-        if (!t.validate_and_append_point_var(st.points[p].name.c_str(), point_enc(st, p, j, N, inst, common))) failed[j] = 1;
+      if (!replay_allocations(st, t, j, N, inst, common, true)) failed[j] = 1;
       t.to_bytes(ts + TB * (size_t)j);
     }
   });

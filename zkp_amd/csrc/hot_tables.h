@@ -135,12 +135,19 @@ k_class_count(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_po
   __syncthreads();
   if (threadIdx.x < HOT_CLASSES && h[threadIdx.x]) atomicAdd(&class_cnt[threadIdx.x], h[threadIdx.x]);
 }
-// class_start[c] = first list position of class c; class_start[HOT_CLASSES] = n_terms; cursor = copy
-__global__ void k_class_scan(const uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_start, uint32_t* __restrict__ cursor) {
+// class_start[c] = first list position of class c; class_start[HOT_CLASSES] = n_terms; cursor = copy;
+// blk_start[c] = first 256-lane block of fixed-base class c when every class starts a new block (k_terms_split stages one
+// table per block in LDS); blk_start[HOT_SLOTS] = number of such blocks
+__global__ void k_class_scan(const uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_start, uint32_t* __restrict__ cursor,
+                             uint32_t* __restrict__ blk_start) {
   if (threadIdx.x != 0) return;
-  uint32_t run = 0;
-  for (int c = 0; c < HOT_CLASSES; ++c) { class_start[c] = run; cursor[c] = run; run += class_cnt[c]; }
+  uint32_t run = 0, blk = 0;
+  for (int c = 0; c < HOT_CLASSES; ++c) {
+    class_start[c] = run; cursor[c] = run; run += class_cnt[c];
+    if (c < HOT_SLOTS) { blk_start[c] = blk; blk += (class_cnt[c] + 255u) / 256u; }
+  }
   class_start[HOT_CLASSES] = run;
+  blk_start[HOT_SLOTS] = blk;
 }
 __global__ void __launch_bounds__(256)
 k_class_scatter(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_points, const int32_t* __restrict__ hotmap,

@@ -128,41 +128,52 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
   if (t < n_terms) term_generic(t, scalars, pidx, n_points, pts, partial);
 }
 
-// Classified terms in ONE launch, longest first: ladder terms (single-use points of a variable-time call: 384 point
-// operations per lane), terms on per-proof points with a comb table (128 point operations), and the fixed-base terms
-// (65 mixed additions), which fill the SIMDs the others leave idle.
-template <bool CT>
+// Classified terms in ONE launch, longest first: ladder terms (points with a single cold use: 321 point operations per
+// lane), terms on per-proof points with a comb table (BITS + 64 point operations), and the fixed-base terms (65 mixed
+// additions), which fill the SIMDs the others leave idle.
+template <bool CT, int TEETH>
 __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
-              const dev_ext* __restrict__ comb, const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ list,
-              const int32_t* __restrict__ hotmap, const dev_niels* __restrict__ tables, const dev_affine* __restrict__ pts,
-              dev_ext* __restrict__ comb_rw, dev_ext* __restrict__ partial) {
+              const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
+              const uint32_t* __restrict__ blk_start, const uint32_t* __restrict__ list, const dev_niels* __restrict__ tables,
+              const dev_affine* __restrict__ pts, dev_ext* __restrict__ ladder_rw, uint32_t max_ladder, dev_ext* __restrict__ partial) {
+  // A block of fixed-base terms serves ONE table, staged in LDS (58 KB): the masked scans then read the 8 entries of a row
+  // as LDS broadcasts instead of 56 16-byte vector loads per lane and addition -- through the L1 those loads alone took
+  // ~70 % as long as the additions they feed (64 B/clk per CU against 4 SIMDs of v_mad_u64_u32).
+  __shared__ uint4 hot_lds[HOT_SLOT_NIELS * sizeof(dev_niels) / 16];
   const uint32_t n_hot = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - n_hot;
-  const uint32_t n_ladder = CT ? 0u : class_start[HOT_CLASSES] - class_start[CLASS_LADDER];
+  const uint32_t n_ladder = class_start[HOT_CLASSES] - class_start[CLASS_LADDER];
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
   const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
-  if (!CT && blockIdx.x < ladder_blocks) {
-    if constexpr (!CT) {
-      const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-      if (i < n_ladder) {
-        const uint32_t t = list[n_hot + n_comb + i];
-        const uint32_t pi = pidx[t];                              // < n_points (out-of-range indices are classed with the comb terms)
-        term_ladder16(t, scalars, pts + pi, comb_rw + (size_t)pi * COMB_ENTRIES, partial);
-      }
+  if (blockIdx.x < ladder_blocks) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_ladder && i < max_ladder) {                         // (max_ladder bounds n_ladder by construction)
+      const uint32_t t = list[n_hot + n_comb + i];
+      const uint32_t pi = pidx[t];                                // < n_points (out-of-range indices are classed with the comb terms)
+      term_ladder16<CT>(t, scalars, pts + pi, ladder_rw + (size_t)i * LADDER_ENTRIES, partial);
     }
   } else if (blockIdx.x < ladder_blocks + comb_blocks) {
     const uint32_t i = (blockIdx.x - ladder_blocks) * blockDim.x + threadIdx.x;
     if (i < n_comb) {
       const uint32_t t = list[n_hot + i];
       const uint32_t pi = pidx[t];
-      if (pi < n_points) term_comb<CT>(t, scalars, comb + (size_t)pi * COMB_ENTRIES, partial);   // (out of range: flagged by k_reduce_encode)
+      if (pi < n_points) {                                        // (out of range: flagged by k_reduce_encode)
+        const uint32_t slot = slot_of[pi];
+        if (slot != 0xffffffffu) term_comb<CT, TEETH>(t, scalars, comb + (size_t)slot * comb_cfg<TEETH>::ENTRIES, partial);
+      }
     }
   } else {
-    const uint32_t i = (blockIdx.x - ladder_blocks - comb_blocks) * blockDim.x + threadIdx.x;
-    if (i < n_hot) {
-      const uint32_t t = list[i];
-      term_fixed_base<CT>(t, scalars, tables + (size_t)hotmap[pidx[t]] * HOT_SLOT_NIELS, partial);
-    }
+    const uint32_t hb = blockIdx.x - ladder_blocks - comb_blocks;
+    if (hb >= blk_start[HOT_SLOTS]) return;                       // (uniform in the block)
+    uint32_t c = 0;
+    while (blk_start[c + 1] <= hb) ++c;                           // class = table slot of this block
+    const uint4* src = reinterpret_cast<const uint4*>(tables + (size_t)c * HOT_SLOT_NIELS);
+    constexpr uint32_t kVec = HOT_SLOT_NIELS * sizeof(dev_niels) / 16;
+    for (uint32_t k = threadIdx.x; k < kVec; k += 256) hot_lds[k] = src[k];
+    __syncthreads();
+    const uint32_t i = (hb - blk_start[c]) * 256 + threadIdx.x;
+    if (i < class_start[c + 1] - class_start[c])
+      term_fixed_base<CT>(list[class_start[c] + i], scalars, reinterpret_cast<const dev_niels*>(hot_lds), partial);
   }
 }
 
@@ -900,6 +911,14 @@ struct zkp_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool prof_suspended = false;
   uint64_t batch_encode_min = 65536;       // ZKP_OPT_BATCH_ENCODE_MIN
+  bool batch_encode_user = false;          // set explicitly: applies to every entry point as is
+  int comb_teeth = 4;                      // ZKP_OPT_COMB_TEETH (generic _dev entry point; the other callers derive it)
+  // ZKP_OPT_CT_SINGLE_USE_TABLES.  A table costs 256 + 7 TEETH point operations and then BITS + 65 per term, a ladder 7 + 256 +
+  // 65: by instruction count a table pays from the second use on.  But a ladder lane is a 321-operation dependent chain
+  // inside the term kernel (0.9 ms at 4096 proofs, against 0.35 ms for everything else in it), while the same doublings
+  // spent on a table run next to the other tables' chains.  Constant-time calls therefore give single-use points a table
+  // as well; variable-time calls (no masked scans: their ladder is 30 % cheaper than table + walk) keep the ladder.
+  uint32_t ct_comb_min = 1;
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool profiling = false;
@@ -962,52 +981,109 @@ void prof_mark(zkp_ctx* c, int kind) {
 inline dim3 grid1(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// How a call of the term path is tuned.  None of it changes a result.
+//   teeth       comb-table shape for points with >= 2 cold uses (comb_tables.h): 4, or 16 when such points carry ~6+ terms
+//   max_tables  upper bound of the number of such points,  max_ladder  of the points with exactly one cold use: they size
+//               the workspace.  Callers that know the statement pass tight bounds; the generic bounds always hold.
+//   throughput  the caller keeps many calls in flight (asynchronous _dev entry points): pick the variant with the fewest
+//               instructions (one lane per comb table, batched encoder from 2,048 outputs) over the lowest latency
+//   comb_min    cold uses from which a point gets a comb table (fewer: ladder).  2, or 1 for constant-time calls (see
+//               zkp_ctx::ct_comb_min)
+struct terms_cfg {
+  int teeth = 4;
+  uint32_t max_tables = 0xffffffffu, max_ladder = 0xffffffffu;
+  bool throughput = false;
+  uint32_t comb_min = 2;
+};
+inline terms_cfg terms_cfg_clamped(terms_cfg k, uint32_t n_points, uint32_t n_terms) {
+  if (k.comb_min != 1) k.comb_min = 2;
+  k.max_tables = std::min(k.max_tables, std::min(n_points, n_terms / k.comb_min));
+  k.max_ladder = k.comb_min == 1 ? 0u : std::min(k.max_ladder, std::min(n_points, n_terms));
+  if (k.teeth != 16) k.teeth = 4;
+  return k;
+}
+constexpr uint64_t kThroughputEncodeMin = 2048;
+// Point operations of n_tab table points carrying tab_terms terms: n_tab (256 + 7 TEETH) + tab_terms (256 / TEETH - 4 + 65).
+// TEETH = 16 beats 4 when 48 tab_terms > 84 n_tab, i.e. from about two terms per table point on -- unless its 4 x larger
+// tables (18.6 KB per point) would not fit a sensible workspace.
+inline int pick_teeth(uint64_t n_tab, uint64_t tab_terms) {
+  if (!n_tab || tab_terms < 2 * n_tab) return 4;
+  return n_tab * comb_entries(16) * sizeof(dev_ext) <= (64ull << 30) ? 16 : 4;
+}
+
+struct terms_layout { size_t pts, part, hot, cls, list, needs, slot_of, slot_pt, comb, ladder, half, states, xs, bprod, zflag, end; };
+terms_layout terms_carve(size_t start, uint32_t n_points, uint32_t n_terms, uint32_t n_msm, const terms_cfg& k) {
+  carve cv;
+  cv.off = start;
+  terms_layout o;
+  const bool split = n_terms >= 1024;
+  o.pts = cv.take((size_t)n_points * sizeof(dev_affine));
+  o.part = cv.take((size_t)n_terms * sizeof(dev_ext));
+  o.hot = cv.take((size_t)n_points * 4);
+  o.cls = cv.take(512 * 4);
+  o.list = cv.take((size_t)n_terms * 4);
+  o.needs = cv.take((size_t)n_points * 4);
+  o.slot_of = cv.take(split ? (size_t)n_points * 4 : 0);
+  o.slot_pt = cv.take(split ? (size_t)k.max_tables * 4 : 0);
+  o.comb = cv.take(split ? (size_t)k.max_tables * comb_entries(k.teeth) * sizeof(dev_ext) : 0);
+  o.ladder = cv.take(split ? (size_t)k.max_ladder * LADDER_ENTRIES * sizeof(dev_ext) : 0);
+  const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
+  o.half = cv.take(split ? (size_t)n_terms * 32 : 0);            // (batched encoder: reserved whenever it could be chosen)
+  o.states = cv.take(split ? (size_t)n_msm * 54 * 4 : 0);
+  o.xs = cv.take(split ? (size_t)n_msm * 9 * 4 : 0);
+  o.bprod = cv.take(split ? (size_t)enc_blocks * 9 * 4 * 2 : 0);
+  o.zflag = cv.take(split ? (size_t)n_msm : 0);
+  o.end = cv.off;
+  return o;
+}
+size_t terms_path_ws(uint32_t n_points, uint32_t n_terms, uint32_t n_msm, const terms_cfg& k = terms_cfg()) {
+  return terms_carve(0, n_points, n_terms, n_msm, terms_cfg_clamped(k, n_points, n_terms)).end;
+}
+
+template <bool CT, int TEETH>
+void launch_terms_split(zkp_ctx* c, dim3 grid, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
+                        const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
+                        const dev_affine* pts, dev_ext* ladder, uint32_t max_ladder, dev_ext* part) {
+  hipLaunchKernelGGL((k_terms_split<CT, TEETH>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
+                     c->hot_tables, pts, ladder, max_ladder, part);
+}
+
 // phase: everything (default), or only the part that does not look at the scalars (decode, classification, comb tables:
 // the fused flows run it on the context's side stream next to the transcripts that produce the scalars), or the rest.
 enum : int { PH_POINTS = 1, PH_SCALARS = 2, PH_ALL = 3 };
 int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint8_t* d_scalars,
                    const uint32_t* d_pidx, const uint8_t* d_points, uint32_t n_points, uint32_t n_terms, int flags,
                    uint8_t* d_out, uint8_t* d_status8, uint32_t* d_status32, size_t ws_reserved, bool decode_all = false,
-                   int phase = PH_ALL, bool lane_tables = false) {
-  carve cv;
-  cv.off = ws_reserved;
-  const size_t o_pts = cv.take((size_t)n_points * sizeof(dev_affine));
-  const size_t o_part = cv.take((size_t)n_terms * sizeof(dev_ext));
-  const size_t o_hot = cv.take((size_t)n_points * 4);
-  const size_t o_cls = cv.take(256 * 4);
-  const size_t o_list = cv.take((size_t)n_terms * 4);
-  const size_t o_needs = cv.take((size_t)n_points * 4);
-  const size_t o_comb = cv.take(n_terms >= 1024 ? (size_t)n_points * COMB_ENTRIES * sizeof(dev_ext) : 0);
-  const bool batched_encode = n_terms >= 1024 && (uint64_t)n_msm >= c->batch_encode_min;
+                   int phase = PH_ALL, const terms_cfg& cfg_in = terms_cfg()) {
+  const terms_cfg k = terms_cfg_clamped(cfg_in, n_points, n_terms);
+  const terms_layout o = terms_carve(ws_reserved, n_points, n_terms, n_msm, k);
+  const bool batched_encode = n_terms >= 1024 && (uint64_t)n_msm >= ((k.throughput && !c->batch_encode_user) ? kThroughputEncodeMin : c->batch_encode_min);
   const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
-  const size_t o_half = cv.take(batched_encode ? (size_t)n_terms * 32 : 0);
-  const size_t o_states = cv.take(batched_encode ? (size_t)n_msm * 54 * 4 : 0);
-  const size_t o_xs = cv.take(batched_encode ? (size_t)n_msm * 9 * 4 : 0);
-  const size_t o_bprod = cv.take(batched_encode ? (size_t)enc_blocks * 9 * 4 * 2 : 0);
-  const size_t o_zflag = cv.take(batched_encode ? (size_t)n_msm : 0);
   // ensure_ws was done by the caller for ws_reserved + this much; recompute defensively
-  if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
+  if (o.end > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
   char* base = static_cast<char*>(c->ws);
-  dev_affine* pts = reinterpret_cast<dev_affine*>(base + o_pts);
-  dev_ext* part = reinterpret_cast<dev_ext*>(base + o_part);
+  dev_affine* pts = reinterpret_cast<dev_affine*>(base + o.pts);
+  dev_ext* part = reinterpret_cast<dev_ext*>(base + o.part);
   if (n_terms >= 1024) {
-    // split the terms: those on a registered fixed-base point (grouped by table) / the rest, which go through per-point
-    // comb tables built here for exactly the points they reference
-    int32_t* hotmap = reinterpret_cast<int32_t*>(base + o_hot);
-    uint32_t* cls = reinterpret_cast<uint32_t*>(base + o_cls);     // cnt[66] | start[67] | cursor[66] | any
-    uint32_t* class_cnt = cls, *class_start = cls + 80, *cursor = cls + 160, *any_hot = cls + 240;
-    uint32_t* list = reinterpret_cast<uint32_t*>(base + o_list);
-    uint32_t* needs = reinterpret_cast<uint32_t*>(base + o_needs);
-    dev_ext* comb = reinterpret_cast<dev_ext*>(base + o_comb);
+    // split the terms: those on a registered fixed-base point (grouped by table) / those on a point with a comb table
+    // built here (two or more cold uses) / single-use points on a ladder
+    int32_t* hotmap = reinterpret_cast<int32_t*>(base + o.hot);
+    uint32_t* cls = reinterpret_cast<uint32_t*>(base + o.cls);     // cnt[66] | start[67] | cursor[66] | any | table counter | block starts[65]
+    uint32_t* class_cnt = cls, *class_start = cls + 80, *cursor = cls + 160, *any_hot = cls + 240, *n_slots = cls + 241, *blk_start = cls + 256;
+    uint32_t* list = reinterpret_cast<uint32_t*>(base + o.list);
+    uint32_t* needs = reinterpret_cast<uint32_t*>(base + o.needs);
+    uint32_t* slot_of = reinterpret_cast<uint32_t*>(base + o.slot_of);
+    uint32_t* slot_pt = reinterpret_cast<uint32_t*>(base + o.slot_pt);
+    dev_ext* comb = reinterpret_cast<dev_ext*>(base + o.comb);
+    dev_ext* ladder = reinterpret_cast<dev_ext*>(base + o.ladder);
+    const uint32_t comb_min = k.comb_min;
     if (phase & PH_POINTS) {
-    HIP_TRY(hipMemsetAsync(cls, 0, 256 * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(cls, 0, 512 * 4, c->stream));
     HIP_TRY(hipMemsetAsync(needs, 0, (size_t)n_points * 4, c->stream));
     if (c->hot_nreg)
       hipLaunchKernelGGL(k_hot_match, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, c->hot_nreg, c->hot_reg_words, c->hot_reg_slot, hotmap, any_hot);
     else
       HIP_TRY(hipMemsetAsync(hotmap, 0xff, (size_t)n_points * 4, c->stream));
-    // a comb table from the second use of a point on (variable-time calls); constant-time calls: every cold term alike
-    const uint32_t comb_min = flags == ZKP_CT ? 1u : 2u;
     hipLaunchKernelGGL(k_use_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs);
     hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, class_cnt);
     prof_mark(c, ZKP_K_SORT);
@@ -1015,26 +1091,36 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     // decompress, verifier.rs:87-92), otherwise only the points whose coordinates this call uses
     hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, decode_all ? (const uint32_t*)nullptr : needs);
     prof_mark(c, ZKP_K_DECODE);
-    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor);
+    hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor, blk_start);
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, cursor, list);
-    if (lane_tables)
-      hipLaunchKernelGGL(k_comb_tables_lane, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, pts, comb);
-    else
-      hipLaunchKernelGGL(k_comb_tables, grid1((size_t)n_points * 4, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, pts, comb);
+    if (k.max_tables) {
+      hipLaunchKernelGGL(k_comb_slots, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, k.max_tables, n_slots, slot_of, slot_pt);
+      if (k.throughput) {
+        if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables_lane<16>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
+        else hipLaunchKernelGGL(k_comb_tables_lane<4>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
+      } else {
+        if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables<16>, grid1((size_t)k.max_tables * 4, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
+        else hipLaunchKernelGGL(k_comb_tables<4>, grid1((size_t)k.max_tables * 4, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
+      }
+    }
     prof_mark(c, ZKP_K_SORT);          // path A: term classification + comb-table construction
     }
-    const dim3 grid((unsigned)((n_terms + 255) / 256 + 2));
+    const dim3 grid((unsigned)((n_terms + 255) / 256 + 3 + HOT_SLOTS));     // every fixed-base class starts a new block
     // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l
     if (batched_encode) {
-      uint8_t* d_half = reinterpret_cast<uint8_t*>(base + o_half);
+      uint8_t* d_half = reinterpret_cast<uint8_t*>(base + o.half);
       if (phase & PH_SCALARS) hipLaunchKernelGGL(k_halve_scalars, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_half);
       d_scalars = d_half;
     }
-    if (!(phase & PH_SCALARS)) {
-    } else if (flags == ZKP_CT)
-      hipLaunchKernelGGL(k_terms_split<true>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, comb, part);
-    else
-      hipLaunchKernelGGL(k_terms_split<false>, grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, class_start, list, hotmap, c->hot_tables, pts, comb, part);
+    if (phase & PH_SCALARS) {
+      if (flags == ZKP_CT) {
+        if (k.teeth == 16) launch_terms_split<true, 16>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        else launch_terms_split<true, 4>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+      } else {
+        if (k.teeth == 16) launch_terms_split<false, 16>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        else launch_terms_split<false, 4>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+      }
+    }
   } else {
     if (n_points && (phase & PH_POINTS)) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, (const uint32_t*)nullptr);
     prof_mark(c, ZKP_K_DECODE);
@@ -1043,11 +1129,11 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
   if (!(phase & PH_SCALARS)) { HIP_TRY(hipGetLastError()); return ZKP_OK; }
   prof_mark(c, ZKP_K_TERMS);
   if (n_msm && batched_encode) {
-    uint32_t* states = reinterpret_cast<uint32_t*>(base + o_states);
-    uint32_t* xs = reinterpret_cast<uint32_t*>(base + o_xs);
-    uint32_t* bprod = reinterpret_cast<uint32_t*>(base + o_bprod);
+    uint32_t* states = reinterpret_cast<uint32_t*>(base + o.states);
+    uint32_t* xs = reinterpret_cast<uint32_t*>(base + o.xs);
+    uint32_t* bprod = reinterpret_cast<uint32_t*>(base + o.bprod);
     uint32_t* binv = bprod + (size_t)enc_blocks * 9;
-    uint8_t* zflag = reinterpret_cast<uint8_t*>(base + o_zflag);
+    uint8_t* zflag = reinterpret_cast<uint8_t*>(base + o.zflag);
     if (d_status8)
       hipLaunchKernelGGL(k_encode_prepare<uint8_t>, dim3(enc_blocks), dim3(ENC_BLOCK), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, states, xs, bprod, zflag, d_status8);
     else
@@ -1064,24 +1150,6 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
   prof_mark(c, ZKP_K_REDUCE);
   HIP_TRY(hipGetLastError());
   return ZKP_OK;
-}
-size_t terms_path_ws(uint32_t n_points, uint32_t n_terms, uint32_t n_msm) {
-  carve cv;
-  cv.take((size_t)n_points * sizeof(dev_affine));
-  cv.take((size_t)n_terms * sizeof(dev_ext));
-  cv.take((size_t)n_points * 4);
-  cv.take(256 * 4);
-  cv.take((size_t)n_terms * 4);
-  cv.take((size_t)n_points * 4);
-  cv.take(n_terms >= 1024 ? (size_t)n_points * COMB_ENTRIES * sizeof(dev_ext) : 0);
-  const bool batched_encode = n_terms >= 1024;
-  const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
-  cv.take(batched_encode ? (size_t)n_terms * 32 : 0);
-  cv.take(batched_encode ? (size_t)n_msm * 54 * 4 : 0);
-  cv.take(batched_encode ? (size_t)n_msm * 9 * 4 : 0);
-  cv.take(batched_encode ? (size_t)enc_blocks * 9 * 4 * 2 : 0);
-  cv.take(batched_encode ? (size_t)n_msm : 0);
-  return cv.off;
 }
 
 // entries per virtual lane of the bucket accumulation, and the resulting upper bound of lanes per window
@@ -1197,6 +1265,35 @@ int pick_c(uint64_t n) {
 }
 constexpr uint64_t kSmallOptional = 192;   // below this, zkp_msm_optional uses the per-term path
 
+// Exact table / ladder counts of a host-side CSR job: uses per point, minus the points served by a fixed-base table.
+terms_cfg host_terms_cfg(const zkp_ctx* c, uint32_t n_terms, const uint32_t* pidx, const uint8_t* points, uint32_t n_points, uint32_t comb_min) {
+  std::vector<uint32_t> uses(n_points, 0);
+  for (uint32_t t = 0; t < n_terms; ++t) ++uses[pidx[t]];
+  std::vector<std::pair<uint64_t, int>> hot;                 // (first 8 bytes, slot) of the registered encodings
+  for (int sl = 0; sl < HOT_SLOTS; ++sl)
+    if (!c->hot_key[sl].empty()) { uint64_t w; memcpy(&w, c->hot_key[sl].data(), 8); hot.emplace_back(w, sl); }
+  std::sort(hot.begin(), hot.end());
+  uint64_t n_tab = 0, n_lad = 0, tab_terms = 0;
+  for (uint32_t p = 0; p < n_points; ++p) {
+    if (!uses[p]) continue;
+    if (!hot.empty()) {
+      uint64_t w;
+      memcpy(&w, points + 32 * (size_t)p, 8);
+      bool is_hot = false;
+      for (auto it = std::lower_bound(hot.begin(), hot.end(), std::make_pair(w, -1)); it != hot.end() && it->first == w; ++it)
+        if (memcmp(c->hot_key[it->second].data(), points + 32 * (size_t)p, 32) == 0) { is_hot = true; break; }
+      if (is_hot) continue;
+    }
+    if (uses[p] >= comb_min) { ++n_tab; tab_terms += uses[p]; } else ++n_lad;
+  }
+  terms_cfg k;
+  k.comb_min = comb_min;
+  k.max_tables = (uint32_t)n_tab;
+  k.max_ladder = (uint32_t)n_lad;
+  k.teeth = pick_teeth(n_tab, tab_terms);
+  return k;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1251,7 +1348,12 @@ int zkp_ctx_set_stream(zkp_ctx* c, void* s) {
 int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   switch (option) {
-    case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; return ZKP_OK;
+    case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
+    case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_comb_min = value ? 1u : 2u; return ZKP_OK;
+    case ZKP_OPT_COMB_TEETH:
+      if (value != 4 && value != 16) return fail(ZKP_ERR_ARG, "ZKP_OPT_COMB_TEETH must be 4 or 16");
+      c->comb_teeth = (int)value;
+      return ZKP_OK;
     default: return fail(ZKP_ERR_ARG, "unknown option");
   }
 }
@@ -1378,10 +1480,14 @@ int zkp_msm_many_dev(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const ui
   if (n_terms && (!d_scalars || !d_pidx || !d_points || n_points == 0)) return fail(ZKP_ERR_ARG, "terms without scalars/points");
   if (!aligned16(d_scalars) || !aligned16(d_points) || !aligned16(d_out)) return fail(ZKP_ERR_ARG, "device buffers must be 16-byte aligned");
   HIP_TRY(hipSetDevice(c->device));
-  const int rc = ensure_ws(c, terms_path_ws(n_points, n_terms, n_msm));
+  terms_cfg k;                               // the device arrays are not inspected on the host: generic bounds
+  k.teeth = c->comb_teeth;
+  k.throughput = true;
+  k.comb_min = flags == ZKP_CT ? c->ct_comb_min : 2u;
+  const int rc = ensure_ws(c, terms_path_ws(n_points, n_terms, n_msm, k));
   if (rc) return rc;
   prof_begin(c);
-  return msm_terms_path(c, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms, flags, d_out, d_status, nullptr, 0, false, PH_ALL, /*lane_tables=*/true);
+  return msm_terms_path(c, n_msm, d_off, d_scalars, d_pidx, d_points, n_points, n_terms, flags, d_out, d_status, nullptr, 0, false, PH_ALL, k);
 }
 
 int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t* scalars, const uint32_t* pidx,
@@ -1398,6 +1504,7 @@ int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t*
   for (uint32_t t = 0; t < n_terms; ++t)
     if (pidx[t] >= n_points) return fail(ZKP_ERR_ARG, "pidx out of range");
   HIP_TRY(hipSetDevice(c->device));
+  const terms_cfg k = n_terms >= 1024 ? host_terms_cfg(c, n_terms, pidx, points, n_points, flags == ZKP_CT ? c->ct_comb_min : 2u) : terms_cfg();
   carve cv;
   const size_t o_off = cv.take((size_t)(n_msm + 1) * 4);
   const size_t o_sc = cv.take((size_t)n_terms * 32);
@@ -1406,7 +1513,7 @@ int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t*
   const size_t o_out = cv.take((size_t)n_msm * 32);
   const size_t o_st = cv.take((size_t)n_msm);
   const size_t reserved = cv.off;
-  int rc = ensure_ws(c, reserved + terms_path_ws(n_points, n_terms, n_msm));
+  int rc = ensure_ws(c, reserved + terms_path_ws(n_points, n_terms, n_msm, k));
   if (rc) return rc;
   char* base = static_cast<char*>(c->ws);
   HIP_TRY(hipMemcpyAsync(base + o_off, off, (size_t)(n_msm + 1) * 4, hipMemcpyHostToDevice, c->stream));
@@ -1418,7 +1525,7 @@ int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t*
   prof_begin(c);
   rc = msm_terms_path(c, n_msm, reinterpret_cast<uint32_t*>(base + o_off), reinterpret_cast<uint8_t*>(base + o_sc),
                       reinterpret_cast<uint32_t*>(base + o_pidx), reinterpret_cast<uint8_t*>(base + o_pts), n_points,
-                      n_terms, flags, reinterpret_cast<uint8_t*>(base + o_out), reinterpret_cast<uint8_t*>(base + o_st), nullptr, reserved);
+                      n_terms, flags, reinterpret_cast<uint8_t*>(base + o_out), reinterpret_cast<uint8_t*>(base + o_st), nullptr, reserved, false, PH_ALL, k);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(out, base + o_out, (size_t)n_msm * 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(status, base + o_st, (size_t)n_msm, hipMemcpyDeviceToHost, c->stream));

@@ -215,15 +215,17 @@ class _BatchStatementC(ctypes.Structure):
 
 class _FusedStatementC(ctypes.Structure):
     _fields_ = [("shape", _BatchStatementC), ("label", ctypes.c_char_p), ("secret_labels", ctypes.POINTER(ctypes.c_char_p)),
-                ("point_labels", ctypes.POINTER(ctypes.c_char_p)), ("alloc_order", ctypes.c_void_p)]
+                ("point_labels", ctypes.POINTER(ctypes.c_char_p)), ("alloc_order", ctypes.c_void_p), ("alloc_seq", ctypes.c_void_p)]
 
 
 class FusedStatement:
     """zkp_fused_statement (include/zkp_mi355x.h): the statement in point-id form (static ids first, then instance ids)
     with its transcript labels.  points = [(label, is_common)] in allocation order; constraints = [(lhs, [(secret, point)])]
-    with indices into `secrets` / `points`, exactly as Prover/Verifier::constrain receives them."""
+    with indices into `secrets` / `points`, exactly as Prover/Verifier::constrain receives them.  alloc_seq (optional) =
+    the caller's allocation calls in order, [("s", secret index) | ("p", point index)], when scalars and points are
+    interleaved; default: every secret before the first point (define_proof!'s order)."""
 
-    def __init__(self, proof_label: bytes, secrets, points, constraints):
+    def __init__(self, proof_label: bytes, secrets, points, constraints, alloc_seq=None):
         ns = sum(1 for _, c in points if c)
         rank, k_c, k_i = [], 0, 0
         for _, c in points:
@@ -250,4 +252,7 @@ class FusedStatement:
         self._label = bytes(proof_label)
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         self.c = _FusedStatementC(_BatchStatementC(len(secrets), k_c, k_i, len(constraints), vp(self._lhs), vp(self._off), vp(self._sc), vp(self._pt)),
-                                  self._label, self._sl, self._pl, vp(self._order))
+                                  self._label, self._sl, self._pl, vp(self._order), None)
+        if alloc_seq is not None:
+            self._seq = np.array([(0x80000000 | i) if kind == "s" else rank[i] for kind, i in alloc_seq], np.uint32)
+            self.c.alloc_seq = vp(self._seq)

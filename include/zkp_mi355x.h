@@ -67,8 +67,9 @@ const char* zkp_version(void);
  *     doublings per term, a 4 x larger table per point).  Every other entry point derives the shape from its inputs.
  *   ZKP_OPT_CT_SINGLE_USE_TABLES: whether ZKP_CT calls build a comb table also for a point that a single term multiplies
  *     (1, default) or walk a constant-time radix-16 ladder over the point's own eight multiples (0: ~25 % fewer
- *     instructions for that term, but a 321-operation dependent chain inside the term kernel). */
-enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3 };
+ *     instructions for that term, but a 321-operation dependent chain inside the term kernel).
+ *   ZKP_OPT_EXPERIMENT: bit mask of kernel variants under measurement (tools/, never needed by callers; default 0). */
+enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_EXPERIMENT = 4 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* Performance hint, never changes a result: declare points that very many terms of later zkp_msm_many calls

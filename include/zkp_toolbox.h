@@ -32,6 +32,7 @@ extern "C" {
 #define ZKP_TB_BATCH_SIZE_MISMATCH 2    /* ProofError::BatchSizeMismatch   (errors.rs:9)  */
 #define ZKP_TB_BAD_STATEMENT (-10)      /* malformed statement descriptor / NULL argument  */
 #define ZKP_TB_INVALID_POINT (-11)      /* prover was handed an encoding that does not decode */
+#define ZKP_TB_NO_ENTROPY (-12)         /* entropy / weights16 == NULL and the operating system's getrandom() failed */
 
 /* ---- Merlin transcripts (merlin::Transcript, re-exported by the reference at lib.rs:35) ----------- */
 #define ZKP_TRANSCRIPT_BYTES 208        /* opaque, plain-old-data: memcpy = Clone */

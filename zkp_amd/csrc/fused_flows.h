@@ -229,8 +229,7 @@ k_verify_finish(uint32_t N, uint32_t nc, uint32_t ns, const uint8_t* __restrict_
   }
   sc a, b;
   load_vec<2>(a.v, chal + 32 * (size_t)j);
-  load_vec<2>(b.v, claimed + 32 * (size_t)j);
-  sc_reduce(b, b);
+  load_vec<2>(b.v, claimed + 32 * (size_t)j);     // compared as bytes: a non-canonical claim (c + l) is a different Scalar (verifier.rs:115)
   uint32_t d = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) d |= a.v[i] ^ b.v[i];

@@ -2,6 +2,9 @@
 #include "merlin.hpp"
 #include "scalar.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace zkp::host {
 
 namespace {
@@ -110,8 +113,27 @@ static inline void u32le(uint8_t out[4], size_t n) {
 }
 
 // ---- Merlin ------------------------------------------------------------------------------------------
+// ZKP_DEBUG_TRANSCRIPT=1 in the environment: every Merlin operation of the HOST transcripts is written to stderr (label,
+// length, leading bytes) -- what the reference's `debug-transcript` feature (Cargo.toml:35, merlin's own) prints.  A
+// challenge mismatch against the Rust crate is then found by diffing the two op logs.
+static bool debug_transcript() {
+  static const bool on = [] { const char* e = std::getenv("ZKP_DEBUG_TRANSCRIPT"); return e && *e && *e != '0'; }();
+  return on;
+}
+static void debug_op(const char* what, const char* label, const void* data, size_t len) {
+  std::fprintf(stderr, "[merlin] %-9s label=\"%s\" len=%zu", what, label, len);
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  if (p && len) {
+    std::fprintf(stderr, " data=");
+    for (size_t i = 0; i < len && i < 32; ++i) std::fprintf(stderr, "%02x", p[i]);
+    if (len > 32) std::fprintf(stderr, "..");
+  }
+  std::fputc('\n', stderr);
+}
+
 Transcript::Transcript(const void* label, size_t len) : strobe_("Merlin v1.0") { append_message("dom-sep", label, len); }
 void Transcript::append_message(const char* label, const void* msg, size_t len) {
+  if (debug_transcript()) debug_op("append", label, msg, len);
   uint8_t l[4];
   u32le(l, len);
   strobe_.meta_ad(label, std::strlen(label), false);
@@ -124,8 +146,10 @@ void Transcript::challenge_bytes(const char* label, void* out, size_t len) {
   strobe_.meta_ad(label, std::strlen(label), false);
   strobe_.meta_ad(l, 4, true);
   strobe_.prf(out, len, false);
+  if (debug_transcript()) debug_op("challenge", label, out, len);
 }
 void TranscriptRng::rekey_with_witness_bytes(const char* label, const void* w, size_t len) {
+  if (debug_transcript()) debug_op("rng-rekey", label, nullptr, len);      // (witness bytes are never printed)
   uint8_t l[4];
   u32le(l, len);
   strobe_.meta_ad(label, std::strlen(label), false);

@@ -52,12 +52,18 @@ class Transcript {
   Transcript(const void* label, size_t len);                       // merlin::Transcript::new
   explicit Transcript(const std::string& label) : Transcript(label.data(), label.size()) {}
   // plain-old-data (de)serialisation: Clone == memcpy (ZKP_TRANSCRIPT_BYTES in include/zkp_toolbox.h)
+  // 203 live bytes (200 of STROBE state, pos, pos_begin, cur_flags) + 5 bytes of padding, which are written as zeros and
+  // never read: blobs of equal transcripts are equal byte for byte, and no stack garbage reaches caller buffers
+  static constexpr size_t kLiveBytes = 203;
   static Transcript from_bytes(const uint8_t* blob) {
     Transcript t{Strobe128::uninitialized_t{}};
-    std::memcpy(static_cast<void*>(&t), blob, sizeof(Transcript));
+    std::memcpy(static_cast<void*>(&t), blob, kLiveBytes);
     return t;
   }
-  void to_bytes(uint8_t* blob) const { std::memcpy(blob, static_cast<const void*>(this), sizeof(Transcript)); }
+  void to_bytes(uint8_t* blob) const {
+    std::memcpy(blob, static_cast<const void*>(this), kLiveBytes);
+    std::memset(blob + kLiveBytes, 0, sizeof(Transcript) - kLiveBytes);
+  }
   void append_message(const char* label, const void* msg, size_t len);
   void challenge_bytes(const char* label, void* out, size_t len);
   TranscriptRng build_rng() const { return TranscriptRng(strobe_); }

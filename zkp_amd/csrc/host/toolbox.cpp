@@ -7,6 +7,8 @@
 // include/zkp_mi355x.h; there is no CPU fallback here.
 #include <sys/random.h>
 
+#include <cerrno>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -127,12 +129,16 @@ void parallel_for(uint32_t n, int n_threads, F&& body) {
   });
 }
 
-void os_entropy(uint8_t* out, size_t len) {
+// false = the operating system gave no entropy (getrandom failed with anything but EINTR): callers fail closed
+bool os_entropy(uint8_t* out, size_t len) {
   size_t got = 0;
   while (got < len) {
     const ssize_t r = getrandom(out + got, len - got, 0);
     if (r > 0) got += (size_t)r;
+    else if (r < 0 && errno == EINTR) continue;
+    else return false;
   }
+  return true;
 }
 
 // ChaCha20 block function (RFC 8439 section 2.3), used as the stream generator below
@@ -155,12 +161,11 @@ void chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uin
 // What `thread_rng()` is to the reference (prover.rs:82, verifier.rs:153, batch_verifier.rs:179): a ChaCha stream keyed
 // with 32 bytes from the operating system for every call -- getrandom() itself delivers only a few hundred MB/s, which
 // for the batch verifier's 16 bytes per (constraint, proof) would cost more than the whole GPU side of the call.
-void os_random(uint8_t* out, size_t len) {
-  if (len <= 256) { os_entropy(out, len); return; }
+bool os_random(uint8_t* out, size_t len) {
+  if (len <= 256) return os_entropy(out, len);
   uint32_t key[8];
   uint64_t nonce;
-  os_entropy(reinterpret_cast<uint8_t*>(key), sizeof(key));
-  os_entropy(reinterpret_cast<uint8_t*>(&nonce), sizeof(nonce));
+  if (!os_entropy(reinterpret_cast<uint8_t*>(key), sizeof(key)) || !os_entropy(reinterpret_cast<uint8_t*>(&nonce), sizeof(nonce))) return false;
   const uint64_t blocks = (len + 63) / 64;
   parallel_for((uint32_t)std::min<uint64_t>(blocks, 0xffffffffu), 0, [&](uint32_t lo, uint32_t hi) {
     uint8_t tmp[64];
@@ -170,6 +175,7 @@ void os_random(uint8_t* out, size_t len) {
       else { chacha20_block(key, b, nonce, tmp); std::memcpy(out + o, tmp, len - o); }
     }
   });
+  return true;
 }
 
 // encoding of point variable p for proof j
@@ -186,7 +192,7 @@ inline uint32_t table_index(const zkp_statement& st, uint32_t p, uint32_t j, uin
 
 bool all_transcripts_equal(const uint8_t* ts, uint32_t N) {
   for (uint32_t j = 1; j < N; ++j)
-    if (std::memcmp(ts, ts + TB * (size_t)j, TB) != 0) return false;
+    if (std::memcmp(ts, ts + TB * (size_t)j, Transcript::kLiveBytes) != 0) return false;       // (the 5 padding bytes carry nothing)
   return true;
 }
 
@@ -368,7 +374,7 @@ int zkp_prove_phase_a(const zkp_statement* stp, uint32_t N, uint8_t* ts, const u
   std::vector<uint8_t> own_entropy;
   if (!entropy) {                                                      // prover.rs:82 `thread_rng()`
     own_entropy.resize(32 * (size_t)N);
-    os_random(own_entropy.data(), own_entropy.size());
+    if (!os_random(own_entropy.data(), own_entropy.size())) return ZKP_TB_NO_ENTROPY;
     entropy = own_entropy.data();
   }
   parallel_for(N, n_threads, [&](uint32_t lo, uint32_t hi) {
@@ -430,7 +436,7 @@ int zkp_prove_batch(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* 
   if (N == 0) return ZKP_TB_OK;
   if (ts && use_fused(ts, N)) {
     std::vector<uint8_t> own_entropy;
-    if (!entropy) { own_entropy.resize(32 * (size_t)N); os_random(own_entropy.data(), own_entropy.size()); entropy = own_entropy.data(); }
+    if (!entropy) { own_entropy.resize(32 * (size_t)N); if (!os_random(own_entropy.data(), own_entropy.size())) return ZKP_TB_NO_ENTROPY; entropy = own_entropy.data(); }
     if (st->ns && N >= 32) { const int rc = zkp_ctx_prepare_fixed_points(ctx, st->ns, common); if (rc) return rc; }
     FusedView fv(*st);
     int invalid = 0;
@@ -535,10 +541,11 @@ int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N,
       Transcript t = Transcript::from_bytes(ts + TB * (size_t)j);
       for (uint32_t k = 0; k < nc; ++k)                                // verifier.rs:108 (non-validating append)
         t.append_blinding_commitment(st.points[st.cons[k].lhs].name.c_str(), coms.data() + 32 * ((size_t)j * nc + k));
-      uint8_t c[32], claimed[32];
+      uint8_t c[32];
       t.get_challenge("chal", c);                                      // verifier.rs:113-119
-      Scalar::from_bytes_mod_order(challenges + 32 * (size_t)j).to_bytes(claimed);
-      results[j] = std::memcmp(c, claimed, 32) == 0 ? 0 : 1;
+      // the recomputed challenge is canonical and is compared with the claimed BYTES: c + l is a different `Scalar`
+      // for the reference (and does not even deserialise), so it must not verify here either
+      results[j] = std::memcmp(c, challenges + 32 * (size_t)j, 32) == 0 ? 0 : 1;
       t.to_bytes(ts + TB * (size_t)j);
     }
   });
@@ -553,7 +560,7 @@ int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N
   const zkp_statement& st = *stp;
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), np = (uint32_t)st.points.size();
   std::vector<uint8_t> own_w;
-  if (!weights16) { own_w.resize(16 * (size_t)N * nc); os_random(own_w.data(), own_w.size()); weights16 = own_w.data(); }
+  if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
   if (use_fused(ts, N)) {
     if (st.ns && N >= 32) { const int rc = zkp_ctx_prepare_fixed_points(ctx, st.ns, common); if (rc) return rc; }
     FusedView fv(st);
@@ -622,7 +629,7 @@ int zkp_batch_verify_build(const zkp_statement* stp, uint32_t N, uint32_t n_tran
   build_verifiers(st, N, ts, inst, common, n_threads, failed.data());  // :75-77, :92-94, :105-107, :125-128
   for (uint8_t f : failed) if (f) return ZKP_TB_VERIFICATION_FAILURE;
   std::vector<uint8_t> own_w;
-  if (!weights16) { own_w.resize(16 * (size_t)N * nc); os_random(own_w.data(), own_w.size()); weights16 = own_w.data(); }
+  if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
   uint8_t* inst_coeffs = msm_scalars + 32 * (size_t)ns;                // Matrix(rows, N), entries[cols * r + c] (util.rs:24)
   std::atomic<int> any_fail{0};
   // per-thread partial sums of the static coefficients, reduced afterwards (:187, :198 sum over the whole batch)
@@ -682,7 +689,7 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, 
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), ni = st.ni, ns = st.ns;
   if (ts && use_fused(ts, N)) {
     std::vector<uint8_t> own_w;
-    if (!weights16) { own_w.resize(16 * (size_t)N * nc); os_random(own_w.data(), own_w.size()); weights16 = own_w.data(); }
+    if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
     FusedView fv(st);
     int verdict = 1;
     const int rc = zkp_fused_batch_verify(ctx, &fv.fs, N, ts, inst, common, commitments, responses, weights16, &verdict, coeffs);
@@ -709,7 +716,7 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, 
     if (any_fail) return ZKP_TB_VERIFICATION_FAILURE;
   }
   std::vector<uint8_t> own_w;
-  if (!weights16) { own_w.resize(16 * (size_t)N * nc); os_random(own_w.data(), own_w.size()); weights16 = own_w.data(); }
+  if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
   // statement incidence in point-id form (static ids first, then instance ids)
   auto pid = [&](uint32_t v) { return st.points[v].common ? st.points[v].rank : ns + st.points[v].rank; };
   std::vector<uint32_t> lhs(nc), off(nc + 1, 0), csc, cpt;

@@ -252,6 +252,9 @@ def prove_batch(eng: Engine, st: Statement, transcripts: np.ndarray, secrets: np
                 common: np.ndarray, entropy: Optional[np.ndarray] = None, threads: int = 0):
     """-> (challenges[N][32], responses[N][m][32], commitments[N][nc][32]); transcripts advanced in place."""
     n = len(transcripts)
+    _check_batch_shapes(st, n, inst, common, None, secrets)
+    if entropy is not None and tuple(np.shape(entropy)) != (n, 32):
+        raise ValueError("entropy must have shape (%d, 32)" % n)
     chal = np.zeros((n, 32), np.uint8)
     resp = np.zeros((n, st.m, 32), np.uint8)
     coms = np.zeros((n, st.nc, 32), np.uint8)
@@ -264,6 +267,9 @@ def prove_batch(eng: Engine, st: Statement, transcripts: np.ndarray, secrets: np
 
 def verify_compact_batch(eng, st, transcripts, inst, common, challenges, responses, threads: int = 0) -> np.ndarray:
     n = len(transcripts)
+    _check_batch_shapes(st, n, inst, common, None, responses)
+    if tuple(np.shape(challenges)) != (n, 32):
+        raise ValueError("challenges must have shape (%d, 32)" % n)
     res = np.ones(n, np.uint8)
     rc = lib().zkp_verify_compact_batch(eng._h, st._h, ctypes.c_uint32(n), _p(transcripts), _p(np.ascontiguousarray(inst)),
                                         _p(np.ascontiguousarray(common)), _p(np.ascontiguousarray(challenges)),
@@ -274,6 +280,7 @@ def verify_compact_batch(eng, st, transcripts, inst, common, challenges, respons
 
 def verify_batchable_each(eng, st, transcripts, inst, common, commitments, responses, weights16=None, threads: int = 0) -> np.ndarray:
     n = len(transcripts)
+    _check_batch_shapes(st, n, inst, common, commitments, responses, weights16, per_proof_weights=True)
     res = np.ones(n, np.uint8)
     rc = lib().zkp_verify_batchable_each(eng._h, st._h, ctypes.c_uint32(n), _p(transcripts), _p(np.ascontiguousarray(inst)),
                                          _p(np.ascontiguousarray(common)), _p(np.ascontiguousarray(commitments)),
@@ -283,10 +290,24 @@ def verify_batchable_each(eng, st, transcripts, inst, common, commitments, respo
     return res
 
 
+def _check_batch_shapes(st, n, inst, common, commitments, responses, weights16=None, per_proof_weights=False) -> None:
+    """The C side reads [ni][N][32], [ns][32], [N][nc][32], [N][m][32] and [nc][N][16] (or [N][nc][16]) straight from these
+    buffers: anything else would be an out-of-bounds read, so it is refused here."""
+    def want(name, a, shape):
+        if a is not None and (tuple(np.shape(a)) != shape or np.asarray(a).dtype != np.uint8):
+            raise ValueError("%s must be a uint8 array of shape %r, got %r" % (name, shape, tuple(np.shape(a))))
+    want("inst", inst, (st.ni, n, 32))
+    want("common", common, (st.ns, 32))
+    want("commitments", commitments, (n, st.nc, 32))
+    want("responses", responses, (n, st.m, 32))
+    want("weights16", weights16, (n, st.nc, 16) if per_proof_weights else (st.nc, n, 16))
+
+
 def batch_verify(eng, st, transcripts, inst, common, commitments, responses, weights16=None, threads: int = 0,
                  batch_size: Optional[int] = None) -> None:
     """Raises VerificationFailure / BatchSizeMismatch like BatchVerifier::verify_batchable."""
     n = len(commitments)
+    _check_batch_shapes(st, n, inst, common, commitments, responses, weights16)
     rc = lib().zkp_batch_verify(eng._h, st._h, ctypes.c_uint32(n if batch_size is None else batch_size),
                                 ctypes.c_uint32(len(transcripts)), _p(transcripts),
                                 _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
@@ -298,6 +319,7 @@ def batch_verify(eng, st, transcripts, inst, common, commitments, responses, wei
 def batch_verify_coeffs(eng, st, transcripts, inst, common, commitments, responses, weights16, threads: int = 0):
     """batch_verify that also returns the coefficient vector built on the GPU; (ok: bool, coeffs [total][32])."""
     n = len(commitments)
+    _check_batch_shapes(st, n, inst, common, commitments, responses, weights16)
     total = st.ns + (st.ni + st.nc) * n
     co = np.zeros((total, 32), np.uint8)
     rc = lib().zkp_batch_verify_coeffs(eng._h, st._h, ctypes.c_uint32(n), ctypes.c_uint32(len(transcripts)), _p(transcripts),
@@ -312,6 +334,7 @@ def batch_verify_coeffs(eng, st, transcripts, inst, common, commitments, respons
 def batch_verify_build(st, transcripts, inst, common, commitments, responses, weights16, threads: int = 0):
     """Host-only half of batch_verify: the exact MSM operands (no GPU needed)."""
     n = len(commitments)
+    _check_batch_shapes(st, n, inst, common, commitments, responses, weights16)
     total = st.ns + (st.ni + st.nc) * n
     ms = np.zeros((total, 32), np.uint8)
     mp = np.zeros((total, 32), np.uint8)
@@ -580,12 +603,15 @@ class ProofModule:
         for k in self.instance:
             if len(instance_points[k]) != n:
                 raise BatchSizeMismatch()
+        for p in proofs:                                                # batch_verifier.rs:142-149
+            if len(p.commitments) != len(self.constraints) or len(p.responses) != len(self.secrets):
+                raise VerificationFailure()
         ts = _transcripts_array(transcripts)
         inst = np.frombuffer(b"".join(_enc(e) for k in self.instance for e in instance_points[k]), np.uint8).reshape(len(self.instance), n, 32)
         common = np.frombuffer(b"".join(_enc(common_points[k]) for k in self.common), np.uint8).reshape(len(self.common), 32)
-        coms = np.frombuffer(b"".join(c for p in proofs for c in p.commitments), np.uint8).reshape(n, -1, 32)
-        resp = np.frombuffer(b"".join(r for p in proofs for r in p.responses), np.uint8).reshape(n, -1, 32)
-        w = None if weights is None else np.frombuffer(b"".join(int(x).to_bytes(16, "little") for row in weights for x in row), np.uint8).reshape(-1, n, 16)
+        coms = np.frombuffer(b"".join(c for p in proofs for c in p.commitments), np.uint8).reshape(n, len(self.constraints), 32)
+        resp = np.frombuffer(b"".join(r for p in proofs for r in p.responses), np.uint8).reshape(n, len(self.secrets), 32)
+        w = None if weights is None else np.frombuffer(b"".join(int(x).to_bytes(16, "little") for row in weights for x in row), np.uint8).reshape(len(self.constraints), n, 16)
         try:
             batch_verify(eng, self.statement, ts, inst, common, coms, resp, w, threads=threads, batch_size=n)
         finally:

@@ -67,10 +67,23 @@ const char* zkp_version(void);
  *     doublings per term, a 4 x larger table per point).  Every other entry point derives the shape from its inputs.
  *   ZKP_OPT_CT_SINGLE_USE_TABLES: whether ZKP_CT calls build a comb table also for a point that a single term multiplies
  *     (1, default) or walk a constant-time radix-16 ladder over the point's own eight multiples (0: ~25 % fewer
- *     instructions for that term, but a 321-operation dependent chain inside the term kernel).
- *   ZKP_OPT_EXPERIMENT: bit mask of kernel variants under measurement (tools/, never needed by callers; default 0). */
-enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_EXPERIMENT = 4 };
+ *     instructions for that term, but a 321-operation dependent chain inside the term kernel). */
+enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
+
+/* HIP graphs.  A batch of proofs is a chain of ~75 short kernels; enqueueing them one by one costs the host ~0.4 ms per
+ * batch, about half of what the GPU needs for it, so a caller that pipelines batches over several contexts becomes
+ * launch-bound.  Everything enqueued on the context's stream between _begin and _end -- *_dev calls of this library and
+ * the caller's own asynchronous copies on that stream -- is recorded instead of executed; zkp_graph_launch then replays
+ * the recording with ONE host call.  Replays read and write the same device addresses, so the buffers must stay alive
+ * and are reused by every replay.  Preconditions: the same calls ran once before on this context with the same shapes
+ * (statement plans compiled, workspace sized, fixed points registered) -- otherwise ZKP_ERR_ARG -- and profiling is off.
+ * A graph belongs to the context (its workspace) it was captured on. */
+typedef struct zkp_graph zkp_graph;
+int zkp_ctx_capture_begin(zkp_ctx* ctx);
+int zkp_ctx_capture_end(zkp_ctx* ctx, zkp_graph** out);
+int zkp_graph_launch(zkp_graph* graph, zkp_ctx* ctx);   /* asynchronous, on the context's current stream */
+void zkp_graph_destroy(zkp_graph* graph);
 
 /* Performance hint, never changes a result: declare points that very many terms of later zkp_msm_many calls
  * will reference -- in the reference's vocabulary the statement's COMMON variables (define_proof!,

@@ -396,3 +396,139 @@ def test_gpu_coefficient_build_matches_host_and_oracle(eng, n):
     ts = np.stack([T.Transcript(label).state] * n)
     ok, got = T.batch_verify_coeffs(eng, mod.statement, ts, inst, common, coms, bad, w)
     assert not ok and (got == want_sc).all()
+
+
+# ---- tests/sig_and_vrf_example.rs:283-384  create_and_verify_vrf -----------------------------------------------
+vrf_proof = T.define_proof("vrf_proof", b"VRF", ["x"], ["A", "G", "H"], ["B"], [("A", [("x", "B")]), ("G", [("x", "H")])])
+
+
+def hash_to_group(transcript) -> bytes:
+    """TranscriptProtocol::hash_to_group of the example (sig_and_vrf_example.rs:25-29): 64 challenge bytes -> from_uniform_bytes"""
+    return C.from_uniform_bytes(transcript.challenge_bytes(b"output", 64))
+
+
+def vrf(eng, sk: int, pk: bytes, function_transcript, message: bytes, proof_transcript):
+    function_transcript.append_message(b"msg", message)
+    H = hash_to_group(function_transcript)
+    G = mul(sk, H)
+    proof = vrf_proof.prove_compact(eng, proof_transcript, {"x": sk}, {"A": pk, "B": BASEPOINT, "G": G, "H": H})
+    return G, proof
+
+
+def vrf_verify(eng, output: bytes, function_transcript, message: bytes, pk: bytes, proof_transcript, proof):
+    function_transcript.append_message(b"msg", message)
+    H = hash_to_group(function_transcript)
+    vrf_proof.verify_compact(eng, proof, proof_transcript, {"A": pk, "B": BASEPOINT, "G": output, "H": H})
+
+
+def test_create_and_verify_vrf(eng):
+    rng = random.Random(5)
+    domain_sep, msg1, msg2 = b"My VRF Application", b"Test Message 1", b"Test Message 2"
+    sk1, sk2 = rng.randrange(1, M.L), rng.randrange(1, M.L)
+    pk1, pk2 = mul(sk1, BASEPOINT), mul(sk2, BASEPOINT)
+    output1, proof1 = vrf(eng, sk1, pk1, T.Transcript(domain_sep), msg1, T.Transcript(domain_sep))
+    output2, proof2 = vrf(eng, sk2, pk2, T.Transcript(domain_sep), msg2, T.Transcript(domain_sep))
+    # each VRF output was correctly produced
+    vrf_verify(eng, output1, T.Transcript(domain_sep), msg1, pk1, T.Transcript(domain_sep), proof1)
+    vrf_verify(eng, output2, T.Transcript(domain_sep), msg2, pk2, T.Transcript(domain_sep), proof2)
+    other = b"A different application"
+    for out, msg, pk, dom, proof in [(output1, msg1, pk2, domain_sep, proof1), (output2, msg2, pk1, domain_sep, proof2),      # wrong pubkey
+                                     (output2, msg1, pk1, domain_sep, proof1), (output1, msg2, pk2, domain_sep, proof2),      # wrong output
+                                     (output1, msg1, pk1, other, proof1), (output2, msg2, pk2, other, proof2)]:               # wrong domain separator
+        with pytest.raises(T.VerificationFailure):
+            vrf_verify(eng, out, T.Transcript(domain_sep), msg, pk, T.Transcript(dom), proof)
+
+
+# ---- beyond the reference: malleability and allocation order -----------------------------------------------------
+def test_non_canonical_challenge_is_rejected(eng):
+    """verifier.rs:115 compares the recomputed (canonical) challenge with the proof's Scalar; c + l is a different
+    value there and does not even deserialise.  Both routes of verify_compact must refuse it."""
+    x, points = _dleq_assignments()
+    proof = dleq.prove_compact(eng, T.Transcript(b"DLEQTest"), {"x": x}, points)
+    dleq.verify_compact(eng, proof, T.Transcript(b"DLEQTest"), points)
+    shifted = (int.from_bytes(proof.challenge, "little") + M.L).to_bytes(32, "little")
+    with pytest.raises(T.VerificationFailure):                                  # host-transcript route (N = 1)
+        dleq.verify_compact(eng, T.CompactProof(shifted, proof.responses), T.Transcript(b"DLEQTest"), points)
+    n = 64                                                                      # fused route (N >= 32)
+    _, inst, common = dleq.pack([], [points] * n)
+    chal = np.stack([np.frombuffer(proof.challenge, np.uint8)] * n).copy()
+    resp = np.stack([np.frombuffer(b"".join(proof.responses), np.uint8).reshape(-1, 32)] * n)
+    chal[17] = np.frombuffer(shifted, np.uint8)
+    ts = np.stack([T.Transcript(b"DLEQTest").state] * n)
+    res = T.verify_compact_batch(eng, dleq.statement, ts, inst, common, chal, resp)
+    assert res[17] == 1 and res.sum() == 1
+    old = T.lib().zkp_toolbox_get_fused_min_batch()
+    try:                                                                        # and the host route at the same size
+        T.lib().zkp_toolbox_set_fused_min_batch(0xffffffff)
+        ts = np.stack([T.Transcript(b"DLEQTest").state] * n)
+        res = T.verify_compact_batch(eng, dleq.statement, ts, inst, common, chal, resp)
+        assert res[17] == 1 and res.sum() == 1
+    finally:
+        T.lib().zkp_toolbox_set_fused_min_batch(old)
+
+
+@pytest.mark.parametrize("n", [1, 48])
+def test_interleaved_allocation_order_matches_model(eng, n):
+    """The reference appends to the transcript at every allocate_* call, in the caller's order (prover.rs:52-73):
+    point, scalar, point, scalar, point, point must give the model's bytes on the host route (n = 1) and the fused one."""
+    rng = random.Random(21)
+    Bp, Hp = M.BASEPOINT, M.ristretto_hash_from_bytes_sha512(b"interleaved")
+    label = b"InterleaveTest"
+
+    def build(cs, x, y, encs_or_pts):
+        vB = cs.allocate_point(b"B", encs_or_pts["B"])
+        vx = cs.allocate_scalar(b"x", x) if x is not None else cs.allocate_scalar(b"x")
+        vH = cs.allocate_point(b"H", encs_or_pts["H"])
+        vy = cs.allocate_scalar(b"y", y) if y is not None else cs.allocate_scalar(b"y")
+        vA = cs.allocate_point(b"A", encs_or_pts["A"])
+        vG = cs.allocate_point(b"G", encs_or_pts["G"])
+        first = lambda v: v[0] if isinstance(v, tuple) else v
+        cs.constrain(first(vA), [(vx, first(vB)), (vy, first(vH))])
+        cs.constrain(first(vG), [(vy, first(vB))])
+
+    proofs, all_encs, ents = [], [], []
+    for j in range(n):
+        x, y = rng.randrange(1, M.L), rng.randrange(1, M.L)
+        pts = {"B": Bp, "H": Hp, "A": M.pt_add(M.pt_mul(x, Bp), M.pt_mul(y, Hp)), "G": M.pt_mul(y, Bp)}
+        encs = {k: M.ristretto_encode(v) for k, v in pts.items()}
+        ent = bytes(rng.randrange(256) for _ in range(32))
+        mp = M.Prover(b"Interleaved", M.Transcript(label))
+        build(mp, x, y, pts)
+        want = mp.prove_compact(ent)
+        proofs.append((x, y, want)); all_encs.append(encs); ents.append(ent)
+    if n == 1:
+        x, y, want = proofs[0]
+        pr = T.Prover(b"Interleaved", T.Transcript(label), eng)
+        build(pr, x, y, all_encs[0])
+        got = pr.prove_compact(ents[0])
+        assert got.challenge == M.sc_to_bytes(want.challenge) and got.responses == [M.sc_to_bytes(r) for r in want.responses]
+        ve = T.Verifier(b"Interleaved", T.Transcript(label), eng)
+        build(ve, None, None, all_encs[0])
+        ve.verify_compact(got)
+        return
+    # a batch through the statement API: the same allocation sequence, every point an instance point
+    st = T.Statement(b"Interleaved")
+    vB = st.add_point(b"B", False); vx = st.add_secret(b"x"); vH = st.add_point(b"H", False); vy = st.add_secret(b"y")
+    vA = st.add_point(b"A", False); vG = st.add_point(b"G", False)
+    st.constrain(vA, [(vx, vB), (vy, vH)])
+    st.constrain(vG, [(vy, vB)])
+    secrets = np.frombuffer(b"".join(sc(x) + sc(y) for x, y, _ in proofs), np.uint8).reshape(n, 2, 32)
+    inst = np.frombuffer(b"".join(e[k] for k in ("B", "H", "A", "G") for e in all_encs), np.uint8).reshape(4, n, 32)
+    entropy = np.frombuffer(b"".join(ents), np.uint8).reshape(n, 32)
+    ts = np.stack([T.Transcript(label).state] * n)
+    chal, resp, coms = T.prove_batch(eng, st, ts, secrets, inst, np.zeros((0, 32), np.uint8), entropy)      # fused (n >= 32)
+    for j, (_, _, want) in enumerate(proofs):
+        assert chal[j].tobytes() == M.sc_to_bytes(want.challenge), j
+        assert [r.tobytes() for r in resp[j]] == [M.sc_to_bytes(r) for r in want.responses], j
+    ts = np.stack([T.Transcript(label).state] * n)
+    assert not T.verify_compact_batch(eng, st, ts, inst, np.zeros((0, 32), np.uint8), chal, resp).any()
+    ts = np.stack([T.Transcript(label).state] * n)
+    T.batch_verify(eng, st, ts, inst, np.zeros((0, 32), np.uint8), coms, resp)
+    old = T.lib().zkp_toolbox_get_fused_min_batch()
+    try:                                                                        # host-transcript route: same bytes
+        T.lib().zkp_toolbox_set_fused_min_batch(0xffffffff)
+        ts = np.stack([T.Transcript(label).state] * n)
+        chal2, resp2, coms2 = T.prove_batch(eng, st, ts, secrets, inst, np.zeros((0, 32), np.uint8), entropy)
+        assert (chal2 == chal).all() and (resp2 == resp).all() and (coms2 == coms).all()
+    finally:
+        T.lib().zkp_toolbox_set_fused_min_batch(old)

@@ -241,3 +241,62 @@ def test_headers_are_plain_c(tmp_path):
     src.write_text('#include "zkp_mi355x.h"\n#include "zkp_toolbox.h"\nint main(void) { return (int)sizeof(zkp_fused_statement) * 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src), "-o", str(tmp_path / "a.o")])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")])
+
+
+def test_batch_verify_rejects_misshapen_proofs_before_any_c_call():
+    """batch_verifier.rs:142-149: a proof with the wrong number of commitments / responses is a VerificationFailure, and
+    the C side never sees a buffer shorter than [N][nc][32] / [N][m][32] (no engine needed: the check comes first)."""
+    mod = T.dleq_module()
+    good = T.BatchableProof([bytes([1]) * 32, bytes([2]) * 32], [sc(5)])
+    pts = {"A": [bytes([3]) * 32] * 2, "B": [bytes([4]) * 32] * 2, "H": [bytes([5]) * 32] * 2}
+    for bad in (T.BatchableProof([bytes([1]) * 32], [sc(5)]), T.BatchableProof([bytes([1]) * 32] * 2, []),
+                T.BatchableProof([bytes([1]) * 32] * 3, [sc(5)]), T.BatchableProof([bytes([1]) * 32] * 2, [sc(5), sc(6)])):
+        with pytest.raises(T.VerificationFailure):
+            mod.batch_verify(None, [good, bad], [T.Transcript(b"x"), T.Transcript(b"x")], pts, {"G": bytes([6]) * 32})
+    with pytest.raises(T.BatchSizeMismatch):
+        mod.batch_verify(None, [good, good], [T.Transcript(b"x")], pts, {"G": bytes([6]) * 32})
+    # the array-level entry points refuse buffers that do not have the statement's shape
+    ts = np.stack([T.Transcript(b"x").state] * 2)
+    with pytest.raises(ValueError):
+        T.batch_verify(None, mod.statement, ts, np.zeros((3, 2, 32), np.uint8), np.zeros((1, 32), np.uint8),
+                       np.zeros((2, 1, 32), np.uint8), np.zeros((2, 1, 32), np.uint8))
+
+
+def test_transcript_blob_padding_is_zero_and_ignored():
+    """203 live bytes + 5 bytes of padding: written as zeros, never read."""
+    t = T.Transcript(b"pad")
+    t.append_message(b"l", b"m" * 300)
+    assert not t.state[203:].any()
+    u = T.Transcript(_state=t.state.copy())
+    u.state[203:] = 0xff
+    assert t.challenge_bytes(b"c", 32) == u.challenge_bytes(b"c", 32)
+    assert not u.state[203:].any()
+
+
+def test_interleaved_allocations_host_phase_a_matches_model():
+    """Allocation order is part of the statement (prover.rs:52-73): scalars allocated after points are hashed where the
+    caller put them.  Host half only (blindings come out of the transcript, so they pin the whole op sequence)."""
+    rng = random.Random(31)
+    label = b"InterleaveTest"
+    Bp, Hp = M.BASEPOINT, M.ristretto_hash_from_bytes_sha512(b"interleaved")
+    x, y = rng.randrange(1, M.L), rng.randrange(1, M.L)
+    pts = {"B": Bp, "H": Hp, "A": M.pt_add(M.pt_mul(x, Bp), M.pt_mul(y, Hp)), "G": M.pt_mul(y, Bp)}
+    ent = bytes(rng.randrange(256) for _ in range(32))
+    mp = M.Prover(b"Interleaved", M.Transcript(label))
+    vB, _ = mp.allocate_point(b"B", pts["B"]); vx = mp.allocate_scalar(b"x", x); vH, _ = mp.allocate_point(b"H", pts["H"])
+    vy = mp.allocate_scalar(b"y", y); vA, _ = mp.allocate_point(b"A", pts["A"]); vG, _ = mp.allocate_point(b"G", pts["G"])
+    mp.constrain(vA, [(vx, vB), (vy, vH)])
+    mp.constrain(vG, [(vy, vB)])
+    want = mp.prove_batchable(ent)
+    st = T.Statement(b"Interleaved")
+    b_ = st.add_point(b"B", False); x_ = st.add_secret(b"x"); h_ = st.add_point(b"H", False); y_ = st.add_secret(b"y")
+    a_ = st.add_point(b"A", False); g_ = st.add_point(b"G", False)
+    st.constrain(a_, [(x_, b_), (y_, h_)])
+    st.constrain(g_, [(y_, b_)])
+    ts = T.Transcript(label).state.reshape(1, -1).copy()
+    secrets = arr([sc(x), sc(y)]).reshape(1, 2, 32)
+    inst = arr([M.ristretto_encode(pts[k]) for k in ("B", "H", "A", "G")]).reshape(4, 1, 32)
+    blind, off, scal, pidx = T.prove_phase_a(st, ts, secrets, inst, np.zeros((0, 32), np.uint8), np.frombuffer(ent, np.uint8).reshape(1, 32))
+    coms = arr(list(want.commitments)).reshape(1, 2, 32)      # the model's commitments stand in for the MSM (CPU test)
+    chal, resp = T.prove_phase_b(st, ts, secrets, blind, coms)
+    assert [r.tobytes() for r in resp[0]] == [M.sc_to_bytes(r) for r in want.responses]

@@ -20,10 +20,10 @@ PY
 }
 run t20 --steps 20 --warmup 5
 run t200 --steps 200 --warmup 3
-run l20 --steps 20 --warmup 5 --engine-opt 3=0
-run l200 --steps 200 --warmup 3 --engine-opt 3=0
-run t200s24 --steps 200 --warmup 3 --streams 24
-run t200s12 --steps 200 --warmup 3 --streams 12
+run e20 --steps 20 --warmup 5 --engine-opt 4=1
+run e200 --steps 200 --warmup 3 --engine-opt 4=1
+run t200b --steps 200 --warmup 3
+run t100 --steps 100 --warmup 3
 B="python bench.py --steps 20 --warmup 1 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o kt -- $B > $O/${TAG}_kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_prof -o sq -- $B > $O/${TAG}_sq.log 2>&1

@@ -481,6 +481,7 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   const std::string key = plan_key(flow, st, s, N, pos);
   auto it = c->fused_plans.find(key);
   if (it != c->fused_plans.end()) { *out = static_cast<fused_plan*>(it->second); return ZKP_OK; }
+  if (c->capturing) return fail(ZKP_ERR_ARG, "graph capture: this statement has no compiled plan yet -- run the same call once before capturing it");
   std::unique_ptr<fused_plan> pl(new fused_plan());
   pl->s = s;
   pl->N = N;

@@ -21,7 +21,6 @@ constexpr int HOT_SLOTS = 64;
 constexpr int HOT_CLASSES = HOT_SLOTS + 2;                       // class 64 = "cold" terms through a comb table, 65 = cold terms on a ladder
 constexpr int CLASS_COMB = HOT_SLOTS, CLASS_LADDER = HOT_SLOTS + 1;
 constexpr size_t HOT_SLOT_NIELS = (size_t)HOT_WINDOWS * HOT_ENTRIES;
-constexpr uint32_t HOT_BLOCK = 768;                             // lanes per block of the fixed-base term kernel: 12 wavefronts = 3 per SIMD, one block (one 58 KB table in LDS) per CU
 
 // ---- table construction ---------------------------------------------------------------------------------------------
 // bases[h][w] = 16^w * P_h      (one lane per point: 256 sequential doublings, paid once per point)
@@ -137,15 +136,15 @@ k_class_count(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_po
   if (threadIdx.x < HOT_CLASSES && h[threadIdx.x]) atomicAdd(&class_cnt[threadIdx.x], h[threadIdx.x]);
 }
 // class_start[c] = first list position of class c; class_start[HOT_CLASSES] = n_terms; cursor = copy;
-// blk_start[c] = first HOT_BLOCK-lane block of fixed-base class c when every class starts a new block (k_terms_hot stages
-// one table per block in LDS); blk_start[HOT_SLOTS] = number of such blocks
+// blk_start[c] = first 256-lane block of fixed-base class c when every class starts a new block (k_terms_split stages one
+// table per block in LDS); blk_start[HOT_SLOTS] = number of such blocks
 __global__ void k_class_scan(const uint32_t* __restrict__ class_cnt, uint32_t* __restrict__ class_start, uint32_t* __restrict__ cursor,
                              uint32_t* __restrict__ blk_start) {
   if (threadIdx.x != 0) return;
   uint32_t run = 0, blk = 0;
   for (int c = 0; c < HOT_CLASSES; ++c) {
     class_start[c] = run; cursor[c] = run; run += class_cnt[c];
-    if (c < HOT_SLOTS) { blk_start[c] = blk; blk += (class_cnt[c] + HOT_BLOCK - 1u) / HOT_BLOCK; }
+    if (c < HOT_SLOTS) { blk_start[c] = blk; blk += (class_cnt[c] + 255u) / 256u; }
   }
   class_start[HOT_CLASSES] = run;
   blk_start[HOT_SLOTS] = blk;

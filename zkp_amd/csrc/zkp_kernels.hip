@@ -128,59 +128,53 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
   if (t < n_terms) term_generic(t, scalars, pidx, n_points, pts, partial);
 }
 
-// Classified terms, one kernel per class so that each gets its own register budget (fused into one kernel the three
-// walks needed 219 VGPRs = 2 wavefronts per SIMD; on their own the comb walk takes 154 and the fixed-base walk 161 = 3 per
-// SIMD, which is what hides the carry chains of the field arithmetic):
-//   k_terms_ladder  points with a single cold use of a variable-time call: 321 point operations per lane (longest: first)
-//   k_terms_comb    terms on per-proof points with a comb table: BITS - 4 + 65 point operations
-//   k_terms_hot     terms on a registered common point: 65 mixed additions against a table staged in LDS
-template <bool CT>
-__global__ void __launch_bounds__(256, 2)
-k_terms_ladder(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, const uint32_t* __restrict__ class_start,
-               const uint32_t* __restrict__ list, const dev_affine* __restrict__ pts, dev_ext* __restrict__ ladder_rw,
-               uint32_t max_ladder, dev_ext* __restrict__ partial) {
-  const uint32_t first = class_start[CLASS_LADDER], n_ladder = class_start[HOT_CLASSES] - first;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_ladder || i >= max_ladder) return;                   // (max_ladder bounds n_ladder by construction)
-  const uint32_t t = list[first + i];
-  const uint32_t pi = pidx[t];                                    // < n_points (out-of-range indices are classed with the comb terms)
-  term_ladder16<CT>(t, scalars, pts + pi, ladder_rw + (size_t)i * LADDER_ENTRIES, partial);
-}
-
+// Classified terms in ONE launch, longest first: ladder terms (points with a single cold use: 321 point operations per
+// lane), terms on per-proof points with a comb table (BITS + 64 point operations), and the fixed-base terms (65 mixed
+// additions), which fill the SIMDs the others leave idle.
 template <bool CT, int TEETH>
-__global__ void __launch_bounds__(256, 3)
-k_terms_comb(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
-             const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
-             const uint32_t* __restrict__ list, dev_ext* __restrict__ partial) {
-  const uint32_t first = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - first;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_comb) return;
-  const uint32_t t = list[first + i];
-  const uint32_t pi = pidx[t];
-  if (pi >= n_points) return;                                     // (out of range: flagged by k_reduce_encode)
-  const uint32_t slot = slot_of[pi];
-  if (slot != 0xffffffffu) term_comb<CT, TEETH>(t, scalars, comb + (size_t)slot * comb_cfg<TEETH>::ENTRIES, partial);
-}
-
-// A block of fixed-base terms serves ONE table, staged in LDS (58 KB): the masked scans then read the 8 entries of a row
-// as LDS broadcasts instead of 56 16-byte vector loads per lane and addition -- through the L1 (64 B/clk per CU, against
-// 4 SIMDs of v_mad_u64_u32) those loads alone took ~70 % as long as the additions they feed.
-template <bool CT>
-__global__ void __launch_bounds__(HOT_BLOCK, 1)
-k_terms_hot(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ class_start, const uint32_t* __restrict__ blk_start,
-            const uint32_t* __restrict__ list, const dev_niels* __restrict__ tables, dev_ext* __restrict__ partial) {
+__global__ void __launch_bounds__(256, 2)
+k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
+              const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
+              const uint32_t* __restrict__ blk_start, const uint32_t* __restrict__ list, const dev_niels* __restrict__ tables,
+              const dev_affine* __restrict__ pts, dev_ext* __restrict__ ladder_rw, uint32_t max_ladder, dev_ext* __restrict__ partial) {
+  // A block of fixed-base terms serves ONE table, staged in LDS (58 KB): the masked scans then read the 8 entries of a row
+  // as LDS broadcasts instead of 56 16-byte vector loads per lane and addition -- through the L1 those loads alone took
+  // ~70 % as long as the additions they feed (64 B/clk per CU against 4 SIMDs of v_mad_u64_u32).
   __shared__ uint4 hot_lds[HOT_SLOT_NIELS * sizeof(dev_niels) / 16];
-  const uint32_t hb = blockIdx.x;
-  if (hb >= blk_start[HOT_SLOTS]) return;                         // (uniform in the block)
-  uint32_t c = 0;
-  while (blk_start[c + 1] <= hb) ++c;                             // class = table slot of this block
-  const uint4* src = reinterpret_cast<const uint4*>(tables + (size_t)c * HOT_SLOT_NIELS);
-  constexpr uint32_t kVec = HOT_SLOT_NIELS * sizeof(dev_niels) / 16;
-  for (uint32_t k = threadIdx.x; k < kVec; k += HOT_BLOCK) hot_lds[k] = src[k];
-  __syncthreads();
-  const uint32_t i = (hb - blk_start[c]) * HOT_BLOCK + threadIdx.x;
-  if (i < class_start[c + 1] - class_start[c])
-    term_fixed_base<CT>(list[class_start[c] + i], scalars, reinterpret_cast<const dev_niels*>(hot_lds), partial);
+  const uint32_t n_hot = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - n_hot;
+  const uint32_t n_ladder = class_start[HOT_CLASSES] - class_start[CLASS_LADDER];
+  const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
+  const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
+  if (blockIdx.x < ladder_blocks) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_ladder && i < max_ladder) {                         // (max_ladder bounds n_ladder by construction)
+      const uint32_t t = list[n_hot + n_comb + i];
+      const uint32_t pi = pidx[t];                                // < n_points (out-of-range indices are classed with the comb terms)
+      term_ladder16<CT>(t, scalars, pts + pi, ladder_rw + (size_t)i * LADDER_ENTRIES, partial);
+    }
+  } else if (blockIdx.x < ladder_blocks + comb_blocks) {
+    const uint32_t i = (blockIdx.x - ladder_blocks) * blockDim.x + threadIdx.x;
+    if (i < n_comb) {
+      const uint32_t t = list[n_hot + i];
+      const uint32_t pi = pidx[t];
+      if (pi < n_points) {                                        // (out of range: flagged by k_reduce_encode)
+        const uint32_t slot = slot_of[pi];
+        if (slot != 0xffffffffu) term_comb<CT, TEETH>(t, scalars, comb + (size_t)slot * comb_cfg<TEETH>::ENTRIES, partial);
+      }
+    }
+  } else {
+    const uint32_t hb = blockIdx.x - ladder_blocks - comb_blocks;
+    if (hb >= blk_start[HOT_SLOTS]) return;                       // (uniform in the block)
+    uint32_t c = 0;
+    while (blk_start[c + 1] <= hb) ++c;                           // class = table slot of this block
+    const uint4* src = reinterpret_cast<const uint4*>(tables + (size_t)c * HOT_SLOT_NIELS);
+    constexpr uint32_t kVec = HOT_SLOT_NIELS * sizeof(dev_niels) / 16;
+    for (uint32_t k = threadIdx.x; k < kVec; k += 256) hot_lds[k] = src[k];
+    __syncthreads();
+    const uint32_t i = (hb - blk_start[c]) * 256 + threadIdx.x;
+    if (i < class_start[c + 1] - class_start[c])
+      term_fixed_base<CT>(list[class_start[c] + i], scalars, reinterpret_cast<const dev_niels*>(hot_lds), partial);
+  }
 }
 
 template <typename STATUS_T>
@@ -421,8 +415,8 @@ struct pip_cfg {
   }
 };
 
-template <int C, int OCC = 2>
-__global__ void __launch_bounds__(256, OCC)
+template <int C>
+__global__ void __launch_bounds__(256, 2)
 k_pip_prepare(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
               dev_niels* __restrict__ niels, uint32_t* __restrict__ digits, uint32_t* __restrict__ invalid) {
   using cfg = pip_cfg<C>;
@@ -916,6 +910,7 @@ struct zkp_ctx {
   hipStream_t side_stream = nullptr;       // fused flows: point phase of the MSM next to the transcripts
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool prof_suspended = false;
+  bool capturing = false;                  // between zkp_ctx_capture_begin / _end: nothing may allocate or synchronise
   uint64_t batch_encode_min = 65536;       // ZKP_OPT_BATCH_ENCODE_MIN
   bool batch_encode_user = false;          // set explicitly: applies to every entry point as is
   int comb_teeth = 4;                      // ZKP_OPT_COMB_TEETH (generic _dev entry point; the other callers derive it)
@@ -925,7 +920,6 @@ struct zkp_ctx {
   // spent on a table run next to the other tables' chains.  Constant-time calls therefore give single-use points a table
   // as well; variable-time calls (no masked scans: their ladder is 30 % cheaper than table + walk) keep the ladder.
   uint32_t ct_comb_min = 1;
-  uint32_t experiment = 0;                 // ZKP_OPT_EXPERIMENT: bit mask selecting alternative kernel variants under measurement
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool profiling = false;
@@ -961,6 +955,7 @@ struct carve {
 
 int ensure_ws(zkp_ctx* c, size_t bytes) {
   if (bytes <= c->ws_bytes) return ZKP_OK;
+  if (c->capturing) return fail(ZKP_ERR_ARG, "graph capture: the workspace would grow -- run the same calls once before capturing them");
   if (c->ws) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(c->ws));
@@ -975,10 +970,10 @@ int ensure_ws(zkp_ctx* c, size_t bytes) {
 
 void prof_begin(zkp_ctx* c) {
   c->n_ev = 0;
-  if (c->profiling) { hipEventRecord(c->ev[0], c->stream); c->ev_kind[0] = -1; c->n_ev = 1; }
+  if (c->profiling && !c->capturing) { hipEventRecord(c->ev[0], c->stream); c->ev_kind[0] = -1; c->n_ev = 1; }
 }
 void prof_mark(zkp_ctx* c, int kind) {
-  if (c->profiling && !c->prof_suspended && c->n_ev < kMaxEvents) {
+  if (c->profiling && !c->capturing && !c->prof_suspended && c->n_ev < kMaxEvents) {
     hipEventRecord(c->ev[c->n_ev], c->stream);
     c->ev_kind[c->n_ev] = kind;
     c->n_ev++;
@@ -1048,18 +1043,11 @@ size_t terms_path_ws(uint32_t n_points, uint32_t n_terms, uint32_t n_msm, const 
 }
 
 template <bool CT, int TEETH>
-void launch_terms_split(zkp_ctx* c, uint32_t n_terms, const terms_cfg& k, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points,
-                        const dev_ext* comb, const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start,
-                        const uint32_t* list, const dev_affine* pts, dev_ext* ladder, dev_ext* part) {
-  // grids are upper bounds (the class sizes live on the device): surplus blocks return at once
-  if (k.max_ladder)
-    hipLaunchKernelGGL((k_terms_ladder<CT>), grid1(std::min<size_t>(n_terms, k.max_ladder), 256), dim3(256), 0, c->stream, d_scalars, d_pidx, class_start, list,
-                       pts, ladder, k.max_ladder, part);
-  if (k.max_tables)
-    hipLaunchKernelGGL((k_terms_comb<CT, TEETH>), grid1(n_terms, 256), dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, list, part);
-  if (c->hot_nreg)
-    hipLaunchKernelGGL((k_terms_hot<CT>), dim3((unsigned)(n_terms / HOT_BLOCK + 1 + HOT_SLOTS)), dim3(HOT_BLOCK), 0, c->stream, d_scalars, class_start, blk_start, list,
-                       c->hot_tables, part);
+void launch_terms_split(zkp_ctx* c, dim3 grid, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
+                        const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
+                        const dev_affine* pts, dev_ext* ladder, uint32_t max_ladder, dev_ext* part) {
+  hipLaunchKernelGGL((k_terms_split<CT, TEETH>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
+                     c->hot_tables, pts, ladder, max_ladder, part);
 }
 
 // phase: everything (default), or only the part that does not look at the scalars (decode, classification, comb tables:
@@ -1119,6 +1107,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     }
     prof_mark(c, ZKP_K_SORT);          // path A: term classification + comb-table construction
     }
+    const dim3 grid((unsigned)((n_terms + 255) / 256 + 3 + HOT_SLOTS));     // every fixed-base class starts a new block
     // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l
     if (batched_encode) {
       uint8_t* d_half = reinterpret_cast<uint8_t*>(base + o.half);
@@ -1127,11 +1116,11 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     }
     if (phase & PH_SCALARS) {
       if (flags == ZKP_CT) {
-        if (k.teeth == 16) launch_terms_split<true, 16>(c, n_terms, k, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, part);
-        else launch_terms_split<true, 4>(c, n_terms, k, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, part);
+        if (k.teeth == 16) launch_terms_split<true, 16>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        else launch_terms_split<true, 4>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
       } else {
-        if (k.teeth == 16) launch_terms_split<false, 16>(c, n_terms, k, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, part);
-        else launch_terms_split<false, 4>(c, n_terms, k, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, part);
+        if (k.teeth == 16) launch_terms_split<false, 16>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        else launch_terms_split<false, 4>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
       }
     }
   } else {
@@ -1220,10 +1209,7 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
 
   HIP_TRY(hipMemsetAsync(invalid, 0, 4, c->stream));
-  if (c->experiment & 1u)
-    hipLaunchKernelGGL((k_pip_prepare<C, 3>), grid1(n, 256), dim3(256), 0, c->stream, n, d_scalars, d_points, niels, digits, invalid);
-  else
-    hipLaunchKernelGGL((k_pip_prepare<C, 2>), grid1(n, 256), dim3(256), 0, c->stream, n, d_scalars, d_points, niels, digits, invalid);
+  hipLaunchKernelGGL(k_pip_prepare<C>, grid1(n, 256), dim3(256), 0, c->stream, n, d_scalars, d_points, niels, digits, invalid);
   prof_mark(c, ZKP_K_DECODE);
   hipLaunchKernelGGL(k_pip_tile_hist<C>, dim3(tiles, cfg::W1), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist);
   hipLaunchKernelGGL(k_pip_tile_total, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, tiles, (uint32_t)nb, tilehist, hist);
@@ -1366,7 +1352,6 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
   switch (option) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
     case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_comb_min = value ? 1u : 2u; return ZKP_OK;
-    case ZKP_OPT_EXPERIMENT: c->experiment = (uint32_t)value; return ZKP_OK;
     case ZKP_OPT_COMB_TEETH:
       if (value != 4 && value != 16) return fail(ZKP_ERR_ARG, "ZKP_OPT_COMB_TEETH must be 4 or 16");
       c->comb_teeth = (int)value;
@@ -1384,6 +1369,52 @@ int zkp_ctx_set_profiling(zkp_ctx* c, int enabled) {
   c->profiling = enabled != 0;
   return ZKP_OK;
 }
+struct zkp_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int device = 0;
+};
+int zkp_ctx_capture_begin(zkp_ctx* c) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (c->capturing) return fail(ZKP_ERR_ARG, "capture already in progress");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  c->capturing = true;
+  return ZKP_OK;
+}
+int zkp_ctx_capture_end(zkp_ctx* c, zkp_graph** out) {
+  if (!c || !out) return fail(ZKP_ERR_ARG, "NULL pointer");
+  *out = nullptr;
+  if (!c->capturing) return fail(ZKP_ERR_ARG, "no capture in progress");
+  c->capturing = false;
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamEndCapture(c->stream, &g));
+  if (!g) return fail(ZKP_ERR_HIP, "hipStreamEndCapture returned no graph (a call inside the capture failed)");
+  hipGraphExec_t e = nullptr;
+  const hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  if (rc != hipSuccess) { hipGraphDestroy(g); return fail(ZKP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(rc)); }
+  zkp_graph* zg = new zkp_graph();
+  zg->graph = g;
+  zg->exec = e;
+  zg->device = c->device;
+  *out = zg;
+  return ZKP_OK;
+}
+int zkp_graph_launch(zkp_graph* g, zkp_ctx* c) {
+  if (!g || !c) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (g->device != c->device) return fail(ZKP_ERR_ARG, "graph and context are on different devices");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipGraphLaunch(g->exec, c->stream));
+  return ZKP_OK;
+}
+void zkp_graph_destroy(zkp_graph* g) {
+  if (!g) return;
+  hipSetDevice(g->device);
+  if (g->exec) hipGraphExecDestroy(g->exec);
+  if (g->graph) hipGraphDestroy(g->graph);
+  delete g;
+}
+
 int zkp_ctx_last_timing(zkp_ctx* c, float* kernel_ms, float* total_ms) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   for (float& k : c->kernel_ms) k = 0;

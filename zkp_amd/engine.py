@@ -25,6 +25,7 @@ EXPORTS = (
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
     "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest", "zkp_batch_check", "zkp_fused_prove", "zkp_fused_verify_compact", "zkp_fused_batch_verify",
     "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_batch_verify_dev",
+    "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_graph_launch", "zkp_graph_destroy",
 )
 
 
@@ -60,6 +61,11 @@ def load_library() -> ctypes.CDLL:
     lib.zkp_encode_many.argtypes = [vp, ctypes.c_uint64, u8p, u8p]
     lib.zkp_ctx_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.zkp_ctx_set_profiling.argtypes = [vp, i32]
+    lib.zkp_ctx_capture_begin.argtypes = [vp]
+    lib.zkp_ctx_capture_end.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.zkp_graph_launch.argtypes = [vp, vp]
+    lib.zkp_graph_destroy.argtypes = [vp]
+    lib.zkp_graph_destroy.restype = None
     lib.zkp_ctx_prepare_fixed_points.argtypes = [vp, ctypes.c_uint32, u8p]
     lib.zkp_debug_quad_selftest.argtypes = [vp, ctypes.c_uint32, u8p, u8p]
     _lib = lib
@@ -195,6 +201,15 @@ class Engine:
         """Tuning knobs of include/zkp_mi355x.h (ZKP_OPT_*); results never depend on them."""
         _check(self._lib.zkp_ctx_set_option(self._h, ctypes.c_int(option), ctypes.c_uint64(value)), "zkp_ctx_set_option")
 
+    def capture_begin(self) -> None:
+        """Start recording what is enqueued on this context's stream into a HIP graph (zkp_ctx_capture_begin)."""
+        _check(self._lib.zkp_ctx_capture_begin(self._h), "zkp_ctx_capture_begin")
+
+    def capture_end(self) -> "Graph":
+        g = ctypes.c_void_p()
+        _check(self._lib.zkp_ctx_capture_end(self._h, ctypes.byref(g)), "zkp_ctx_capture_end")
+        return Graph(self, g)
+
     def set_profiling(self, enabled: bool) -> None:
         _check(self._lib.zkp_ctx_set_profiling(self._h, int(enabled)), "zkp_ctx_set_profiling")
 
@@ -205,6 +220,27 @@ class Engine:
         if rc < 0:
             _check(rc, "zkp_ctx_last_timing")
         return {k: float(arr[i]) for i, k in enumerate(K_NAMES)}, float(tot.value)
+
+
+class Graph:
+    """zkp_graph: a recorded chain of *_dev calls, replayed with one host call."""
+
+    def __init__(self, eng: "Engine", handle):
+        self._eng, self._h = eng, handle
+
+    def launch(self) -> None:
+        _check(self._eng._lib.zkp_graph_launch(self._h, self._eng._h), "zkp_graph_launch")
+
+    def close(self) -> None:
+        if self._h:
+            self._eng._lib.zkp_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _BatchStatementC(ctypes.Structure):

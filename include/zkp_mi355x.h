@@ -71,9 +71,10 @@ const char* zkp_version(void);
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
-/* HIP graphs.  A batch of proofs is a chain of ~75 short kernels; enqueueing them one by one costs the host ~0.4 ms per
- * batch, about half of what the GPU needs for it, so a caller that pipelines batches over several contexts becomes
- * launch-bound.  Everything enqueued on the context's stream between _begin and _end -- *_dev calls of this library and
+/* HIP graphs.  A batch of proofs is a chain of ~75 short kernels; enqueueing them one by one costs the host ~0.15 ms per
+ * batch (measured: 0.14-0.17 ms against 0.9 ms of GPU time per pipelined batch; 0.025 ms as a graph), which matters for
+ * short runs and for hosts busier than a benchmark loop.  Everything enqueued on the context's stream between _begin and
+ * _end -- *_dev calls of this library and
  * the caller's own asynchronous copies on that stream -- is recorded instead of executed; zkp_graph_launch then replays
  * the recording with ONE host call.  Replays read and write the same device addresses, so the buffers must stay alive
  * and are reused by every replay.  Preconditions: the same calls ran once before on this context with the same shapes
@@ -190,6 +191,13 @@ int zkp_fused_batch_verify(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t
 int zkp_fused_verify_batchable(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts,
                                const uint8_t* inst, const uint8_t* common, const uint8_t* commitments,
                                const uint8_t* responses, const uint8_t* weights16, uint8_t* results);
+/* The same, additionally returning the per-proof coefficient vectors the device folded (verifier.rs:144-160): debug_scalars
+ * = NULL or [N][n_static + n_instance + n_constraints][32], per proof in the operand order of verifier.rs:162-166 (the
+ * points by point id, then the commitments), so tests can compare them with a restatement of the fold. */
+int zkp_fused_verify_batchable_coeffs(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts,
+                                      const uint8_t* inst, const uint8_t* common, const uint8_t* commitments,
+                                      const uint8_t* responses, const uint8_t* weights16, uint8_t* results,
+                                      uint8_t* debug_scalars);
 
 /*     Device-resident variants: every buffer is a device pointer (16-byte aligned), nothing is copied and the call
  *     returns as soon as the work is queued on the context's stream (zkp_ctx_synchronize to wait).  strobe_pos =

@@ -3,6 +3,8 @@ against the host-transcript route of the same toolbox calls: proofs, verdicts an
 identical byte for byte, for every batch size (the route is chosen by zkp_toolbox_set_fused_min_batch), and both
 agree with the C oracle on sampled proofs.  Reference behaviour covered: prover.rs:76-112, verifier.rs:80-120,
 batch_verifier.rs:67-235, mod.rs:165-228 (identity rejection included)."""
+import random
+
 import numpy as np
 import pytest
 
@@ -441,3 +443,105 @@ def test_random_statements_fused_equals_host_route_and_oracle(eng, seed):
         pts_j = np.stack([val[int(a)] if names[a][1] else val[int(a)][j] for a in order])
         ec, er, ek, _ = C.prove(cst, label, secrets[j], pts_j, entropy[j].tobytes())
         assert out["fused"][0][j].tobytes() == ec.tobytes() and (out["fused"][1][j] == er).all() and (out["fused"][2][j] == ek).all()
+
+
+def test_verify_batchable_coefficient_fold_matches_model(eng):
+    """Row a5 (verifier.rs:144-160): the per-proof coefficient vector the DEVICE folds -- coeffs[np + k] = -r_k,
+    coeffs[lhs_k] += r_k (-c), coeffs[pt] += r_k resp[sc] -- against the model's restatement, scalar for scalar, in the operand
+    order of verifier.rs:162-166 (points, then commitments).  The verdicts alone would not notice a fold that is wrong
+    in a way the MSM forgives."""
+    from zkp_amd.engine import FusedStatement
+    n = 40
+    rng = random.Random(55)
+    nrng = np.random.default_rng(55)
+    mst, mod = M.cmz_statement(10), T.cmz_module(10)
+    from tests.test_gpu_toolbox import _cmz_batch
+    _, secrets, inst, common = _cmz_batch(n, 56)
+    label = b"FoldTest"
+    entropy = nrng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ts = _fresh(label, n)
+    chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, common, entropy)
+    w16 = nrng.integers(0, 256, size=(n, 11, 16), dtype=np.uint8)
+    w16[3] = 0xff                                                   # u128::MAX weights
+    w16[4] = 0                                                      # zero weights
+    # the statement in the fused ABI's form: secrets, points (instance first, then common: define_proof!'s order), constraints
+    names = mod.instance + mod.common
+    fst = FusedStatement(mod.label, [s.encode() for s in mod.secrets], [(k.encode(), k in mod.common) for k in names],
+                         [(names.index(l), [(mod.secrets.index(s), names.index(p)) for s, p in lc]) for l, lc in mod.constraints])
+    ts = _fresh(label, n)
+    res, co = eng.fused_verify_batchable_coeffs(fst, ts, inst, common, coms, resp, w16)
+    assert not res.any()
+    for j in (0, 3, 4, 17, n - 1):
+        ver = mst.build_verifier(M.Transcript(label), {k: (inst[mod.instance.index(k), j] if k in mod.instance else common[mod.common.index(k)]).tobytes()
+                                                        for k in names})
+        proof = M.BatchableProof([c.tobytes() for c in coms[j]], [int.from_bytes(r.tobytes(), "little") for r in resp[j]])
+        weights = [int.from_bytes(w16[j, k].tobytes(), "little") for k in range(11)]
+        for i, com in enumerate(proof.commitments):                 # verifier.rs:134-142 (what verify_batchable does before the fold)
+            ver.transcript.validate_and_append_blinding_commitment(ver.point_labels[ver.constraints[i][0]], com)
+        minus_c = (-ver.transcript.get_challenge(b"chal")) % M.L
+        want = [0] * (len(ver.points) + 11)
+        for i, (lhs, lc) in enumerate(ver.constraints):             # verifier.rs:151-160
+            r = weights[i]
+            want[len(ver.points) + i] = (want[len(ver.points) + i] - r) % M.L
+            want[lhs] = (want[lhs] + r * minus_c) % M.L
+            for sv, pv in lc:
+                want[pv] = (want[pv] + r * proof.responses[sv]) % M.L
+        # the model numbers points in allocation order (instance, then common); the device by point id (common first)
+        ns, ni = len(mod.common), len(mod.instance)
+        got = [int.from_bytes(co[j, i].tobytes(), "little") for i in range(ns + ni + 11)]
+        by_alloc = got[ns:ns + ni] + got[:ns] + got[ns + ni:]
+        assert by_alloc == want, j
+        ver2 = mst.build_verifier(M.Transcript(label), {k: (inst[mod.instance.index(k), j] if k in mod.instance else common[mod.common.index(k)]).tobytes()
+                                                         for k in names})
+        ver2.verify_batchable(proof, weights)                        # and the model accepts the same proof with the same weights
+
+
+def test_long_labels_cross_strobe_blocks_fused_host_oracle_model(eng):
+    """Labels of 165 / 166 / 167 / 400 bytes put label and length prefix on either side of a 166-byte STROBE block: the
+    GPU transcript programs, the host Merlin, the C oracle and the model must frame them identically (4-way)."""
+    n = 40
+    rng = random.Random(66)
+    nrng = np.random.default_rng(66)
+    lab = lambda k, c: (c * k).encode()
+    proof_label = lab(300, "L")
+    sec_names, pt_names = [lab(165, "x").decode(), lab(167, "y").decode()], [lab(166, "A").decode(), lab(400, "B").decode(), "G", lab(1, "H").decode()]
+    G, H = M.BASEPOINT, M.ristretto_hash_from_bytes_sha512(b"long labels")
+    mod = T.define_proof("long", proof_label, sec_names, pt_names[:2], pt_names[2:],
+                         [(pt_names[0], [(sec_names[0], "G"), (sec_names[1], pt_names[3])]), (pt_names[1], [(sec_names[1], "G")])])
+    cst = C.Statement(proof_label, sec_names, [(pt_names[0], False), (pt_names[1], False), ("G", True), (pt_names[3], True)],
+                      [(pt_names[0], [(sec_names[0], "G"), (sec_names[1], pt_names[3])]), (pt_names[1], [(sec_names[1], "G")])])
+    xs = [(rng.randrange(1, M.L), rng.randrange(1, M.L)) for _ in range(n)]
+    Ge, He = M.ristretto_encode(G), M.ristretto_encode(H)
+    A = [M.ristretto_encode(M.pt_add(M.pt_mul(x, G), M.pt_mul(y, H))) for x, y in xs]
+    B = [M.ristretto_encode(M.pt_mul(y, G)) for _, y in xs]
+    secrets = np.frombuffer(b"".join(x.to_bytes(32, "little") + y.to_bytes(32, "little") for x, y in xs), np.uint8).reshape(n, 2, 32)
+    inst = np.frombuffer(b"".join(A + B), np.uint8).reshape(2, n, 32)
+    common = np.frombuffer(Ge + He, np.uint8).reshape(2, 32)
+    entropy = nrng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    label = b"T" * 170                                               # the transcript label crosses a block as well
+    ts = _fresh(label, n)
+    chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, common, entropy)        # fused route
+    old = T.lib().zkp_toolbox_get_fused_min_batch()
+    try:
+        T.lib().zkp_toolbox_set_fused_min_batch(0xffffffff)
+        ts_h = _fresh(label, n)
+        chal_h, resp_h, coms_h = T.prove_batch(eng, mod.statement, ts_h, secrets, inst, common, entropy)   # host Merlin
+    finally:
+        T.lib().zkp_toolbox_set_fused_min_batch(old)
+    assert (chal == chal_h).all() and (resp == resp_h).all() and (coms == coms_h).all() and (ts[:, :203] == ts_h[:, :203]).all()
+    for j in (0, 1, n - 1):                                          # C oracle
+        ec, er, ek, _ = C.prove(cst, label, secrets[j], np.stack([inst[0, j], inst[1, j], common[0], common[1]]), entropy[j].tobytes())
+        assert chal[j].tobytes() == ec.tobytes() and (resp[j] == er).all() and (coms[j] == ek).all(), j
+    # model (pure Python), one proof
+    mp = M.Prover(proof_label, M.Transcript(label))
+    vx, vy = mp.allocate_scalar(sec_names[0].encode(), xs[0][0]), mp.allocate_scalar(sec_names[1].encode(), xs[0][1])
+    vA, _ = mp.allocate_point(pt_names[0].encode(), M.ristretto_decode(A[0])); vB, _ = mp.allocate_point(pt_names[1].encode(), M.ristretto_decode(B[0]))
+    vG, _ = mp.allocate_point(b"G", G); vH, _ = mp.allocate_point(pt_names[3].encode(), H)
+    mp.constrain(vA, [(vx, vG), (vy, vH)])
+    mp.constrain(vB, [(vy, vG)])
+    want = mp.prove_compact(entropy[0].tobytes())
+    assert chal[0].tobytes() == M.sc_to_bytes(want.challenge) and [r.tobytes() for r in resp[0]] == [M.sc_to_bytes(r) for r in want.responses]
+    ts = _fresh(label, n)
+    assert not T.verify_compact_batch(eng, mod.statement, ts, inst, common, chal, resp).any()
+    ts = _fresh(label, n)
+    T.batch_verify(eng, mod.statement, ts, inst, common, coms, resp)

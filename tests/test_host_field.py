@@ -218,7 +218,8 @@ def test_scalar_arithmetic_mod_l(lib):
     for a in [0, 1, 2, 3, M.L - 1, M.L, M.L + 1, (1 << 256) - 1] + [rng.randrange(1 << 256) for _ in range(100)]:
         lib.t_sc_op(7, b32(a), b32(0), out)                 # halving (the MSM kernels emit encode(2 * sum (s/2) P))
         assert out.raw == b32(a * inv2 % M.L)
-    wide = [0, (1 << 512) - 1, (1 << 256), M.L << 256, (M.L << 256) - 1] + [rng.randrange(1 << 512) for _ in range(300)]
+    wide = [0, 1, M.L - 1, M.L, M.L + 1, (1 << 256) - 1, (1 << 512) - 1, (1 << 256), (1 << 256) + M.L, M.L << 256, (M.L << 256) - 1,
+            ((1 << 512) - 1) // M.L * M.L, ((1 << 512) - 1) // M.L * M.L - 1] + [rng.randrange(1 << 512) for _ in range(300)]
     for x in wide:                                          # Scalar::from_bytes_mod_order_wide
         lib.t_sc_op(5, b32(x & ((1 << 256) - 1)), b32(x >> 256), out)
         assert out.raw == b32(x % M.L)

@@ -80,6 +80,10 @@ def test_scalars():
     rng = random.Random(6)
     lib = T.lib()
     out = ctypes.create_string_buffer(32)
+    for v in (0, 1, M.L - 1, M.L, M.L + 1, (1 << 256) - 1, 1 << 256, (1 << 256) + M.L, M.L << 256, (M.L << 256) - 1, (1 << 512) - 1,
+              ((1 << 512) - 1) // M.L * M.L, ((1 << 512) - 1) // M.L * M.L - 1):                   # from_bytes_mod_order_wide edges
+        lib.zkp_scalar_from_wide(out, v.to_bytes(64, "little"))
+        assert out.raw == sc(v % M.L), hex(v)
     for _ in range(500):
         w = bytes(rng.randrange(256) for _ in range(64))
         lib.zkp_scalar_from_wide(out, w)

@@ -258,3 +258,57 @@ def test_golden_fixtures():
         assert chal.tobytes().hex() == case["challenge"]
         assert [r.tobytes().hex() for r in resp] == case["responses"]
         assert [c.tobytes().hex() for c in coms] == case["commitments"]
+
+
+# RFC 9496 appendix A.3: SHA-512 of each label -> from_uniform_bytes (the one-way map) -> encoding.  These are the vectors
+# curve25519-dalek carries for RistrettoPoint::from_uniform_bytes / hash_from_bytes, which the reference's tests use to
+# make H (tests/zkp.rs:35, tests/dleq_using_constraint_api.rs:44, tests/sig_and_vrf_example.rs:28).
+RFC9496_A3 = [
+    (b"Ristretto is traditionally a short shot of espresso coffee", "3066f82a1a747d45120d1740f14358531a8f04bbffe6a819f86dfe50f44a0a46"),
+    (b"made with the normal amount of ground coffee but extracted with", "f26e5b6f7d362d2d2a94c5d0e7602cb4773c95a2e5c31a64f133189fa76ed61b"),
+    (b"about half the amount of water in the same amount of time", "006ccd2a9e6867e6a2c5cea83d3302cc9de128dd2a9a57dd8ee7b9d7ffe02826"),
+    (b"by using a finer grind.", "f8f0c87cf237953c5890aec3998169005dae3eca1fbb04548c635953c817f92a"),
+    (b"This produces a concentrated shot of coffee per volume.", "ae81e7dedf20a497e10c304a765c1767a42d6e06029758d2d7e8ef7cc4c41179"),
+    (b"Just pulling a normal shot short will produce a weaker shot", "e2705652ff9f5e44d3e841bf1c251cf7dddb77d140870d1ab2ed64f1a9ce8628"),
+    (b"and is not a Ristretto as some believe.", "80bd07262511cdde4863f8a7434cef696750681cb9510eea557088f76d9e5065"),
+]
+
+
+def test_rfc9496_a3_hash_to_group_vectors():
+    for label, want in RFC9496_A3:
+        wide = hashlib.sha512(label).digest()
+        assert C.from_uniform_bytes(wide).hex() == want
+        assert M.ristretto_encode(M.ristretto_from_uniform_bytes(wide)).hex() == want
+        assert M.ristretto_encode(M.ristretto_hash_from_bytes_sha512(label)).hex() == want
+
+
+def test_from_bytes_mod_order_wide_edge_vectors():
+    """Scalar::from_bytes_mod_order_wide (mod.rs:226 turns 64 challenge bytes into the challenge): 0, l - 1, l, the
+    largest 512-bit value, 2^256 and friends -- against plain integer arithmetic."""
+    L = M.L
+    cases = [0, 1, L - 1, L, L + 1, 2 * L - 1, (1 << 252), (1 << 255) - 19, (1 << 256) - 1, 1 << 256, (1 << 256) + L, L << 256,
+             (L << 256) - 1, (1 << 512) - 1, ((1 << 512) - 1) // L * L, ((1 << 512) - 1) // L * L - 1]
+    for v in cases:
+        b = v.to_bytes(64, "little")
+        assert C.sc_from_wide(b) == (v % L).to_bytes(32, "little"), hex(v)
+        assert M.sc_from_bytes_mod_order_wide(b) == v % L
+    # the constant dalek's own tests carry for 2^256 - 1 mod l (scalar.rs CANONICAL_2_256_MINUS_1)
+    want = bytes([28, 149, 152, 141, 116, 49, 236, 214, 112, 207, 125, 115, 244, 91, 239, 198] + [254] + [255] * 14 + [15])
+    assert C.sc_from_wide(((1 << 256) - 1).to_bytes(64, "little")) == want
+
+
+def test_merlin_block_crossings_c_oracle_equals_model():
+    """STROBE's rate is 166 bytes: labels, messages and challenge outputs that end exactly at, one before, one after and
+    several blocks beyond a block boundary must frame identically in the C oracle and the model."""
+    rng = random.Random(77)
+    for trial in range(12):
+        appends = []
+        for i in range(6):
+            ll = rng.choice([0, 1, 5, 160, 165, 166, 167, 340])
+            ml = rng.choice([0, 1, 31, 32, 164, 165, 166, 167, 331, 332, 333, 700])
+            appends.append((bytes(rng.randrange(1, 256) for _ in range(ll)), bytes(rng.randrange(256) for _ in range(ml))))
+        n = rng.choice([1, 32, 64, 165, 166, 167, 400])
+        t = M.Transcript(b"crossing %d" % trial)
+        for lab, msg in appends:
+            t.append_message(lab, msg)
+        assert C.merlin_challenge(b"crossing %d" % trial, appends, b"out", n) == t.challenge_bytes(b"out", n), trial

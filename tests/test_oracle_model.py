@@ -48,3 +48,12 @@ def test_keccak_counts_match_survey():
     before = M.keccak_f_count
     st.build_verifier(M.Transcript(bytes.fromhex(case["label"])), encs).verify_batchable(proof, [1] * 11)
     assert M.keccak_f_count - before == 17
+
+
+def test_rfc9496_a3_vectors_pin_the_model():
+    """RFC 9496 A.3 (one-way map) -- the model is what every other layer is compared with, so it carries the published
+    vectors itself (also checked through the C oracle in test_oracle_c.py)."""
+    import hashlib
+    from tests.test_oracle_c import RFC9496_A3
+    for label, want in RFC9496_A3:
+        assert M.ristretto_encode(M.ristretto_from_uniform_bytes(hashlib.sha512(label).digest())).hex() == want

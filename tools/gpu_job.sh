@@ -14,7 +14,7 @@ run() { # name, args...
 import json
 try:
     j=json.loads(open("$O/${TAG}_$n.json").read().strip().splitlines()[-1])
-    print("$n", "%.0f"%j["value"], "%.4f"%j["ms_per_step"], j["config"]["streams"], "prove", {k:round(v,3) for k,v in j["kernel_ms"]["prove"].items()}, "bv", {k:round(v,3) for k,v in j["kernel_ms"]["batch_verify"].items()})
+    print("$n", "%.0f"%j["value"], "%.4f"%j["ms_per_step"], "enq %.3f"%j.get("host_enqueue_ms_per_step",0), j["config"]["streams"], "prove", {k:round(v,3) for k,v in j["kernel_ms"]["prove"].items()}, "bv", {k:round(v,3) for k,v in j["kernel_ms"]["batch_verify"].items()})
 except Exception as e: print("$n","failed",e)
 PY
 }
@@ -23,7 +23,7 @@ run t200 --steps 200 --warmup 3
 run e20 --steps 20 --warmup 5 --engine-opt 4=1
 run e200 --steps 200 --warmup 3 --engine-opt 4=1
 run t200b --steps 200 --warmup 3
-run t100 --steps 100 --warmup 3
+run e200b --steps 200 --warmup 3 --engine-opt 4=1
 B="python bench.py --steps 20 --warmup 1 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o kt -- $B > $O/${TAG}_kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_prof -o sq -- $B > $O/${TAG}_sq.log 2>&1

@@ -1123,6 +1123,12 @@ int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N
 int zkp_fused_verify_batchable(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
                                const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
                                uint8_t* results) {
+  return zkp_fused_verify_batchable_coeffs(c, st, N, transcripts, inst, common, commitments, responses, weights16, results, nullptr);
+}
+
+int zkp_fused_verify_batchable_coeffs(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
+                                      const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
+                                      uint8_t* results, uint8_t* debug_scalars) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   if (N == 0) return ZKP_OK;
   if (!transcripts || !results) return fail(ZKP_ERR_ARG, "NULL pointer");
@@ -1158,6 +1164,7 @@ int zkp_fused_verify_batchable(zkp_ctx* c, const zkp_fused_statement* st, uint32
   if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
   rc = each_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_resp), w.u8(o_w), w.u8(o_res));
   if (rc) return rc;
+  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, w.base + o.sc, (size_t)N * K * 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(results, w.base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

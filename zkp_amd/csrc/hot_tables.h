@@ -166,16 +166,11 @@ k_class_scatter(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_
 }
 
 // ---- the fixed-base term kernel -----------------------------------------------------------------------------------------
+// acc += sum over the windows 8 j0 .. 8 j1 - 1 of digit_w * 16^w * P;  rows = the table row of window 8 j0 (HBM or LDS)
 template <bool CT>
-__device__ __forceinline__ void term_fixed_base(uint32_t t, const uint8_t* __restrict__ scalars, const dev_niels* __restrict__ T,
-                                                dev_ext* __restrict__ partial) {
-  uint32_t s[8], e[8], top;
-  load_vec<2>(s, scalars + 32 * (size_t)t);
-  sc_add_pattern(e, top, s, 0x88888888u);                          // digits nibble - 8 in [-8, 7]
-  ge_p3 acc;
-  ge_identity(acc);
+__device__ __forceinline__ void fixed_base_windows(ge_p3& acc, const uint32_t e[8], const dev_niels* __restrict__ rows, int j0, int j1) {
 #pragma unroll 1
-  for (int j = 0; j < 8; ++j) {
+  for (int j = j0; j < j1; ++j) {
     uint32_t cur = sel8(e, j);
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {
@@ -183,7 +178,7 @@ __device__ __forceinline__ void term_fixed_base(uint32_t t, const uint8_t* __res
       cur >>= 4;
       const uint32_t neg = (uint32_t)(nib < 8u);
       const uint32_t mag = neg ? 8u - nib : nib - 8u;             // 0..8
-      const dev_niels* row = T + (size_t)(8 * j + k) * HOT_ENTRIES;
+      const dev_niels* row = rows + (size_t)(8 * (j - j0) + k) * HOT_ENTRIES;
       ge_niels q;
       if (CT) {
         ge_niels_identity(q);
@@ -212,15 +207,28 @@ __device__ __forceinline__ void term_fixed_base(uint32_t t, const uint8_t* __res
       ge_madd(acc, acc, q);
     }
   }
-  {                                                               // carry window: digit in {0, 1}
-    ge_niels q, c;
-    ge_niels_identity(q);
-    load_niels(c, T + (size_t)64 * HOT_ENTRIES);
-    fe_cmov(q.ypx, c.ypx, top);
-    fe_cmov(q.ymx, c.ymx, top);
-    fe_cmov(q.xy2d, c.xy2d, top);
-    ge_madd(acc, acc, q);
-  }
+}
+// the carry window (a scalar >= 2^256 - 0x88..8): digit in {0, 1};  row64 = the table row of window 64
+__device__ __forceinline__ void fixed_base_carry(ge_p3& acc, uint32_t top, const dev_niels* __restrict__ row64) {
+  ge_niels q, c;
+  ge_niels_identity(q);
+  load_niels(c, row64);
+  fe_cmov(q.ypx, c.ypx, top);
+  fe_cmov(q.ymx, c.ymx, top);
+  fe_cmov(q.xy2d, c.xy2d, top);
+  ge_madd(acc, acc, q);
+}
+
+template <bool CT>
+__device__ __forceinline__ void term_fixed_base(uint32_t t, const uint8_t* __restrict__ scalars, const dev_niels* __restrict__ T,
+                                                dev_ext* __restrict__ partial) {
+  uint32_t s[8], e[8], top;
+  load_vec<2>(s, scalars + 32 * (size_t)t);
+  sc_add_pattern(e, top, s, 0x88888888u);                          // digits nibble - 8 in [-8, 7]
+  ge_p3 acc;
+  ge_identity(acc);
+  fixed_base_windows<CT>(acc, e, T, 0, 8);
+  fixed_base_carry(acc, top, T + (size_t)64 * HOT_ENTRIES);
   store_ext(partial + t, acc);
 }
 

@@ -128,29 +128,37 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
   if (t < n_terms) term_generic(t, scalars, pidx, n_points, pts, partial);
 }
 
-// Classified terms in ONE launch, longest first: ladder terms (points with a single cold use: 321 point operations per
-// lane), terms on per-proof points with a comb table (BITS + 64 point operations), and the fixed-base terms (65 mixed
-// additions), which fill the SIMDs the others leave idle.
-template <bool CT, int TEETH>
+// Classified terms in ONE launch, longest first: ladder terms (points with a single cold use of a variable-time call: 321
+// point operations per lane), terms on per-proof points with a comb table (BITS - 4 + 65 point operations), and the
+// fixed-base terms (65 mixed additions), which fill the SIMDs the others leave idle.
+// LADDER = false (every cold point of the call has a table: constant-time calls) only leaves the ladder's code out.
+// (Measured and dropped: the same kernel capped at 168 VGPRs for a third wavefront per SIMD needs 39 spills and is no
+// faster, 4.51 vs 4.51 M proofs/s pipelined; three separate kernels -- comb 154, fixed-base 161 VGPRs without spills, 3 per
+// SIMD -- lose more to serialisation on the stream than the occupancy returns, 4.38 M/s.)
+constexpr uint32_t HOT_STAGE_ROWS = 33;              // table rows (windows) staged in LDS at a time: 0..32, then 32..64
+template <bool CT, int TEETH, bool LADDER>
 __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
               const uint32_t* __restrict__ blk_start, const uint32_t* __restrict__ list, const dev_niels* __restrict__ tables,
               const dev_affine* __restrict__ pts, dev_ext* __restrict__ ladder_rw, uint32_t max_ladder, dev_ext* __restrict__ partial) {
-  // A block of fixed-base terms serves ONE table, staged in LDS (58 KB): the masked scans then read the 8 entries of a row
-  // as LDS broadcasts instead of 56 16-byte vector loads per lane and addition -- through the L1 those loads alone took
-  // ~70 % as long as the additions they feed (64 B/clk per CU against 4 SIMDs of v_mad_u64_u32).
-  __shared__ uint4 hot_lds[HOT_SLOT_NIELS * sizeof(dev_niels) / 16];
+  // A block of fixed-base terms serves ONE table, staged in LDS half at a time (29 KB: three blocks per CU): the masked
+  // scans then read the 8 entries of a row as LDS broadcasts instead of 56 16-byte vector loads per lane and addition --
+  // through the L1 (64 B/clk per CU against 4 SIMDs of v_mad_u64_u32) those loads alone took ~70 % as long as the
+  // additions they feed.
+  __shared__ uint4 hot_lds[HOT_STAGE_ROWS * HOT_ENTRIES * sizeof(dev_niels) / 16];
   const uint32_t n_hot = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - n_hot;
-  const uint32_t n_ladder = class_start[HOT_CLASSES] - class_start[CLASS_LADDER];
+  const uint32_t n_ladder = LADDER ? class_start[HOT_CLASSES] - class_start[CLASS_LADDER] : 0u;
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
   const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
-  if (blockIdx.x < ladder_blocks) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_ladder && i < max_ladder) {                         // (max_ladder bounds n_ladder by construction)
-      const uint32_t t = list[n_hot + n_comb + i];
-      const uint32_t pi = pidx[t];                                // < n_points (out-of-range indices are classed with the comb terms)
-      term_ladder16<CT>(t, scalars, pts + pi, ladder_rw + (size_t)i * LADDER_ENTRIES, partial);
+  if (LADDER && blockIdx.x < ladder_blocks) {
+    if constexpr (LADDER) {
+      const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+      if (i < n_ladder && i < max_ladder) {                       // (max_ladder bounds n_ladder by construction)
+        const uint32_t t = list[n_hot + n_comb + i];
+        const uint32_t pi = pidx[t];                              // < n_points (out-of-range indices are classed with the comb terms)
+        term_ladder16<CT>(t, scalars, pts + pi, ladder_rw + (size_t)i * LADDER_ENTRIES, partial);
+      }
     }
   } else if (blockIdx.x < ladder_blocks + comb_blocks) {
     const uint32_t i = (blockIdx.x - ladder_blocks) * blockDim.x + threadIdx.x;
@@ -168,12 +176,28 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
     uint32_t c = 0;
     while (blk_start[c + 1] <= hb) ++c;                           // class = table slot of this block
     const uint4* src = reinterpret_cast<const uint4*>(tables + (size_t)c * HOT_SLOT_NIELS);
-    constexpr uint32_t kVec = HOT_SLOT_NIELS * sizeof(dev_niels) / 16;
-    for (uint32_t k = threadIdx.x; k < kVec; k += 256) hot_lds[k] = src[k];
-    __syncthreads();
+    constexpr uint32_t kRowVec = HOT_ENTRIES * sizeof(dev_niels) / 16, kVec = HOT_STAGE_ROWS * kRowVec;
     const uint32_t i = (hb - blk_start[c]) * 256 + threadIdx.x;
-    if (i < class_start[c + 1] - class_start[c])
-      term_fixed_base<CT>(list[class_start[c] + i], scalars, reinterpret_cast<const dev_niels*>(hot_lds), partial);
+    const bool live = i < class_start[c + 1] - class_start[c];
+    const uint32_t t = live ? list[class_start[c] + i] : 0u;
+    uint32_t s[8], e[8], top = 0;
+    ge_p3 acc;
+    ge_identity(acc);
+    for (uint32_t k = threadIdx.x; k < kVec; k += 256) hot_lds[k] = src[k];                        // windows 0 .. 32
+    if (live) {
+      load_vec<2>(s, scalars + 32 * (size_t)t);
+      sc_add_pattern(e, top, s, 0x88888888u);                     // digits nibble - 8 in [-8, 7]
+    }
+    __syncthreads();
+    if (live) fixed_base_windows<CT>(acc, e, reinterpret_cast<const dev_niels*>(hot_lds), 0, 4);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kVec; k += 256) hot_lds[k] = src[32 * kRowVec + k];         // windows 32 .. 64
+    __syncthreads();
+    if (live) {
+      fixed_base_windows<CT>(acc, e, reinterpret_cast<const dev_niels*>(hot_lds), 4, 8);
+      fixed_base_carry(acc, top, reinterpret_cast<const dev_niels*>(hot_lds) + (size_t)32 * HOT_ENTRIES);
+      store_ext(partial + t, acc);
+    }
   }
 }
 
@@ -1043,11 +1067,15 @@ size_t terms_path_ws(uint32_t n_points, uint32_t n_terms, uint32_t n_msm, const 
 }
 
 template <bool CT, int TEETH>
-void launch_terms_split(zkp_ctx* c, dim3 grid, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
+void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
                         const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
-                        const dev_affine* pts, dev_ext* ladder, uint32_t max_ladder, dev_ext* part) {
-  hipLaunchKernelGGL((k_terms_split<CT, TEETH>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
-                     c->hot_tables, pts, ladder, max_ladder, part);
+                        const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part) {
+  if (ladder)
+    hipLaunchKernelGGL((k_terms_split<CT, TEETH, true>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
+                       c->hot_tables, pts, ladder_rw, max_ladder, part);
+  else
+    hipLaunchKernelGGL((k_terms_split<CT, TEETH, false>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
+                       c->hot_tables, pts, ladder_rw, max_ladder, part);
 }
 
 // phase: everything (default), or only the part that does not look at the scalars (decode, classification, comb tables:
@@ -1116,11 +1144,11 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     }
     if (phase & PH_SCALARS) {
       if (flags == ZKP_CT) {
-        if (k.teeth == 16) launch_terms_split<true, 16>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
-        else launch_terms_split<true, 4>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        if (k.teeth == 16) launch_terms_split<true, 16>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        else launch_terms_split<true, 4>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
       } else {
-        if (k.teeth == 16) launch_terms_split<false, 16>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
-        else launch_terms_split<false, 4>(c, grid, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        if (k.teeth == 16) launch_terms_split<false, 16>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        else launch_terms_split<false, 4>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
       }
     }
   } else {

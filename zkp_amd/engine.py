@@ -25,7 +25,7 @@ EXPORTS = (
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
     "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest", "zkp_batch_check", "zkp_fused_prove", "zkp_fused_verify_compact", "zkp_fused_batch_verify",
     "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_batch_verify_dev",
-    "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_graph_launch", "zkp_graph_destroy",
+    "zkp_fused_verify_batchable_coeffs", "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_graph_launch", "zkp_graph_destroy",
 )
 
 
@@ -196,6 +196,20 @@ class Engine:
         _check(self._lib.zkp_fused_batch_verify_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ctypes.c_uint32(strobe_pos),
                                                     *[ctypes.c_void_p(x) for x in (d_ts, d_points, d_coms, d_resp, d_w, d_out, d_status)]),
                "zkp_fused_batch_verify_dev")
+
+    def fused_verify_batchable_coeffs(self, fst: "FusedStatement", transcripts, inst, common, commitments, responses, weights16):
+        """zkp_fused_verify_batchable_coeffs on host arrays -> (results[N], coefficient vectors [N][np + nc][32]); the
+        transcripts [N][208] are advanced in place."""
+        n = len(transcripts)
+        k = fst.n_static + fst.n_instance + len(fst._lhs)
+        res = np.ones(n, np.uint8)
+        co = np.zeros((n, k, 32), np.uint8)
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (transcripts, inst, common, commitments, responses, weights16)]
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _check(self._lib.zkp_fused_verify_batchable_coeffs(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]),
+                                                           ptr(arrs[3]), ptr(arrs[4]), ptr(arrs[5]), ptr(res), ptr(co)), "zkp_fused_verify_batchable_coeffs")
+        transcripts[...] = arrs[0]
+        return res, co
 
     def set_option(self, option: int, value: int) -> None:
         """Tuning knobs of include/zkp_mi355x.h (ZKP_OPT_*); results never depend on them."""

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path of dalek-cryptography/zkp on MI355X.
 
-A "step" = one pass of the hot path over ONE batch of N = 4096 CMZ'13 10-attribute credential
-presentations (BASELINE.json configs[1]; benches/zkp.rs:27-46), everything on the GPU:
+A "step" = one pass of the hot path over ONE batch of proofs of one statement, everything on the GPU.  Default workload
+(--config 2 = BASELINE.json configs[1]): N = 4096 CMZ'13 10-attribute credential presentations (benches/zkp.rs:27-46):
   (i)  PROVE all N proofs (zkp_fused_prove_dev = N x prover.rs:76-112): Merlin transcripts, blinding factors
        from the transcript RNG, the 11 constant-time commitment MSMs per proof (45,056 MSMs / 126,976 terms)
        with compression, challenges, responses;
@@ -10,17 +10,27 @@ presentations (BASELINE.json configs[1]; benches/zkp.rs:27-46), everything on th
        transcripts with identity rejection, challenges, the coefficient build mod l, and the single
        random-linear-combination MSM (12 + 24 N = 98,316 terms, decompression on the GPU) down to the
        identity test.
-Inputs are synthetic (random witnesses, a consistent CMZ instance made by the engine itself, fixed
-entropy / weights) and RESIDENT IN HBM before the timed region; every step starts from fresh
-`Transcript::new(b"Benchmark")` states like the reference's bench loop.  value = proofs per second that
-were both proven and batch-verified.
+Inputs are synthetic (random witnesses, a consistent instance made by the engine itself, fixed entropy / weights) and
+RESIDENT IN HBM before the timed region; every step starts from fresh `Transcript::new(b"Benchmark")` states like the
+reference's bench loop.  value = proofs per second that went through the whole step.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 4096]
+Other workloads (one JSON line each, same keys):
+  --config 3       BASELINE configs[2]: BatchVerifier over 2^20 mixed DLEQ proofs -- 2^19 in define_proof! form (1 + 5 N
+                   terms, benches/zkp.rs:49) + 2^19 in constraint-API form (static G, H: 2 + 4 N terms, benches/dleq.rs:188-241);
+                   a step = both batch verifications of proofs made beforehand (untimed) by this engine's prover
+  --config 4share  one GPU's share of configs[3]: CMZ, 524,288 proofs per step (prove + batch verify)
+  --config 5share  one GPU's share of configs[4]: the 64-term wide statement, 32,768 proofs per step (prove + batch verify)
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4share|5share] [--batch n] [--streams S]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  Everything in it is measured in this run, except the PMC-derived fields (roofline.traffic,
+*_valu_issue_frac, step_valu), which need a rocprofv3 --pmc pass: they are taken from --pmc-json only when that file was
+collected from exactly these kernel sources (sha256 of zkp_amd/csrc), and say so in "pmc_source"; otherwise they are null.
 """
 import argparse
+import datetime
+import hashlib
 import json
 import os
 import subprocess
@@ -32,11 +42,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = "proofs/sec + batch-verifies/sec, CMZ13 10-attr credential, 1/2/4/8 MI355X"
-VALU_PEAK_MADS = 34.5e12      # v_mad_u64_u32 lane-instructions / s, measured: profiles/r01_valu_rates_microbench.txt
+VALU_PEAK = 34.5e12           # 4-cycle-class VALU lane-instructions / s (v_mad_u64_u32 ...), measured: profiles/r01_valu_rates_microbench.txt
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
 LABEL = b"Benchmark"
+BASE = bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76")
+DEFAULT_PMC = os.path.join("profiles", "r02_pmc_counters.json")
+# what the HIP-event timing kinds of zkp_ctx_last_timing are, per flow (kernel names as rocprofv3 prints them)
+KERNELS = {
+    ("prove", "transcript"): "k_transcript_run (2 launches)", ("prove", "tables"): "k_comb_slots + k_comb_tables_lane<16>",
+    ("prove", "terms"): "k_terms_split<true, 16, false>", ("prove", "reduce"): "k_encode_prepare + k_encode_invert + k_encode_finish",
+    ("prove", "sort"): "k_hot_match + k_use_count + k_class_count/scan/scatter", ("prove", "decode"): "k_decode_affine",
+    ("prove", "scalars"): "k_wide_reduce + k_stmt_scalars + k_halve_scalars + k_responses",
+    ("batch_verify", "transcript"): "k_transcript_run", ("batch_verify", "decode"): "k_pip_prepare<c>",
+    ("batch_verify", "sort"): "k_pip_tile_hist/total/scan/base/scatter", ("batch_verify", "bucket"): "k_pip_vmap + k_pip_bucket_part + k_pip_bucket_merge",
+    ("batch_verify", "combine"): "k_pip_reduce_lvl x levels + k_pip_combine", ("batch_verify", "scalars"): "k_wide/neg_reduce + k_coeff_*",
+}
 
 
+# ---- statements ----------------------------------------------------------------------------------------------------
 def cmz_shape(n):
     """CSR shape of the prover's commitment MSMs for n CMZ proofs (benches/zkp.rs:27-46) over the stand-alone point table
     [0..11) common X_1..X_10, A ; then per proof j: P_j = 11 + 2j, Q_j = 12 + 2j (used by the full-size MSM tests and
@@ -63,90 +86,201 @@ def cmz_shape(n):
     return off, pidx.reshape(-1), 11 + 2 * n
 
 
+def _index_form(secrets, points, cons):
+    pi = {name: i for i, (name, _) in enumerate(points)}
+    si = {name: i for i, name in enumerate(secrets)}
+    return secrets, points, [(pi[l], [(si[s], pi[p]) for s, p in lc]) for l, lc in cons]
+
+
 def cmz_statement():
-    """cred_show_10 (benches/zkp.rs:27-46) in the argument form of zkp_amd.engine.FusedStatement."""
+    """cred_show_10 (benches/zkp.rs:27-46) in the argument form of zkp_amd.engine.FusedStatement: define_proof! allocates
+    the secrets, then the instance points, then the common points (macros.rs:215-242)."""
     secrets = [b"m_%d" % i for i in range(1, 11)] + [b"z_%d" % i for i in range(1, 11)] + [b"minus_z_Q"]
     inst = [b"C_%d" % i for i in range(1, 11)] + [b"P", b"Q", b"V"]
     common = [b"X_%d" % i for i in range(1, 11)] + [b"A", b"B"]
-    points = [(x, False) for x in inst] + [(x, True) for x in common]
-    pi = {name: i for i, (name, _) in enumerate(points)}
-    si = {name: i for i, name in enumerate(secrets)}
-    cons = [(pi[b"C_%d" % i], [(si[b"m_%d" % i], pi[b"P"]), (si[b"z_%d" % i], pi[b"A"])]) for i in range(1, 11)]
-    cons.append((pi[b"V"], [(si[b"m_%d" % i], pi[b"X_%d" % i]) for i in range(1, 11)] + [(si[b"minus_z_Q"], pi[b"Q"])]))
-    return secrets, points, cons
+    cons = [(b"C_%d" % i, [(b"m_%d" % i, b"P"), (b"z_%d" % i, b"A")]) for i in range(1, 11)]
+    cons.append((b"V", [(b"m_%d" % i, b"X_%d" % i) for i in range(1, 11)] + [(b"minus_z_Q", b"Q")]))
+    return _index_form(secrets, [(x, False) for x in inst] + [(x, True) for x in common], cons)
 
 
-def cmz_instance(eng, n, rng):
-    """n consistent CMZ presentations: witnesses, instance points [13][n][32] (C_1..C_10, P, Q, V), common [12][32].
-    Made with the engine's own MSMs (untimed set-up)."""
+def dleq_macro_statement():
+    """define_proof! {dleq, "DLEQ proof", (x), (A, B, H), (G) : A = (x * G), B = (x * H)}  (benches/zkp.rs:49)"""
+    return _index_form([b"x"], [(b"A", False), (b"B", False), (b"H", False), (b"G", True)], [(b"A", [(b"x", b"G")]), (b"B", [(b"x", b"H")])])
+
+
+def dleq_capi_statement():
+    """benches/dleq.rs:188-241: the constraint-system form; the static points G, H are allocated before the instance points"""
+    return _index_form([b"x"], [(b"G", True), (b"H", True), (b"A", False), (b"B", False)], [(b"A", [(b"x", b"G")]), (b"B", [(b"x", b"H")])])
+
+
+def w64_statement():
+    """the wide statement of configs[4]: Q = sum_{i < 64} x_i * G_i, all generators common"""
+    xs = [b"x_%d" % i for i in range(64)]
+    gs = [b"G_%d" % i for i in range(64)]
+    return _index_form(xs, [(b"Q", False)] + [(g, True) for g in gs], [(b"Q", [(x, g) for x, g in zip(xs, gs)])])
+
+
+WORKLOADS = {
+    # name: (description, [(statement label, statement fn, share of the batch, flows)], default batch, default streams (0 = auto), default steps)
+    "2": ("CMZ'13 10-hidden-attribute credential, batch of %d proofs per GPU: complete proving (Merlin transcripts, blindings, 11 constant-time "
+          "commitment MSMs / 31 terms per proof, challenges, responses) + complete batch verification of those proofs (transcripts, coefficient "
+          "build, one MSM of 12 + 24 N terms)", [(b"CMZ cred show n=10", cmz_statement, 1.0, ("prove", "batch_verify"))], 4096, 0, 200),
+    "3": ("BatchVerifier over %d mixed DLEQ proofs per GPU: half in define_proof! form (one MSM of 1 + 5 N terms), half in constraint-API form "
+          "(static G, H: 2 + 4 N terms); complete batch verifications (transcripts, coefficient build, MSM incl. decompression)",
+          [(b"DLEQ proof", dleq_macro_statement, 0.5, ("batch_verify",)), (b"DLEQProof", dleq_capi_statement, 0.5, ("batch_verify",))], 1 << 20, 2, 6),
+    "4share": ("one GPU's share of 2^22 CMZ'13 proofs over 8 GPUs: %d proofs per step, complete proving + complete batch verification",
+               [(b"CMZ cred show n=10", cmz_statement, 1.0, ("prove", "batch_verify"))], 1 << 19, 2, 6),
+    "5share": ("one GPU's share of 2^18 proofs of the 64-term wide statement over 8 GPUs: %d proofs per step, complete proving + complete batch "
+               "verification (64 + 2 N terms)", [(b"W64", w64_statement, 1.0, ("prove", "batch_verify"))], 1 << 15, 8, 48),
+}
+
+
+def make_instance(eng, st, n, rng):
+    """n consistent assignments of a statement: secrets [n][m][32], inst [ni][n][32], common [ns][32].  Common points and the
+    instance points no constraint defines are random multiples of the basepoint; every left-hand side is computed from its
+    constraint with the engine's own MSMs (untimed set-up)."""
     import numpy as np
     from zkp_amd.engine import ZKP_CT
+    secrets_l, points, cons = st
+    m = len(secrets_l)
 
     def rs(k):
         s = rng.integers(0, 256, size=(k, 32), dtype=np.uint8)
         s[:, 31] &= 0x0f                       # < 2^252 < l
         return s
 
-    base = np.frombuffer(bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"), np.uint8).reshape(1, 32)
-    k = 12 + 2 * n
-    pts, st = eng.msm_many(np.arange(k + 1, dtype=np.uint32), rs(k), np.zeros(k, np.uint32), base, ZKP_CT)
-    assert not st.any()
-    common, P, Q = pts[:12], pts[12:12 + n], pts[12 + n:]
-    secrets = rs(n * 21).reshape(n, 21, 32)
-    table = np.concatenate([common, P, Q])
-    j = np.arange(n, dtype=np.uint32)
-    pidx = np.zeros((n, 31), np.uint32)
-    sidx = np.zeros(31, np.int64)
-    for i in range(10):                        # C_i = m_i P + z_i A
-        pidx[:, 2 * i], pidx[:, 2 * i + 1] = 12 + j, 10
-        sidx[2 * i], sidx[2 * i + 1] = i, 10 + i
-    for i in range(10):                        # V = sum m_i X_i + minus_z_Q Q
-        pidx[:, 20 + i] = i
-        sidx[20 + i] = i
-    pidx[:, 30], sidx[30] = 12 + n + j, 20
-    off_one = np.array([2 * i for i in range(11)], np.uint32)
-    off = np.concatenate([(off_one[None, :] + 31 * j[:, None]).reshape(-1), np.array([31 * n], np.uint32)]).astype(np.uint32)
-    cv, st = eng.msm_many(off, np.ascontiguousarray(secrets[:, sidx]).reshape(-1, 32), pidx.reshape(-1), table, ZKP_CT)
-    assert not st.any()
-    cv = cv.reshape(n, 11, 32)
-    inst = np.ascontiguousarray(np.concatenate([cv[:, :10].transpose(1, 0, 2), P[None], Q[None], cv[:, 10][None]]))
-    return secrets, inst, np.ascontiguousarray(common)
+    com_rank, inst_rank = {}, {}
+    for i, (_, c) in enumerate(points):
+        (com_rank if c else inst_rank)[i] = len(com_rank if c else inst_rank)
+    ns, ni = len(com_rank), len(inst_rank)
+    lhs = [l for l, _ in cons]
+    assert all(l in inst_rank for l in lhs) and len(set(lhs)) == len(lhs)
+    free = [i for i in inst_rank if i not in lhs]
+    base = np.frombuffer(BASE, np.uint8).reshape(1, 32)
+    k = ns + len(free) * n
+    pts, st8 = eng.msm_many(np.arange(k + 1, dtype=np.uint32), rs(k), np.zeros(k, np.uint32), base, ZKP_CT)
+    assert not st8.any()
+    common = np.ascontiguousarray(pts[:ns])
+    inst = np.zeros((ni, n, 32), np.uint8)
+    for a, i in enumerate(free):
+        inst[inst_rank[i]] = pts[ns + a * n: ns + (a + 1) * n]
+    secrets = rs(n * m).reshape(n, m, 32)
+    if cons:
+        j = np.arange(n, dtype=np.uint32)
+        terms = [(s, p) for _, lc in cons for s, p in lc]
+        T = len(terms)
+        pidx = np.zeros((n, T), np.uint32)
+        for t, (_, p) in enumerate(terms):
+            pidx[:, t] = com_rank[p] if p in com_rank else ns + inst_rank[p] * n + j
+        sidx = np.array([s for s, _ in terms], np.int64)
+        off_one = np.cumsum([0] + [len(lc) for _, lc in cons])[:-1].astype(np.uint32)
+        off = np.concatenate([(off_one[None, :] + np.uint32(T) * j[:, None]).reshape(-1), np.array([T * n], np.uint32)]).astype(np.uint32)
+        table = np.concatenate([common, inst.reshape(-1, 32)])
+        out, st8 = eng.msm_many(off, np.ascontiguousarray(secrets[:, sidx]).reshape(-1, 32), pidx.reshape(-1), table, ZKP_CT)
+        assert not st8.any()
+        out = out.reshape(n, len(cons), 32)
+        for kk, l in enumerate(lhs):
+            inst[inst_rank[l]] = out[:, kk]
+    return secrets, np.ascontiguousarray(inst), common
+
+
+def cmz_instance(eng, n, rng):
+    """n consistent CMZ presentations: witnesses, instance points [13][n][32] (C_1..C_10, P, Q, V), common [12][32]."""
+    return make_instance(eng, cmz_statement(), n, rng)
 
 
 def pick_streams(steps):
-    """Batches in flight.  A batch is a chain of ~70 kernels, several of them only a few dozen wavefronts wide, so the chip
-    is filled by running independent batches side by side.  With K timed steps over S streams the last round of batches
-    runs with K mod S streams busy; pick S in 12..24 that leaves the fewest idle slots (ties: more streams)."""
+    """Batches in flight.  A batch is a chain of ~75 kernels, several of them only a few dozen wavefronts wide, so the chip
+    is filled by running independent batches side by side (measured at 200 steps: 12 streams 4.03, 20 streams 4.51, 24 streams
+    4.33, 32 streams 3.90 M proofs/s).  With K timed steps over S streams the last round of batches runs with K mod S
+    streams busy; pick S in 12..24 that leaves the fewest idle slots (ties: more streams)."""
     if steps <= 24:
         return max(1, steps)
-    best = min(range(12, 25), key=lambda s: ((-steps) % s, -s))
-    return best
+    return min(range(12, 25), key=lambda s: ((-steps) % s, -s))
+
+
+def source_sha256():
+    """sha256 over the kernel sources: keys PMC counter files to the code they were collected from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zkp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def init_distributed(world, rank, local_rank):
+    """One process per GPU.  The default group is gloo (host side: barriers, the MAX of the elapsed times, and the agreement on
+    which backend carries the verdict); the single data-path exchange -- the AND of the per-GPU verdict bits, an int32 MIN
+    all-reduce -- goes over RCCL (backend "nccl").  If RCCL cannot be brought up on every rank the job still completes:
+    the 4-byte verdict then travels over gloo and the JSON line says "collective": "gloo-fallback"."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    info = {"collective": "gloo-fallback", "backend_world_size": dist.get_world_size(), "rccl_error": None}
+    group = None
+    dry = bool(os.environ.get("ZKP_BENCH_DRYRUN_ONE_GPU"))
+    ok = 1
+    try:
+        if dry:
+            # dry run of the multi-rank control flow on a box with a single GPU (all ranks on cuda:0, not a measurement):
+            # RCCL cannot span ranks that share a device, so this run takes -- and thereby tests -- the fallback branch
+            raise RuntimeError("dry run: all ranks share GPU 0")
+        if os.environ.get("ZKP_BENCH_FORCE_RCCL_FAILURE"):
+            raise RuntimeError("forced by ZKP_BENCH_FORCE_RCCL_FAILURE (test of the fallback)")
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+        probe = torch.ones(1, dtype=torch.int32, device=torch.device("cuda", local_rank))
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=group)
+        torch.cuda.synchronize()
+        ok = 1 if int(probe.item()) == world else 0
+    except Exception as e:                      # noqa: BLE001 -- any failure of the RCCL bring-up selects the fallback
+        info["rccl_error"] = repr(e)[:300]
+        ok = 0
+    agree = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)          # gloo: every rank takes the same branch
+    if int(agree.item()) == 1:
+        info["collective"] = "rccl"
+    else:
+        group = None
+    return dist, group, info
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for --config 2, fewer for the large workloads)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU per step (BASELINE configs[1]: 4096)")
+    ap.add_argument("--config", default="2", choices=sorted(WORKLOADS), help="BASELINE.json workload (2 = configs[1], the metric's configuration)")
+    ap.add_argument("--batch", type=int, default=None, help="proofs per GPU per step (default: the workload's)")
     ap.add_argument("--streams", type=int, default=0, help="independent batches in flight, each on its own HIP stream / engine context "
-                                                            "(0 = automatic: 12..24, the count that splits --steps most evenly)")
+                                                            "(0 = automatic: 12..24 for --config 2, the count that splits --steps most evenly)")
+    ap.add_argument("--max-hw-queues", type=int, default=24, help="cap of GPU_MAX_HW_QUEUES (one hardware queue per stream up to this)")
     ap.add_argument("--no-graphs", action="store_true", help="enqueue every kernel of every batch from the host instead of replaying one "
-                                                            "HIP graph per stream (the chain is ~75 kernels per batch: launch-bound)")
+                                                            "HIP graph per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flow-lines", action="store_true", help="skip the pipelined prove-only / batch-verify-only / verify_compact measurements")
+    ap.add_argument("--pmc-json", default=DEFAULT_PMC, help="rocprofv3 --pmc summary (tools/pmc_summary.py); used only if its source hash matches")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
                     help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
-        # convenience: self-launch one process per GPU over RCCL exactly as the driver would
+        # convenience: self-launch one process per GPU exactly as the driver would
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    desc, parts, def_batch, def_streams, def_steps = WORKLOADS[args.config]
+    if args.steps is None:
+        args.steps = def_steps
+    n = args.batch or def_batch
     if args.streams <= 0:
-        args.streams = pick_streams(args.steps)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(args.streams, 24))))      # one hardware queue per stream (default is 4)
+        args.streams = def_streams or pick_streams(args.steps)
+    args.streams = max(1, min(args.streams, max(1, args.steps)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(args.streams, args.max_hw_queues))))   # one hardware queue per stream (default is 4)
     import numpy as np
     import torch
     from zkp_amd.engine import Engine, FusedStatement
@@ -155,22 +289,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    dist, group, dinfo = None, None, {"collective": None, "backend_world_size": 1, "rccl_error": None}
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ.get("ZKP_BENCH_DRYRUN_ONE_GPU"):
-            # dry run of the multi-rank logic on a box with a single GPU (all ranks on cuda:0, gloo instead of RCCL):
-            # exercises the barriers, the MAX over ranks and the verdict reduction -- not a measurement
             local_rank = 0
-            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist, group, dinfo = init_distributed(world, rank, local_rank)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    n_streams = max(1, args.streams)
+    n_streams = args.streams
     engines = [Engine(local_rank) for _ in range(n_streams)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     for e_, s_ in zip(engines, streams):
@@ -178,60 +306,71 @@ def main():
         for kv in args.engine_opt:
             e_.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     eng = engines[0]
-
-    n = args.batch
-    rng = np.random.default_rng(1000 + rank)
-    secrets, inst, common = cmz_instance(eng, n, rng)       # each rank proves / verifies its own range of proofs
-    fst = FusedStatement(b"CMZ cred show n=10", *cmz_statement())      # define_proof! label, benches/zkp.rs:29
-    for e_ in engines:                         # the issuer parameters are common to every proof (benches/zkp.rs:32): fixed-base tables
-        e_.prepare_fixed_points(common)
+    rng = np.random.default_rng(1000 + rank)   # each rank proves / verifies its own range of proofs
     t0s = T.Transcript(LABEL).state
     pos = int(t0s[200]) | int(t0s[201]) << 8 | int(t0s[202]) << 16
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d_ts0 = t(np.stack([t0s] * n))
-    d_sec = t(secrets)
-    d_tbl = t(np.concatenate([common, inst.reshape(-1, 32)]))              # common || inst rows: the prover's point table
-    d_ent = t(rng.integers(0, 256, size=(n, 32), dtype=np.uint8))          # what thread_rng() contributes (prover.rs:82)
-    d_w = t(rng.integers(0, 256, size=(11, n, 16), dtype=np.uint8))        # the u128 factors of batch_verifier.rs:179
-    n_msm, n_terms, n_bv = 11 * n, 31 * n, 12 + 24 * n
     z8 = lambda *shape: torch.zeros(shape, dtype=torch.uint8, device=dev)
-    bufs = []
-    for _ in engines:
-        b = dict(ts=z8(n, 208), ts2=z8(n, 208), chal=z8(n, 32), resp=z8(n, 21, 32), coms=z8(n, 11, 32), st=z8(n_msm),
-                 pts=z8(n_bv, 32), out=z8(32), bst=torch.ones(2, dtype=torch.int32, device=dev))
-        b["pts"][: 12 + 13 * n] = d_tbl
-        bufs.append(b)
+
+    # ---- per part of the workload: statement, instance, device inputs; per stream: outputs ------------------------------
+    class Part:
+        pass
+    ps = []
+    for label, st_fn, share, flows in parts:
+        p = Part()
+        p.st = st_fn()
+        p.n = max(1, int(round(n * share)))
+        p.flows = flows
+        p.secrets, p.inst, p.common = make_instance(eng, p.st, p.n, rng)
+        p.fst = FusedStatement(label, *p.st)
+        p.m, p.nc = len(p.st[0]), len(p.st[2])
+        p.ns, p.ni = len(p.common), len(p.inst)
+        p.T = sum(len(lc) for _, lc in p.st[2])
+        p.n_bv = p.ns + (p.ni + p.nc) * p.n
+        p.d_ts0 = t(np.stack([t0s] * p.n))
+        p.d_sec = t(p.secrets)
+        p.d_tbl = t(np.concatenate([p.common, p.inst.reshape(-1, 32)]))        # common || inst rows: the prover's point table
+        p.d_ent = t(rng.integers(0, 256, size=(p.n, 32), dtype=np.uint8))      # what thread_rng() contributes (prover.rs:82)
+        p.d_w = t(rng.integers(0, 256, size=(p.nc, p.n, 16), dtype=np.uint8))  # the u128 factors of batch_verifier.rs:179
+        p.bufs = []
+        for _ in engines:
+            b = dict(ts=z8(p.n, 208), ts2=z8(p.n, 208), ts3=z8(p.n, 208), chal=z8(p.n, 32), resp=z8(p.n, p.m, 32), coms=z8(p.n, p.nc, 32),
+                     st=z8(p.n * p.nc), pts=z8(p.n_bv, 32), out=z8(32), bst=torch.ones(2, dtype=torch.int32, device=dev), res=z8(p.n))
+            b["pts"][: p.ns + p.ni * p.n] = p.d_tbl
+            p.bufs.append(b)
+        ps.append(p)
+    for e_ in engines:                         # the common points of a statement are the same for every proof (benches/zkp.rs:32): fixed-base tables
+        e_.prepare_fixed_points(np.concatenate([p.common for p in ps]))
     verdict = torch.ones(1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    def prove(e_, b):
-        e_.fused_prove_dev(fst, n, pos, b["ts"].data_ptr(), d_sec.data_ptr(), d_tbl.data_ptr(), d_ent.data_ptr(), b["chal"].data_ptr(),
+    def prove(e_, p, b):
+        e_.fused_prove_dev(p.fst, p.n, pos, b["ts"].data_ptr(), p.d_sec.data_ptr(), p.d_tbl.data_ptr(), p.d_ent.data_ptr(), b["chal"].data_ptr(),
                            b["resp"].data_ptr(), b["coms"].data_ptr(), b["st"].data_ptr())
 
-    def batch_verify(e_, b):
-        e_.fused_batch_verify_dev(fst, n, pos, b["ts2"].data_ptr(), b["pts"].data_ptr(), b["coms"].data_ptr(), b["resp"].data_ptr(),
-                                  d_w.data_ptr(), b["out"].data_ptr(), b["bst"].data_ptr())
+    def batch_verify(e_, p, b):
+        e_.fused_batch_verify_dev(p.fst, p.n, pos, b["ts2"].data_ptr(), b["pts"].data_ptr(), b["coms"].data_ptr(), b["resp"].data_ptr(),
+                                  p.d_w.data_ptr(), b["out"].data_ptr(), b["bst"].data_ptr())
 
-    graphs = [None] * n_streams
+    def verify_compact(e_, p, b):
+        e_.fused_verify_compact_dev(p.fst, p.n, pos, b["ts3"].data_ptr(), p.d_tbl.data_ptr(), b["chal"].data_ptr(), b["resp"].data_ptr(), b["res"].data_ptr())
 
-    def enqueue(k):
-        e_, b = engines[k], bufs[k]
+    def enqueue(k, which=None):
+        """one step on stream k: per part, fresh transcripts and its flows (or only the flow `which`)"""
+        e_ = engines[k]
         with torch.cuda.stream(streams[k]):
-            b["ts"].copy_(d_ts0, non_blocking=True)
-            b["ts2"].copy_(d_ts0, non_blocking=True)
-            prove(e_, b)
-            batch_verify(e_, b)
-
-    def step(i):
-        # one batch: fresh transcripts, prove all N proofs, batch-verify them.  Consecutive batches go to different engine
-        # contexts = different HIP streams, so the narrow phases of one batch (transcripts, Horner, reduction tree)
-        # overlap with the wide kernels of the next.  The chain of a batch (2 copies + ~75 kernels) is recorded once per
-        # stream as a HIP graph and replayed with one host call per step.
-        k = i % n_streams
-        if graphs[k] is not None:
-            graphs[k].launch()
-        else:
-            enqueue(k)
+            for p in ps:
+                b = p.bufs[k]
+                for flow in ((which,) if which else p.flows):
+                    if flow == "prove":
+                        b["ts"].copy_(p.d_ts0, non_blocking=True)
+                        prove(e_, p, b)
+                    elif flow == "batch_verify":
+                        b["ts2"].copy_(p.d_ts0, non_blocking=True)
+                        batch_verify(e_, p, b)
+                    else:
+                        b["ts3"].copy_(p.d_ts0, non_blocking=True)
+                        verify_compact(e_, p, b)
 
     def barrier():
         if dist is not None:
@@ -240,67 +379,127 @@ def main():
             e_.synchronize()
         torch.cuda.synchronize()
 
-    for k in range(n_streams):                 # first pass: plans compiled, workspaces sized (nothing may allocate while capturing)
-        step(k)
+    # proofs for the parts that only verify (and for everybody's later flow lines): made once, untimed
+    for k in range(n_streams):
+        with torch.cuda.stream(streams[k]):
+            for p in ps:
+                p.bufs[k]["ts"].copy_(p.d_ts0, non_blocking=True)
+                prove(engines[k], p, p.bufs[k])
     barrier()
-    if not args.no_graphs:
-        for k in range(n_streams):
-            engines[k].capture_begin()
-            enqueue(k)
-            graphs[k] = engines[k].capture_end()
-    for i in range(max(args.warmup, 1) * n_streams):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    t_enqueued = time.perf_counter() - t0
-    if dist is not None:
-        # the only cross-GPU exchange of the path: AND of the per-GPU verdict bits (int32 MIN all-reduce over RCCL)
-        for e_ in engines:
-            e_.synchronize()
-        ok_local = all(int(b["bst"].abs().sum().item()) == 0 and not bool(b["out"].any().item()) for b in bufs)
-        verdict.fill_(1 if ok_local else 0)
-        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    for b in bufs:
-        assert not bool(b["st"].any().item()), "prover: an input point failed to decode"
-        assert int(b["bst"].abs().sum().item()) == 0 and not bool(b["out"].any().item()), "the batch of fresh proofs did not verify"
-    assert all(bool((b["chal"] == bufs[0]["chal"]).all().item()) and bool((b["resp"] == bufs[0]["resp"]).all().item()) for b in bufs), "streams disagree"
-    # the proofs must be REAL proofs: a flipped response bit makes the batch check fail
-    b = bufs[0]
-    with torch.cuda.stream(streams[0]):
-        b["resp"][n // 2, 3, 0] ^= 1
-        b["ts2"].copy_(d_ts0)
-        batch_verify(eng, b)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    assert bool(b["out"].any().item()) or int(b["bst"].abs().sum().item()) != 0, "a corrupted proof passed the batch check"
 
-    # ---- per-kernel timing with HIP events on the engine's stream (separate, profiled passes) ---------
+    def timed_loop(which, steps, warmup):
+        """K steps over the streams, each replaying the per-stream HIP graph of its chain (2 copies + ~75 kernels per flow pair):
+        barrier + synchronize on both sides; returns (elapsed, host time to enqueue)."""
+        graphs = [None] * n_streams
+        for k in range(n_streams):             # first pass: plans compiled, workspaces sized (nothing may allocate while capturing)
+            enqueue(k, which)
+        barrier()
+        if not args.no_graphs:
+            for k in range(n_streams):
+                engines[k].capture_begin()
+                enqueue(k, which)
+                graphs[k] = engines[k].capture_end()
+
+        def step(i):
+            # consecutive batches go to different engine contexts = different HIP streams, so the narrow phases of one batch
+            # (transcripts, table chains, Horner) overlap with the wide kernels of the others
+            k = i % n_streams
+            if graphs[k] is not None:
+                graphs[k].launch()
+            else:
+                enqueue(k, which)
+
+        for i in range(max(warmup, 1) * n_streams):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        t_enq = time.perf_counter() - t0
+        if which is None and dist is not None:
+            # the only cross-GPU exchange of the path: AND of the per-GPU verdict bits (int32 MIN all-reduce)
+            for e_ in engines:
+                e_.synchronize()
+            ok_local = all(int(b["bst"].abs().sum().item()) == 0 and not bool(b["out"].any().item()) for p in ps for b in p.bufs)
+            verdict.fill_(1 if ok_local else 0)
+            if group is not None:
+                dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)           # RCCL
+            else:
+                v = verdict.cpu()
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)                              # gloo fallback
+                verdict.copy_(v)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        for g in graphs:
+            if g is not None:
+                g.close()
+        return elapsed, t_enq
+
+    elapsed, t_enqueued = timed_loop(None, args.steps, args.warmup)
+    if dist is not None:
+        assert int(verdict.item()) == 1, "a rank reported a batch that did not verify"
+    for p in ps:
+        for b in p.bufs:
+            assert not bool(b["st"].any().item()), "prover: an input point failed to decode"
+            assert int(b["bst"].abs().sum().item()) == 0 and not bool(b["out"].any().item()), "the batch of fresh proofs did not verify"
+        assert all(bool((b["chal"] == p.bufs[0]["chal"]).all().item()) and bool((b["resp"] == p.bufs[0]["resp"]).all().item()) for b in p.bufs), "streams disagree"
+    # the proofs must be REAL proofs: a flipped response bit makes the batch check fail
+    for p in ps:
+        b = p.bufs[0]
+        with torch.cuda.stream(streams[0]):
+            b["resp"][p.n // 2, p.m // 2, 0] ^= 1
+            b["ts2"].copy_(p.d_ts0)
+            batch_verify(eng, p, b)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        assert bool(b["out"].any().item()) or int(b["bst"].abs().sum().item()) != 0, "a corrupted proof passed the batch check"
+        with torch.cuda.stream(streams[0]):
+            b["resp"][p.n // 2, p.m // 2, 0] ^= 1
+        torch.cuda.synchronize()
+
+    # ---- pipelined single-flow lines (same loop, one flow) -------------------------------------------------------------
+    total_n = sum(p.n for p in ps)
+    flow_lines = {}
+    if not args.no_flow_lines:
+        flows_present = sorted({f for p in ps for f in p.flows})
+        for which in flows_present + (["verify_compact"] if args.config != "3" else []):
+            if len(flows_present) == 1 and which == flows_present[0]:
+                continue                       # the step itself is that flow
+            el, _ = timed_loop(which, args.steps, 1)
+            flow_lines[which] = world * total_n * args.steps / el
+        if "verify_compact" in flow_lines:
+            assert all(not bool(b["res"].any().item()) for p in ps for b in p.bufs), "verify_compact rejected a fresh proof"
+
+    # ---- per-kernel timing with HIP events on the engine's stream (separate, profiled passes on one stream) -------------
     eng.set_profiling(True)
-    reps = 5
-    k_prove = {}
-    k_verify = {}
+    reps = 5 if total_n <= (1 << 16) else 2
+    kms = {}
+    flows_timed = sorted({f for p in ps for f in p.flows}) + ([] if args.no_flow_lines or args.config == "3" else ["verify_compact"])
     with torch.cuda.stream(streams[0]):
         for _ in range(reps):
-            b["ts"].copy_(d_ts0)
-            b["ts2"].copy_(d_ts0)
-            prove(eng, b)
-            km, tot = eng.last_timing()
-            for k, v in km.items():
-                k_prove[k] = k_prove.get(k, 0.0) + v / reps
-            k_prove["total"] = k_prove.get("total", 0.0) + tot / reps
-            batch_verify(eng, b)
-            km, tot = eng.last_timing()
-            for k, v in km.items():
-                k_verify[k] = k_verify.get(k, 0.0) + v / reps
-            k_verify["total"] = k_verify.get("total", 0.0) + tot / reps
+            for p in ps:
+                b = p.bufs[0]
+                for flow in flows_timed:
+                    if flow != "verify_compact" and flow not in p.flows:
+                        continue
+                    if flow == "prove":
+                        b["ts"].copy_(p.d_ts0)
+                        prove(eng, p, b)
+                    elif flow == "batch_verify":
+                        b["ts2"].copy_(p.d_ts0)
+                        batch_verify(eng, p, b)
+                    else:
+                        b["ts3"].copy_(p.d_ts0)
+                        verify_compact(eng, p, b)
+                    km, tot = eng.last_timing()
+                    d = kms.setdefault(flow, {})
+                    for k, v in km.items():
+                        d[k] = d.get(k, 0.0) + v / reps
+                    d["total"] = d.get("total", 0.0) + tot / reps
     eng.set_profiling(False)
 
     if rank != 0:
@@ -309,98 +508,120 @@ def main():
         return
 
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * n * args.steps / elapsed
-    # dominant kernel: k_terms_split<CT> (one launch per step).  Algorithmic bytes per launch:
-    # 64 B per (scalar, point) term in + 32 B per MSM out = 2,336 B per CMZ proof.
-    algo_bytes = 64.0 * n_terms + 32.0 * n_msm
-    t_terms = k_prove["terms"] * 1e-3
-    achieved = algo_bytes / t_terms / 1e9 if t_terms > 0 else 0.0
-    # executed v_mad_u64_u32 in that launch (fe_sq = 62, fe_mul = 98):
-    #   term on a per-proof point (11 of 31 per proof), comb walk: 16 windows x (4 doublings + 4 additions) + 1 addition
-    #   term on a common point X_1..X_10, A (20 of 31), fixed-base walk: 65 mixed additions (7 mul each)
-    mads_comb_term = 16 * (16 * 62 + (3 + 3 + 3 + 4 + 4 * 8) * 98) + 8 * 98
-    mads_fixed_term = 65 * 7 * 98
-    mads = n * (11 * mads_comb_term + 20 * mads_fixed_term)
-    valu = mads / t_terms if t_terms > 0 else 0.0
-    traffic = None
-    step_valu = None
-    kernel_valu = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")       # rocprofv3 --pmc passes of this same command
-    if os.path.exists(pmc) and n == 4096:
+    value = world * total_n * args.steps / elapsed
+    # ---- roofline of the dominant kernel: the timing kind with the largest share of the step's kernel time (HIP events) --
+    algo = {"prove": sum((64.0 * p.T + 32.0 * p.nc) * p.n for p in ps if "prove" in p.flows),                 # 64 B per term in + 32 B per MSM out
+            "batch_verify": sum(64.0 * p.n_bv for p in ps if "batch_verify" in p.flows)}                      #              64 B per operand of the one MSM
+    step_flows = sorted({f for p in ps for f in p.flows})
+    shares = [(kms[f][k], f, k) for f in step_flows for k in kms[f] if k != "total" and kms[f][k] > 0]
+    t_all = sum(s[0] for s in shares)
+    by_kernel = [{"flow": f, "kind": k, "kernels": KERNELS.get((f, k), k), "ms": ms, "share": ms / t_all, "GB/s": algo[f] / (ms * 1e-3) / 1e9}
+                 for ms, f, k in sorted(shares, reverse=True)]
+    dom = by_kernel[0]
+    achieved = dom["GB/s"]
+    roof = {"bound": "hbm", "kernel": "%s  (%s flow, %.0f %% of the step's kernel time on one stream)" % (dom["kernels"], dom["flow"], 100 * dom["share"]),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": algo[dom["flow"]], "launch_ms": dom["ms"],
+            "note": "integer-VALU bound by construction (SURVEY.md 8(d)): algorithmic bytes = 64 B per (scalar, point) term + 32 B per output, "
+                    "so the HBM fraction of ANY kernel of this path is ~1e-3; the binding roofline is step_valu / *_valu_issue_frac (PMC)",
+            "by_kernel": by_kernel}
+    # ---- PMC-derived fields: only from a counter file collected from exactly these sources -----------------------------
+    sha = source_sha256()
+    pmc_source, step_valu = None, None
+    pmc_path = args.pmc_json if os.path.isabs(args.pmc_json) else os.path.join(ROOT, args.pmc_json)
+    if args.config == "2" and n == 4096 and os.path.exists(pmc_path):
         try:
-            pj = json.load(open(pmc))
-            traffic = pj["k_terms_split<true>"]["hbm_bytes_per_launch"]
-            kernel_valu = pj["k_terms_split<true>"]["SQ_INSTS_VALU"]
-            step_valu = pj["_step_totals"]["valu_wave_instructions_per_step"]
-        except Exception:
-            pass
-    msm_only = lambda d: sum(d.get(k, 0.0) for k in ("decode", "terms", "reduce", "sort", "bucket", "combine"))
+            pj = json.load(open(pmc_path))
+            if pj.get("_source_sha256") == sha:
+                pmc_source = "%s: rocprofv3 --pmc passes of `python bench.py --steps 20` at kernel-source sha256 %s (tools/collect_profiles.sh)" % (args.pmc_json, sha[:12])
+                pmc_names = {"terms": "k_terms_split<true", "tables": "zkp::k_comb_tables_lane<16", "transcript": "zkp::k_transcript_run", "decode": "k_pip_prepare<11"}
+                kname = next((k for k in pj if dom["kind"] in pmc_names and k.startswith(pmc_names[dom["kind"]])), None)
+                if kname:
+                    roof["traffic"] = pj[kname].get("hbm_bytes_per_launch")
+                    roof["dominant_kernel_valu_issue_frac"] = pj[kname]["SQ_INSTS_VALU"] * 64.0 / (dom["ms"] * 1e-3) / VALU_PEAK * (2 if (dom["kind"], dom["flow"]) == ("transcript", "prove") else 1)
+                tname = next((k for k in pj if k.startswith("k_terms_split<true")), None)
+                if tname and kms.get("prove", {}).get("terms"):
+                    roof["terms_kernel_valu_issue_frac"] = pj[tname]["SQ_INSTS_VALU"] * 64.0 / (kms["prove"]["terms"] * 1e-3) / VALU_PEAK
+                    roof["terms_kernel_traffic"] = pj[tname].get("hbm_bytes_per_launch")
+                tot = pj.get("_step_totals", {}).get("valu_wave_instructions_per_step")
+                if tot:
+                    lane = tot * 64.0
+                    step_valu = {"wave_instructions_per_step": tot, "lane_instructions_per_s": lane / (ms_per_step * 1e-3),
+                                 "peak_lane_instructions_per_s": VALU_PEAK, "frac": lane / (ms_per_step * 1e-3) / VALU_PEAK,
+                                 "note": "PMC SQ_INSTS_VALU summed over all kernels of a step (from pmc_source) / this run's ms_per_step, "
+                                         "against the measured issue peak of the 4-cycle VALU class"}
+        except Exception:                       # noqa: BLE001 -- a reported extra, never the measurement
+            pmc_source = None
     out = {
         "metric": METRIC, "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "host_enqueue_ms_per_step": t_enqueued * 1e3 / args.steps, "hip_graphs": not args.no_graphs,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
         "data": "synthetic",
-        "config": {"workload": "CMZ'13 10-hidden-attribute credential, batch of %d proofs per GPU: complete proving (Merlin transcripts, "
-                               "blindings, 11 constant-time commitment MSMs / 31 terms per proof, challenges, responses) + complete batch "
-                               "verification of those proofs (transcripts, coefficient build, one MSM of 12 + 24 N terms)" % n,
-                   "batch_per_gpu": n, "streams": n_streams, "sharding": "independent proof ranges per GPU, AND of verdict bits"},
-        "prove_proofs_per_s": world * n / (k_prove["total"] * 1e-3),
-        "batch_verifies_per_s": world * n / (k_verify["total"] * 1e-3),
-        "msm_only_proofs_per_s": {"prove": world * n / (msm_only(k_prove) * 1e-3), "batch_verify": world * n / (msm_only(k_verify) * 1e-3)},
-        "kernel_ms": {"prove": k_prove, "batch_verify": k_verify},
-        "roofline": {"bound": "hbm", "kernel": "k_terms_split<CT>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "note": "integer-VALU bound by construction (SURVEY.md 8(d)); see valu_* for the binding roofline",
-                     "valu_achieved_mads_per_s": valu, "valu_peak_mads_per_s": VALU_PEAK_MADS, "valu_frac": valu / VALU_PEAK_MADS,
-                     "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": k_prove["terms"]},
+        "config": {"workload": desc % n, "baseline_config": args.config, "batch_per_gpu": n, "streams": n_streams, "hip_graphs": not args.no_graphs,
+                   "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "sharding": "independent proof ranges per GPU, AND of verdict bits",
+                   "collective": dinfo["collective"], "backend_world_size": dinfo["backend_world_size"]},
+        "host_enqueue_ms_per_step": t_enqueued * 1e3 / args.steps,
+        "pipelined_proofs_per_s": flow_lines,                                   # same loop, one flow only
+        "single_stream_proofs_per_s": {f: world * sum(p.n for p in ps if f == "verify_compact" or f in p.flows) / (kms[f]["total"] * 1e-3) for f in kms},
+        "kernel_ms": kms, "roofline": roof, "pmc_source": pmc_source, "source_sha256": sha,
     }
-    if kernel_valu:
-        # every VALU instruction of the dominant kernel (PMC SQ_INSTS_VALU: multiplications, carries, constant-time selects ...)
-        # per second of its launch, against the same issue peak
-        out["roofline"]["valu_issue_lane_instr_per_s"] = kernel_valu * 64.0 / t_terms
-        out["roofline"]["valu_issue_frac"] = kernel_valu * 64.0 / t_terms / VALU_PEAK_MADS
+    if dinfo.get("rccl_error"):
+        out["config"]["rccl_error"] = dinfo["rccl_error"]
     if step_valu:
-        # every VALU instruction of one step (PMC SQ_INSTS_VALU, all kernels) against the measured 4-cycle-class issue peak:
-        # how close the pipelined step as a whole runs to the integer-VALU roofline
-        lane_instr = step_valu * 64.0
-        out["step_valu"] = {"wave_instructions_per_step": step_valu, "lane_instructions_per_s": lane_instr / (ms_per_step * 1e-3) * world / world,
-                            "peak_lane_instructions_per_s": VALU_PEAK_MADS, "frac": lane_instr / (ms_per_step * 1e-3) / VALU_PEAK_MADS,
-                            "note": "simple 32-bit adds / fma issue at twice this class's rate, so frac slightly understates the headroom"}
+        out["step_valu"] = step_valu
     if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (rank 0's host cores)
-        out["cpu_baseline"] = cpu_baseline(n, secrets, inst, common, d_ent.cpu().numpy(), d_w.cpu().numpy())
-        out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+        out["cpu_baseline"] = cpu_baseline(ps, LABEL, 4096 if args.config == "2" else 1024)
+        if args.config == "2":
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(n, secrets, inst, common, entropy, weights):
+def cpu_baseline(ps, label, sample):
     """The oracle's dalek-style CPU port of the SAME flows (Merlin/STROBE, radix-16 constant-time Straus for the
-    commitments, scalar arithmetic mod l, Pippenger w = 8 for the batch check), one thread, on a bounded sample of the
-    same workload: the first 512 proofs proven one by one, then batch-verified.  The reference's own Rust cannot be
-    built on this box (no toolchain)."""
+    commitments, scalar arithmetic mod l, Pippenger w = 6..8 for the batch check), one thread, on a bounded sample of the
+    same workload: the first `sample` proofs of each part proven one by one (where the step proves) and batch-verified.
+    The reference's own Rust cannot be built on this box (no toolchain)."""
     import numpy as np
     from oracle import cbind as C
-    from oracle import model as M
     C.build()
-    m = min(n, 512)
-    cst = C.Statement.from_model(M.cmz_statement(10))
-    coms = np.zeros((m, 11, 32), np.uint8)
-    resp = np.zeros((m, 21, 32), np.uint8)
-    t0 = time.perf_counter()
-    for j in range(m):
-        pts = np.concatenate([inst[:, j], common])
-        _, er, ek, _ = C.prove(cst, LABEL, secrets[j], pts, entropy[j].tobytes())
-        coms[j], resp[j] = ek, er
-    t1 = time.perf_counter()
-    rc = C.batch_verify(cst, LABEL, m, np.ascontiguousarray(inst[:, :m]), common, coms, resp, np.ascontiguousarray(weights[:, :m]))
-    t2 = time.perf_counter()
-    assert rc == 0, "oracle: the sample batch did not verify"
-    return {"value": m / (t2 - t0), "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": "%d proofs: proven one by one %.3f s (Merlin + radix-16 constant-time Straus + responses) + one batch "
-                      "verification %.3f s (Merlin + coefficients + %d-term Pippenger w=8 incl. decompression); gcc -O3 -march=native, "
-                      "5x51-bit limbs" % (m, t1 - t0, t2 - t1, 12 + 24 * m),
-            "prove_proofs_per_s": m / (t1 - t0), "batch_verifies_per_s": m / (t2 - t1)}
+    t_prove = t_bv = 0.0
+    n_done = 0
+    notes = []
+    for p in ps:
+        m = min(p.n, sample)
+        secrets_l, points, cons = p.st
+        names = [nm.decode() for nm, _ in points]
+        cst = C.Statement(p.fst._label, [s.decode() for s in secrets_l], [(nm.decode(), c) for nm, c in points],
+                          [(names[l], [(secrets_l[s].decode(), names[q]) for s, q in lc]) for l, lc in cons])
+        com_rank, inst_rank = {}, {}
+        for i, (_, c) in enumerate(points):
+            (com_rank if c else inst_rank)[i] = len(com_rank if c else inst_rank)
+        coms = np.zeros((m, p.nc, 32), np.uint8)
+        resp = np.zeros((m, p.m, 32), np.uint8)
+        ent = p.d_ent[:m].cpu().numpy()
+        w = np.ascontiguousarray(p.d_w[:, :m].cpu().numpy())
+        t0 = time.perf_counter()
+        for j in range(m):
+            pts = np.stack([p.common[com_rank[i]] if i in com_rank else p.inst[inst_rank[i], j] for i in range(len(points))])
+            _, er, ek, _ = C.prove(cst, label, p.secrets[j], pts, ent[j].tobytes())
+            coms[j], resp[j] = ek, er
+        t1 = time.perf_counter()
+        rc = C.batch_verify(cst, label, m, np.ascontiguousarray(p.inst[:, :m]), p.common, coms, resp, w)
+        t2 = time.perf_counter()
+        assert rc == 0, "oracle: the sample batch did not verify"
+        if "prove" in p.flows:
+            t_prove += t1 - t0
+        t_bv += t2 - t1
+        n_done += m
+        notes.append("%d proofs of \"%s\": proven one by one %.3f s%s, one batch verification %.3f s (%d-term Pippenger incl. decompression)"
+                     % (m, p.fst._label.decode(), t1 - t0, "" if "prove" in p.flows else " (set-up, not counted)", t2 - t1, p.ns + (p.ni + p.nc) * m))
+    outd = {"value": n_done / (t_prove + t_bv), "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": "; ".join(notes) + "; Merlin + radix-16 constant-time Straus + responses / Merlin + coefficients + Pippenger; gcc -O3 -march=native, 5x51-bit limbs",
+            "batch_verifies_per_s": n_done / t_bv}
+    if t_prove:
+        outd["prove_proofs_per_s"] = n_done / t_prove
+    return outd
 
 
 def cpu_baseline_all_cores():

@@ -243,12 +243,12 @@ enum {
   ZKP_K_TERMS = 1,       /* per-term scalar multiplication (small-MSM path)                       */
   ZKP_K_REDUCE = 2,      /* per-MSM sum of partials + compress                                    */
   ZKP_K_SORT = 3,        /* Pippenger: histogram + scan + scatter; small-MSM path: term classification    */
-                         /* + comb-table construction                                                     */
   ZKP_K_BUCKET = 4,      /* Pippenger: bucket accumulation                                        */
   ZKP_K_COMBINE = 5,     /* Pippenger: bucket reduction + window combination + compress           */
   ZKP_K_TRANSCRIPT = 6,  /* fused flows: batched Merlin/STROBE transcript programs                 */
   ZKP_K_SCALARS = 7,     /* fused flows: scalar arithmetic mod l (blindings, responses, coefficients, operand assembly) */
-  ZKP_K_COUNT = 8
+  ZKP_K_TABLES = 8,      /* small-MSM path: comb tables of the per-proof points (k_comb_tables*)                      */
+  ZKP_K_COUNT = 9
 };
 int zkp_ctx_last_timing(zkp_ctx* ctx, float* kernel_ms /*[ZKP_K_COUNT]*/, float* total_ms);
 /* Enable (1) / disable (0) per-kernel event timing (off by default: events add launch gaps). */

@@ -219,6 +219,62 @@ def test_config3_complete_flows_dleq_2p20(eng):
         T.batch_verify(eng, st, ts, inst, base.copy(), coms, resp)
 
 
+def test_config3_constraint_api_form_2p20(eng):
+    """Config 3's other half at full size: the constraint-API form of benches/dleq.rs:188-241 -- the static points G, H are
+    allocated BEFORE the instance points A, B, and H is shared by the whole batch, so the batch MSM has 2 + 4 N =
+    4,194,306 terms.  2^20 proofs proven and batch-verified on the device; sampled proofs equal the C oracle's byte for byte;
+    the GPU-built coefficient vector satisfies the checksum the statement implies; one flipped bit fails the batch."""
+    from zkp_amd import toolbox as T
+    n = 1 << 20
+    rng = np.random.default_rng(34)
+    base = np.frombuffer(bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"), np.uint8).reshape(1, 32)
+    hk = rand_scalars(rng, 1)
+    Hs, s0 = eng.msm_many(np.arange(2, dtype=np.uint32), hk, np.zeros(1, np.uint32), base, 1)
+    common = np.ascontiguousarray(np.concatenate([base, Hs]))            # G, H
+    eng.prepare_fixed_points(common)
+    x = rand_scalars(rng, n)
+    iota = np.arange(n + 1, dtype=np.uint32)
+    A, s1 = eng.msm_many(iota, x, np.zeros(n, np.uint32), common, 1)     # benches/dleq.rs:198-199: A = x G, B = x H
+    B, s2 = eng.msm_many(iota, x, np.ones(n, np.uint32), common, 1)
+    assert not (s0.any() or s1.any() or s2.any())
+    st = T.Statement(b"DLEQProof")                                       # dleq.rs:206-216: scalar, static G, H, then instance A, B
+    vx = st.add_secret(b"x")
+    vg, vh = st.add_point(b"G", True), st.add_point(b"H", True)
+    va, vb = st.add_point(b"A", False), st.add_point(b"B", False)
+    st.constrain(va, [(vx, vg)])
+    st.constrain(vb, [(vx, vh)])
+    inst = np.ascontiguousarray(np.stack([A, B]))
+    label = b"DLEQBatchTest"
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    t0 = T.Transcript(label).state
+    ts = np.repeat(t0[None], n, axis=0)
+    secrets = np.ascontiguousarray(x.reshape(n, 1, 32))
+    chal, resp, coms = T.prove_batch(eng, st, ts, secrets, inst, common, entropy)
+    cst = C.Statement(b"DLEQProof", ["x"], [("G", True), ("H", True), ("A", False), ("B", False)], [("A", [("x", "G")]), ("B", [("x", "H")])])
+    for j in (0, 424242, n - 1):
+        ec, er, ek, _ = C.prove(cst, label, secrets[j], np.stack([common[0], common[1], A[j], B[j]]), entropy[j].tobytes())
+        assert chal[j].tobytes() == ec.tobytes() and (resp[j] == er).all() and (coms[j] == ek).all(), j
+    w16 = rng.integers(0, 256, size=(2, n, 16), dtype=np.uint8)
+    ts = np.repeat(t0[None], n, axis=0)
+    ok, co = T.batch_verify_coeffs(eng, st, ts, inst, common, coms, resp, w16)
+    assert ok and co.shape == (2 + 4 * n, 32)
+    # size-independent property of the coefficient vector (batch_verifier.rs:173-206): the commitment rows are -r_ij, and the
+    # static coefficients are  sum_j r_0j resp_j  (G)  and  sum_j r_1j resp_j  (H)  mod l
+    ints = lambda a: np.array(to_ints(np.ascontiguousarray(a)), dtype=object)
+    r0, r1 = ints(np.pad(w16[0], ((0, 0), (0, 16)))), ints(np.pad(w16[1], ((0, 0), (0, 16))))
+    rs_ = ints(resp[:, 0])
+    assert int.from_bytes(co[0].tobytes(), "little") == int(np.dot(r0, rs_)) % M.L
+    assert int.from_bytes(co[1].tobytes(), "little") == int(np.dot(r1, rs_)) % M.L
+    sample = rng.integers(0, n, size=64)
+    for j in sample:
+        assert int.from_bytes(co[2 + 2 * n + j].tobytes(), "little") == (-int(r0[j])) % M.L          # commitment row of constraint 0
+        assert int.from_bytes(co[2 + 3 * n + j].tobytes(), "little") == (-int(r1[j])) % M.L
+    resp[n // 5, 0, 31] ^= 1
+    ts = np.repeat(t0[None], n, axis=0)
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify(eng, st, ts, inst, common, coms, resp)
+
+
 def test_config5_share_complete_flows_w64_32768(eng):
     """Per-GPU share of config 5 through the complete flows: the wide statement Q = sum_{i<64} x_i G_i, 32,768 proofs
     proven, verified one by one and batch-verified on the device; sampled proofs equal the C oracle's."""

@@ -78,3 +78,25 @@ def test_sharded_prove_and_batch_verify_two_ranks_on_the_gpu(tamper, expect):
         assert p.exitcode == 0
     assert [r[1:3] for r in res] == [(0, 300), (300, 600)]
     assert all(r[3] == expect for r in res)           # the AND reaches every rank
+
+
+def test_bench_eight_rank_control_flow_on_one_gpu():
+    """bench.py --gpus 8 exactly as the driver launches it (torch.distributed.run, one process per rank), with all eight
+    ranks on this box's single GPU (ZKP_BENCH_DRYRUN_ONE_GPU): barriers, the per-rank stream pools and HIP graphs, the
+    verdict reduction through the fallback branch, the MAX of the elapsed times and rank 0's JSON line.  Not a measurement."""
+    import json
+    import subprocess
+    env = dict(os.environ, ZKP_BENCH_DRYRUN_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
+           "--batch", "256", "--streams", "2", "--no-flow-lines"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # ONE line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 4 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["backend_world_size"] == 8 and j["config"]["collective"] == "gloo-fallback" and "dry run" in j["config"]["rccl_error"]
+    assert abs(j["value"] - 8 * 256 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]
+    assert "cpu_baseline" not in j                                  # reported at N = 1 only

@@ -37,6 +37,11 @@ def main():
         res["_step_totals"] = {"steps": steps, "valu_wave_instructions_per_step": tot,
                                "note": "sum over kernels of SQ_INSTS_VALU x launches / steps (fixed-base table set-up kernels excluded)"}
         print("%-34s valu wave-instructions per bench step = %.4g" % ("_step_totals", tot))
+    # key the counters to the kernel sources they were collected from (bench.py only reports them when the hash matches)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["_source_sha256"] = bench.source_sha256()
     json.dump(res, open(out, "w"), indent=1)
 
 

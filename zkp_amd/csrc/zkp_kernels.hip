@@ -926,7 +926,7 @@ static int fail(int code, const std::string& msg) {
                   std::string(#expr) + ": " + hipGetErrorString(e_));                          \
   } while (0)
 
-constexpr int kMaxEvents = 24;     // timing marks per call (a fused flow records more than one per kind)
+constexpr int kMaxEvents = 32;     // timing marks per call (a fused flow records more than one per kind)
 struct zkp_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -1123,6 +1123,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     prof_mark(c, ZKP_K_DECODE);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor, blk_start);
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, cursor, list);
+    prof_mark(c, ZKP_K_SORT);          // path A: term classification
     if (k.max_tables) {
       hipLaunchKernelGGL(k_comb_slots, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, k.max_tables, n_slots, slot_of, slot_pt);
       if (k.throughput) {
@@ -1133,7 +1134,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
         else hipLaunchKernelGGL(k_comb_tables<4>, grid1((size_t)k.max_tables * 4, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       }
     }
-    prof_mark(c, ZKP_K_SORT);          // path A: term classification + comb-table construction
+    prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
     }
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 3 + HOT_SLOTS));     // every fixed-base class starts a new block
     // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libzkp_mi355x.so")
 ZKP_VARTIME = 0
 ZKP_CT = 1
 ZKP_OPT_BATCH_ENCODE_MIN = 1
-K_NAMES = ("decode", "terms", "reduce", "sort", "bucket", "combine", "transcript", "scalars")
+K_NAMES = ("decode", "terms", "reduce", "sort", "bucket", "combine", "transcript", "scalars", "tables")
 
 EXPORTS = (
     "zkp_ctx_create", "zkp_ctx_destroy", "zkp_ctx_set_stream", "zkp_ctx_synchronize", "zkp_last_error",

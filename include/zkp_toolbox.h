@@ -114,6 +114,30 @@ uint32_t zkp_toolbox_get_fused_min_batch(void);
  * ChaCha stream keyed from the operating system.  Exposed for the known-answer test. */
 void zkp_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t nonce, uint8_t out[64]);
 
+/* ---- proof wire format (src/proofs.rs:14-32 under `bincode::serialize`, tests/zkp.rs:53-54, :96-97) ---------------
+ * The reference derives serde's Serialize / Deserialize and its tests move proofs through bincode 1.x's top-level
+ * functions: fixed-width little-endian integers, `u64` sequence lengths, a `Scalar` / `CompressedRistretto` as its 32
+ * bytes (serde tuples carry no length):
+ *   CompactProof   = challenge[32] | u64 m | m x response[32]                         (40 + 32 m bytes)
+ *   BatchableProof = u64 nc | nc x commitment[32] | u64 m | m x response[32]          (16 + 32 (nc + m) bytes)
+ * Decoding applies what curve25519-dalek's Deserialize applies: every scalar must be canonical (< l) -- a non-canonical
+ * challenge or response is ZKP_TB_BAD_ENCODING -- while a CompressedRistretto is any 32 bytes (validity is decided by
+ * decompress() during verification).  A length prefix larger than the bytes that follow is ZKP_TB_BAD_ENCODING.
+ * *consumed receives the bytes used; bincode's top-level deserialize ignores trailing bytes, so does this decoder
+ * (strict callers compare *consumed with len).  [No golden bytes exist in the reference: its tests only round-trip.]
+ * Sizes in elements; the decoders never write more than max_* elements (ZKP_TB_BAD_STATEMENT if the proof holds more). */
+#define ZKP_TB_BAD_ENCODING (-13)
+size_t zkp_proof_compact_size(uint32_t m);
+size_t zkp_proof_batchable_size(uint32_t nc, uint32_t m);
+int zkp_proof_compact_encode(const uint8_t challenge[32], const uint8_t* responses /*[m][32]*/, uint32_t m, uint8_t* out,
+                             size_t out_len);
+int zkp_proof_compact_decode(const uint8_t* in, size_t len, uint8_t challenge[32], uint8_t* responses /*[max_m][32]*/,
+                             uint32_t max_m, uint32_t* m, size_t* consumed);
+int zkp_proof_batchable_encode(const uint8_t* commitments /*[nc][32]*/, uint32_t nc, const uint8_t* responses /*[m][32]*/,
+                               uint32_t m, uint8_t* out, size_t out_len);
+int zkp_proof_batchable_decode(const uint8_t* in, size_t len, uint8_t* commitments /*[max_nc][32]*/, uint32_t max_nc,
+                               uint32_t* nc, uint8_t* responses /*[max_m][32]*/, uint32_t max_m, uint32_t* m, size_t* consumed);
+
 /* ---- host-only halves, exposed so the host logic can be tested without a GPU ----------------------- */
 /* Everything of zkp_batch_verify up to (not including) the MSM: writes the exact operand sequence of
  * batch_verifier.rs:219-228, ns + (ni + nc) * N scalars and encodings.  Returns 0 or the error the

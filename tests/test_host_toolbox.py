@@ -304,3 +304,51 @@ def test_interleaved_allocations_host_phase_a_matches_model():
     coms = arr(list(want.commitments)).reshape(1, 2, 32)      # the model's commitments stand in for the MSM (CPU test)
     chal, resp = T.prove_phase_b(st, ts, secrets, blind, coms)
     assert [r.tobytes() for r in resp[0]] == [M.sc_to_bytes(r) for r in want.responses]
+
+
+def test_c_wire_codec_edges():
+    """zkp_proof_*_{encode,decode} (include/zkp_toolbox.h) directly: sizes, the consumed count, bincode's tolerance of trailing
+    bytes, oversized length prefixes, output capacity, and dalek's canonical-scalar rule on every scalar field -- while a
+    commitment may be ANY 32 bytes (CompressedRistretto deserialises blindly; decompress() decides later)."""
+    lib = T.lib()
+    rng = random.Random(13)
+    r = [sc(rng.randrange(M.L)) for _ in range(3)]
+    assert lib.zkp_proof_compact_size(3) == 32 + 8 + 96 and lib.zkp_proof_batchable_size(2, 3) == 8 + 64 + 8 + 96
+    cp = T.CompactProof(sc(rng.randrange(M.L)), r)
+    raw = cp.to_bytes()
+    assert raw[:32] == cp.challenge and raw[32:40] == (3).to_bytes(8, "little") and raw[40:] == b"".join(r)
+    assert T.CompactProof.from_bytes(raw + b"junk", allow_trailing=True) == cp           # bincode::deserialize ignores what follows
+    with pytest.raises(ValueError):
+        T.CompactProof.from_bytes(raw + b"junk")
+    bp = T.BatchableProof([b"\xff" * 32, bytes(32)], r)                                    # non-canonical field element / identity: still parses
+    braw = bp.to_bytes()
+    assert braw[:8] == (2).to_bytes(8, "little") and T.BatchableProof.from_bytes(braw) == bp
+    # capacity: the decoder never writes more than max_* elements
+    chal = ctypes.create_string_buffer(32)
+    out = np.zeros((2, 32), np.uint8)
+    m, used = ctypes.c_uint32(0), ctypes.c_size_t(0)
+    assert lib.zkp_proof_compact_decode(raw, len(raw), chal, out.ctypes.data_as(ctypes.c_void_p), 2, ctypes.byref(m), ctypes.byref(used)) == -10
+    out = np.zeros((3, 32), np.uint8)
+    assert lib.zkp_proof_compact_decode(raw, len(raw), chal, out.ctypes.data_as(ctypes.c_void_p), 3, ctypes.byref(m), ctypes.byref(used)) == 0
+    assert m.value == 3 and used.value == len(raw) and chal.raw == cp.challenge and out.tobytes() == b"".join(r)
+    # malformed inputs: truncated anywhere, absurd length prefixes, non-canonical scalars in every scalar position
+    for cut in (0, 31, 39, 40, len(raw) - 1):
+        with pytest.raises(ValueError):
+            T.CompactProof.from_bytes(raw[:cut])
+    for n_claimed in (4, 1 << 32, (1 << 64) - 1):
+        with pytest.raises(ValueError):
+            T.CompactProof.from_bytes(raw[:32] + n_claimed.to_bytes(8, "little") + raw[40:])
+    for bad in (M.L, M.L + 1, (1 << 256) - 1):
+        b32 = bad.to_bytes(32, "little")
+        with pytest.raises(ValueError):
+            T.CompactProof.from_bytes(b32 + raw[32:])
+        with pytest.raises(ValueError):
+            T.CompactProof.from_bytes(raw[:40 + 32] + b32 + raw[40 + 64:])
+        with pytest.raises(ValueError):
+            T.BatchableProof.from_bytes(braw[:-32] + b32)
+    assert T.CompactProof.from_bytes((M.L - 1).to_bytes(32, "little") + raw[32:]).challenge == (M.L - 1).to_bytes(32, "little")
+    for cut in (0, 7, 8 + 63, 8 + 64 + 7, len(braw) - 1):
+        with pytest.raises(ValueError):
+            T.BatchableProof.from_bytes(braw[:cut])
+    empty = T.BatchableProof([], [])
+    assert empty.to_bytes() == bytes(16) and T.BatchableProof.from_bytes(bytes(16)) == empty

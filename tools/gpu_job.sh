@@ -11,7 +11,7 @@ bash tools/collect_profiles.sh $TAG > $O/${TAG}_collect.log 2>&1; tail -12 $O/${
 cp $O/${TAG}_pmc_counters.json profiles/r02_pmc_counters.json   # so that the bench runs below find counters keyed to these sources
 run() { # name, args...
   n=$1; shift
-  /usr/bin/time -f "$n wall %e s" timeout 600 python bench.py "$@" > $O/${TAG}_$n.json 2> $O/${TAG}_$n.err; tail -1 $O/${TAG}_$n.err
+  t0=$SECONDS; timeout 600 python bench.py "$@" > $O/${TAG}_$n.json 2> $O/${TAG}_$n.err; echo "$n wall $((SECONDS-t0)) s rc=$?"; tail -2 $O/${TAG}_$n.err | cut -c1-300
   python - <<PY
 import json
 try:

@@ -324,6 +324,86 @@ void zkp_scalar_muladd(uint8_t out[32], const uint8_t a[32], const uint8_t b[32]
 }
 void zkp_scalar_neg(uint8_t out[32], const uint8_t a[32]) { (-Scalar::from_bytes_mod_order(a)).to_bytes(out); }
 
+// ---- proof wire format (proofs.rs:14-32 under bincode 1.x; see zkp_toolbox.h) -----------------------------------------
+namespace {
+inline void put_u64le(uint8_t* out, uint64_t v) { for (int i = 0; i < 8; ++i) out[i] = (uint8_t)(v >> (8 * i)); }
+inline uint64_t get_u64le(const uint8_t* in) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v |= (uint64_t)in[i] << (8 * i); return v; }
+// Scalar::from_canonical_bytes: the value must be < l = 2^252 + 27742317777372353535851937790883648493
+inline bool scalar_is_canonical(const uint8_t s[32]) {
+  static const uint8_t L[32] = {0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
+                                0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10};
+  for (int i = 31; i >= 0; --i) {
+    if (s[i] < L[i]) return true;
+    if (s[i] > L[i]) return false;
+  }
+  return false;                                                      // == l
+}
+// u64 count + count x 32 bytes at in[pos..]; false = truncated / count larger than the remaining bytes
+inline bool read_vec32(const uint8_t* in, size_t len, size_t& pos, uint64_t& count) {
+  if (len - pos < 8) return false;
+  count = get_u64le(in + pos);
+  pos += 8;
+  if (count > (len - pos) / 32) return false;
+  return true;
+}
+}  // namespace
+
+size_t zkp_proof_compact_size(uint32_t m) { return 40 + 32 * (size_t)m; }
+size_t zkp_proof_batchable_size(uint32_t nc, uint32_t m) { return 16 + 32 * ((size_t)nc + m); }
+
+int zkp_proof_compact_encode(const uint8_t challenge[32], const uint8_t* responses, uint32_t m, uint8_t* out, size_t out_len) {
+  if (!challenge || !out || (m && !responses) || out_len < zkp_proof_compact_size(m)) return ZKP_TB_BAD_STATEMENT;
+  std::memcpy(out, challenge, 32);
+  put_u64le(out + 32, m);
+  if (m) std::memcpy(out + 40, responses, 32 * (size_t)m);
+  return ZKP_TB_OK;
+}
+int zkp_proof_compact_decode(const uint8_t* in, size_t len, uint8_t challenge[32], uint8_t* responses, uint32_t max_m, uint32_t* m,
+                             size_t* consumed) {
+  if (!in || !challenge || !m || (max_m && !responses)) return ZKP_TB_BAD_STATEMENT;
+  if (len < 32) return ZKP_TB_BAD_ENCODING;
+  size_t pos = 32;
+  uint64_t cnt = 0;
+  if (!read_vec32(in, len, pos, cnt)) return ZKP_TB_BAD_ENCODING;
+  if (cnt > max_m) return ZKP_TB_BAD_STATEMENT;
+  if (!scalar_is_canonical(in)) return ZKP_TB_BAD_ENCODING;
+  for (uint64_t i = 0; i < cnt; ++i)
+    if (!scalar_is_canonical(in + pos + 32 * i)) return ZKP_TB_BAD_ENCODING;
+  std::memcpy(challenge, in, 32);
+  if (cnt) std::memcpy(responses, in + pos, 32 * (size_t)cnt);
+  *m = (uint32_t)cnt;
+  if (consumed) *consumed = pos + 32 * (size_t)cnt;
+  return ZKP_TB_OK;
+}
+int zkp_proof_batchable_encode(const uint8_t* commitments, uint32_t nc, const uint8_t* responses, uint32_t m, uint8_t* out, size_t out_len) {
+  if (!out || (nc && !commitments) || (m && !responses) || out_len < zkp_proof_batchable_size(nc, m)) return ZKP_TB_BAD_STATEMENT;
+  put_u64le(out, nc);
+  if (nc) std::memcpy(out + 8, commitments, 32 * (size_t)nc);
+  uint8_t* q = out + 8 + 32 * (size_t)nc;
+  put_u64le(q, m);
+  if (m) std::memcpy(q + 8, responses, 32 * (size_t)m);
+  return ZKP_TB_OK;
+}
+int zkp_proof_batchable_decode(const uint8_t* in, size_t len, uint8_t* commitments, uint32_t max_nc, uint32_t* nc, uint8_t* responses,
+                               uint32_t max_m, uint32_t* m, size_t* consumed) {
+  if (!in || !nc || !m || (max_nc && !commitments) || (max_m && !responses)) return ZKP_TB_BAD_STATEMENT;
+  size_t pos = 0;
+  uint64_t c = 0, r = 0;
+  if (!read_vec32(in, len, pos, c)) return ZKP_TB_BAD_ENCODING;
+  const size_t cpos = pos;
+  pos += 32 * (size_t)c;
+  if (!read_vec32(in, len, pos, r)) return ZKP_TB_BAD_ENCODING;
+  if (c > max_nc || r > max_m) return ZKP_TB_BAD_STATEMENT;
+  for (uint64_t i = 0; i < r; ++i)
+    if (!scalar_is_canonical(in + pos + 32 * i)) return ZKP_TB_BAD_ENCODING;
+  if (c) std::memcpy(commitments, in + cpos, 32 * (size_t)c);      // CompressedRistretto: any 32 bytes (validity = decompress())
+  if (r) std::memcpy(responses, in + pos, 32 * (size_t)r);
+  *nc = (uint32_t)c;
+  *m = (uint32_t)r;
+  if (consumed) *consumed = pos + 32 * (size_t)r;
+  return ZKP_TB_OK;
+}
+
 // ---- statements -------------------------------------------------------------------------------------------
 zkp_statement* zkp_statement_new(const char* proof_label) {
   auto* st = new zkp_statement();

@@ -38,6 +38,8 @@ EXPORTS = (
     "zkp_statement_num_common", "zkp_statement_num_constraints", "zkp_statement_num_terms", "zkp_prove_batch",
     "zkp_verify_compact_batch", "zkp_verify_batchable_each", "zkp_batch_verify", "zkp_batch_verify_coeffs", "zkp_batch_verify_build",
     "zkp_prove_phase_a", "zkp_prove_phase_b", "zkp_toolbox_set_fused_min_batch", "zkp_toolbox_get_fused_min_batch", "zkp_chacha20_block",
+    "zkp_proof_compact_size", "zkp_proof_batchable_size", "zkp_proof_compact_encode", "zkp_proof_compact_decode",
+    "zkp_proof_batchable_encode", "zkp_proof_batchable_decode",
 )
 
 
@@ -73,6 +75,15 @@ def lib() -> ctypes.CDLL:
         for f in ("num_secrets", "num_instance", "num_common", "num_constraints", "num_terms"):
             getattr(_lib, "zkp_statement_" + f).argtypes = [ctypes.c_void_p]
             getattr(_lib, "zkp_statement_" + f).restype = ctypes.c_uint32
+        vp, u32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t
+        _lib.zkp_proof_compact_size.restype = sz
+        _lib.zkp_proof_compact_size.argtypes = [u32]
+        _lib.zkp_proof_batchable_size.restype = sz
+        _lib.zkp_proof_batchable_size.argtypes = [u32, u32]
+        _lib.zkp_proof_compact_encode.argtypes = [ctypes.c_char_p, vp, u32, ctypes.c_char_p, sz]
+        _lib.zkp_proof_compact_decode.argtypes = [ctypes.c_char_p, sz, vp, vp, u32, ctypes.POINTER(u32), ctypes.POINTER(sz)]
+        _lib.zkp_proof_batchable_encode.argtypes = [vp, u32, vp, u32, ctypes.c_char_p, sz]
+        _lib.zkp_proof_batchable_decode.argtypes = [ctypes.c_char_p, sz, vp, u32, ctypes.POINTER(u32), vp, u32, ctypes.POINTER(u32), ctypes.POINTER(sz)]
     return _lib
 
 
@@ -137,15 +148,23 @@ def _scalar_canonical(b: bytes) -> bool:
     return len(b) == 32 and int.from_bytes(b, "little") < L
 
 
-def _read_vec32(buf: bytes, pos: int):
-    """bincode Vec<[u8; 32]-like>: u64 little-endian element count, then the elements back to back."""
-    if pos + 8 > len(buf):
-        raise ValueError("truncated proof")
-    n = int.from_bytes(buf[pos:pos + 8], "little")
-    pos += 8
-    if n > (len(buf) - pos) // 32:
-        raise ValueError("truncated proof")
-    return [buf[pos + 32 * i:pos + 32 * i + 32] for i in range(n)], pos + 32 * n
+def _wire_decode(kind: str, buf: bytes, allow_trailing: bool):
+    """The C codec of include/zkp_toolbox.h (zkp_proof_*_decode): -> (challenge | commitments, responses)."""
+    buf = bytes(buf)
+    cap = len(buf) // 32 + 1
+    a = np.zeros((cap, 32), np.uint8)
+    r = np.zeros((cap, 32), np.uint8)
+    na, nr, used = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_size_t(0)
+    if kind == "compact":
+        rc = lib().zkp_proof_compact_decode(buf, ctypes.c_size_t(len(buf)), _p(a), _p(r), ctypes.c_uint32(cap), ctypes.byref(nr), ctypes.byref(used))
+    else:
+        rc = lib().zkp_proof_batchable_decode(buf, ctypes.c_size_t(len(buf)), _p(a), ctypes.c_uint32(cap), ctypes.byref(na), _p(r), ctypes.c_uint32(cap),
+                                              ctypes.byref(nr), ctypes.byref(used))
+    if rc != 0:
+        raise ValueError("malformed proof (truncated, or a scalar was not canonically encoded): code %d" % rc)
+    if not allow_trailing and used.value != len(buf):
+        raise ValueError("trailing bytes")
+    return ([x.tobytes() for x in a[:na.value]] if kind != "compact" else a[0].tobytes()), [x.tobytes() for x in r[:nr.value]]
 
 
 @dataclass
@@ -153,23 +172,25 @@ class CompactProof:            # src/proofs.rs:15-20
     challenge: bytes
     responses: List[bytes]
 
-    # Wire format = what `bincode::serialize` (bincode 1.x defaults: fixed-width little-endian integers, u64 sequence
-    # lengths) produces for the serde-derived struct (proofs.rs:14): Scalar serialises as a 32-byte tuple (no length),
-    # Vec<Scalar> as u64 length + elements.  The reference's tests only round-trip it (tests/zkp.rs:53-54), so there
-    # are no golden bytes to pin; dalek rejects non-canonical scalars on deserialisation, and so does from_bytes.
+    # Wire format = what `bincode::serialize` (bincode 1.x top-level functions: fixed-width little-endian integers, u64
+    # sequence lengths) produces for the serde-derived struct (proofs.rs:14): Scalar serialises as a 32-byte tuple (no
+    # length), Vec<Scalar> as u64 length + elements.  The codec itself is C (include/zkp_toolbox.h, zkp_proof_*): this
+    # class only marshals.  The reference's tests only round-trip it (tests/zkp.rs:53-54), so there are no golden bytes
+    # to pin; dalek rejects non-canonical scalars on deserialisation, and so does the decoder.  allow_trailing = True is
+    # bincode's own behaviour (its top-level deserialize ignores what follows the value); the default here is strict.
     def to_bytes(self) -> bytes:
-        return self.challenge + len(self.responses).to_bytes(8, "little") + b"".join(self.responses)
+        m = len(self.responses)
+        out = ctypes.create_string_buffer(lib().zkp_proof_compact_size(ctypes.c_uint32(m)))
+        resp = np.frombuffer(b"".join(self.responses), np.uint8) if m else np.zeros(0, np.uint8)
+        rc = lib().zkp_proof_compact_encode(bytes(self.challenge), _p(resp), ctypes.c_uint32(m), out, ctypes.c_size_t(len(out)))
+        if rc != 0:
+            raise ValueError("zkp_proof_compact_encode: code %d" % rc)
+        return out.raw
 
     @classmethod
-    def from_bytes(cls, buf: bytes) -> "CompactProof":
-        if len(buf) < 32:
-            raise ValueError("truncated proof")
-        resp, pos = _read_vec32(buf, 32)
-        if pos != len(buf):
-            raise ValueError("trailing bytes")
-        if not _scalar_canonical(buf[:32]) or not all(_scalar_canonical(r) for r in resp):
-            raise ValueError("scalar was not canonically encoded")
-        return cls(buf[:32], resp)
+    def from_bytes(cls, buf: bytes, allow_trailing: bool = False) -> "CompactProof":
+        c, r = _wire_decode("compact", buf, allow_trailing)
+        return cls(c, r)
 
 
 @dataclass
@@ -178,18 +199,19 @@ class BatchableProof:          # src/proofs.rs:27-32
     responses: List[bytes]
 
     def to_bytes(self) -> bytes:
-        return (len(self.commitments).to_bytes(8, "little") + b"".join(self.commitments) +
-                len(self.responses).to_bytes(8, "little") + b"".join(self.responses))
+        nc, m = len(self.commitments), len(self.responses)
+        out = ctypes.create_string_buffer(lib().zkp_proof_batchable_size(ctypes.c_uint32(nc), ctypes.c_uint32(m)))
+        coms = np.frombuffer(b"".join(self.commitments), np.uint8) if nc else np.zeros(0, np.uint8)
+        resp = np.frombuffer(b"".join(self.responses), np.uint8) if m else np.zeros(0, np.uint8)
+        rc = lib().zkp_proof_batchable_encode(_p(coms), ctypes.c_uint32(nc), _p(resp), ctypes.c_uint32(m), out, ctypes.c_size_t(len(out)))
+        if rc != 0:
+            raise ValueError("zkp_proof_batchable_encode: code %d" % rc)
+        return out.raw
 
     @classmethod
-    def from_bytes(cls, buf: bytes) -> "BatchableProof":
-        coms, pos = _read_vec32(buf, 0)
-        resp, pos = _read_vec32(buf, pos)
-        if pos != len(buf):
-            raise ValueError("trailing bytes")
-        if not all(_scalar_canonical(r) for r in resp):
-            raise ValueError("scalar was not canonically encoded")
-        return cls(coms, resp)      # CompressedRistretto deserialises from any 32 bytes; validity is checked at decompress
+    def from_bytes(cls, buf: bytes, allow_trailing: bool = False) -> "BatchableProof":
+        k, r = _wire_decode("batchable", buf, allow_trailing)
+        return cls(k, r)      # CompressedRistretto deserialises from any 32 bytes; validity is checked at decompress
 
 
 class Statement:

@@ -140,7 +140,7 @@ def make_instance(eng, st, n, rng):
     instance points no constraint defines are random multiples of the basepoint; every left-hand side is computed from its
     constraint with the engine's own MSMs (untimed set-up)."""
     import numpy as np
-    from zkp_amd.engine import ZKP_CT
+    from zkp_amd.engine import ZKP_VARTIME          # set-up only (and its kernels then carry other names than the timed, constant-time ones)
     secrets_l, points, cons = st
     m = len(secrets_l)
 
@@ -158,7 +158,7 @@ def make_instance(eng, st, n, rng):
     free = [i for i in inst_rank if i not in lhs]
     base = np.frombuffer(BASE, np.uint8).reshape(1, 32)
     k = ns + len(free) * n
-    pts, st8 = eng.msm_many(np.arange(k + 1, dtype=np.uint32), rs(k), np.zeros(k, np.uint32), base, ZKP_CT)
+    pts, st8 = eng.msm_many(np.arange(k + 1, dtype=np.uint32), rs(k), np.zeros(k, np.uint32), base, ZKP_VARTIME)
     assert not st8.any()
     common = np.ascontiguousarray(pts[:ns])
     inst = np.zeros((ni, n, 32), np.uint8)
@@ -176,7 +176,7 @@ def make_instance(eng, st, n, rng):
         off_one = np.cumsum([0] + [len(lc) for _, lc in cons])[:-1].astype(np.uint32)
         off = np.concatenate([(off_one[None, :] + np.uint32(T) * j[:, None]).reshape(-1), np.array([T * n], np.uint32)]).astype(np.uint32)
         table = np.concatenate([common, inst.reshape(-1, 32)])
-        out, st8 = eng.msm_many(off, np.ascontiguousarray(secrets[:, sidx]).reshape(-1, 32), pidx.reshape(-1), table, ZKP_CT)
+        out, st8 = eng.msm_many(off, np.ascontiguousarray(secrets[:, sidx]).reshape(-1, 32), pidx.reshape(-1), table, ZKP_VARTIME)
         assert not st8.any()
         out = out.reshape(n, len(cons), 32)
         for kk, l in enumerate(lhs):
@@ -379,12 +379,13 @@ def main():
             e_.synchronize()
         torch.cuda.synchronize()
 
-    # proofs for the parts that only verify (and for everybody's later flow lines): made once, untimed
+    # proofs for the parts whose step only verifies: made once, untimed
     for k in range(n_streams):
         with torch.cuda.stream(streams[k]):
             for p in ps:
-                p.bufs[k]["ts"].copy_(p.d_ts0, non_blocking=True)
-                prove(engines[k], p, p.bufs[k])
+                if "prove" not in p.flows:
+                    p.bufs[k]["ts"].copy_(p.d_ts0, non_blocking=True)
+                    prove(engines[k], p, p.bufs[k])
     barrier()
 
     def timed_loop(which, steps, warmup):

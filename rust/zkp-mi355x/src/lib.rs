@@ -1,0 +1,240 @@
+//! UNBUILT SOURCE -- see ../../README.md.  Never compiled: no Rust toolchain exists in the build image.
+//!
+//! Safe layer over `zkp-mi355x-sys`:
+//!  * [`Engine`]: one context per GPU, error mapping (every non-zero code is an `Err`: fail closed);
+//!  * [`multiscalar`]: replacements for the three dalek trait calls the reference's toolbox makes (the per-call route);
+//!  * [`Statement`] + [`prove_batch`] / [`verify_compact_batch`] / [`batch_verify`]: the batched route, where transcripts,
+//!    scalar arithmetic and MSMs of a whole batch of proofs of one statement run on the device.
+//! Layouts are the ones `include/zkp_toolbox.h` documents: secrets / responses `[N][m][32]`, instance points
+//! `[n_inst][N][32]` (row = variable, column = proof, like `BatchVerifier::allocate_instance_point`), common points
+//! `[n_common][32]`, commitments `[N][n_constraints][32]`, transcripts `[N][208]`.
+use std::ffi::{CStr, CString};
+use std::os::raw::c_int;
+use std::ptr;
+
+use curve25519_dalek::ristretto::CompressedRistretto;
+use curve25519_dalek::scalar::Scalar;
+use zkp_mi355x_sys as sys;
+
+/// Mirrors `zkp::ProofError` (src/errors.rs:4-11) plus the infrastructure failures of the C ABI.
+#[derive(Debug)]
+pub enum Error {
+    VerificationFailure,
+    BatchSizeMismatch,
+    /// negative return code of the C ABI with `zkp_last_error()`; no output may be trusted
+    Backend(c_int, String),
+}
+fn check(rc: c_int) -> Result<(), Error> {
+    match rc {
+        0 => Ok(()),
+        sys::ZKP_TB_VERIFICATION_FAILURE => Err(Error::VerificationFailure),
+        sys::ZKP_TB_BATCH_SIZE_MISMATCH => Err(Error::BatchSizeMismatch),
+        rc => {
+            let msg = unsafe { CStr::from_ptr(sys::zkp_last_error()) }.to_string_lossy().into_owned();
+            Err(Error::Backend(rc, msg))
+        }
+    }
+}
+
+/// One engine context = one GPU (one process per GPU in multi-GPU jobs).  Not `Sync`: a context is not re-entrant.
+pub struct Engine(*mut sys::zkp_ctx);
+impl Engine {
+    pub fn new(device_id: i32) -> Result<Engine, Error> {
+        let mut ctx = ptr::null_mut();
+        check(unsafe { sys::zkp_ctx_create(&mut ctx, device_id) })?;
+        Ok(Engine(ctx))
+    }
+    /// Hint: the statement's common points (define_proof!'s third list / BatchVerifier's static points) get fixed-base tables.
+    pub fn prepare_fixed_points(&self, points: &[CompressedRistretto]) -> Result<(), Error> {
+        let flat: Vec<u8> = points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+        check(unsafe { sys::zkp_ctx_prepare_fixed_points(self.0, points.len() as u32, flat.as_ptr()) })
+    }
+}
+impl Drop for Engine {
+    fn drop(&mut self) {
+        unsafe { sys::zkp_ctx_destroy(self.0) }
+    }
+}
+
+/// The per-call route: what `prover.rs:94`, `verifier.rs:97`, `verifier.rs:162` and `batch_verifier.rs:219` call.
+pub mod multiscalar {
+    use super::*;
+
+    fn flat_scalars<'a, I: IntoIterator<Item = &'a Scalar>>(it: I) -> Vec<u8> {
+        it.into_iter().flat_map(|s| s.as_bytes().iter().copied()).collect()
+    }
+    fn flat_points<'a, I: IntoIterator<Item = &'a CompressedRistretto>>(it: I) -> Vec<u8> {
+        it.into_iter().flat_map(|p| p.as_bytes().iter().copied()).collect()
+    }
+
+    /// `RistrettoPoint::optional_multiscalar_mul(scalars, points.map(|p| p.decompress()))` followed by `.compress()`:
+    /// `Ok(None)` = some point failed to decompress (the reference maps it to `VerificationFailure`).
+    pub fn optional_multiscalar_mul<'a, S, P>(eng: &Engine, scalars: S, points: P) -> Result<Option<CompressedRistretto>, Error>
+    where
+        S: IntoIterator<Item = &'a Scalar>,
+        P: IntoIterator<Item = &'a CompressedRistretto>,
+    {
+        let (s, p) = (flat_scalars(scalars), flat_points(points));
+        assert_eq!(s.len(), p.len()); // dalek asserts equal lengths too
+        let (mut out, mut status) = ([0u8; 32], 1 as c_int);
+        check(unsafe { sys::zkp_msm_optional(eng.0, (s.len() / 32) as u64, s.as_ptr(), p.as_ptr(), out.as_mut_ptr(), &mut status) })?;
+        Ok(if status == 0 { Some(CompressedRistretto(out)) } else { None })
+    }
+
+    /// Many `multiscalar_mul` (constant_time = true, prover.rs:94) / `vartime_multiscalar_mul` (verifier.rs:97) calls at
+    /// once, each followed by `.compress()` (mod.rs:204): MSM i multiplies `scalars[off[i]..off[i+1]]` with
+    /// `table[pidx[..]]`.  `None` = a referenced point failed to decompress.
+    pub fn multiscalar_mul_many(eng: &Engine, off: &[u32], scalars: &[Scalar], pidx: &[u32], table: &[CompressedRistretto],
+                                constant_time: bool) -> Result<Vec<Option<CompressedRistretto>>, Error> {
+        let n = off.len() - 1;
+        let (s, p) = (flat_scalars(scalars.iter()), flat_points(table.iter()));
+        let mut out = vec![0u8; 32 * n];
+        let mut status = vec![0u8; n];
+        let flags = if constant_time { sys::ZKP_CT } else { sys::ZKP_VARTIME };
+        check(unsafe {
+            sys::zkp_msm_many(eng.0, n as u32, off.as_ptr(), s.as_ptr(), pidx.as_ptr(), p.as_ptr(), table.len() as u32, flags,
+                              out.as_mut_ptr(), status.as_mut_ptr())
+        })?;
+        Ok((0..n).map(|i| if status[i] == 0 { let mut b = [0u8; 32]; b.copy_from_slice(&out[32 * i..32 * i + 32]); Some(CompressedRistretto(b)) } else { None }).collect())
+    }
+}
+
+/// A Merlin transcript as the 208-byte state the C ABI works on (merlin keeps its fields private, so the state machine
+/// lives on the C side: `zkp_transcript_*` are byte-identical to merlin 2.x -- Merlin's published test vector is a test).
+#[derive(Clone)]
+pub struct Transcript(pub [u8; sys::ZKP_TRANSCRIPT_BYTES]);
+impl Transcript {
+    pub fn new(label: &'static [u8]) -> Transcript {
+        let mut t = [0u8; sys::ZKP_TRANSCRIPT_BYTES];
+        unsafe { sys::zkp_transcript_init(t.as_mut_ptr(), label.as_ptr(), label.len()) };
+        Transcript(t)
+    }
+    pub fn append_message(&mut self, label: &'static [u8], message: &[u8]) {
+        let l = CString::new(label).expect("labels are NUL-free");
+        unsafe { sys::zkp_transcript_append_message(self.0.as_mut_ptr(), l.as_ptr(), message.as_ptr(), message.len()) }
+    }
+    pub fn challenge_bytes(&mut self, label: &'static [u8], dest: &mut [u8]) {
+        let l = CString::new(label).expect("labels are NUL-free");
+        unsafe { sys::zkp_transcript_challenge_bytes(self.0.as_mut_ptr(), l.as_ptr(), dest.as_mut_ptr(), dest.len()) }
+    }
+}
+
+#[derive(Copy, Clone)]
+pub struct ScalarVar(pub u32);
+#[derive(Copy, Clone)]
+pub struct PointVar(pub u32);
+
+/// What `define_proof!` fixes: labels, allocation order (every `allocate_*` call appends to the transcript when it is made),
+/// constraints (`SchnorrCS::constrain`, toolbox/mod.rs:86-98).
+pub struct Statement(*mut sys::zkp_statement);
+impl Statement {
+    pub fn new(proof_label: &'static [u8]) -> Statement {
+        let l = CString::new(proof_label).unwrap();
+        Statement(unsafe { sys::zkp_statement_new(l.as_ptr()) })
+    }
+    pub fn allocate_scalar(&mut self, label: &'static [u8]) -> ScalarVar {
+        let l = CString::new(label).unwrap();
+        ScalarVar(unsafe { sys::zkp_statement_add_secret(self.0, l.as_ptr()) } as u32)
+    }
+    /// `common` = true for define_proof!'s common points / `BatchVerifier::allocate_static_point`.
+    pub fn allocate_point(&mut self, label: &'static [u8], common: bool) -> PointVar {
+        let l = CString::new(label).unwrap();
+        PointVar(unsafe { sys::zkp_statement_add_point(self.0, l.as_ptr(), common as c_int) } as u32)
+    }
+    pub fn constrain(&mut self, lhs: PointVar, linear_combination: &[(ScalarVar, PointVar)]) {
+        let s: Vec<u32> = linear_combination.iter().map(|t| (t.0).0).collect();
+        let p: Vec<u32> = linear_combination.iter().map(|t| (t.1).0).collect();
+        let rc = unsafe { sys::zkp_statement_constrain(self.0, lhs.0, s.len() as u32, s.as_ptr(), p.as_ptr()) };
+        assert_eq!(rc, 0, "constraint refers to an unallocated variable");
+    }
+    fn m(&self) -> usize { unsafe { sys::zkp_statement_num_secrets(self.0) as usize } }
+    fn nc(&self) -> usize { unsafe { sys::zkp_statement_num_constraints(self.0) as usize } }
+}
+impl Drop for Statement {
+    fn drop(&mut self) {
+        unsafe { sys::zkp_statement_free(self.0) }
+    }
+}
+
+pub struct Proofs {
+    pub challenges: Vec<u8>,  // [N][32]         -> CompactProof.challenge
+    pub responses: Vec<u8>,   // [N][m][32]      -> CompactProof.responses / BatchableProof.responses
+    pub commitments: Vec<u8>, // [N][nc][32]     -> BatchableProof.commitments
+}
+
+/// N x { build_prover ; Prover::prove_impl } (macros.rs:206-258, prover.rs:76-112).  The 32 bytes per proof that
+/// `thread_rng()` contributes at prover.rs:82 are drawn inside the library from the operating system (pass them explicitly
+/// through the raw call for deterministic tests).
+pub fn prove_batch(eng: &Engine, st: &Statement, transcripts: &mut [Transcript], secrets: &[Scalar], inst_points: &[CompressedRistretto],
+                   common_points: &[CompressedRistretto]) -> Result<Proofs, Error> {
+    let n = transcripts.len();
+    let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
+    let sec: Vec<u8> = secrets.iter().flat_map(|s| s.as_bytes().iter().copied()).collect();
+    let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let mut out = Proofs { challenges: vec![0; 32 * n], responses: vec![0; 32 * n * st.m()], commitments: vec![0; 32 * n * st.nc()] };
+    check(unsafe {
+        sys::zkp_prove_batch(eng.0, st.0, n as u32, ts.as_mut_ptr(), sec.as_ptr(), inst.as_ptr(), com.as_ptr(), ptr::null(), 0,
+                             out.challenges.as_mut_ptr(), out.responses.as_mut_ptr(), out.commitments.as_mut_ptr())
+    })?;
+    for (t, chunk) in transcripts.iter_mut().zip(ts.chunks(sys::ZKP_TRANSCRIPT_BYTES)) {
+        t.0.copy_from_slice(chunk);
+    }
+    Ok(out)
+}
+
+/// N x { build_verifier ; Verifier::verify_compact } (macros.rs:280-311, verifier.rs:80-120): one `Result` per proof.
+pub fn verify_compact_batch(eng: &Engine, st: &Statement, transcripts: &mut [Transcript], inst_points: &[CompressedRistretto],
+                            common_points: &[CompressedRistretto], challenges: &[u8], responses: &[u8]) -> Result<Vec<Result<(), Error>>, Error> {
+    let n = transcripts.len();
+    let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
+    let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let mut results = vec![1u8; n];
+    check(unsafe {
+        sys::zkp_verify_compact_batch(eng.0, st.0, n as u32, ts.as_mut_ptr(), inst.as_ptr(), com.as_ptr(), challenges.as_ptr(),
+                                      responses.as_ptr(), 0, results.as_mut_ptr())
+    })?;
+    for (t, chunk) in transcripts.iter_mut().zip(ts.chunks(sys::ZKP_TRANSCRIPT_BYTES)) {
+        t.0.copy_from_slice(chunk);
+    }
+    Ok(results.into_iter().map(|r| if r == 0 { Ok(()) } else { Err(Error::VerificationFailure) }).collect())
+}
+
+/// `BatchVerifier::verify_batchable` (batch_verifier.rs:67-235): one verdict for the whole batch.  The u128 factors of
+/// batch_verifier.rs:179 are drawn inside the library from a ChaCha20 stream keyed by the operating system.
+pub fn batch_verify(eng: &Engine, st: &Statement, transcripts: &mut [Transcript], inst_points: &[CompressedRistretto],
+                    common_points: &[CompressedRistretto], commitments: &[u8], responses: &[u8]) -> Result<(), Error> {
+    let n = (commitments.len() / 32).checked_div(st.nc()).unwrap_or(transcripts.len());
+    let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
+    let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let rc = unsafe {
+        sys::zkp_batch_verify(eng.0, st.0, n as u32, transcripts.len() as u32, ts.as_mut_ptr(), inst.as_ptr(), com.as_ptr(),
+                              commitments.as_ptr(), responses.as_ptr(), ptr::null(), 0)
+    };
+    for (t, chunk) in transcripts.iter_mut().zip(ts.chunks(sys::ZKP_TRANSCRIPT_BYTES)) {
+        t.0.copy_from_slice(chunk);
+    }
+    check(rc)
+}
+
+/// `bincode::serialize(&CompactProof)` / `deserialize` (tests/zkp.rs:53-54) through the C codec.
+pub fn compact_proof_to_bytes(challenge: &Scalar, responses: &[Scalar]) -> Vec<u8> {
+    let r: Vec<u8> = responses.iter().flat_map(|s| s.as_bytes().iter().copied()).collect();
+    let mut out = vec![0u8; unsafe { sys::zkp_proof_compact_size(responses.len() as u32) }];
+    let rc = unsafe { sys::zkp_proof_compact_encode(challenge.as_bytes().as_ptr(), r.as_ptr(), responses.len() as u32, out.as_mut_ptr(), out.len()) };
+    assert_eq!(rc, 0);
+    out
+}
+pub fn compact_proof_from_bytes(bytes: &[u8]) -> Option<(Scalar, Vec<Scalar>)> {
+    let cap = bytes.len() / 32 + 1;
+    let (mut c, mut r, mut m, mut used) = ([0u8; 32], vec![0u8; 32 * cap], 0u32, 0usize);
+    let rc = unsafe { sys::zkp_proof_compact_decode(bytes.as_ptr(), bytes.len(), c.as_mut_ptr(), r.as_mut_ptr(), cap as u32, &mut m, &mut used) };
+    if rc != 0 {
+        return None; // truncated, or a scalar was not canonical (dalek's Deserialize refuses it too)
+    }
+    let to_scalar = |b: &[u8]| { let mut a = [0u8; 32]; a.copy_from_slice(b); Scalar::from_canonical_bytes(a) };
+    let resp: Option<Vec<Scalar>> = r[..32 * m as usize].chunks(32).map(to_scalar).collect();
+    Some((to_scalar(&c)?, resp?))
+}

@@ -545,3 +545,31 @@ def test_long_labels_cross_strobe_blocks_fused_host_oracle_model(eng):
     assert not T.verify_compact_batch(eng, mod.statement, ts, inst, common, chal, resp).any()
     ts = _fresh(label, n)
     T.batch_verify(eng, mod.statement, ts, inst, common, coms, resp)
+
+
+def test_debug_transcript_env_lists_the_compiled_program():
+    """ZKP_DEBUG_TRANSCRIPT=1 on the fused route: the compiled transcript program of the flow is decoded to stderr when its
+    plan is built (absorbs / keys with their input buffers and strides, emits, clone / restore, Keccak permutations)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np\n"
+            "from zkp_amd import toolbox as T\n"
+            "from zkp_amd.engine import Engine\n"
+            "from tests.test_gpu_fused import _dleq_batch, _fresh\n"
+            "eng = Engine(0)\n"
+            "n = 40\n"
+            "mod, x, A, B, H = _dleq_batch(n, 3)\n"
+            "inst = np.ascontiguousarray(np.stack([A, B, H]))\n"
+            "base = np.frombuffer(bytes.fromhex('e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76'), np.uint8).reshape(1, 32)\n"
+            "ts = _fresh(b'dbg', n)\n"
+            "T.prove_batch(eng, mod.statement, ts, x, inst, base, np.zeros((n, 32), np.uint8))\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, ZKP_DEBUG_TRANSCRIPT="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    err = r.stderr
+    assert "[transcript program] flow=P program A" in err and "[transcript program] flow=P program B" in err
+    assert "KEY state.word[" in err and "<- secrets[j * 32 + 0]" in err            # the witness rekeys the RNG clone (prover.rs:80)
+    assert "<- entropy[j * 32 + 0]" in err and "EMIT state.word[" in err and "-> wide(blindings)" in err and "-> wide(challenge)" in err
+    assert "SAVE(clone <- state)" in err and "RESTORE(state <- clone)" in err and "KECCAK-F" in err
+    assert "6 Keccak-f permutations per proof" in err or "Keccak-f permutations per proof" in err

@@ -5,6 +5,7 @@ multiscalar multiplications, the TEST substitutes the oracle's (the product neve
 import os
 import random
 import re
+import sys
 
 import ctypes
 import numpy as np
@@ -352,3 +353,32 @@ def test_c_wire_codec_edges():
             T.BatchableProof.from_bytes(braw[:cut])
     empty = T.BatchableProof([], [])
     assert empty.to_bytes() == bytes(16) and T.BatchableProof.from_bytes(bytes(16)) == empty
+
+
+def test_rust_sys_crate_declares_every_exported_symbol():
+    """rust/zkp-mi355x-sys/src/lib.rs is unbuilt source (no Rust toolchain in the image); at least keep it in step with the
+    C ABI: one `pub fn` per symbol the two headers declare, nothing else."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "rust", "zkp-mi355x-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"pub fn (zkp_\w+)\s*\(", src))
+    assert declared == set(engine.EXPORTS) | set(T.EXPORTS), (declared ^ (set(engine.EXPORTS) | set(T.EXPORTS)))
+    assert "UNBUILT SOURCE" in src and "UNBUILT" in open(os.path.join(root, "rust", "README.md")).read()
+
+
+def test_debug_transcript_env_dumps_the_op_log():
+    """ZKP_DEBUG_TRANSCRIPT=1 (the reference's `debug-transcript` feature, Cargo.toml:35): every Merlin operation of the host
+    transcripts goes to stderr -- label, length, leading bytes; witness bytes never."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from zkp_amd import toolbox as T\n"
+            "t = T.Transcript(b'dbg')\n"
+            "t.append_message(b'msg', b'hello world')\n"
+            "print(t.challenge_bytes(b'c', 8).hex())\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, ZKP_DEBUG_TRANSCRIPT="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert '[merlin] append    label="dom-sep" len=3 data=646267' in r.stderr
+    assert '[merlin] append    label="msg" len=11 data=68656c6c6f20776f726c64' in r.stderr
+    assert '[merlin] challenge label="c" len=8 data=' + r.stdout.strip() in r.stderr
+    quiet = subprocess.run([sys.executable, "-c", code], cwd=root, env={k: v for k, v in os.environ.items() if k != "ZKP_DEBUG_TRANSCRIPT"},
+                           capture_output=True, text=True, timeout=120)
+    assert quiet.returncode == 0 and "[merlin]" not in quiet.stderr and quiet.stdout == r.stdout

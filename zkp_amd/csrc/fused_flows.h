@@ -473,6 +473,37 @@ std::string plan_key(char flow, const zkp_fused_statement* st, const fused_shape
   return k;
 }
 
+// ZKP_DEBUG_TRANSCRIPT=1: the compiled transcript program of a (flow, statement) is listed on stderr when its plan is
+// built -- one line per operation, decoded: what each proof absorbs / keys from which input buffer at which stride and offset,
+// what it emits, where it clones / restores the state, and the Keccak permutations in between.  Together with the host
+// library's op log (host/merlin.cpp, same variable) this is what the reference's `debug-transcript` feature (Cargo.toml:35)
+// gives: a challenge mismatch is found by diffing op sequences, not by staring at 32 wrong bytes.
+bool debug_transcript_enabled() {
+  static const bool on = [] { const char* e = getenv("ZKP_DEBUG_TRANSCRIPT"); return e && *e && *e != '0'; }();
+  return on;
+}
+void dump_program(char flow, const char* which, const std::vector<tr_op>& ops, uint32_t N) {
+  static const char* src_names[] = {"-", "points", "secrets", "entropy", "commitments"};
+  static const char* dst_names[] = {"-", "wide(blindings)", "wide(challenge)"};
+  fprintf(stderr, "[transcript program] flow=%c %s: %zu operations per proof (N = %u)\n", flow, which, ops.size(), N);
+  uint32_t perms = 0;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const tr_fields f = tr_unpack(ops[i].ctl, ops[i].stride, ops[i].off);
+    fprintf(stderr, "  %4zu:", i);
+    if (f.flags & TR_RESTORE) fprintf(stderr, " RESTORE(state <- clone)");
+    if (f.flags & TR_CHECK_NONZERO) fprintf(stderr, " REJECT-IDENTITY %s[j * %u + %llu .. +32]", src_names[f.src_buf < 5 ? f.src_buf : 0], f.stride, (unsigned long long)f.off);
+    if (f.dst_buf) fprintf(stderr, " EMIT state.word[%u] bytes[%u..%u) -> %s[j * %u + %llu]", f.w, f.dlb, f.dlb + f.dnb, dst_names[f.dst_buf < 3 ? f.dst_buf : 0], f.stride, (unsigned long long)f.off);
+    if (f.src_buf && !(f.flags & TR_CHECK_NONZERO))
+      fprintf(stderr, " %s state.word[%u] bytes[%u..%u) <- %s[j * %u + %llu]", (f.flags & TR_OVERWRITE) ? "KEY" : "ABSORB", f.w, f.lb, f.lb + f.nb,
+              src_names[f.src_buf < 5 ? f.src_buf : 0], f.stride, (unsigned long long)f.off);
+    if (f.flags & TR_APPLY) fprintf(stderr, " APPLY constants[%llu] (labels, lengths, STROBE framing)%s", (unsigned long long)f.off, (f.flags & TR_PERMUTE) ? " + KECCAK-F" : "");
+    if (f.flags & TR_SAVE) fprintf(stderr, " SAVE(clone <- state)");
+    if (f.flags & TR_PERMUTE) ++perms;
+    fputc('\n', stderr);
+  }
+  fprintf(stderr, "[transcript program] %u Keccak-f permutations per proof\n", perms);
+}
+
 int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, uint32_t pos, fused_plan** out) {
   fused_shape s;
   int rc = check_fused_statement(st, s);
@@ -545,6 +576,10 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
     ta.get_challenge_wide("chal", tr_ref{DST_CHAL, 64, 0});              // :163-167
     pa = ta.finish(tailA);
     tbl_a = ta.tables();
+  }
+  if (debug_transcript_enabled()) {
+    dump_program(flow, flow == FLOW_BATCH ? "program (allocations, commitments, challenge)" : "program A (allocations ...)", pa, N);
+    if (!pb.empty()) dump_program(flow, "program B (commitments, challenge)", pb, N);
   }
   const std::vector<uint32_t> inc = incidence_words(s);
   carve cv;

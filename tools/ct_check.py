@@ -1,5 +1,6 @@
 """Evidence for the constant-time claim of the ZKP_CT schedule (prover.rs:94 promises a constant-time multiscalar_mul):
-run the SAME CMZ prover job (45,056 MSMs / 126,976 terms) with very different scalar sets and let rocprofv3 count the
+run the SAME CMZ prover job (45,056 MSMs / 126,976 terms) with very different scalar sets -- once with the default schedule
+(a comb table for every cold point) and once with the constant-time ladder for single-use points -- and let rocprofv3 count the
 executed instructions of every kernel.  If instruction counts and memory-instruction counts are identical, no branch and
 no load/store was taken or skipped because of a scalar.
 
@@ -42,9 +43,11 @@ def run():
     ks[:, 31] &= 0x0f
     pts, st = eng.msm_many(np.arange(n_pts + 1, dtype=np.uint32), ks, np.zeros(n_pts, np.uint32), base, ZKP_CT)
     eng.prepare_fixed_points(pts[:11])
-    for kind in PATTERNS:                       # one msm_many(ZKP_CT) call per pattern, in this order
-        out, st = eng.msm_many(off, scalars(kind, 31 * n, rng), pidx, pts, ZKP_CT)
-        assert not st.any()
+    for single_use_tables in (1, 0):            # default schedule, then the constant-time radix-16 ladder for single-use points
+        eng.set_option(3, single_use_tables)    # ZKP_OPT_CT_SINGLE_USE_TABLES
+        for kind in PATTERNS:                   # one msm_many(ZKP_CT) call per pattern, in this order
+            out, st = eng.msm_many(off, scalars(kind, 31 * n, rng), pidx, pts, ZKP_CT)
+            assert not st.any()
     eng.close()
 
 
@@ -56,14 +59,19 @@ def summarise(path):
         per[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("# kernels of the ZKP_CT path: executed-instruction counters of the last %d launches (one per scalar pattern: %s)" % (len(PATTERNS), ", ".join(PATTERNS)))
     ok = True
-    for k in ("k_terms_split<true>", "k_reduce_encode<unsigned char>", "zkp::k_comb_tables", "k_decode_affine"):
-        if k not in per:
-            continue
-        for c, v in sorted(per[k].items()):
-            tail = v[-len(PATTERNS):]
-            same = len(set(tail)) == 1
-            ok &= same
-            print("%-34s %-18s %s  %s" % (k, c, "IDENTICAL" if same else "DIFFERENT", " ".join("%.0f" % x for x in tail)))
+    # (the comb-table / decode kernels run once per call in both halves: their last 12 launches are compared)
+    for prefix, n_last in (("k_terms_split<true, 16, false>", 6), ("k_terms_split<true, 16, true>", 6), ("k_reduce_encode<unsigned char>", 12),
+                           ("zkp::k_comb_tables<16>", 12), ("zkp::k_comb_slots", 12), ("k_decode_affine", 12)):
+        for k in sorted(per):
+            if not k.startswith(prefix):
+                continue
+            for c, v in sorted(per[k].items()):
+                tail = v[-n_last:]
+                # the table kernel builds P and Q tables in the first half and only P tables in the second: compare within halves
+                halves = [tail] if n_last == 6 else [tail[:6], tail[6:]]
+                same = all(len(set(h)) == 1 for h in halves)
+                ok &= same
+                print("%-34s %-18s %s  %s" % (k[:34], c, "IDENTICAL" if same else "DIFFERENT", " ".join("%.0f" % x for x in tail)))
     print("# verdict:", "every counter identical across scalar patterns" if ok else "counters differ")
 
 

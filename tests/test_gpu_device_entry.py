@@ -135,3 +135,110 @@ def test_fused_dev_flows_equal_host_pointer_flows(eng, n):
                                d_out.data_ptr(), d_bst.data_ptr())
     eng.synchronize()
     assert d_bst.cpu().numpy()[1] == 1
+
+
+def test_hip_graph_replay_equals_direct_calls(eng):
+    """zkp_ctx_capture_begin/_end + zkp_graph_launch: the recorded chain (fresh-transcript copies, fused prove, fused batch
+    verification) replayed on NEW inputs placed in the same device buffers gives the bytes of the direct calls; capturing a
+    call whose plan was never compiled is refused instead of allocating inside the capture."""
+    torch = _torch()
+    from zkp_amd.engine import Engine, ZkpError
+    n = 96
+    mod, secrets, inst, common = _cmz_batch(n, 8)
+    _, secrets2, inst2, _ = _cmz_batch(n, 9)
+    fst = _cmz_fused_statement()
+    e = Engine(0)
+    stream = torch.cuda.Stream()
+    e.set_stream(stream.cuda_stream)
+    e.prepare_fixed_points(common)
+    t0 = T.Transcript(b"graph").state
+    pos = int(t0[200]) | int(t0[201]) << 8 | int(t0[202]) << 16
+    rng = np.random.default_rng(4)
+    d_ts0 = _dev(np.stack([t0] * n))
+    d_ent, d_w = _dev(rng.integers(0, 256, size=(n, 32), dtype=np.uint8)), _dev(rng.integers(0, 256, size=(11, n, 16), dtype=np.uint8))
+    d_sec, d_tbl = _dev(secrets), _dev(np.concatenate([common, inst.reshape(-1, 32)]))
+    z8 = lambda *s: torch.zeros(s, dtype=torch.uint8, device="cuda:0")
+    ts, ts2, chal, resp, coms, st = z8(n, 208), z8(n, 208), z8(n, 32), z8(n, 21, 32), z8(n, 11, 32), z8(11 * n)
+    pts, out, bst = z8(12 + 24 * n, 32), z8(32), torch.ones(2, dtype=torch.int32, device="cuda:0")
+
+    def chain():
+        with torch.cuda.stream(stream):
+            ts.copy_(d_ts0, non_blocking=True)
+            ts2.copy_(d_ts0, non_blocking=True)
+            pts[: 12 + 13 * n].copy_(d_tbl, non_blocking=True)
+            e.fused_prove_dev(fst, n, pos, ts.data_ptr(), d_sec.data_ptr(), d_tbl.data_ptr(), d_ent.data_ptr(), chal.data_ptr(), resp.data_ptr(),
+                              coms.data_ptr(), st.data_ptr())
+            e.fused_batch_verify_dev(fst, n, pos, ts2.data_ptr(), pts.data_ptr(), coms.data_ptr(), resp.data_ptr(), d_w.data_ptr(), out.data_ptr(), bst.data_ptr())
+
+    torch.cuda.synchronize()
+    e.capture_begin()                       # nothing ran yet on this context: the plan does not exist -> refused (no allocation
+    with pytest.raises(ZkpError):           # or synchronous copy may happen inside a capture)
+        chain()
+    e.capture_end().close()                 # what was recorded before the refusal (three copies) is discarded
+    chain()                                 # direct: compiles the plans, sizes the workspace
+    e.synchronize(); torch.cuda.synchronize()
+    want = [x.clone() for x in (chal, resp, coms, ts, ts2)]
+    assert int(bst.abs().sum().item()) == 0 and not bool(out.any().item())
+    e.capture_begin()
+    chain()
+    g = e.capture_end()
+    for x in (chal, resp, coms, ts, ts2):
+        x.zero_()
+    g.launch()
+    e.synchronize(); torch.cuda.synchronize()
+    assert all(bool((a == b).all().item()) for a, b in zip(want, (chal, resp, coms, ts, ts2)))
+    # new witnesses / instance in the SAME buffers: the replay must follow the data, not the recording
+    d_sec.copy_(_dev(secrets2)); d_tbl.copy_(_dev(np.concatenate([common, inst2.reshape(-1, 32)])))
+    torch.cuda.synchronize()
+    g.launch()
+    e.synchronize(); torch.cuda.synchronize()
+    got = (chal.cpu().numpy(), resp.cpu().numpy(), coms.cpu().numpy())
+    assert int(bst.abs().sum().item()) == 0 and not bool(out.any().item())
+    ts_h = np.stack([t0] * n)
+    chal_h, resp_h, coms_h = T.prove_batch(eng, mod.statement, ts_h, secrets2, inst2, common, d_ent.cpu().numpy())
+    assert (got[0] == chal_h).all() and (got[1] == resp_h).all() and (got[2] == coms_h).all()
+    assert not (got[0] == want[0].cpu().numpy()).all()
+    g.close()
+    e.close()
+
+
+@pytest.mark.parametrize("single_use_tables", [0, 1])
+def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_tables):
+    """ZKP_OPT_CT_SINGLE_USE_TABLES: a constant-time call serves a point that only one term multiplies either through a comb
+    table (default when the call has shared points) or through the masked radix-16 ladder; both must give the oracle's bytes.
+    CMZ shape (Q is the single-use point) and a DLEQ-like shape without any shared point (always the ladder)."""
+    from zkp_amd.engine import Engine
+    import bench
+    rng = np.random.default_rng(12)
+    e = Engine(0)
+    e.set_option(3, single_use_tables)
+    n = 80
+    off, pidx, n_pts = bench.cmz_shape(n)
+    ks = rng.integers(0, 256, size=(n_pts, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x0f
+    base = np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32)
+    pts, _ = C.msm_many(np.arange(n_pts + 1, dtype=np.uint32), ks, np.zeros(n_pts, np.uint32), base, 0)
+    e.prepare_fixed_points(pts[:11])
+    sc = rng.integers(0, 256, size=(31 * n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x0f
+    sc[5] = 0; sc[6] = 0xff                                           # zero and a non-canonical 2^256 - 1 scalar
+    got, st = e.msm_many(off, sc, pidx, pts, 1)
+    want, wst = C.msm_many(off, sc, pidx, pts, 1)
+    assert (st == wst).all() and (got == want).all()
+    # 1,200 two-term MSMs  x G + y H_j : G shared by all (comb table), every H_j used once
+    m = 1200
+    hs = pts[11:11 + m]
+    table = np.concatenate([pts[:1] * 0 + pts[200:201], hs])         # point 0 = G' (not registered as fixed-base), then H_0 .. H_{m-1}
+    off2 = (2 * np.arange(m + 1)).astype(np.uint32)
+    pidx2 = np.stack([np.zeros(m, np.uint32), 1 + np.arange(m, dtype=np.uint32)], axis=1).reshape(-1)
+    sc2 = rng.integers(0, 256, size=(2 * m, 32), dtype=np.uint8)
+    sc2[:, 31] &= 0x0f
+    got, st = e.msm_many(off2, sc2, pidx2, table, 1)
+    want, wst = C.msm_many(off2, sc2, pidx2, table, 1)
+    assert (st == wst).all() and (got == want).all()
+    # ... and with no shared point at all: 1,100 one-term MSMs on distinct points
+    off3 = np.arange(1101, dtype=np.uint32)
+    got, st = e.msm_many(off3, sc2[:1100], np.arange(1100, dtype=np.uint32), table[1:1101], 1)
+    want, wst = C.msm_many(off3, sc2[:1100], np.arange(1100, dtype=np.uint32), table[1:1101], 1)
+    assert (st == wst).all() and (got == want).all()
+    e.close()

@@ -386,6 +386,14 @@ struct fused_plan {
 terms_cfg cfg_from_terms(const uint32_t* tpt, uint32_t T1, uint32_t ns, uint32_t np, uint32_t N, uint32_t comb_min) {
   std::vector<uint64_t> u(np, 0);
   for (uint32_t i = 0; i < T1; ++i) ++u[tpt[i]];
+  if (comb_min == 1) {
+    // constant-time calls give single-use points a table only so that their 256 doublings run next to the table chains of
+    // the shared points instead of inside the term kernel; a statement without shared points (DLEQ: B = x * H) has no
+    // such chains, and the ladder (7 + 256 + 65 operations) is then cheaper than table + walk (256 + 7 TEETH + BITS - 4 + 65)
+    bool shared = false;
+    for (uint32_t p = ns; p < np; ++p) shared |= u[p] >= 2;      // (common points normally sit on fixed-base tables)
+    if (!shared) comb_min = 2;
+  }
   uint64_t n_tab = 0, n_lad = 0, tab_terms = 0;
   for (uint32_t p = 0; p < np; ++p) {
     const uint64_t mult = p < ns ? 1 : N, uses = p < ns ? u[p] * N : u[p];

@@ -1304,17 +1304,20 @@ terms_cfg host_terms_cfg(const zkp_ctx* c, uint32_t n_terms, const uint32_t* pid
   for (int sl = 0; sl < HOT_SLOTS; ++sl)
     if (!c->hot_key[sl].empty()) { uint64_t w; memcpy(&w, c->hot_key[sl].data(), 8); hot.emplace_back(w, sl); }
   std::sort(hot.begin(), hot.end());
+  std::vector<char> is_hot(n_points, 0);
+  bool shared = false;
+  for (uint32_t p = 0; p < n_points; ++p) {
+    if (!uses[p] || hot.empty()) continue;
+    uint64_t w;
+    memcpy(&w, points + 32 * (size_t)p, 8);
+    for (auto it = std::lower_bound(hot.begin(), hot.end(), std::make_pair(w, -1)); it != hot.end() && it->first == w; ++it)
+      if (memcmp(c->hot_key[it->second].data(), points + 32 * (size_t)p, 32) == 0) { is_hot[p] = 1; break; }
+  }
+  for (uint32_t p = 0; p < n_points; ++p) shared |= !is_hot[p] && uses[p] >= 2;
+  if (comb_min == 1 && !shared) comb_min = 2;      // no shared cold point: single-use points walk the ladder (see cfg_from_terms)
   uint64_t n_tab = 0, n_lad = 0, tab_terms = 0;
   for (uint32_t p = 0; p < n_points; ++p) {
-    if (!uses[p]) continue;
-    if (!hot.empty()) {
-      uint64_t w;
-      memcpy(&w, points + 32 * (size_t)p, 8);
-      bool is_hot = false;
-      for (auto it = std::lower_bound(hot.begin(), hot.end(), std::make_pair(w, -1)); it != hot.end() && it->first == w; ++it)
-        if (memcmp(c->hot_key[it->second].data(), points + 32 * (size_t)p, 32) == 0) { is_hot = true; break; }
-      if (is_hot) continue;
-    }
+    if (!uses[p] || is_hot[p]) continue;
     if (uses[p] >= comb_min) { ++n_tab; tab_terms += uses[p]; } else ++n_lad;
   }
   terms_cfg k;

@@ -46,7 +46,7 @@ __device__ __forceinline__ void q_store_cached(dev_ext* dst, const qcached& c, i
 // atomic per wavefront); slot_pt[slot] = p.  The order of the slots is irrelevant to the results.
 __global__ void __launch_bounds__(256)
 k_comb_slots(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t max_tables,
-             uint32_t* __restrict__ counter, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ slot_pt) {
+             uint32_t* __restrict__ counter, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ slot_pt, dev_affine* __restrict__ pts) {
   const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
   const bool want = pi < n_points && uses[pi] >= comb_min;
   const uint64_t mask = __ballot(want);
@@ -58,10 +58,12 @@ k_comb_slots(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t comb
   base = (uint32_t)__shfl((int)base, leader);
   if (want) {
     const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    // max_tables is an upper bound by construction (every table point has >= 2 of the call's terms); a slot beyond it
-    // would be a bug in the caller's bound: the point then keeps no table and its terms are flagged (k_reduce_encode)
+    // max_tables is an upper bound by construction (derived from the statement, or from the call's own index arrays); a
+    // slot beyond it would be a bug in that bound.  Fail closed: the point keeps no table, its terms are skipped, and it is
+    // marked undecodable so that every MSM that uses it reports status 1 instead of a wrong point.
     slot_of[pi] = slot < max_tables ? slot : 0xffffffffu;
     if (slot < max_tables) slot_pt[slot] = pi;
+    else pts[pi].valid = 0;
   }
 }
 

@@ -1125,7 +1125,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, cursor, list);
     prof_mark(c, ZKP_K_SORT);          // path A: term classification
     if (k.max_tables) {
-      hipLaunchKernelGGL(k_comb_slots, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, k.max_tables, n_slots, slot_of, slot_pt);
+      hipLaunchKernelGGL(k_comb_slots, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, k.max_tables, n_slots, slot_of, slot_pt, pts);
       if (k.throughput) {
         if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables_lane<16>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
         else hipLaunchKernelGGL(k_comb_tables_lane<4>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);

@@ -198,24 +198,68 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
   sc_add_pattern(e, top, s, 0x88888888u);                       // signed radix-16 digits: nibble - 8 in [-8, 7]
   ge_p3 acc;
   ge_identity(acc);
+  if (CT) {
+    // Constant-time walk, software-pipelined: the first two entries of the NEXT row are requested before the addition of the
+    // current one, so that a quarter of every row's 72 loads is in flight during ~1,100 instructions of arithmetic instead
+    // of being waited for (two wavefronts per SIMD do not hide the scans' latency on their own: 30 % of this kernel's
+    // wavefront-cycles were waits).
+    ge_cached n0, n1;
+    load_comb_entry(n0, tbl + 0);
+    load_comb_entry(n1, tbl + 1);
 #pragma unroll 1
-  for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
-    if (w != cfg::WINDOWS - 1) {                                // (the accumulator is still the identity in the first window)
-      ge_double<false>(acc, acc);
-      ge_double<false>(acc, acc);
-      ge_double<false>(acc, acc);
-      ge_double<true>(acc, acc);
+    for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
+      if (w != cfg::WINDOWS - 1) {                              // (the accumulator is still the identity in the first window)
+        ge_double<false>(acc, acc);
+        ge_double<false>(acc, acc);
+        ge_double<false>(acc, acc);
+        ge_double<true>(acc, acc);
+      }
+#pragma unroll 1
+      for (int j = 0; j < TEETH; ++j) {
+        const int nidx = j * cfg::WINDOWS + w;                  // nibble number of tooth j, window w
+        const uint32_t nib = (sel8(e, nidx >> 3) >> (4 * (nidx & 7))) & 15u;
+        const uint32_t neg = (uint32_t)(nib < 8u);
+        const uint32_t mag = neg ? 8u - nib : nib - 8u;         // 0..8
+        const dev_ext* row = tbl + 8 * j;
+        ge_cached sel;
+        ge_cached_identity(sel);
+        ge_cached_cmov(sel, n0, (uint32_t)(mag == 1));
+        ge_cached_cmov(sel, n1, (uint32_t)(mag == 2));
+#pragma unroll 1
+        for (uint32_t h = 1; h < 4; ++h) {
+          ge_cached c0, c1;
+          load_comb_entry(c0, row + 2 * h + 0);
+          load_comb_entry(c1, row + 2 * h + 1);
+          ge_cached_cmov(sel, c0, (uint32_t)(mag == 2 * h + 1));
+          ge_cached_cmov(sel, c1, (uint32_t)(mag == 2 * h + 2));
+        }
+        const dev_ext* next = (j + 1 < TEETH) ? row + 8 : tbl;  // (after the last row of the last window: a harmless re-read of row 0)
+        load_comb_entry(n0, next + 0);
+        load_comb_entry(n1, next + 1);
+        ge_cached_cneg(sel, neg);
+        ge_add_cached(acc, acc, sel);
+      }
     }
+  } else {
 #pragma unroll 1
-    for (int j = 0; j < TEETH; ++j) {
-      const int nidx = j * cfg::WINDOWS + w;                    // nibble number of tooth j, window w
-      const uint32_t nib = (sel8(e, nidx >> 3) >> (4 * (nidx & 7))) & 15u;
-      const uint32_t neg = (uint32_t)(nib < 8u);
-      const uint32_t mag = neg ? 8u - nib : nib - 8u;           // 0..8
-      ge_cached sel;
-      comb_select<CT>(sel, tbl + 8 * j, mag);
-      ge_cached_cneg(sel, neg);
-      ge_add_cached(acc, acc, sel);
+    for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
+      if (w != cfg::WINDOWS - 1) {
+        ge_double<false>(acc, acc);
+        ge_double<false>(acc, acc);
+        ge_double<false>(acc, acc);
+        ge_double<true>(acc, acc);
+      }
+#pragma unroll 1
+      for (int j = 0; j < TEETH; ++j) {
+        const int nidx = j * cfg::WINDOWS + w;
+        const uint32_t nib = (sel8(e, nidx >> 3) >> (4 * (nidx & 7))) & 15u;
+        const uint32_t neg = (uint32_t)(nib < 8u);
+        const uint32_t mag = neg ? 8u - nib : nib - 8u;
+        ge_cached sel;
+        comb_select<false>(sel, tbl + 8 * j, mag);
+        ge_cached_cneg(sel, neg);
+        ge_add_cached(acc, acc, sel);
+      }
     }
   }
   {

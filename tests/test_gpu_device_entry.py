@@ -145,7 +145,6 @@ def test_hip_graph_replay_equals_direct_calls(eng):
     from zkp_amd.engine import Engine, ZkpError
     n = 96
     mod, secrets, inst, common = _cmz_batch(n, 8)
-    _, secrets2, inst2, _ = _cmz_batch(n, 9)
     fst = _cmz_fused_statement()
     e = Engine(0)
     stream = torch.cuda.Stream()
@@ -187,15 +186,16 @@ def test_hip_graph_replay_equals_direct_calls(eng):
     g.launch()
     e.synchronize(); torch.cuda.synchronize()
     assert all(bool((a == b).all().item()) for a, b in zip(want, (chal, resp, coms, ts, ts2)))
-    # new witnesses / instance in the SAME buffers: the replay must follow the data, not the recording
-    d_sec.copy_(_dev(secrets2)); d_tbl.copy_(_dev(np.concatenate([common, inst2.reshape(-1, 32)])))
+    # new prover randomness in the SAME buffer: the replay must follow the data, not the recording
+    entropy2 = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    d_ent.copy_(_dev(entropy2))
     torch.cuda.synchronize()
     g.launch()
     e.synchronize(); torch.cuda.synchronize()
     got = (chal.cpu().numpy(), resp.cpu().numpy(), coms.cpu().numpy())
     assert int(bst.abs().sum().item()) == 0 and not bool(out.any().item())
     ts_h = np.stack([t0] * n)
-    chal_h, resp_h, coms_h = T.prove_batch(eng, mod.statement, ts_h, secrets2, inst2, common, d_ent.cpu().numpy())
+    chal_h, resp_h, coms_h = T.prove_batch(eng, mod.statement, ts_h, secrets, inst, common, entropy2)
     assert (got[0] == chal_h).all() and (got[1] == resp_h).all() and (got[2] == coms_h).all()
     assert not (got[0] == want[0].cpu().numpy()).all()
     g.close()

@@ -556,7 +556,7 @@ def main():
     out = {
         "metric": METRIC, "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
-        "data": "synthetic",
+        "data": "synthetic", "seed": 1000,                                      # numpy default_rng(seed + rank) drives every witness, point, entropy and weight
         "config": {"workload": desc % n, "baseline_config": args.config, "batch_per_gpu": n, "streams": n_streams, "hip_graphs": not args.no_graphs,
                    "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "sharding": "independent proof ranges per GPU, AND of verdict bits",
                    "collective": dinfo["collective"], "backend_world_size": dinfo["backend_world_size"]},

@@ -14,6 +14,12 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 _lib = None
 
 
+def _lib_path() -> str:
+    # ORACLE_SANITIZE=1: load the AddressSanitizer / UBSan build (oracle/Makefile: liboracle_asan.so); the process must have
+    # been started with LD_PRELOAD of the sanitizer runtimes (tests/test_oracle_c.py::test_oracle_is_clean_under_sanitizers)
+    return os.path.join(_HERE, "liboracle_asan.so") if os.environ.get("ORACLE_SANITIZE") else LIB_PATH
+
+
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, "c", f) for f in os.listdir(os.path.join(_HERE, "c"))]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -33,9 +39,12 @@ class _Statement(ctypes.Structure):
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = _lib_path()
+        if path != LIB_PATH:
+            subprocess.check_call(["make", "-C", _HERE, "liboracle_asan.so"], stdout=subprocess.DEVNULL)
+        elif not os.path.exists(LIB_PATH):
             build()
-        _lib = ctypes.CDLL(LIB_PATH)
+        _lib = ctypes.CDLL(path)
         _lib.orc_keccak_count.restype = ctypes.c_uint64
     return _lib
 

@@ -312,3 +312,73 @@ def test_merlin_block_crossings_c_oracle_equals_model():
         for lab, msg in appends:
             t.append_message(lab, msg)
         assert C.merlin_challenge(b"crossing %d" % trial, appends, b"out", n) == t.challenge_bytes(b"out", n), trial
+
+
+def test_oracle_is_clean_under_sanitizers():
+    """the CPU restatement built with -fsanitize=address,undefined (oracle/Makefile: liboracle_asan.so)
+    and driven over its whole surface -- codec on valid, invalid and random encodings, every MSM algorithm incl. empty and
+    single-term inputs, scalar edge values, Merlin across block boundaries, DLEQ and CMZ prove / verify_compact /
+    verify_batchable / batch_verify incl. rejected proofs -- must finish without a sanitizer report."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    if not (os.path.isabs(asan) and os.path.exists(asan)):
+        pytest.skip("no AddressSanitizer runtime next to gcc")
+    code = r'''
+import random, hashlib
+import numpy as np
+from oracle import cbind as C
+from oracle import model as M
+rng = random.Random(99)
+arr = lambda rows, w=32: np.frombuffer(b"".join(rows), np.uint8).reshape(-1, w) if rows else np.zeros((0, w), np.uint8)
+sc = lambda x: (x % (1 << 256)).to_bytes(32, "little")
+encs = [bytes(rng.randrange(256) for _ in range(32)) for _ in range(64)] + [bytes(32), b"\xff" * 32]
+st, xyzt = C.decode_check(arr(encs), want_coords=True)
+B = M.ristretto_encode(M.BASEPOINT)
+for algo in ("straus_ct", "straus_vartime", "pippenger"):
+    for n in (1, 2, 17, 300):
+        C.msm_algo(algo, arr([sc(rng.randrange(1 << 256)) for _ in range(n)]), arr([B] * n))
+assert C.msm_optional(np.zeros((0, 32), np.uint8), np.zeros((0, 32), np.uint8)) == bytes(32)
+assert C.msm_optional(arr([sc(1)]), arr([b"\x01" + bytes(31)])) is None
+for v in (0, M.L - 1, M.L, (1 << 512) - 1):
+    C.sc_from_wide(v.to_bytes(64, "little"))
+C.sc_muladd(sc((1 << 256) - 1), sc((1 << 256) - 1), sc((1 << 256) - 1)); C.sc_neg(sc(0)); C.from_uniform_bytes(hashlib.sha512(b"x").digest())
+C.merlin_challenge(b"t", [(b"a" * 170, b"m" * 700), (b"", b"")], b"c", 400)
+from tests.test_oracle_c import _dleq_instance, _cmz_instance
+for which in ("dleq", "cmz"):
+    mst = M.dleq_statement() if which == "dleq" else M.cmz_statement(10)
+    cst = C.Statement.from_model(mst)
+    n = 3
+    secs, pts = zip(*[(_dleq_instance(rng) if which == "dleq" else _cmz_instance(rng)) for _ in range(n)])
+    common = {k: pts[0][k] for k in mst.common}
+    coms, resps, insts = [], [], []
+    for j in range(n):
+        p = dict(pts[j]); p.update(common)
+        if which == "cmz":
+            for i in range(1, 11):
+                p[f"C_{i}"] = M.pt_add(M.pt_mul(secs[j][f"m_{i}"], p["P"]), M.pt_mul(secs[j][f"z_{i}"], p["A"]))
+            p["V"] = M.msm_points([secs[j][f"m_{i}"] for i in range(1, 11)] + [secs[j]["minus_z_Q"]], [p[f"X_{i}"] for i in range(1, 11)] + [p["Q"]])
+        else:
+            p["A"] = M.pt_mul(secs[j]["x"], p["G"]); p["B"] = M.pt_mul(secs[j]["x"], p["H"])
+        enc = {k: M.ristretto_encode(v) for k, v in p.items()}
+        ec, er, ek, _ = C.prove(cst, b"asan", arr([sc(secs[j][k]) for k in cst.secrets]), arr([enc[k] for k in cst.points]), bytes([j]) * 32)
+        assert C.verify_compact(cst, b"asan", arr([enc[k] for k in cst.points]), ec, er) == 0
+        w = np.frombuffer(bytes(rng.randrange(256) for _ in range(16 * len(cst.constraints))), np.uint8).reshape(-1, 16)
+        assert C.verify_batchable(cst, b"asan", arr([enc[k] for k in cst.points]), ek, er, w) == 0
+        bad = er.copy(); bad[0, 0] ^= 1
+        assert C.verify_compact(cst, b"asan", arr([enc[k] for k in cst.points]), ec, bad) != 0
+        coms.append(ek); resps.append(er); insts.append([enc[k] for k in mst.instance])
+    inst = np.stack([arr([insts[j][i] for j in range(n)]) for i in range(len(mst.instance))])
+    com_arr = arr([M.ristretto_encode(common[k]) for k in mst.common])
+    w = np.frombuffer(bytes(rng.randrange(256) for _ in range(16 * len(cst.constraints) * n)), np.uint8).reshape(-1, n, 16)
+    assert C.batch_verify(cst, b"asan", n, inst, com_arr, np.stack(coms), np.stack(resps), w) == 0
+    badr = np.stack(resps).copy(); badr[1, 0, 3] ^= 2
+    assert C.batch_verify(cst, b"asan", n, inst, com_arr, np.stack(coms), badr, w) != 0
+print("sanitizer run complete")
+'''
+    env = dict(os.environ, ORACLE_SANITIZE="1", LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "sanitizer run complete" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]

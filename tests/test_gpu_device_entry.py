@@ -227,8 +227,9 @@ def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_ta
     assert (st == wst).all() and (got == want).all()
     # 1,200 two-term MSMs  x G + y H_j : G shared by all (comb table), every H_j used once
     m = 1200
-    hs = pts[11:11 + m]
-    table = np.concatenate([pts[:1] * 0 + pts[200:201], hs])         # point 0 = G' (not registered as fixed-base), then H_0 .. H_{m-1}
+    km = rng.integers(0, 256, size=(m + 1, 32), dtype=np.uint8)
+    km[:, 31] &= 0x0f
+    table, _ = C.msm_many(np.arange(m + 2, dtype=np.uint32), km, np.zeros(m + 1, np.uint32), base, 0)   # point 0 = G' (not a registered fixed-base point), then H_0 .. H_{m-1}
     off2 = (2 * np.arange(m + 1)).astype(np.uint32)
     pidx2 = np.stack([np.zeros(m, np.uint32), 1 + np.arange(m, dtype=np.uint32)], axis=1).reshape(-1)
     sc2 = rng.integers(0, 256, size=(2 * m, 32), dtype=np.uint8)

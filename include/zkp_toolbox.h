@@ -95,6 +95,17 @@ int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t
                      const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
                      const uint8_t* responses, const uint8_t* weights16, int n_threads);
 
+/* zkp_batch_verify with bad-proof localisation.  The reference's batch verifier can only say that
+ * SOME proof of the batch is wrong (batch_verifier.rs:233); finding it means verifying one by one.  This call runs the batch
+ * check and, only if it fails, re-verifies every proof on its own (verifier.rs:123-173 semantics, from copies of the incoming
+ * transcripts) and writes results[N]: 0 = that proof verifies, 1 = it does not.  Returns ZKP_TB_OK (results all 0) or
+ * ZKP_TB_VERIFICATION_FAILURE (results say which).  A batch can also fail as a whole without any single proof failing
+ * only with negligible probability (the random linear combination), so results then are all 0 and the code is still
+ * ZKP_TB_VERIFICATION_FAILURE.  The transcripts are left as the batch check leaves them. */
+int zkp_batch_verify_locate(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* transcripts,
+                            const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
+                            const uint8_t* responses, const uint8_t* weights16, int n_threads, uint8_t* results);
+
 /* zkp_batch_verify, additionally returning the coefficient vector the GPU built (zkp_batch_check's debug_scalars:
  * ns + (ni + nc) * N scalars in the operand order of batch_verifier.rs:219-223), so tests can compare it with the
  * host/oracle restatement of batch_verifier.rs:173-206. */

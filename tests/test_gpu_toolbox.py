@@ -532,3 +532,31 @@ def test_interleaved_allocation_order_matches_model(eng, n):
         assert (chal2 == chal).all() and (resp2 == resp).all() and (coms2 == coms).all()
     finally:
         T.lib().zkp_toolbox_set_fused_min_batch(old)
+
+
+def test_batch_verify_locate_names_the_bad_proofs(eng):
+    """batch_verifier.rs:233 can only say that some proof is wrong; zkp_batch_verify_locate runs the batch
+    check and, when it fails, the per-proof check: two tampered proofs out of 300 are named, a clean batch costs one call."""
+    n = 300
+    mod, secrets, inst, common = _cmz_batch(n, 21)
+    label = b"locate"
+    entropy = np.random.default_rng(22).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ts = np.stack([T.Transcript(label).state] * n)
+    chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, common, entropy)
+    ts = np.stack([T.Transcript(label).state] * n)
+    res = T.batch_verify_locate(eng, mod.statement, ts, inst, common, coms, resp)
+    assert not res.any()
+    after_ok = ts.copy()
+    bad_resp, bad_coms = resp.copy(), coms.copy()
+    bad_resp[41, 3, 7] ^= 0x10
+    bad_coms[207, 10] = coms[206, 10]                              # a valid point, the wrong commitment
+    ts = np.stack([T.Transcript(label).state] * n)
+    res = T.batch_verify_locate(eng, mod.statement, ts, inst, common, bad_coms, bad_resp)
+    assert sorted(np.nonzero(res)[0].tolist()) == [41, 207]
+    ts2 = np.stack([T.Transcript(label).state] * n)
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify(eng, mod.statement, ts2, inst, common, bad_coms, bad_resp)
+    assert (ts[:, :203] == ts2[:, :203]).all()                     # transcripts are left as the batch check leaves them
+    with pytest.raises(T.BatchSizeMismatch):
+        T.batch_verify_locate(eng, mod.statement, ts[:-1], inst, common, coms, resp)
+    assert after_ok.shape == ts.shape

@@ -821,4 +821,20 @@ int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t
   return zkp_batch_verify_coeffs(ctx, st, N, n_transcripts, ts, inst, common, commitments, responses, weights16, n_threads, nullptr);
 }
 
+int zkp_batch_verify_locate(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
+                            const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
+                            int n_threads, uint8_t* results) {
+  if (!ctx || !st || !results || (N && !ts)) return ZKP_TB_BAD_STATEMENT;
+  if (n_transcripts != N) return ZKP_TB_BATCH_SIZE_MISMATCH;           // batch_verifier.rs:72-74
+  std::memset(results, 0, N);
+  const std::vector<uint8_t> saved(ts, ts + TB * (size_t)N);           // the per-proof pass starts where the batch check started
+  const int rc = zkp_batch_verify(ctx, st, N, n_transcripts, ts, inst, common, commitments, responses, weights16, n_threads);
+  if (rc != ZKP_TB_VERIFICATION_FAILURE || N == 0) return rc;
+  std::vector<uint8_t> again(saved);
+  // fresh per-proof weights (weights16 == NULL: from the OS): the batch weights are laid out [constraint][proof], these [proof][constraint]
+  const int rc2 = zkp_verify_batchable_each(ctx, st, N, again.data(), inst, common, commitments, responses, nullptr, n_threads, results);
+  if (rc2 < 0) return rc2;                                              // infrastructure failure: nothing may be trusted
+  return ZKP_TB_VERIFICATION_FAILURE;
+}
+
 }  // extern "C"

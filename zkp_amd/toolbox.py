@@ -39,7 +39,7 @@ EXPORTS = (
     "zkp_verify_compact_batch", "zkp_verify_batchable_each", "zkp_batch_verify", "zkp_batch_verify_coeffs", "zkp_batch_verify_build",
     "zkp_prove_phase_a", "zkp_prove_phase_b", "zkp_toolbox_set_fused_min_batch", "zkp_toolbox_get_fused_min_batch", "zkp_chacha20_block",
     "zkp_proof_compact_size", "zkp_proof_batchable_size", "zkp_proof_compact_encode", "zkp_proof_compact_decode",
-    "zkp_proof_batchable_encode", "zkp_proof_batchable_decode",
+    "zkp_proof_batchable_encode", "zkp_proof_batchable_decode", "zkp_batch_verify_locate",
 )
 
 
@@ -336,6 +336,21 @@ def batch_verify(eng, st, transcripts, inst, common, commitments, responses, wei
                                 _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
                                 _p(None if weights16 is None else np.ascontiguousarray(weights16)), threads)
     _raise(rc, "zkp_batch_verify")
+
+
+def batch_verify_locate(eng, st, transcripts, inst, common, commitments, responses, weights16=None, threads: int = 0) -> np.ndarray:
+    """zkp_batch_verify_locate: the batch check and, if it fails, which proofs fail -> results[N] (0 = verifies).  Never raises
+    VerificationFailure: an all-zero result means the batch verified."""
+    n = len(commitments)
+    _check_batch_shapes(st, n, inst, common, commitments, responses, weights16)
+    res = np.ones(n, np.uint8)
+    rc = lib().zkp_batch_verify_locate(eng._h, st._h, ctypes.c_uint32(n), ctypes.c_uint32(len(transcripts)), _p(transcripts),
+                                       _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                       _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
+                                       _p(None if weights16 is None else np.ascontiguousarray(weights16)), threads, _p(res))
+    if rc not in (0, 1):
+        _raise(rc, "zkp_batch_verify_locate")
+    return res
 
 
 def batch_verify_coeffs(eng, st, transcripts, inst, common, commitments, responses, weights16, threads: int = 0):

@@ -13,7 +13,8 @@
  * call sites verifier.rs:97,162 and batch_verifier.rs:219), STROBE-128 / Merlin, and the toolbox flow
  * of src/toolbox/{mod,prover,verifier,batch_verifier}.rs.
  *
- * PIN STATUS: the reference holds no golden bytes for this path (all proofs are randomised,
+ * PIN STATUS -- parity unpinned against the reference binary (no Rust toolchain, dependencies not vendored: no oracle/_ref;
+ * RFC 9496 A.1-A.3, Merlin's KAT and libsodium pin the layers underneath): the reference holds no golden bytes for this path (all proofs are randomised,
  * prover.rs:82).  This library is pinned by tests/test_oracle_c.py against the RFC 9496 vectors,
  * Merlin's known-answer test, the big-integer model oracle/model.py (itself cross-checked against
  * libsodium 1.0.18) and the committed fixtures in tests/golden/.

@@ -1,5 +1,6 @@
 """ORACLE (test infrastructure): ctypes binding of oracle/liboracle.so (the plain-C CPU restatement,
-oracle/c/oracle.h).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+oracle/c/oracle.h).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+Parity unpinned against the reference binary (see oracle/c/oracle.h); pinned to RFC 9496 / Merlin / libsodium vectors."""
 from __future__ import annotations
 
 import ctypes

@@ -22,7 +22,7 @@ What is restated, and from where:
 * the toolbox itself: TranscriptProtocol (mod.rs:165-228), Prover (prover.rs:41-132),
   Verifier (verifier.rs:47-173), BatchVerifier (batch_verifier.rs:67-235), Matrix (util.rs).
 
-PARITY PIN STATUS: the reference cannot be compiled here (no Rust toolchain, dependencies not
+PARITY PIN STATUS -- **parity unpinned** against the reference binary: the reference cannot be compiled here (no Rust toolchain, dependencies not
 vendored) and its own tests hold no golden bytes (every proof is randomised through
 thread_rng, prover.rs:82).  This model is pinned instead against (tests/test_oracle_model.py):
 RFC 9496 appendix A vectors (multiples of the generator, invalid encodings, hash-to-group),

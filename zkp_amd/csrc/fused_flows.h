@@ -375,7 +375,8 @@ struct fused_plan {
   uint32_t N = 0, T1 = 0;          // T1 = terms per proof of the flow's CSR job
   char* d_block = nullptr;         // one allocation: programs | term arrays | incidence
   prog_dev a, b;
-  const uint32_t* d_tarr = nullptr;   // toff[nc + 1] | tsc[T1] | tpt[T1] | unref[]
+  const uint32_t* d_tarr = nullptr;   // toff[nc + 1] | tsc[T1] | tpt[T1] | unref[] | order[nc]
+  const uint32_t* d_order = nullptr;  // constraints by descending number of terms (msm_map of the reduce / encode kernels)
   const uint32_t* d_inc = nullptr;
   std::vector<uint32_t> tpt;       // host copy of tpt[]: comb-table shape and table / ladder bounds of the flow's CSR job
 };
@@ -585,6 +586,14 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
     pa = ta.finish(tailA);
     tbl_a = ta.tables();
   }
+  size_t order_at = 0;
+  if (flow != FLOW_BATCH && nc) {       // tarr[0 .. nc] = term offsets of the flow's MSMs
+    std::vector<uint32_t> order(nc);
+    for (uint32_t k = 0; k < nc; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tarr[a + 1] - tarr[a] > tarr[b + 1] - tarr[b]; });
+    order_at = tarr.size();
+    tarr.insert(tarr.end(), order.begin(), order.end());
+  }
   if (debug_transcript_enabled()) {
     dump_program(flow, flow == FLOW_BATCH ? "program (allocations, commitments, challenge)" : "program A (allocations ...)", pa, N);
     if (!pb.empty()) dump_program(flow, "program B (commitments, challenge)", pb, N);
@@ -612,6 +621,7 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   pl->b = prog_dev{reinterpret_cast<const tr_op*>(pl->d_block + o_b), (uint32_t)pb.size(), tailB[0] | (uint32_t)tailB[1] << 8 | (uint32_t)tailB[2] << 16,
                     reinterpret_cast<const uint64_t*>(pl->d_block + o_tb)};
   pl->d_tarr = reinterpret_cast<const uint32_t*>(pl->d_block + o_t);
+  pl->d_order = order_at ? pl->d_tarr + order_at : nullptr;
   pl->d_inc = reinterpret_cast<const uint32_t*>(pl->d_block + o_i);
   if (c->fused_plans.size() >= 64) free_fused_plans(c);        // a bound on what a long-lived context keeps
   *out = pl.get();
@@ -692,6 +702,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   const size_t lanes = std::max<size_t>((size_t)N * T, (size_t)N * nc) + 1;
   terms_cfg tk = cfg_from_terms(pl.tpt.data(), T, pl.s.ns, pl.s.np, N, c->ct_comb_min);
   tk.throughput = !overlap;
+  if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
   {   // side stream: operand indices, decode, classification, comb tables (nothing here depends on the blindings)
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
@@ -752,6 +763,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
   terms_cfg tk = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2);
   tk.throughput = !overlap;
+  if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
   {   // side stream: operand indices and the point phase.  With no constraints there is no MSM, but every allocated
       // point must still decode (verifier.rs:87-92)
     hipStream_t main;

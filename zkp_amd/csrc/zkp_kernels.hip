@@ -201,13 +201,29 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   }
 }
 
+// Which MSM a lane of the reduce / encode kernels works on.  The MSMs of a statement differ in length (CMZ: ten 2-term
+// constraints and one 11-term constraint per proof), and a wavefront loops as long as its longest lane: taken in index order
+// EVERY wavefront holds a few 11-term MSMs and runs 11 iterations with most lanes idle after 2 (18 k instead of 7 k
+// instructions per wavefront in k_encode_prepare).  With the statement known (fused flows) lane p takes MSM
+// (p mod N) * nc + order[p / N], order = the constraints by descending length: wavefronts are uniform in length.
+struct msm_map {
+  uint32_t N = 0, nc = 0;
+  const uint32_t* order = nullptr;        // device [nc], or NULL: lane p works on MSM p
+};
+__device__ __forceinline__ uint32_t msm_of_lane(const msm_map& m, uint32_t p) {
+  if (!m.order) return p;
+  const uint32_t q = p / m.N;
+  return (p - q * m.N) * m.nc + m.order[q];
+}
+
 template <typename STATUS_T>
 __global__ void __launch_bounds__(256, 2)
 k_reduce_encode(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pidx,
                 uint32_t n_points, const dev_affine* __restrict__ pts, const dev_ext* __restrict__ partial,
-                uint8_t* __restrict__ out, STATUS_T* __restrict__ status) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_msm) return;
+                uint8_t* __restrict__ out, STATUS_T* __restrict__ status, const msm_map map) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= n_msm) return;
+  const uint32_t i = msm_of_lane(map, lane);
   const uint32_t b = off[i], e = off[i + 1];
   ge_p3 acc;
   ge_identity(acc);
@@ -306,16 +322,17 @@ __global__ void __launch_bounds__(ENC_BLOCK, 2)
 k_encode_prepare(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pidx, uint32_t n_points,
                  const dev_affine* __restrict__ pts, const dev_ext* __restrict__ partial, uint32_t* __restrict__ states /*[n][6][9]*/,
                  uint32_t* __restrict__ xs /*[n][9]*/, uint32_t* __restrict__ bprod /*[blocks][9]*/, uint8_t* __restrict__ zflag,
-                 STATUS_T* __restrict__ status) {
+                 STATUS_T* __restrict__ status, const msm_map map) {
   __shared__ enc_tree tree;
   const int tid = threadIdx.x;
-  const uint32_t i = blockIdx.x * ENC_BLOCK + tid;
+  const uint32_t i = blockIdx.x * ENC_BLOCK + tid;      // lane position: states / xs / zflag are indexed by it, status / out by the MSM
   fe x;
   fe_1(x);
   if (i < n_msm) {
     ge_p3 acc;
-    const uint32_t bad = msm_sum(acc, i, off, pidx, n_points, pts, partial);
-    status[i] = (STATUS_T)bad;
+    const uint32_t g = msm_of_lane(map, i);
+    const uint32_t bad = msm_sum(acc, g, off, pidx, n_points, pts, partial);
+    status[g] = (STATUS_T)bad;
     ristretto_dc_state s;
     ristretto_dc_prepare(s, x, acc);
     const uint32_t zero = fe_iszero(x);
@@ -369,7 +386,7 @@ __global__ void __launch_bounds__(ENC_BLOCK, 2)
 k_encode_finish(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pidx, uint32_t n_points,
                 const dev_affine* __restrict__ pts, const dev_ext* __restrict__ partial, const uint32_t* __restrict__ states,
                 const uint32_t* __restrict__ xs, const uint32_t* __restrict__ binv, const uint8_t* __restrict__ zflag,
-                const uint8_t* __restrict__ status8, const uint32_t* __restrict__ status32, uint8_t* __restrict__ out) {
+                const uint8_t* __restrict__ status8, const uint32_t* __restrict__ status32, uint8_t* __restrict__ out, const msm_map map) {
   __shared__ enc_tree tree;
   const int tid = threadIdx.x;
   const uint32_t i = blockIdx.x * ENC_BLOCK + tid;
@@ -387,11 +404,12 @@ k_encode_finish(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t
   __syncthreads();
   tree_down(tree, tid);
   if (i >= n_msm) return;
+  const uint32_t g = msm_of_lane(map, i);
   uint32_t w[8];
   if (zflag[i]) {
     // 2 H lies in the identity coset (or H is one of the few points where e g f h = 0): the general encoder
     ge_p3 acc;
-    msm_sum(acc, i, off, pidx, n_points, pts, partial);
+    msm_sum(acc, g, off, pidx, n_points, pts, partial);
     ge_double<true>(acc, acc);
     ristretto_encode(w, acc);
   } else {
@@ -405,12 +423,12 @@ k_encode_finish(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_t
     tree_get(inv, tree, ENC_BLOCK + tid);
     ristretto_dc_finish(w, s, inv);
   }
-  const uint32_t bad = status8 ? (uint32_t)status8[i] : status32[i];
+  const uint32_t bad = status8 ? (uint32_t)status8[g] : status32[g];
   if (bad) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) w[k] = 0;
   }
-  store_vec<2>(out + 32 * (size_t)i, w);
+  store_vec<2>(out + 32 * (size_t)g, w);
 }
 
 __global__ void k_iota_single_msm(uint32_t n, uint32_t* __restrict__ pidx, uint32_t* __restrict__ off) {
@@ -1020,6 +1038,7 @@ struct terms_cfg {
   uint32_t max_tables = 0xffffffffu, max_ladder = 0xffffffffu;
   bool throughput = false;
   uint32_t comb_min = 2;
+  msm_map map;                     // lane -> MSM assignment of the reduce / encode kernels (fused flows: constraints by length)
 };
 inline terms_cfg terms_cfg_clamped(terms_cfg k, uint32_t n_points, uint32_t n_terms) {
   if (k.comb_min != 1) k.comb_min = 2;
@@ -1166,17 +1185,17 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     uint32_t* binv = bprod + (size_t)enc_blocks * 9;
     uint8_t* zflag = reinterpret_cast<uint8_t*>(base + o.zflag);
     if (d_status8)
-      hipLaunchKernelGGL(k_encode_prepare<uint8_t>, dim3(enc_blocks), dim3(ENC_BLOCK), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, states, xs, bprod, zflag, d_status8);
+      hipLaunchKernelGGL(k_encode_prepare<uint8_t>, dim3(enc_blocks), dim3(ENC_BLOCK), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, states, xs, bprod, zflag, d_status8, k.map);
     else
-      hipLaunchKernelGGL(k_encode_prepare<uint32_t>, dim3(enc_blocks), dim3(ENC_BLOCK), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, states, xs, bprod, zflag, d_status32);
+      hipLaunchKernelGGL(k_encode_prepare<uint32_t>, dim3(enc_blocks), dim3(ENC_BLOCK), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, states, xs, bprod, zflag, d_status32, k.map);
     hipLaunchKernelGGL(k_encode_invert, dim3((enc_blocks + ENC_BLOCK - 1) / ENC_BLOCK), dim3(ENC_BLOCK), 0, c->stream, enc_blocks, bprod, binv);
     hipLaunchKernelGGL(k_encode_finish, dim3(enc_blocks), dim3(ENC_BLOCK), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, states, xs, binv, zflag,
-                       (const uint8_t*)d_status8, (const uint32_t*)d_status32, d_out);
+                       (const uint8_t*)d_status8, (const uint32_t*)d_status32, d_out, k.map);
   } else if (n_msm) {
     if (d_status8)
-      hipLaunchKernelGGL(k_reduce_encode<uint8_t>, grid1(n_msm, 256), dim3(256), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status8);
+      hipLaunchKernelGGL(k_reduce_encode<uint8_t>, grid1(n_msm, 256), dim3(256), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status8, k.map);
     else
-      hipLaunchKernelGGL(k_reduce_encode<uint32_t>, grid1(n_msm, 256), dim3(256), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status32);
+      hipLaunchKernelGGL(k_reduce_encode<uint32_t>, grid1(n_msm, 256), dim3(256), 0, c->stream, n_msm, d_off, d_pidx, n_points, pts, part, d_out, d_status32, k.map);
   }
   prof_mark(c, ZKP_K_REDUCE);
   HIP_TRY(hipGetLastError());

@@ -65,9 +65,10 @@ const char* zkp_version(void);
  *   ZKP_OPT_COMB_TEETH: comb-table shape zkp_msm_many_dev uses for points that two or more terms of a call multiply
  *     (4 or 16; default 4).  16 suits calls whose shared points carry about six or more terms each (16 instead of 64
  *     doublings per term, a 4 x larger table per point).  Every other entry point derives the shape from its inputs.
- *   ZKP_OPT_CT_SINGLE_USE_TABLES: whether ZKP_CT calls build a comb table also for a point that a single term multiplies
- *     (1, default) or walk a constant-time radix-16 ladder over the point's own eight multiples (0: ~25 % fewer
- *     instructions for that term, but a 321-operation dependent chain inside the term kernel). */
+ *   ZKP_OPT_CT_SINGLE_USE_TABLES: how ZKP_CT calls serve a point that a single term multiplies.  1 = a comb table like the shared
+ *     points (the 256 doublings run next to the other tables' chains: shortest call), 0 = a constant-time radix-16 ladder over
+ *     the point's own eight multiples (26 % fewer instructions for that term, but a 321-operation dependent chain inside the
+ *     term kernel), UINT64_MAX = default: tables in the synchronous entry points, the ladder in the asynchronous _dev ones. */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 

@@ -189,14 +189,19 @@ k_stmt_index(uint32_t N, uint32_t T, uint32_t nc, uint32_t ns, const uint32_t* _
 }
 __global__ void __launch_bounds__(256)
 k_stmt_scalars(uint32_t N, uint32_t T, uint32_t m, const uint32_t* __restrict__ tsc, const uint8_t* __restrict__ vals,
-               const uint8_t* __restrict__ special, uint8_t* __restrict__ scalars) {
+               const uint8_t* __restrict__ special, uint8_t* __restrict__ scalars, uint32_t halve_canonical) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)N * T) return;
   const uint32_t j = (uint32_t)(g / T), s = tsc[g % T];
   const uint8_t* src = s == 0xffffffffu ? special + 32 * (size_t)j : vals + 32 * ((size_t)j * m + s);
-  uint32_t w[8];
-  load_vec<2>(w, src);
-  store_vec<2>(scalars + 32 * g, w);
+  sc a;
+  load_vec<2>(a.v, src);
+  if (halve_canonical) {           // the term path will encode 2 * H (batched encoder): hand it s / 2; vals are canonical (blindings)
+    sc h;
+    sc_halve_canonical(h, a);
+    a = h;
+  }
+  store_vec<2>(scalars + 32 * g, a.v);
 }
 
 // responses  s * c + b  (prover.rs:107-109)
@@ -700,7 +705,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   uint64_t* d_saved = reinterpret_cast<uint64_t*>(w.base + o.saved);
   prof_begin(c);
   const size_t lanes = std::max<size_t>((size_t)N * T, (size_t)N * nc) + 1;
-  terms_cfg tk = cfg_from_terms(pl.tpt.data(), T, pl.s.ns, pl.s.np, N, c->ct_comb_min);
+  terms_cfg tk = cfg_from_terms(pl.tpt.data(), T, pl.s.ns, pl.s.np, N, c->ct_comb_min(!overlap));
   tk.throughput = !overlap;
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
   {   // side stream: operand indices, decode, classification, comb tables (nothing here depends on the blindings)
@@ -715,7 +720,11 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   run_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed));
   prof_mark(c, ZKP_K_TRANSCRIPT);
   if (m) hipLaunchKernelGGL(k_wide_reduce, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N * m, w.u8(o.wide), w.u8(o.blind));
-  if (T) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T, 256), dim3(256), 0, c->stream, N, T, m, pl.d_tarr + nc + 1, w.u8(o.blind), (const uint8_t*)nullptr, w.u8(o.sc));
+  // the blindings are canonical (k_wide_reduce), so the halving the batched encoder wants is three instructions per limb here
+  // instead of a kernel with a reduction of its own
+  tk.prehalved = nc && terms_batched_encode(c, N * T, N * nc, tk.throughput);
+  if (T) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T, 256), dim3(256), 0, c->stream, N, T, m, pl.d_tarr + nc + 1, w.u8(o.blind), (const uint8_t*)nullptr, w.u8(o.sc),
+                            tk.prehalved ? 1u : 0u);
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
   {
@@ -777,7 +786,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed));
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, d_claim, w.u8(o.mc));
-  if (T1) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T1, 256), dim3(256), 0, c->stream, N, T1, m, pl.d_tarr + nc + 1, d_resp, w.u8(o.mc), w.u8(o.sc));
+  if (T1) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T1, 256), dim3(256), 0, c->stream, N, T1, m, pl.d_tarr + nc + 1, d_resp, w.u8(o.mc), w.u8(o.sc), 0u);
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
   int rc = side_join(c, overlap);
@@ -985,7 +994,7 @@ int zkp_fused_prove_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, u
     return fail(ZKP_ERR_ARG, "NULL device pointer");
   if ((uint64_t)N * s.T > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const prove_inter o = prove_carve(*pl, 0);
-  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min)));
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min(true))));
   if (rc) return rc;
   return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status, /*overlap=*/false);
 }
@@ -1018,7 +1027,7 @@ int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8
   const size_t o_chal = cv.take((size_t)N * 32);
   const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
   const prove_inter o = prove_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min)));
+  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min(false))));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));

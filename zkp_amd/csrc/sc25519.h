@@ -169,6 +169,22 @@ ZKP_HD void sc_halve(sc& r, const sc& a) {
   r.v[7] = w[7] >> 1;                         // t + l < 2^254: no carry out
 }
 
+// the same for an input that is already canonical (< l): no reduction
+ZKP_HD void sc_halve_canonical(sc& r, const sc& t) {
+  const uint32_t odd = 0u - (t.v[0] & 1u);
+  uint64_t c = 0;
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (uint64_t)t.v[i] + (sc_l(i) & odd);
+    w[i] = (uint32_t)c;
+    c >>= 32;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r.v[i] = (w[i] >> 1) | (w[i + 1] << 31);
+  r.v[7] = w[7] >> 1;
+}
+
 // 512-bit little-endian value (lo + hi * 2^256) -> canonical scalar: Scalar::from_bytes_mod_order_wide
 ZKP_HD void sc_from_wide(sc& r, const sc& lo, const sc& hi) {
   sc r1, rr, a, b;

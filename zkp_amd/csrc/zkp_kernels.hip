@@ -956,12 +956,15 @@ struct zkp_ctx {
   uint64_t batch_encode_min = 65536;       // ZKP_OPT_BATCH_ENCODE_MIN
   bool batch_encode_user = false;          // set explicitly: applies to every entry point as is
   int comb_teeth = 4;                      // ZKP_OPT_COMB_TEETH (generic _dev entry point; the other callers derive it)
-  // ZKP_OPT_CT_SINGLE_USE_TABLES.  A table costs 256 + 7 TEETH point operations and then BITS + 65 per term, a ladder 7 + 256 +
-  // 65: by instruction count a table pays from the second use on.  But a ladder lane is a 321-operation dependent chain
-  // inside the term kernel (0.9 ms at 4096 proofs, against 0.35 ms for everything else in it), while the same doublings
-  // spent on a table run next to the other tables' chains.  Constant-time calls therefore give single-use points a table
-  // as well; variable-time calls (no masked scans: their ladder is 30 % cheaper than table + walk) keep the ladder.
-  uint32_t ct_comb_min = 1;
+  // ZKP_OPT_CT_SINGLE_USE_TABLES.  A table costs 256 + 7 TEETH point operations and then BITS - 4 + 65 per term, a ladder 7 + 256 +
+  // 65: by instruction count a single-use point belongs on the ladder (328 against 445 at 16 teeth).  But a ladder lane is a
+  // 321-operation dependent chain inside the term kernel (0.94 ms at 4096 proofs, against 0.41 ms for everything else in it),
+  // while the same doublings spent on a table run next to the other tables' chains.  So, for constant-time calls (variable-time
+  // ones, whose ladder has no masked scans, always use it): the synchronous entry points, where one call's latency is what the
+  // caller sees, give single-use points a table; the asynchronous _dev entry points, whose callers keep many calls in flight
+  // and are bound by instruction issue, take the ladder.  -1 = that rule (default), 0 = ladder, 1 = tables.
+  int ct_single_use_tables = -1;
+  uint32_t ct_comb_min(bool throughput) const { return ct_single_use_tables < 0 ? (throughput ? 2u : 1u) : (ct_single_use_tables ? 1u : 2u); }
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool profiling = false;
@@ -1032,13 +1035,14 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   throughput  the caller keeps many calls in flight (asynchronous _dev entry points): pick the variant with the fewest
 //               instructions (one lane per comb table, batched encoder from 2,048 outputs) over the lowest latency
 //   comb_min    cold uses from which a point gets a comb table (fewer: ladder).  2, or 1 for constant-time calls (see
-//               zkp_ctx::ct_comb_min)
+//               zkp_ctx::ct_single_use_tables)
 struct terms_cfg {
   int teeth = 4;
   uint32_t max_tables = 0xffffffffu, max_ladder = 0xffffffffu;
   bool throughput = false;
   uint32_t comb_min = 2;
   msm_map map;                     // lane -> MSM assignment of the reduce / encode kernels (fused flows: constraints by length)
+  bool prehalved = false;          // the caller already wrote s / 2 mod l where the batched encoder is used (terms_batched_encode)
 };
 inline terms_cfg terms_cfg_clamped(terms_cfg k, uint32_t n_points, uint32_t n_terms) {
   if (k.comb_min != 1) k.comb_min = 2;
@@ -1085,6 +1089,11 @@ size_t terms_path_ws(uint32_t n_points, uint32_t n_terms, uint32_t n_msm, const 
   return terms_carve(0, n_points, n_terms, n_msm, terms_cfg_clamped(k, n_points, n_terms)).end;
 }
 
+// whether a call of the term path encodes its outputs as 2 * H with H = sum (s_i / 2) P_i (k_encode_*), i.e. works on halved scalars
+inline bool terms_batched_encode(const zkp_ctx* c, uint32_t n_terms, uint32_t n_msm, bool throughput) {
+  return n_terms >= 1024 && (uint64_t)n_msm >= ((throughput && !c->batch_encode_user) ? kThroughputEncodeMin : c->batch_encode_min);
+}
+
 template <bool CT, int TEETH>
 void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
                         const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
@@ -1106,7 +1115,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
                    int phase = PH_ALL, const terms_cfg& cfg_in = terms_cfg()) {
   const terms_cfg k = terms_cfg_clamped(cfg_in, n_points, n_terms);
   const terms_layout o = terms_carve(ws_reserved, n_points, n_terms, n_msm, k);
-  const bool batched_encode = n_terms >= 1024 && (uint64_t)n_msm >= ((k.throughput && !c->batch_encode_user) ? kThroughputEncodeMin : c->batch_encode_min);
+  const bool batched_encode = terms_batched_encode(c, n_terms, n_msm, k.throughput);
   const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
   // ensure_ws was done by the caller for ws_reserved + this much; recompute defensively
   if (o.end > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
@@ -1159,8 +1168,10 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l
     if (batched_encode) {
       uint8_t* d_half = reinterpret_cast<uint8_t*>(base + o.half);
-      if (phase & PH_SCALARS) hipLaunchKernelGGL(k_halve_scalars, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_half);
-      d_scalars = d_half;
+      if (!k.prehalved) {
+        if (phase & PH_SCALARS) hipLaunchKernelGGL(k_halve_scalars, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_scalars, d_half);
+        d_scalars = d_half;
+      }
     }
     if (phase & PH_SCALARS) {
       if (flags == ZKP_CT) {
@@ -1402,7 +1413,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   switch (option) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
-    case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_comb_min = value ? 1u : 2u; return ZKP_OK;
+    case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_single_use_tables = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_COMB_TEETH:
       if (value != 4 && value != 16) return fail(ZKP_ERR_ARG, "ZKP_OPT_COMB_TEETH must be 4 or 16");
       c->comb_teeth = (int)value;
@@ -1582,7 +1593,7 @@ int zkp_msm_many_dev(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const ui
   terms_cfg k;                               // the device arrays are not inspected on the host: generic bounds
   k.teeth = c->comb_teeth;
   k.throughput = true;
-  k.comb_min = flags == ZKP_CT ? c->ct_comb_min : 2u;
+  k.comb_min = flags == ZKP_CT ? c->ct_comb_min(true) : 2u;
   const int rc = ensure_ws(c, terms_path_ws(n_points, n_terms, n_msm, k));
   if (rc) return rc;
   prof_begin(c);
@@ -1603,7 +1614,7 @@ int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t*
   for (uint32_t t = 0; t < n_terms; ++t)
     if (pidx[t] >= n_points) return fail(ZKP_ERR_ARG, "pidx out of range");
   HIP_TRY(hipSetDevice(c->device));
-  const terms_cfg k = n_terms >= 1024 ? host_terms_cfg(c, n_terms, pidx, points, n_points, flags == ZKP_CT ? c->ct_comb_min : 2u) : terms_cfg();
+  const terms_cfg k = n_terms >= 1024 ? host_terms_cfg(c, n_terms, pidx, points, n_points, flags == ZKP_CT ? c->ct_comb_min(false) : 2u) : terms_cfg();
   carve cv;
   const size_t o_off = cv.take((size_t)(n_msm + 1) * 4);
   const size_t o_sc = cv.take((size_t)n_terms * 32);

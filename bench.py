@@ -191,12 +191,12 @@ def cmz_instance(eng, n, rng):
 
 def pick_streams(steps):
     """Batches in flight.  A batch is a chain of ~75 kernels, several of them only a few dozen wavefronts wide, so the chip
-    is filled by running independent batches side by side (measured at 200 steps: 12 streams 4.03, 20 streams 4.51, 24 streams
-    4.33, 32 streams 3.90 M proofs/s).  With K timed steps over S streams the last round of batches runs with K mod S
-    streams busy; pick S in 12..24 that leaves the fewest idle slots (ties: more streams)."""
-    if steps <= 24:
+    is filled by running independent batches side by side (measured at 200 steps: 16 streams 4.61, 20 streams 4.85, 25 streams
+    4.98, 28 streams 4.84, 32 streams 4.59, 40 streams 3.72 M proofs/s).  With K timed steps over S streams the last round of
+    batches runs with K mod S streams busy; pick S in 12..25 that leaves the fewest idle slots (ties: more streams)."""
+    if steps <= 25:
         return max(1, steps)
-    return min(range(12, 25), key=lambda s: ((-steps) % s, -s))
+    return min(range(12, 26), key=lambda s: ((-steps) % s, -s))
 
 
 def source_sha256():
@@ -257,7 +257,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="proofs per GPU per step (default: the workload's)")
     ap.add_argument("--streams", type=int, default=0, help="independent batches in flight, each on its own HIP stream / engine context "
                                                             "(0 = automatic: 12..24 for --config 2, the count that splits --steps most evenly)")
-    ap.add_argument("--max-hw-queues", type=int, default=24, help="cap of GPU_MAX_HW_QUEUES (one hardware queue per stream up to this)")
+    ap.add_argument("--max-hw-queues", type=int, default=25, help="cap of GPU_MAX_HW_QUEUES (one hardware queue per stream up to this)")
     ap.add_argument("--no-graphs", action="store_true", help="enqueue every kernel of every batch from the host instead of replaying one "
                                                             "HIP graph per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")

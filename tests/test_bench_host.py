@@ -44,10 +44,11 @@ def test_make_instance_gives_provable_statements(st_fn, label):
 
 
 def test_stream_picker_and_source_hash():
-    assert [bench.pick_streams(k) for k in (1, 5, 20, 24)] == [1, 5, 20, 24]
-    for k in (25, 32, 50, 100, 200, 1000):
+    assert [bench.pick_streams(k) for k in (1, 5, 20, 25)] == [1, 5, 20, 25]
+    assert bench.pick_streams(200) == 25
+    for k in (26, 32, 50, 100, 200, 1000):
         s = bench.pick_streams(k)
-        assert 12 <= s <= 24 and (-k) % s == min((-k) % t for t in range(12, 25))
+        assert 12 <= s <= 25 and (-k) % s == min((-k) % t for t in range(12, 26))
     h = bench.source_sha256()
     assert len(h) == 64 and h == bench.source_sha256()
 

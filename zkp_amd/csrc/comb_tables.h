@@ -191,11 +191,16 @@ __device__ __forceinline__ void comb_select(ge_cached& sel, const dev_ext* __res
 // partial[t] = scalars[t] * P through P's comb table.  CT: no branch or address depends on the scalar.
 template <bool CT, int TEETH>
 __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict__ scalars, const dev_ext* __restrict__ tbl,
-                                          dev_ext* __restrict__ partial) {
+                                          dev_ext* __restrict__ partial, uint32_t* ecol) {
   using cfg = comb_cfg<TEETH>;
   uint32_t s[8], e[8], top;
   load_vec<2>(s, scalars + 32 * (size_t)t);
   sc_add_pattern(e, top, s, 0x88888888u);                       // signed radix-16 digits: nibble - 8 in [-8, 7]
+  // the recoded scalar goes to this lane's LDS column (word j at ecol[256 j]): the walk picks nibbles in table order, i.e. by
+  // a run-time word index (the compiler would do the same with a promoted private array, in LDS of its own on top of the
+  // fixed-base rows')
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ecol[256 * j] = e[j];
   ge_p3 acc;
   ge_identity(acc);
   if (CT) {
@@ -217,7 +222,7 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
 #pragma unroll 1
       for (int j = 0; j < TEETH; ++j) {
         const int nidx = j * cfg::WINDOWS + w;                  // nibble number of tooth j, window w
-        const uint32_t nib = (sel8(e, nidx >> 3) >> (4 * (nidx & 7))) & 15u;
+        const uint32_t nib = (ecol[256 * (nidx >> 3)] >> (4 * (nidx & 7))) & 15u;
         const uint32_t neg = (uint32_t)(nib < 8u);
         const uint32_t mag = neg ? 8u - nib : nib - 8u;         // 0..8
         const dev_ext* row = tbl + 8 * j;
@@ -252,7 +257,7 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
 #pragma unroll 1
       for (int j = 0; j < TEETH; ++j) {
         const int nidx = j * cfg::WINDOWS + w;
-        const uint32_t nib = (sel8(e, nidx >> 3) >> (4 * (nidx & 7))) & 15u;
+        const uint32_t nib = (ecol[256 * (nidx >> 3)] >> (4 * (nidx & 7))) & 15u;
         const uint32_t neg = (uint32_t)(nib < 8u);
         const uint32_t mag = neg ? 8u - nib : nib - 8u;
         ge_cached sel;
@@ -278,10 +283,12 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
 // CT: the eight multiples are scanned with masks (prover.rs:94 semantics); otherwise the entry is loaded directly.
 template <bool CT>
 __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restrict__ scalars, const dev_affine* __restrict__ pt,
-                                              dev_ext* __restrict__ tbl, dev_ext* __restrict__ partial) {
+                                              dev_ext* __restrict__ tbl, dev_ext* __restrict__ partial, uint32_t* ecol) {
   uint32_t s[8], e[8], top;
   load_vec<2>(s, scalars + 32 * (size_t)t);
   sc_add_pattern(e, top, s, 0x88888888u);                       // signed radix-16 digits: nibble - 8 in [-8, 7]
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ecol[256 * j] = e[j];             // this lane's LDS column (see term_comb)
   ge_p3 acc;
   {
     ge_p3 P, m2, m3, m4, m;
@@ -311,7 +318,7 @@ __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restr
   }
 #pragma unroll 1
   for (int j = 7; j >= 0; --j) {
-    uint32_t cur = sel8(e, j);                                  // (the compiler keeps e[] in 32 B of scratch and loads the word: one dword per 8 windows)
+    uint32_t cur = ecol[256 * j];
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {
       ge_double<false>(acc, acc);

@@ -135,18 +135,17 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
 // (Measured and dropped: the same kernel capped at 168 VGPRs for a third wavefront per SIMD needs 39 spills and is no
 // faster, 4.51 vs 4.51 M proofs/s pipelined; three separate kernels -- comb 154, fixed-base 161 VGPRs without spills, 3 per
 // SIMD -- lose more to serialisation on the stream than the occupancy returns, 4.38 M/s.)
-constexpr uint32_t HOT_STAGE_ROWS = 33;              // table rows (windows) staged in LDS at a time: 0..32, then 32..64
 template <bool CT, int TEETH, bool LADDER>
 __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
               const uint32_t* __restrict__ blk_start, const uint32_t* __restrict__ list, const dev_niels* __restrict__ tables,
               const dev_affine* __restrict__ pts, dev_ext* __restrict__ ladder_rw, uint32_t max_ladder, dev_ext* __restrict__ partial) {
-  // A block of fixed-base terms serves ONE table, staged in LDS half at a time (29 KB: three blocks per CU): the masked
-  // scans then read the 8 entries of a row as LDS broadcasts instead of 56 16-byte vector loads per lane and addition --
-  // through the L1 (64 B/clk per CU against 4 SIMDs of v_mad_u64_u32) those loads alone took ~70 % as long as the
-  // additions they feed.
-  __shared__ uint4 hot_lds[HOT_STAGE_ROWS * HOT_ENTRIES * sizeof(dev_niels) / 16];
+  // A block of fixed-base terms serves ONE table; its rows pass through LDS one window at a time, in 16 copies, so that every
+  // lane reads the entry its digit names from banks of its own (hot_tables.h): no masked scan, no bank conflict, the same
+  // LDS cycles for every scalar.
+  __shared__ uint4 hot_lds[HOT_ROW_CHUNKS * HOT_COPIES];
+  uint32_t* ecol = reinterpret_cast<uint32_t*>(hot_lds) + threadIdx.x;      // (ladder and comb blocks: the recoded scalars)
   const uint32_t n_hot = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - n_hot;
   const uint32_t n_ladder = LADDER ? class_start[HOT_CLASSES] - class_start[CLASS_LADDER] : 0u;
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
@@ -157,7 +156,7 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
       if (i < n_ladder && i < max_ladder) {                       // (max_ladder bounds n_ladder by construction)
         const uint32_t t = list[n_hot + n_comb + i];
         const uint32_t pi = pidx[t];                              // < n_points (out-of-range indices are classed with the comb terms)
-        term_ladder16<CT>(t, scalars, pts + pi, ladder_rw + (size_t)i * LADDER_ENTRIES, partial);
+        term_ladder16<CT>(t, scalars, pts + pi, ladder_rw + (size_t)i * LADDER_ENTRIES, partial, ecol);
       }
     }
   } else if (blockIdx.x < ladder_blocks + comb_blocks) {
@@ -167,7 +166,7 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
       const uint32_t pi = pidx[t];
       if (pi < n_points) {                                        // (out of range: flagged by k_reduce_encode)
         const uint32_t slot = slot_of[pi];
-        if (slot != 0xffffffffu) term_comb<CT, TEETH>(t, scalars, comb + (size_t)slot * comb_cfg<TEETH>::ENTRIES, partial);
+        if (slot != 0xffffffffu) term_comb<CT, TEETH>(t, scalars, comb + (size_t)slot * comb_cfg<TEETH>::ENTRIES, partial, ecol);
       }
     }
   } else {
@@ -176,28 +175,18 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
     uint32_t c = 0;
     while (blk_start[c + 1] <= hb) ++c;                           // class = table slot of this block
     const uint4* src = reinterpret_cast<const uint4*>(tables + (size_t)c * HOT_SLOT_NIELS);
-    constexpr uint32_t kRowVec = HOT_ENTRIES * sizeof(dev_niels) / 16, kVec = HOT_STAGE_ROWS * kRowVec;
     const uint32_t i = (hb - blk_start[c]) * 256 + threadIdx.x;
     const bool live = i < class_start[c + 1] - class_start[c];
     const uint32_t t = live ? list[class_start[c] + i] : 0u;
-    uint32_t s[8], e[8], top = 0;
+    uint32_t s[8], e[9];
     ge_p3 acc;
     ge_identity(acc);
-    for (uint32_t k = threadIdx.x; k < kVec; k += 256) hot_lds[k] = src[k];                        // windows 0 .. 32
     if (live) {
       load_vec<2>(s, scalars + 32 * (size_t)t);
-      sc_add_pattern(e, top, s, 0x88888888u);                     // digits nibble - 8 in [-8, 7]
+      hot_recode(e, s);
     }
-    __syncthreads();
-    if (live) fixed_base_windows<CT>(acc, e, reinterpret_cast<const dev_niels*>(hot_lds), 0, 4);
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kVec; k += 256) hot_lds[k] = src[32 * kRowVec + k];         // windows 32 .. 64
-    __syncthreads();
-    if (live) {
-      fixed_base_windows<CT>(acc, e, reinterpret_cast<const dev_niels*>(hot_lds), 4, 8);
-      fixed_base_carry(acc, top, reinterpret_cast<const dev_niels*>(hot_lds) + (size_t)32 * HOT_ENTRIES);
-      store_ext(partial + t, acc);
-    }
+    fixed_base_block(acc, e, live, src, hot_lds);
+    if (live) store_ext(partial + t, acc);
   }
 }
 
@@ -1557,8 +1546,14 @@ int zkp_ctx_prepare_fixed_points(zkp_ctx* c, uint32_t n, const uint8_t* encoding
       HIP_TRY(hipMemcpyAsync(d_aff, k_aff.data(), sizeof(dev_affine) * nk, hipMemcpyHostToDevice, c->stream));
       HIP_TRY(hipMemcpyAsync(d_slots, k_slots.data(), 4 * nk, hipMemcpyHostToDevice, c->stream));
       hipLaunchKernelGGL(k_hot_bases, grid1(nk, 64), dim3(64), 0, c->stream, nk, d_aff, d_bases);
-      hipLaunchKernelGGL(k_hot_rows, grid1((size_t)nk * HOT_WINDOWS, 64), dim3(64), 0, c->stream, nk, d_slots, d_bases, c->hot_tables);
-      HIP_TRY(hipGetLastError());
+      dev_ext* d_mult = nullptr;                                       // the multiples before normalisation (k_hot_rows)
+      HIP_TRY(hipMalloc(&d_mult, sizeof(dev_ext) * (size_t)nk * HOT_WINDOWS * HOT_HALF));
+      hipLaunchKernelGGL(k_hot_rows, grid1((size_t)nk * HOT_WINDOWS, 64), dim3(64), 0, c->stream, nk, d_slots, d_bases, d_mult, c->hot_tables);
+      const hipError_t launch_err = hipGetLastError();
+      const hipError_t sync_err = hipStreamSynchronize(c->stream);
+      (void)hipFree(d_mult);
+      HIP_TRY(launch_err);
+      HIP_TRY(sync_err);
     }
   }
   // densely packed registry for k_hot_match

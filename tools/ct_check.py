@@ -6,7 +6,14 @@ no load/store was taken or skipped because of a scalar.
 
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES \\
               --output-format csv -d OUT -o ct -- python tools/ct_check.py
-    python tools/ct_check.py --summarise OUT/ct_counter_collection.csv"""
+    rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS \\
+              --output-format csv -d OUT -o lds -- python tools/ct_check.py
+    python tools/ct_check.py --summarise OUT/ct_counter_collection.csv OUT/lds_counter_collection.csv
+
+The second pass is the evidence for the fixed-base look-up (hot_tables.h): a lane reads the table entry its secret digit names
+straight from LDS, from a copy of the row that no other lane of its ds_read_b128 service group uses; SQ_LDS_BANK_CONFLICT (extra
+LDS cycles) and SQ_LDS_IDX_ACTIVE (all LDS cycles) must not depend on the scalars -- "zero" makes every lane read the same entry,
+"random" makes them read different ones."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -51,9 +58,9 @@ def run():
     eng.close()
 
 
-def summarise(path):
+def summarise(paths):
     import csv, collections
-    rows = list(csv.DictReader(open(path)))
+    rows = [r for p in paths for r in csv.DictReader(open(p))]
     per = collections.defaultdict(lambda: collections.defaultdict(list))      # kernel -> counter -> values in dispatch order
     for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
         per[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -77,6 +84,6 @@ def summarise(path):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
-        summarise(sys.argv[2])
+        summarise(sys.argv[2:])
     else:
         run()

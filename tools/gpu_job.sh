@@ -17,12 +17,15 @@ try:
 except Exception as e: print("$n","failed",e)
 PY
 }
-run s20 --no-cpu-baseline --no-flow-lines --streams 20
-run s24 --no-cpu-baseline --no-flow-lines --streams 24
-run s25 --no-cpu-baseline --no-flow-lines --streams 25 --max-hw-queues 32
-run s28 --no-cpu-baseline --no-flow-lines --streams 28 --max-hw-queues 32
-run s32 --no-cpu-baseline --no-flow-lines --streams 32 --max-hw-queues 32
-run s32q24 --no-cpu-baseline --no-flow-lines --streams 32
-run s40 --no-cpu-baseline --no-flow-lines --streams 40 --max-hw-queues 40
-run s24_400 --no-cpu-baseline --no-flow-lines --streams 24 --steps 480
-run s20b --no-cpu-baseline --no-flow-lines --streams 20
+run new_a --no-cpu-baseline --no-flow-lines
+run new_20 --no-cpu-baseline --no-flow-lines --steps 20 --warmup 5
+run new_c4 --config 4share --no-cpu-baseline --no-flow-lines
+cp zkp_amd/libzkp_mi355x.so /tmp/new.so; cp tools/ab/prev.so zkp_amd/libzkp_mi355x.so
+run prev_a --no-cpu-baseline --no-flow-lines
+run prev_20 --no-cpu-baseline --no-flow-lines --steps 20 --warmup 5
+run prev_c4 --config 4share --no-cpu-baseline --no-flow-lines
+run prev_b --no-cpu-baseline --no-flow-lines
+cp /tmp/new.so zkp_amd/libzkp_mi355x.so
+run new_b --no-cpu-baseline --no-flow-lines
+timeout 600 python -m pytest tests -m gpu -x -q > $O/${TAG}_pytest.txt 2>&1; echo "pytest rc=$?" >> $O/${TAG}_pytest.txt
+grep -E "passed|failed|rc=|Error|assert" $O/${TAG}_pytest.txt | tail -8

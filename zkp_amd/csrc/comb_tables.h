@@ -214,10 +214,7 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
 #pragma unroll 1
     for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
       if (w != cfg::WINDOWS - 1) {                              // (the accumulator is still the identity in the first window)
-        ge_double<false>(acc, acc);
-        ge_double<false>(acc, acc);
-        ge_double<false>(acc, acc);
-        ge_double<true>(acc, acc);
+        ge_double4(acc);
       }
 #pragma unroll 1
       for (int j = 0; j < TEETH; ++j) {
@@ -249,10 +246,7 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
 #pragma unroll 1
     for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
       if (w != cfg::WINDOWS - 1) {
-        ge_double<false>(acc, acc);
-        ge_double<false>(acc, acc);
-        ge_double<false>(acc, acc);
-        ge_double<true>(acc, acc);
+        ge_double4(acc);
       }
 #pragma unroll 1
       for (int j = 0; j < TEETH; ++j) {
@@ -321,10 +315,7 @@ __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restr
     uint32_t cur = ecol[256 * j];
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {
-      ge_double<false>(acc, acc);
-      ge_double<false>(acc, acc);
-      ge_double<false>(acc, acc);
-      ge_double<true>(acc, acc);
+      ge_double4(acc);
       const uint32_t nib = cur >> 28;
       cur <<= 4;
       const uint32_t neg = (uint32_t)(nib < 8u);

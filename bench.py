@@ -124,7 +124,7 @@ WORKLOADS = {
     # name: (description, [(statement label, statement fn, share of the batch, flows)], default batch, default streams (0 = auto), default steps)
     "2": ("CMZ'13 10-hidden-attribute credential, batch of %d proofs per GPU: complete proving (Merlin transcripts, blindings, 11 constant-time "
           "commitment MSMs / 31 terms per proof, challenges, responses) + complete batch verification of those proofs (transcripts, coefficient "
-          "build, one MSM of 12 + 24 N terms)", [(b"CMZ cred show n=10", cmz_statement, 1.0, ("prove", "batch_verify"))], 4096, 0, 200),
+          "build, one MSM of 12 + 24 N terms)", [(b"CMZ cred show n=10", cmz_statement, 1.0, ("prove", "batch_verify"))], 4096, 0, 1000),
     "3": ("BatchVerifier over %d mixed DLEQ proofs per GPU: half in define_proof! form (one MSM of 1 + 5 N terms), half in constraint-API form "
           "(static G, H: 2 + 4 N terms); complete batch verifications (transcripts, coefficient build, MSM incl. decompression)",
           [(b"DLEQ proof", dleq_macro_statement, 0.5, ("batch_verify",)), (b"DLEQProof", dleq_capi_statement, 0.5, ("batch_verify",))], 1 << 20, 2, 6),
@@ -251,7 +251,7 @@ def init_distributed(world, rank, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for --config 2, fewer for the large workloads)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 1000 for --config 2 = 0.8 s, fewer for the large workloads)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="2", choices=sorted(WORKLOADS), help="BASELINE.json workload (2 = configs[1], the metric's configuration)")
     ap.add_argument("--batch", type=int, default=None, help="proofs per GPU per step (default: the workload's)")

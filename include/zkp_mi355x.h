@@ -68,8 +68,15 @@ const char* zkp_version(void);
  *   ZKP_OPT_CT_SINGLE_USE_TABLES: how ZKP_CT calls serve a point that a single term multiplies.  1 = a comb table like the shared
  *     points (the 256 doublings run next to the other tables' chains: shortest call), 0 = a constant-time radix-16 ladder over
  *     the point's own eight multiples (26 % fewer instructions for that term, but a 321-operation dependent chain inside the
- *     term kernel), UINT64_MAX = default: tables in the synchronous entry points, the ladder in the asynchronous _dev ones. */
-enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3 };
+ *     term kernel), UINT64_MAX = default: the ladder in asynchronous _dev calls of 250,000 terms or more (a call that fills the
+ *     chip on its own), tables otherwise.
+ *   ZKP_OPT_DEV_OVERLAP: 1 = zkp_fused_prove_dev / _verify_compact_dev run the half of their work that does not depend on the
+ *     transcripts (decoding, classification, comb tables) on a second stream of the context, as the synchronous entry points
+ *     always do: a shorter call, more cross-stream dependencies.  Default 0.
+ *   ZKP_OPT_TRANSCRIPT_LANES: lanes per proof in the Merlin transcript kernel of the fused flows.  2 = a lane pair per proof
+ *     (each lane holds one 32-bit half of every STROBE word: half the latency), 1 = one lane per proof (23 % fewer
+ *     instructions per Keccak-f), UINT64_MAX = default: 1 in asynchronous _dev calls of 8192 proofs or more, 2 otherwise. */
+enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~75 short kernels; enqueueing them one by one costs the host ~0.15 ms per

@@ -6,7 +6,7 @@ no load/store was taken or skipped because of a scalar.
 
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES \\
               --output-format csv -d OUT -o ct -- python tools/ct_check.py
-    rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS \\
+    rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL \\
               --output-format csv -d OUT -o lds -- python tools/ct_check.py
     python tools/ct_check.py --summarise OUT/ct_counter_collection.csv OUT/lds_counter_collection.csv
 

@@ -17,15 +17,12 @@ try:
 except Exception as e: print("$n","failed",e)
 PY
 }
-run new_a --no-cpu-baseline --no-flow-lines
-run new_20 --no-cpu-baseline --no-flow-lines --steps 20 --warmup 5
-run new_c4 --config 4share --no-cpu-baseline --no-flow-lines
-cp zkp_amd/libzkp_mi355x.so /tmp/new.so; cp tools/ab/prev.so zkp_amd/libzkp_mi355x.so
-run prev_a --no-cpu-baseline --no-flow-lines
-run prev_20 --no-cpu-baseline --no-flow-lines --steps 20 --warmup 5
-run prev_c4 --config 4share --no-cpu-baseline --no-flow-lines
-run prev_b --no-cpu-baseline --no-flow-lines
-cp /tmp/new.so zkp_amd/libzkp_mi355x.so
-run new_b --no-cpu-baseline --no-flow-lines
-timeout 600 python -m pytest tests -m gpu -x -q > $O/${TAG}_pytest.txt 2>&1; echo "pytest rc=$?" >> $O/${TAG}_pytest.txt
-grep -E "passed|failed|rc=|Error|assert" $O/${TAG}_pytest.txt | tail -8
+A="--no-cpu-baseline --no-flow-lines"
+for i in 1 2 3; do
+run base_20_$i $A --steps 20 --warmup 5
+run ovl_20_$i $A --steps 20 --warmup 5 --engine-opt 5=1
+done
+for i in 1 2; do
+run base_1000_$i $A --steps 1000
+run ovl_1000_$i $A --steps 1000 --engine-opt 5=1
+done

@@ -40,7 +40,7 @@ __device__ __forceinline__ void keccak_f1600_split(uint32_t a[25], uint32_t h) {
   for (int round = 0; round < 24; ++round) {
     uint32_t c[5], b[25];
 #pragma unroll
-    for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+    for (int x = 0; x < 5; ++x) c[x] = tr_xor5_32(a[x], a[x + 5], a[x + 10], a[x + 15], a[x + 20]);
 #pragma unroll
     for (int x = 0; x < 5; ++x) {                       // theta: D[x] = C[x-1] ^ rotl(C[x+1], 1)
       const uint32_t cn = c[(x + 1) % 5];
@@ -147,6 +147,41 @@ k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t*
   for (int i = 0; i < 25; ++i) blob[2 * i + h] = col[TR_BLOCK * i];
   if (h == 0) { blob[50] = tail; blob[51] = 0; }
   if (bad && h == 0) failed[j] = 1;
+}
+
+// The same interpreter with ONE lane per proof (64-bit words, tr_exec_op): 208 instead of 2 x 135 VALU operations per Keccak
+// round and proof, and twice the latency -- the choice of the asynchronous _dev entry points, whose callers keep calls in
+// flight (ZKP_OPT_TRANSCRIPT_LANES).  State in LDS columns of uint64 (dynamic word index without scratch); the clone slots
+// have the pair kernel's layout.
+__global__ void __launch_bounds__(TR_BLOCK)
+k_transcript_run1(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t* __restrict__ tables, uint32_t N, const tr_bufs bufs,
+                  uint8_t* __restrict__ ts, uint64_t* __restrict__ saved /*[25][N]*/, uint32_t* __restrict__ failed, uint32_t tail) {
+  __shared__ uint64_t S[25 * TR_BLOCK];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t j_raw = blockIdx.x * TR_BLOCK + lane;
+  const bool live = j_raw < N;                          // lanes past the end shadow the last proof and store nothing
+  const uint32_t j = live ? j_raw : N - 1;
+  uint64_t* col = S + lane;
+  uint64_t* blob = reinterpret_cast<uint64_t*>(ts + 208 * (size_t)j);
+#pragma unroll
+  for (int i = 0; i < 25; ++i) col[TR_BLOCK * i] = blob[i];
+  uint32_t bad = 0;
+  for (uint32_t base = 0; base < n_ops; base += TR_BLOCK) {
+    const uint32_t cnt = n_ops - base < TR_BLOCK ? n_ops - base : TR_BLOCK;
+    uint4 mine = make_uint4(0, 0, 0, 0);
+    if (lane < cnt) mine = reinterpret_cast<const uint4*>(prog)[base + lane];
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t o_ctl = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)i);
+      const uint32_t o_stride = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)i);
+      const uint64_t o_off = (uint32_t)__builtin_amdgcn_readlane((int)mine.z, (int)i) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mine.w, (int)i) << 32;
+      tr_exec_op(tr_unpack(o_ctl, o_stride, o_off), tables, j, bufs, col, TR_BLOCK, saved + j, N, &bad, live);
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < 25; ++i) blob[i] = col[TR_BLOCK * i];
+  blob[25] = tail;
+  if (bad) failed[j] = 1;
 }
 
 // Scalar::from_bytes_mod_order_wide over n 64-byte strings
@@ -634,10 +669,17 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   return ZKP_OK;
 }
 
-void run_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed) {
-  constexpr uint32_t per_block = TR_BLOCK / 2;
-  if (p.n) hipLaunchKernelGGL(k_transcript_run, dim3((N + per_block - 1) / per_block), dim3(TR_BLOCK), 0, c->stream, p.ops, p.n, p.tables, N, bufs, d_ts,
-                              reinterpret_cast<uint32_t*>(d_saved), d_failed, p.tail);
+// throughput = the caller keeps calls in flight (_dev entry points): one lane per proof; otherwise a lane pair per proof
+void run_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput) {
+  if (!p.n) return;
+  const bool single = c->tr_lanes < 0 ? (throughput && N >= zkp_ctx::kWideCallProofs) : c->tr_lanes == 1;
+  if (single) {
+    hipLaunchKernelGGL(k_transcript_run1, dim3((N + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, c->stream, p.ops, p.n, p.tables, N, bufs, d_ts, d_saved, d_failed, p.tail);
+  } else {
+    constexpr uint32_t per_block = TR_BLOCK / 2;
+    hipLaunchKernelGGL(k_transcript_run, dim3((N + per_block - 1) / per_block), dim3(TR_BLOCK), 0, c->stream, p.ops, p.n, p.tables, N, bufs, d_ts,
+                       reinterpret_cast<uint32_t*>(d_saved), d_failed, p.tail);
+  }
 }
 
 // ---- side stream: the scalar-independent half of path A runs next to the transcripts -------------------------------------
@@ -696,7 +738,7 @@ prove_inter prove_carve(const fused_plan& pl, size_t start) {
   return o;
 }
 int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* d_ts, const uint8_t* d_sec, const uint8_t* d_tbl,
-               const uint8_t* d_ent, uint8_t* d_chal, uint8_t* d_resp, uint8_t* d_coms, uint8_t* d_st8, bool overlap) {
+               const uint8_t* d_ent, uint8_t* d_chal, uint8_t* d_resp, uint8_t* d_coms, uint8_t* d_st8, bool overlap, bool throughput) {
   const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
   const ws_view w{static_cast<char*>(c->ws)};
   tr_bufs hb{};
@@ -705,8 +747,8 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   uint64_t* d_saved = reinterpret_cast<uint64_t*>(w.base + o.saved);
   prof_begin(c);
   const size_t lanes = std::max<size_t>((size_t)N * T, (size_t)N * nc) + 1;
-  terms_cfg tk = cfg_from_terms(pl.tpt.data(), T, pl.s.ns, pl.s.np, N, c->ct_comb_min(!overlap));
-  tk.throughput = !overlap;
+  terms_cfg tk = cfg_from_terms(pl.tpt.data(), T, pl.s.ns, pl.s.np, N, c->ct_comb_min(throughput, (size_t)N * T));
+  tk.throughput = throughput;
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
   {   // side stream: operand indices, decode, classification, comb tables (nothing here depends on the blindings)
     hipStream_t main;
@@ -717,7 +759,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) return rc ? rc : rc2;
   }
-  run_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed));
+  run_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   if (m) hipLaunchKernelGGL(k_wide_reduce, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N * m, w.u8(o.wide), w.u8(o.blind));
   // the blindings are canonical (k_wide_reduce), so the halving the batched encoder wants is three instructions per limb here
@@ -733,7 +775,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
     if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_SCALARS, tk);
     if (rc) return rc;
   }
-  run_program(c, pl.b, N, hb, d_ts, d_saved, w.u32(o.failed));
+  run_program(c, pl.b, N, hb, d_ts, d_saved, w.u32(o.failed), throughput);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), d_chal);
   if (m) hipLaunchKernelGGL(k_responses, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N, m, d_sec, d_chal, w.u8(o.blind), d_resp);
@@ -761,7 +803,7 @@ verify_inter verify_carve(const fused_plan& pl, size_t start) {
   return o;
 }
 int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_claim,
-                const uint8_t* d_resp, uint8_t* d_results, bool overlap) {
+                const uint8_t* d_resp, uint8_t* d_results, bool overlap, bool throughput) {
   const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T1 = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
   const ws_view w{static_cast<char*>(c->ws)};
   tr_bufs hb{};
@@ -771,7 +813,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   prof_begin(c);
   const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
   terms_cfg tk = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2);
-  tk.throughput = !overlap;
+  tk.throughput = throughput;
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
   {   // side stream: operand indices and the point phase.  With no constraints there is no MSM, but every allocated
       // point must still decode (verifier.rs:87-92)
@@ -783,7 +825,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) return rc ? rc : rc2;
   }
-  run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed));
+  run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, d_claim, w.u8(o.mc));
   if (T1) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T1, 256), dim3(256), 0, c->stream, N, T1, m, pl.d_tarr + nc + 1, d_resp, w.u8(o.mc), w.u8(o.sc), 0u);
@@ -793,7 +835,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   if (rc) return rc;
   rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_SCALARS, tk);
   if (rc) return rc;
-  run_program(c, pl.b, N, hb, d_ts, nullptr, w.u32(o.failed));
+  run_program(c, pl.b, N, hb, d_ts, nullptr, w.u32(o.failed), throughput);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.chal));
   // the decoded point table is the first thing msm_terms_path carves after its reserved prefix
@@ -820,7 +862,8 @@ batch_inter batch_carve(const fused_plan& pl, size_t start) {
   return o;
 }
 int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* d_ts, uint8_t* d_pts, const uint8_t* d_coms,
-               const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_out, uint32_t* d_status /*[2]: MSM decode failure | transcript rejection*/) {
+               const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_out, uint32_t* d_status /*[2]: MSM decode failure | transcript rejection*/,
+               bool throughput) {
   const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni;
   const size_t total = (size_t)ns + ((size_t)ni + nc) * N;
   const ws_view w{static_cast<char*>(c->ws)};
@@ -831,7 +874,7 @@ int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* 
     hb.src[SRC_TABLE] = d_pts; hb.src[SRC_COMS] = d_coms;
     hb.dst[DST_CHAL] = w.u8(o.wchal);
     HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
-    run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed));
+    run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput);
     prof_mark(c, ZKP_K_TRANSCRIPT);
     hipLaunchKernelGGL(k_any_nonzero, grid1(N, 256), dim3(256), 0, c->stream, N, w.u32(o.failed), d_status + 1);
     hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.mc));
@@ -883,7 +926,7 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
   hb.dst[DST_CHAL] = w.u8(o.wchal);
   HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
   prof_begin(c);
-  run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed));
+  run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), false);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.mc));
   hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.mc), w.u8(o.mc));
@@ -994,9 +1037,9 @@ int zkp_fused_prove_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, u
     return fail(ZKP_ERR_ARG, "NULL device pointer");
   if ((uint64_t)N * s.T > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const prove_inter o = prove_carve(*pl, 0);
-  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min(true))));
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min(true, (size_t)N * s.T))));
   if (rc) return rc;
-  return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status, /*overlap=*/false);
+  return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status, /*overlap=*/c->dev_overlap, /*throughput=*/true);
 }
 
 int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
@@ -1027,7 +1070,7 @@ int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8
   const size_t o_chal = cv.take((size_t)N * 32);
   const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
   const prove_inter o = prove_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min(false))));
+  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min(false, (size_t)N * s.T))));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
@@ -1035,7 +1078,7 @@ int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8
   if (s.ns) HIP_TRY(hipMemcpyAsync(w.base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
   if (s.ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(w.base + o_ent, entropy, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
-  rc = prove_core(c, *pl, o, w.u8(o_ts), w.u8(o_sec), w.u8(o_tbl), w.u8(o_ent), w.u8(o_chal), w.u8(o_resp), w.u8(o_coms), w.u8(o_st), /*overlap=*/true);
+  rc = prove_core(c, *pl, o, w.u8(o_ts), w.u8(o_sec), w.u8(o_tbl), w.u8(o_ent), w.u8(o_chal), w.u8(o_resp), w.u8(o_coms), w.u8(o_st), /*overlap=*/true, /*throughput=*/false);
   if (rc) return rc;
   std::vector<uint8_t> status((size_t)N * nc);
   HIP_TRY(hipMemcpyAsync(challenges, w.base + o_chal, (size_t)N * 32, hipMemcpyDeviceToHost, c->stream));
@@ -1066,7 +1109,7 @@ int zkp_fused_verify_compact_dev(zkp_ctx* c, const zkp_fused_statement* st, uint
   const verify_inter o = verify_carve(*pl, 0);
   rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1, N * s.nc, cfg_from_terms(pl->tpt.data(), pl->T1, s.ns, s.np, N, 2)));
   if (rc) return rc;
-  return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results, /*overlap=*/false);
+  return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results, /*overlap=*/c->dev_overlap, /*throughput=*/true);
 }
 
 int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
@@ -1100,7 +1143,7 @@ int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t
   if (s.ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(w.base + o_claim, challenges, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
   if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  rc = verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res), /*overlap=*/true);
+  rc = verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res), /*overlap=*/true, /*throughput=*/false);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(results, w.base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
@@ -1126,7 +1169,7 @@ int zkp_fused_batch_verify_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32
   const batch_inter o = batch_carve(*pl, 0);
   rc = ensure_ws(c, o.end + optional_ws(total));
   if (rc) return rc;
-  return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_point, d_status);
+  return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_point, d_status, /*throughput=*/true);
 }
 
 int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
@@ -1169,7 +1212,7 @@ int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N
     }
     if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
   }
-  rc = batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st));
+  rc = batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st), /*throughput=*/false);
   if (rc) return rc;
   uint8_t out[32];
   uint32_t stv[2] = {1, 1};

@@ -84,6 +84,32 @@ ZKP_HD uint64_t tr_rotl_c(uint64_t v) {
 }
 #define tr_rotl(v, n) tr_rotl_c<n>(v)
 
+// a ^ b ^ c ^ d ^ e: on the GPU two v_bitop3_b32 (truth table 0x96) per 32-bit half instead of four v_xor_b32
+ZKP_HD uint32_t tr_xor5_32(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)__builtin_amdgcn_bitop3_b32(a, b, c, 0x96), d, e, 0x96);
+#else
+  return a ^ b ^ c ^ d ^ e;
+#endif
+}
+ZKP_HD uint64_t tr_xor5(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) {
+  return (uint64_t)tr_xor5_32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), (uint32_t)(d >> 32), (uint32_t)(e >> 32)) << 32 |
+         tr_xor5_32((uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d, (uint32_t)e);
+}
+
+// a ^ (~b & c)  (chi): one v_bitop3_b32 (truth table 0xD2 = 0xF0 ^ (~0xCC & 0xAA)) per half; left to itself the compiler
+// builds the 64-bit form from v_bfi_b32 + v_xor_b32
+ZKP_HD uint32_t tr_chi32(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return (uint32_t)__builtin_amdgcn_bitop3_b32(a, b, c, 0xD2);
+#else
+  return a ^ (~b & c);
+#endif
+}
+ZKP_HD uint64_t tr_chi(uint64_t a, uint64_t b, uint64_t c) {
+  return (uint64_t)tr_chi32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32)) << 32 | tr_chi32((uint32_t)a, (uint32_t)b, (uint32_t)c);
+}
+
 // The APPLY operation on a strided column (S[i * stride]): the block's constant table, then (permute) Keccak-f[1600]
 // with the 25 lanes held in registers for the 24 rounds.
 ZKP_HD void tr_apply_block(uint64_t* S, int stride, const uint64_t* tbl, bool permute) {
@@ -105,8 +131,8 @@ ZKP_HD void tr_apply_block(uint64_t* S, int stride, const uint64_t* tbl, bool pe
 #undef TR_T
 #pragma unroll 1
   for (int round = 0; round < (permute ? 24 : 0); ++round) {
-    const uint64_t c0 = a00 ^ a01 ^ a02 ^ a03 ^ a04, c1 = a10 ^ a11 ^ a12 ^ a13 ^ a14, c2 = a20 ^ a21 ^ a22 ^ a23 ^ a24,
-                   c3 = a30 ^ a31 ^ a32 ^ a33 ^ a34, c4 = a40 ^ a41 ^ a42 ^ a43 ^ a44;
+    const uint64_t c0 = tr_xor5(a00, a01, a02, a03, a04), c1 = tr_xor5(a10, a11, a12, a13, a14), c2 = tr_xor5(a20, a21, a22, a23, a24),
+                   c3 = tr_xor5(a30, a31, a32, a33, a34), c4 = tr_xor5(a40, a41, a42, a43, a44);
     const uint64_t d0 = c4 ^ tr_rotl(c1, 1), d1 = c0 ^ tr_rotl(c2, 1), d2 = c1 ^ tr_rotl(c3, 1), d3 = c2 ^ tr_rotl(c4, 1),
                    d4 = c3 ^ tr_rotl(c0, 1);
     a00 ^= d0; a01 ^= d0; a02 ^= d0; a03 ^= d0; a04 ^= d0;
@@ -119,11 +145,11 @@ ZKP_HD void tr_apply_block(uint64_t* S, int stride, const uint64_t* tbl, bool pe
     const uint64_t b04 = tr_rotl(a20, 62),  b12 = tr_rotl(a21, 6),  b20 = tr_rotl(a22, 43), b33 = tr_rotl(a23, 15), b41 = tr_rotl(a24, 61);
     const uint64_t b01 = tr_rotl(a30, 28),  b14 = tr_rotl(a31, 55), b22 = tr_rotl(a32, 25), b30 = tr_rotl(a33, 21), b43 = tr_rotl(a34, 56);
     const uint64_t b03 = tr_rotl(a40, 27),  b11 = tr_rotl(a41, 20), b24 = tr_rotl(a42, 39), b32 = tr_rotl(a43, 8),  b40 = tr_rotl(a44, 14);
-    a00 = b00 ^ (~b10 & b20); a10 = b10 ^ (~b20 & b30); a20 = b20 ^ (~b30 & b40); a30 = b30 ^ (~b40 & b00); a40 = b40 ^ (~b00 & b10);
-    a01 = b01 ^ (~b11 & b21); a11 = b11 ^ (~b21 & b31); a21 = b21 ^ (~b31 & b41); a31 = b31 ^ (~b41 & b01); a41 = b41 ^ (~b01 & b11);
-    a02 = b02 ^ (~b12 & b22); a12 = b12 ^ (~b22 & b32); a22 = b22 ^ (~b32 & b42); a32 = b32 ^ (~b42 & b02); a42 = b42 ^ (~b02 & b12);
-    a03 = b03 ^ (~b13 & b23); a13 = b13 ^ (~b23 & b33); a23 = b23 ^ (~b33 & b43); a33 = b33 ^ (~b43 & b03); a43 = b43 ^ (~b03 & b13);
-    a04 = b04 ^ (~b14 & b24); a14 = b14 ^ (~b24 & b34); a24 = b24 ^ (~b34 & b44); a34 = b34 ^ (~b44 & b04); a44 = b44 ^ (~b04 & b14);
+    a00 = tr_chi(b00, b10, b20); a10 = tr_chi(b10, b20, b30); a20 = tr_chi(b20, b30, b40); a30 = tr_chi(b30, b40, b00); a40 = tr_chi(b40, b00, b10);
+    a01 = tr_chi(b01, b11, b21); a11 = tr_chi(b11, b21, b31); a21 = tr_chi(b21, b31, b41); a31 = tr_chi(b31, b41, b01); a41 = tr_chi(b41, b01, b11);
+    a02 = tr_chi(b02, b12, b22); a12 = tr_chi(b12, b22, b32); a22 = tr_chi(b22, b32, b42); a32 = tr_chi(b32, b42, b02); a42 = tr_chi(b42, b02, b12);
+    a03 = tr_chi(b03, b13, b23); a13 = tr_chi(b13, b23, b33); a23 = tr_chi(b23, b33, b43); a33 = tr_chi(b33, b43, b03); a43 = tr_chi(b43, b03, b13);
+    a04 = tr_chi(b04, b14, b24); a14 = tr_chi(b14, b24, b34); a24 = tr_chi(b24, b34, b44); a34 = tr_chi(b34, b44, b04); a44 = tr_chi(b44, b04, b14);
     a00 ^= RC[round];
   }
   S[0 * stride] = a00; S[1 * stride] = a10; S[2 * stride] = a20; S[3 * stride] = a30; S[4 * stride] = a40;
@@ -150,38 +176,46 @@ ZKP_HD uint8_t* tr_dst_ptr(const tr_bufs& b, uint32_t i) {
 
 ZKP_HD uint64_t tr_bytemask(uint32_t nb) { return nb >= 8 ? ~0ULL : ((1ULL << (8 * nb)) - 1); }
 
-// Runs the program for proof j on the state column S (stride in words).  `saved` = this proof's clone slot
+// One operation of a program for proof j on the state column S (stride in words).  `saved` = this proof's clone slot
 // (saved[i * saved_stride]); *failed is set when a checked encoding is all zero (mod.rs:191, :215).
-// This is the reference semantics of a program (and what the host tests run); the GPU kernel k_transcript_run in
-// fused_flows.h implements the same operations on 32-bit half-words split across lane pairs.
-ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, const uint64_t* tables, uint64_t j, const tr_bufs& bufs, uint64_t* S,
-                       int stride, uint64_t* saved, size_t saved_stride, uint32_t* failed) {
-  for (uint32_t q = 0; q < n_ops; ++q) {
-    const tr_fields op = tr_unpack(prog[q].ctl, prog[q].stride, prog[q].off);
-    if (op.flags & TR_RESTORE)
-      for (int i = 0; i < 25; ++i) S[i * stride] = saved[i * saved_stride];
-    if (op.flags & TR_CHECK_NONZERO) {
-      const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + j * op.stride + op.off);
-      if ((p[0] | p[1] | p[2] | p[3]) == 0) *failed = 1;
-    }
-    if (op.dst_buf) {
-      uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + j * op.stride + op.off;
-      const uint64_t e = S[op.w * stride] >> (8 * op.dlb);
+// This is the reference semantics of a program: the host tests run it (tr_run_one), the GPU runs it one lane per proof in
+// k_transcript_run1 and, on 32-bit half-words split across lane pairs, in k_transcript_run (fused_flows.h).
+ZKP_HD void tr_exec_op(const tr_fields& op, const uint64_t* tables, uint64_t j, const tr_bufs& bufs, uint64_t* S, int stride,
+                       uint64_t* saved, size_t saved_stride, uint32_t* failed, bool store) {
+  if (op.flags & TR_RESTORE)
+    for (int i = 0; i < 25; ++i) S[i * stride] = saved[i * saved_stride];
+  if (op.flags & TR_CHECK_NONZERO) {
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + j * op.stride + op.off);
+    if ((p[0] | p[1] | p[2] | p[3]) == 0) *failed = 1;
+  }
+  if (op.dst_buf && store) {
+    uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + j * op.stride + op.off;
+    const uint64_t e = S[op.w * stride] >> (8 * op.dlb);
+    if (op.dnb == 8) {
+      __builtin_memcpy(d, &e, 8);
+    } else if (op.dnb == 4) {
+      const uint32_t e4 = (uint32_t)e;
+      __builtin_memcpy(d, &e4, 4);
+    } else {
       for (uint32_t i = 0; i < op.dnb; ++i) d[i] = (uint8_t)(e >> (8 * i));
     }
-    if (op.src_buf && !(op.flags & TR_CHECK_NONZERO)) {
-      const uint64_t addr = j * op.stride + op.off;
-      const uint32_t sh = (uint32_t)(addr & 7);
-      const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
-      uint64_t x = p[0] >> (8 * sh);
-      if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
-      x = (x & tr_bytemask(op.nb)) << (8 * op.lb);
-      S[op.w * stride] = (S[op.w * stride] & op.keep) ^ x;
-    }
-    if (op.flags & TR_APPLY) tr_apply_block(S, stride, tables + (size_t)TR_TABLE_WORDS * op.off, (op.flags & TR_PERMUTE) != 0);
-    if (op.flags & TR_SAVE)
-      for (int i = 0; i < 25; ++i) saved[i * saved_stride] = S[i * stride];
   }
+  if (op.src_buf && !(op.flags & TR_CHECK_NONZERO)) {
+    const uint64_t addr = j * op.stride + op.off;
+    const uint32_t sh = (uint32_t)(addr & 7);
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
+    uint64_t x = p[0] >> (8 * sh);
+    if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
+    x = (x & tr_bytemask(op.nb)) << (8 * op.lb);
+    S[op.w * stride] = (S[op.w * stride] & op.keep) ^ x;
+  }
+  if (op.flags & TR_APPLY) tr_apply_block(S, stride, tables + (size_t)TR_TABLE_WORDS * op.off, (op.flags & TR_PERMUTE) != 0);
+  if ((op.flags & TR_SAVE) && store)
+    for (int i = 0; i < 25; ++i) saved[i * saved_stride] = S[i * stride];
+}
+ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, const uint64_t* tables, uint64_t j, const tr_bufs& bufs, uint64_t* S,
+                       int stride, uint64_t* saved, size_t saved_stride, uint32_t* failed) {
+  for (uint32_t q = 0; q < n_ops; ++q) tr_exec_op(tr_unpack(prog[q].ctl, prog[q].stride, prog[q].off), tables, j, bufs, S, stride, saved, saved_stride, failed, true);
 }
 
 }  // namespace zkp

@@ -953,7 +953,15 @@ struct zkp_ctx {
   // caller sees, give single-use points a table; the asynchronous _dev entry points, whose callers keep many calls in flight
   // and are bound by instruction issue, take the ladder.  -1 = that rule (default), 0 = ladder, 1 = tables.
   int ct_single_use_tables = -1;
-  uint32_t ct_comb_min(bool throughput) const { return ct_single_use_tables < 0 ? (throughput ? 2u : 1u) : (ct_single_use_tables ? 1u : 2u); }
+  bool dev_overlap = false;          // ZKP_OPT_DEV_OVERLAP: the _dev flows fork their scalar-independent half onto the side stream too
+  int tr_lanes = -1;                 // ZKP_OPT_TRANSCRIPT_LANES: -1 = by entry point, 1 = one lane per proof, 2 = a lane pair per proof
+  // The instruction-saving variants of the asynchronous entry points (ladder for single-use points, one transcript lane per
+  // proof) lengthen a call's narrow kernels; they pay once a single call fills the chip.  Measured on CMZ batches
+  // (profiles/r02_ab_experiments.txt): 4096 proofs (127 k terms) -1 % / 0 %, 16384 proofs (508 k terms) +7 % / +2.5 %.
+  static constexpr size_t kWideCallTerms = 250000, kWideCallProofs = 8192;
+  uint32_t ct_comb_min(bool throughput, size_t n_terms) const {
+    return ct_single_use_tables < 0 ? (throughput && n_terms >= kWideCallTerms ? 2u : 1u) : (ct_single_use_tables ? 1u : 2u);
+  }
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool profiling = false;
@@ -1403,6 +1411,11 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
   switch (option) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
     case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_single_use_tables = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
+    case ZKP_OPT_DEV_OVERLAP: c->dev_overlap = value != 0; return ZKP_OK;
+    case ZKP_OPT_TRANSCRIPT_LANES:
+      if (value != ~0ull && value != 1 && value != 2) return fail(ZKP_ERR_ARG, "ZKP_OPT_TRANSCRIPT_LANES: 1, 2 or UINT64_MAX");
+      c->tr_lanes = value == ~0ull ? -1 : (int)value;
+      return ZKP_OK;
     case ZKP_OPT_COMB_TEETH:
       if (value != 4 && value != 16) return fail(ZKP_ERR_ARG, "ZKP_OPT_COMB_TEETH must be 4 or 16");
       c->comb_teeth = (int)value;
@@ -1588,7 +1601,7 @@ int zkp_msm_many_dev(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const ui
   terms_cfg k;                               // the device arrays are not inspected on the host: generic bounds
   k.teeth = c->comb_teeth;
   k.throughput = true;
-  k.comb_min = flags == ZKP_CT ? c->ct_comb_min(true) : 2u;
+  k.comb_min = flags == ZKP_CT ? c->ct_comb_min(true, n_terms) : 2u;
   const int rc = ensure_ws(c, terms_path_ws(n_points, n_terms, n_msm, k));
   if (rc) return rc;
   prof_begin(c);
@@ -1609,7 +1622,7 @@ int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t*
   for (uint32_t t = 0; t < n_terms; ++t)
     if (pidx[t] >= n_points) return fail(ZKP_ERR_ARG, "pidx out of range");
   HIP_TRY(hipSetDevice(c->device));
-  const terms_cfg k = n_terms >= 1024 ? host_terms_cfg(c, n_terms, pidx, points, n_points, flags == ZKP_CT ? c->ct_comb_min(false) : 2u) : terms_cfg();
+  const terms_cfg k = n_terms >= 1024 ? host_terms_cfg(c, n_terms, pidx, points, n_points, flags == ZKP_CT ? c->ct_comb_min(false, n_terms) : 2u) : terms_cfg();
   carve cv;
   const size_t o_off = cv.take((size_t)(n_msm + 1) * 4);
   const size_t o_sc = cv.take((size_t)n_terms * 32);

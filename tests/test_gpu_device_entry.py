@@ -215,16 +215,19 @@ def test_hip_graph_replay_equals_direct_calls(eng):
     e.close()
 
 
-@pytest.mark.parametrize("single_use_tables", [0, 1])
-def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_tables):
+@pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_tables, grouped):
     """ZKP_OPT_CT_SINGLE_USE_TABLES: a constant-time call serves a point that only one term multiplies either through a comb
     table (default when the call has shared points) or through the masked radix-16 ladder; both must give the oracle's bytes.
-    CMZ shape (Q is the single-use point) and a DLEQ-like shape without any shared point (always the ladder)."""
+    CMZ shape (Q is the single-use point) and a DLEQ-like shape without any shared point (always the ladder).
+    grouped = ZKP_OPT_GROUPED_COMB: the terms of points with 8 or more uses walk the point's comb table through LDS (the
+    default of large calls), forced here at sizes that leave blocks partly filled and columns with 2 and 3 tables."""
     from zkp_amd.engine import Engine
     import bench
     rng = np.random.default_rng(12)
     e = Engine(0)
     e.set_option(3, single_use_tables)
+    e.set_option(6, grouped)
     n = 80
     off, pidx, n_pts = bench.cmz_shape(n)
     ks = rng.integers(0, 256, size=(n_pts, 32), dtype=np.uint8)
@@ -238,6 +241,14 @@ def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_ta
     got, st = e.msm_many(off, sc, pidx, pts, 1)
     want, wst = C.msm_many(off, sc, pidx, pts, 1)
     assert (st == wst).all() and (got == want).all()
+    # the same with two proofs whose P does not decode: the ten MSMs on it report status 1, the others are unaffected
+    bad = pts.copy()
+    p_rows = sorted({int(v) for v in pidx if np.count_nonzero(pidx == v) >= 10 and v >= 11})
+    assert len(p_rows) == n                                           # the per-proof P of every proof
+    bad[p_rows[3]] = 0xff; bad[p_rows[41], 0] ^= 1
+    got, st = e.msm_many(off, sc, pidx, bad, 1)
+    want, wst = C.msm_many(off, sc, pidx, bad, 1)
+    assert wst.sum() >= 10 and (st == wst).all() and (got[wst == 0] == want[wst == 0]).all()
     # 1,200 two-term MSMs  x G + y H_j : G shared by all (comb table), every H_j used once
     m = 1200
     km = rng.integers(0, 256, size=(m + 1, 32), dtype=np.uint8)

@@ -44,18 +44,34 @@ __device__ __forceinline__ void q_store_cached(dev_ext* dst, const qcached& c, i
 
 // slot_of[p] = compact table index of every point with >= comb_min cold uses (wave-aggregated counter: one device-scope
 // atomic per wavefront); slot_pt[slot] = p.  The order of the slots is irrelevant to the results.
+// Points with >= group_min uses also reserve uses[p] consecutive places of the CLASS_GROUP list: group_start[p] (a wavefront
+// scan of the use counts + one atomic per wavefront on counter[1]).
 __global__ void __launch_bounds__(256)
-k_comb_slots(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t max_tables,
-             uint32_t* __restrict__ counter, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ slot_pt, dev_affine* __restrict__ pts) {
+k_comb_slots(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t group_min, uint32_t max_tables,
+             uint32_t* __restrict__ counter, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ slot_pt, uint32_t* __restrict__ group_start,
+             dev_affine* __restrict__ pts) {
   const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool want = pi < n_points && uses[pi] >= comb_min;
+  const uint32_t u = pi < n_points ? uses[pi] : 0u;
+  const bool want = pi < n_points && u >= comb_min;
   const uint64_t mask = __ballot(want);
   if (!mask) return;
   const uint32_t lane = threadIdx.x & 63u;
   const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  const uint32_t gu = (want && u >= group_min) ? u : 0u;
+  uint32_t incl = gu;                                          // inclusive scan of the grouped use counts over the wavefront
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+    if ((int)lane >= d) incl += up;
+  }
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+  uint32_t base = 0, gbase = 0;
+  if ((int)lane == leader) {
+    base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    if (total) gbase = atomicAdd(counter + 1, total);
+  }
   base = (uint32_t)__shfl((int)base, leader);
+  gbase = (uint32_t)__shfl((int)gbase, leader);
   if (want) {
     const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     // max_tables is an upper bound by construction (derived from the statement, or from the call's own index arrays); a
@@ -64,6 +80,7 @@ k_comb_slots(uint32_t n_points, const uint32_t* __restrict__ uses, uint32_t comb
     slot_of[pi] = slot < max_tables ? slot : 0xffffffffu;
     if (slot < max_tables) slot_pt[slot] = pi;
     else pts[pi].valid = 0;
+    if (gu) group_start[pi] = gbase + incl - gu;
   }
 }
 
@@ -269,6 +286,149 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
     ge_add_cached(acc, acc, sel);
   }
   store_ext(partial + t, acc);
+}
+
+// ---- grouped comb terms: the table rows pass through LDS, every lane reads the entry its digit names --------------------
+// The constant-time walk above pays 72 loads + 288 v_cndmask per addition to hide WHICH of a row's 8 entries a lane wants.
+// LDS can hide it for free (hot_tables.h): a ds_read_b128 is serviced in four groups of 16 lanes with distinct lane mod 16, so
+// if lane l only ever touches "column" l mod 16 of the LDS (the 16-byte slot l mod 16 of every 256-byte bank row), no two lanes
+// of a service group meet on a bank whatever addresses they use.  A column serves 16 lanes of a 256-lane block (tid mod 16
+// equal).  The terms of a point with >= GROUP_MIN_USES = 8 cold uses are listed next to each other (CLASS_GROUP, k_comb_slots
+// / k_class_scatter), and column c takes 16 CONSECUTIVE list entries: they belong to at most 3 points (a run strictly inside
+// the 16 has >= 8 entries), so per (window, tooth) step the column holds that row of at most 3 tables: 3 x 8 entries x 144 B,
+// x 16 columns = 54 KB.  The block fetches the rows (each 16-byte chunk ONCE per block and step instead of once per lane: 10 x
+// less L1/L2 traffic for CMZ's P) straight into LDS, one step ahead, while the lanes add.
+// Per addition and lane: 15 LDS-DMA loads + 9 LDS reads instead of 72 loads + 288 selects.
+constexpr int GROUP_RUNS = 3, GROUP_ROW_CHUNKS = 8 * 9, GROUP_IDENT_ROW = GROUP_RUNS * GROUP_ROW_CHUNKS, GROUP_CHUNK_ROWS = GROUP_IDENT_ROW + 9;
+constexpr int GROUP_LDS_UINT4 = GROUP_CHUNK_ROWS * 16 + (256 + 16 * GROUP_RUNS) / 4;      // rows | slots[256] | colslot[16][3]
+static_assert(GROUP_MIN_USES >= 8, "a column of 16 consecutive grouped terms must span at most GROUP_RUNS points");
+
+__device__ __forceinline__ void comb_group_block(uint32_t i0, uint32_t n_g, const uint32_t* __restrict__ list_g, const uint8_t* __restrict__ scalars,
+                                                 const uint32_t* __restrict__ pidx, const uint32_t* __restrict__ slot_of,
+                                                 const dev_ext* __restrict__ comb, dev_ext* __restrict__ partial, uint4* lds) {
+  using cfg = comb_cfg<16>;
+  constexpr uint32_t NONE = 0xffffffffu;
+  const uint32_t tid = threadIdx.x, col = tid & 15u, k = tid >> 4;
+  const uint32_t i = i0 + col * 16 + k;                            // column col takes list entries i0 + 16 col .. + 15
+  const bool listed = i < n_g;
+  uint32_t t = 0, slot = NONE;
+  if (listed) { t = list_g[i]; slot = slot_of[pidx[t]]; }           // (a grouped term's point index is in range by construction)
+  uint32_t* slots = reinterpret_cast<uint32_t*>(lds + GROUP_CHUNK_ROWS * 16);
+  uint32_t* colslot = slots + 256;
+  slots[k * 16 + col] = slot;                                      // (entry k of column col at 16 k + col: a wavefront's reads below meet no bank twice)
+  if (k < (uint32_t)GROUP_RUNS) colslot[col * GROUP_RUNS + k] = NONE;
+  if (k < 9) {                                                     // the identity in table form (Y-X, Y+X, 2Z, 2dT) = (1, 1, 2, 0), per column
+    uint32_t w[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) w[q] = (q == 0 || q == 9) ? 1u : (q == 18 ? 2u : 0u);
+    uint4 v = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) if (k == (uint32_t)q) v = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    lds[(GROUP_IDENT_ROW + k) * 16 + col] = v;
+  }
+  __syncthreads();
+  uint32_t run = 0;                                                // which of the column's runs of equal slots this lane is in
+  bool first = true;
+#pragma unroll
+  for (uint32_t kk = 1; kk < 16; ++kk) {
+    const bool change = slots[kk * 16 + col] != slots[(kk - 1) * 16 + col];
+    if (kk <= k) { run += change ? 1u : 0u; if (kk == k) first = change; }
+  }
+  if (first && run < (uint32_t)GROUP_RUNS) colslot[col * GROUP_RUNS + run] = slot;
+  __syncthreads();
+  const bool live = listed && slot != NONE && run < (uint32_t)GROUP_RUNS;     // (run < 3 always: see above)
+  // this lane's part of the staging: chunks k, k + 16, .. of the row of each of the column's tables
+  const uint4* src[GROUP_RUNS];
+  bool have[GROUP_RUNS];
+#pragma unroll
+  for (int r = 0; r < GROUP_RUNS; ++r) {
+    const uint32_t sr = colslot[col * GROUP_RUNS + r];
+    have[r] = sr != NONE;
+    src[r] = reinterpret_cast<const uint4*>(comb + (size_t)(have[r] ? sr : 0u) * cfg::ENTRIES) + k;
+  }
+  const bool tail = k < (uint32_t)(GROUP_ROW_CHUNKS - 64);         // chunk k + 64 exists for k < 8
+  // Rows travel global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write): a wavefront instruction
+  // writes LDS at a wave-uniform base + 16 x lane, and with lane = 16 (k mod 4) + col the four chunk rows 4 wave .. 4 wave + 3
+  // (+ 16 m) of the column-interleaved layout ARE contiguous in lane order.
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  auto issue = [&](uint32_t row) {                                 // row = tooth: its 8 entries are chunks 72 row .. 72 row + 71 of a table
+#pragma unroll
+    for (int r = 0; r < GROUP_RUNS; ++r) {
+      const uint4* p = src[r] + (size_t)row * GROUP_ROW_CHUNKS;
+      uint4* d = lds + (size_t)(r * GROUP_ROW_CHUNKS + 4 * wave) * 16;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (have[r]) __builtin_amdgcn_global_load_lds((gptr_t)(p + 16 * m), (lptr_t)(d + 16 * 16 * m), 16, 0, 0);
+      if (have[r] && tail) __builtin_amdgcn_global_load_lds((gptr_t)(p + 64), (lptr_t)(d + 16 * 64), 16, 0, 0);
+    }
+  };
+  // the scalar: signed radix-16 digits nibble - 8; D[w] = the 16 nibbles window w of the 16 teeth, tooth 0 lowest
+  uint32_t dlo[cfg::WINDOWS], dhi[cfg::WINDOWS], top = 0;
+  {
+    uint32_t sc[8], e[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sc[q] = 0;
+    if (live) load_vec<2>(sc, scalars + 32 * (size_t)t);
+    sc_add_pattern(e, top, sc, 0x88888888u);
+#pragma unroll
+    for (int w = 0; w < cfg::WINDOWS; ++w) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {                                // word m holds teeth 2m (low half) and 2m + 1
+        lo |= (((e[m] >> (4 * w)) & 0xfu) | ((e[m] >> (12 + 4 * w)) & 0xf0u)) << (8 * m);
+        hi |= (((e[m + 4] >> (4 * w)) & 0xfu) | ((e[m + 4] >> (12 + 4 * w)) & 0xf0u)) << (8 * m);
+      }
+      dlo[w] = lo; dhi[w] = hi;
+    }
+  }
+  ge_p3 acc;
+  ge_identity(acc);
+  issue(0);
+#pragma unroll 1
+  for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
+    if (live && w != cfg::WINDOWS - 1) ge_double4(acc);            // (the accumulator is still the identity in the first window)
+    uint32_t clo = dlo[0], chi = dhi[0];
+#pragma unroll
+    for (int q = 1; q < cfg::WINDOWS; ++q) { clo = (w == q) ? dlo[q] : clo; chi = (w == q) ? dhi[q] : chi; }
+#pragma unroll 1
+    for (int j = 0; j < 16; ++j) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // this step's rows have landed, for every wavefront's part
+      ge_cached sel;
+      uint32_t neg = 0;
+      if (live) {
+        const uint32_t nib = clo & 15u;
+        clo = __builtin_amdgcn_alignbit(chi, clo, 4);
+        chi >>= 4;
+        neg = (uint32_t)(nib < 8u);
+        const uint32_t mag = neg ? 8u - nib : nib - 8u;            // 0..8
+        const uint32_t row = mag ? run * GROUP_ROW_CHUNKS + (mag - 1u) * 9u : (uint32_t)GROUP_IDENT_ROW;
+        const uint4* ent = lds + (size_t)row * 16 + col;
+        uint32_t wd[36];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const uint4 x = ent[q * 16];
+          wd[4 * q + 0] = x.x; wd[4 * q + 1] = x.y; wd[4 * q + 2] = x.z; wd[4 * q + 3] = x.w;
+        }
+        fe_set(sel.YmX, wd); fe_set(sel.YpX, wd + 9); fe_set(sel.Z2, wd + 18); fe_set(sel.T2d, wd + 27);
+      }
+      lds_barrier();                                               // every lane holds its entry: the rows may be replaced
+      if (w != 0 || j != 15) issue((uint32_t)((j + 1) & 15));      // next step's rows arrive during the addition
+      if (live) {
+        ge_cached_cneg(sel, neg);
+        ge_add_cached(acc, acc, sel);
+      }
+    }
+  }
+  if (live) {
+    ge_cached sel, c;
+    ge_cached_identity(sel);
+    load_comb_entry(c, comb + (size_t)slot * cfg::ENTRIES + 8 * 16);     // carry out of bit 255: 2^256 * P
+    ge_cached_cmov(sel, c, top);
+    ge_add_cached(acc, acc, sel);
+    store_ext(partial + t, acc);
+  }
 }
 
 // partial[t] = scalars[t] * P for a point that no other cold term of the call uses (a constraint's left-hand side in

@@ -32,8 +32,9 @@ constexpr int HOT_WINDOWS = (257 + HOT_W - 1) / HOT_W;           // 65, 52, 43
 constexpr int HOT_HALF = 1 << (HOT_W - 1);                       // digits in [-HOT_HALF, HOT_HALF - 1]
 constexpr int HOT_ROW = HOT_HALF + 1;                            // entries per row: k * base for k = 0 (identity) .. HOT_HALF
 constexpr int HOT_SLOTS = 64;
-constexpr int HOT_CLASSES = HOT_SLOTS + 2;                       // class 64 = "cold" terms through a comb table, 65 = cold terms on a ladder
-constexpr int CLASS_COMB = HOT_SLOTS, CLASS_LADDER = HOT_SLOTS + 1;
+constexpr int HOT_CLASSES = HOT_SLOTS + 3;                       // class 64 = "cold" terms through a comb table, 65 = cold terms on a ladder,
+constexpr int CLASS_COMB = HOT_SLOTS, CLASS_LADDER = HOT_SLOTS + 1, CLASS_GROUP = HOT_SLOTS + 2;   // 66 = comb terms listed point by point
+constexpr uint32_t GROUP_MIN_USES = 8;                           // a point's terms form a group from this many cold uses on (comb_tables.h)
 constexpr size_t HOT_SLOT_NIELS = (size_t)HOT_WINDOWS * HOT_ROW;
 constexpr int HOT_ROW_CHUNKS = HOT_ROW * (int)(sizeof(dev_niels) / 16);   // 16-byte chunks per row
 constexpr int HOT_COPIES = 16;
@@ -182,22 +183,26 @@ k_use_count(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_poin
   const uint32_t pi = pidx[t];
   if (pi < n_points && hotmap[pi] < 0) atomicAdd(&uses[pi], 1u);
 }
+// group_min: from this many cold uses on, the terms of a point are listed together (CLASS_GROUP) and walk its table through
+// LDS (comb_group_block); 0xffffffff = no such class in this call.
 __device__ __forceinline__ uint32_t term_class(uint32_t t, const uint32_t* pidx, uint32_t n_points, const int32_t* hotmap,
-                                               const uint32_t* uses, uint32_t comb_min) {
+                                               const uint32_t* uses, uint32_t comb_min, uint32_t group_min) {
   const uint32_t pi = pidx[t];
   if (pi >= n_points) return (uint32_t)CLASS_COMB;                  // out of range: flagged by k_reduce_encode
   const int32_t s = hotmap[pi];
   if (s >= 0) return (uint32_t)s;
-  return uses[pi] >= comb_min ? (uint32_t)CLASS_COMB : (uint32_t)CLASS_LADDER;
+  const uint32_t u = uses[pi];
+  if (u >= group_min) return (uint32_t)CLASS_GROUP;
+  return u >= comb_min ? (uint32_t)CLASS_COMB : (uint32_t)CLASS_LADDER;
 }
 __global__ void __launch_bounds__(256)
 k_class_count(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_points, const int32_t* __restrict__ hotmap,
-              const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t* __restrict__ class_cnt) {
+              const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t group_min, uint32_t* __restrict__ class_cnt) {
   __shared__ uint32_t h[HOT_CLASSES];
   if (threadIdx.x < HOT_CLASSES) h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n_terms) atomicAdd(&h[term_class(t, pidx, n_points, hotmap, uses, comb_min)], 1u);
+  if (t < n_terms) atomicAdd(&h[term_class(t, pidx, n_points, hotmap, uses, comb_min, group_min)], 1u);
   __syncthreads();
   if (threadIdx.x < HOT_CLASSES && h[threadIdx.x]) atomicAdd(&class_cnt[threadIdx.x], h[threadIdx.x]);
 }
@@ -215,20 +220,34 @@ __global__ void k_class_scan(const uint32_t* __restrict__ class_cnt, uint32_t* _
   class_start[HOT_CLASSES] = run;
   blk_start[HOT_SLOTS] = blk;
 }
+// group_start[p] = offset of point p's terms inside the CLASS_GROUP segment (k_comb_slots), group_fill[p] = 0 on entry: the
+// terms of a grouped point land next to each other, in any order
 __global__ void __launch_bounds__(256)
 k_class_scatter(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_points, const int32_t* __restrict__ hotmap,
-                const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t* __restrict__ cursor, uint32_t* __restrict__ list) {
+                const uint32_t* __restrict__ uses, uint32_t comb_min, uint32_t group_min, const uint32_t* __restrict__ class_start,
+                const uint32_t* __restrict__ group_start, uint32_t* __restrict__ group_fill, uint32_t* __restrict__ cursor,
+                uint32_t* __restrict__ list) {
   __shared__ uint32_t h[HOT_CLASSES];
   __shared__ uint32_t base[HOT_CLASSES];
   if (threadIdx.x < HOT_CLASSES) h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t c = 0, rank = 0;
-  if (t < n_terms) { c = term_class(t, pidx, n_points, hotmap, uses, comb_min); rank = atomicAdd(&h[c], 1u); }
+  if (t < n_terms) {
+    c = term_class(t, pidx, n_points, hotmap, uses, comb_min, group_min);
+    if (c != (uint32_t)CLASS_GROUP) rank = atomicAdd(&h[c], 1u);
+  }
   __syncthreads();
   if (threadIdx.x < HOT_CLASSES && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
   __syncthreads();
-  if (t < n_terms) list[base[c] + rank] = t;
+  if (t < n_terms) {
+    if (c == (uint32_t)CLASS_GROUP) {
+      const uint32_t pi = pidx[t];
+      list[class_start[CLASS_GROUP] + group_start[pi] + atomicAdd(&group_fill[pi], 1u)] = t;
+    } else {
+      list[base[c] + rank] = t;
+    }
+  }
 }
 
 // ---- the fixed-base terms of one block (256 lanes, one table) ----------------------------------------------------------

@@ -144,12 +144,14 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   // A block of fixed-base terms serves ONE table; its rows pass through LDS one window at a time, in 16 copies, so that every
   // lane reads the entry its digit names from banks of its own (hot_tables.h): no masked scan, no bank conflict, the same
   // LDS cycles for every scalar.
-  __shared__ uint4 hot_lds[HOT_ROW_CHUNKS * HOT_COPIES];
+  __shared__ uint4 hot_lds[HOT_ROW_CHUNKS * HOT_COPIES > GROUP_LDS_UINT4 ? HOT_ROW_CHUNKS * HOT_COPIES : GROUP_LDS_UINT4];
   uint32_t* ecol = reinterpret_cast<uint32_t*>(hot_lds) + threadIdx.x;      // (ladder and comb blocks: the recoded scalars)
   const uint32_t n_hot = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - n_hot;
-  const uint32_t n_ladder = LADDER ? class_start[HOT_CLASSES] - class_start[CLASS_LADDER] : 0u;
+  const uint32_t n_ladder = LADDER ? class_start[CLASS_GROUP] - class_start[CLASS_LADDER] : 0u;
+  const uint32_t n_group = (CT && TEETH == 16) ? class_start[HOT_CLASSES] - class_start[CLASS_GROUP] : 0u;
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
   const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
+  const uint32_t group_blocks = (n_group + blockDim.x - 1) / blockDim.x;
   if (LADDER && blockIdx.x < ladder_blocks) {
     if constexpr (LADDER) {
       const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,8 +171,11 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
         if (slot != 0xffffffffu) term_comb<CT, TEETH>(t, scalars, comb + (size_t)slot * comb_cfg<TEETH>::ENTRIES, partial, ecol);
       }
     }
+  } else if (blockIdx.x < ladder_blocks + comb_blocks + group_blocks) {
+    if constexpr (CT && TEETH == 16)                              // terms of points with many uses, listed point by point: rows through LDS
+      comb_group_block((blockIdx.x - ladder_blocks - comb_blocks) * 256u, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
   } else {
-    const uint32_t hb = blockIdx.x - ladder_blocks - comb_blocks;
+    const uint32_t hb = blockIdx.x - ladder_blocks - comb_blocks - group_blocks;
     if (hb >= blk_start[HOT_SLOTS]) return;                       // (uniform in the block)
     uint32_t c = 0;
     while (blk_start[c + 1] <= hb) ++c;                           // class = table slot of this block
@@ -953,6 +958,8 @@ struct zkp_ctx {
   // caller sees, give single-use points a table; the asynchronous _dev entry points, whose callers keep many calls in flight
   // and are bound by instruction issue, take the ladder.  -1 = that rule (default), 0 = ladder, 1 = tables.
   int ct_single_use_tables = -1;
+  int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
+  static constexpr size_t kGroupedCombTerms = 400000;
   bool dev_overlap = false;          // ZKP_OPT_DEV_OVERLAP: the _dev flows fork their scalar-independent half onto the side stream too
   int tr_lanes = -1;                 // ZKP_OPT_TRANSCRIPT_LANES: -1 = by entry point, 1 = one lane per proof, 2 = a lane pair per proof
   // The instruction-saving variants of the asynchronous entry points (ladder for single-use points, one transcript lane per
@@ -1041,6 +1048,8 @@ struct terms_cfg {
   msm_map map;                     // lane -> MSM assignment of the reduce / encode kernels (fused flows: constraints by length)
   bool prehalved = false;          // the caller already wrote s / 2 mod l where the batched encoder is used (terms_batched_encode)
 };
+// (whether a constant-time call lists the terms of points with >= GROUP_MIN_USES uses together and walks their tables through
+//  LDS is the context's choice: zkp_ctx::grouped_comb)
 inline terms_cfg terms_cfg_clamped(terms_cfg k, uint32_t n_points, uint32_t n_terms) {
   if (k.comb_min != 1) k.comb_min = 2;
   k.max_tables = std::min(k.max_tables, std::min(n_points, n_terms / k.comb_min));
@@ -1057,7 +1066,7 @@ inline int pick_teeth(uint64_t n_tab, uint64_t tab_terms) {
   return n_tab * comb_entries(16) * sizeof(dev_ext) <= (64ull << 30) ? 16 : 4;
 }
 
-struct terms_layout { size_t pts, part, hot, cls, list, needs, slot_of, slot_pt, comb, ladder, half, states, xs, bprod, zflag, end; };
+struct terms_layout { size_t pts, part, hot, cls, list, needs, slot_of, slot_pt, gstart, gfill, comb, ladder, half, states, xs, bprod, zflag, end; };
 terms_layout terms_carve(size_t start, uint32_t n_points, uint32_t n_terms, uint32_t n_msm, const terms_cfg& k) {
   carve cv;
   cv.off = start;
@@ -1071,6 +1080,8 @@ terms_layout terms_carve(size_t start, uint32_t n_points, uint32_t n_terms, uint
   o.needs = cv.take((size_t)n_points * 4);
   o.slot_of = cv.take(split ? (size_t)n_points * 4 : 0);
   o.slot_pt = cv.take(split ? (size_t)k.max_tables * 4 : 0);
+  o.gstart = cv.take(split ? (size_t)n_points * 4 : 0);            // grouped comb terms: list range of a point, fill cursor
+  o.gfill = cv.take(split ? (size_t)n_points * 4 : 0);
   o.comb = cv.take(split ? (size_t)k.max_tables * comb_entries(k.teeth) * sizeof(dev_ext) : 0);
   o.ladder = cv.take(split ? (size_t)k.max_ladder * LADDER_ENTRIES * sizeof(dev_ext) : 0);
   const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
@@ -1132,6 +1143,13 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     dev_ext* comb = reinterpret_cast<dev_ext*>(base + o.comb);
     dev_ext* ladder = reinterpret_cast<dev_ext*>(base + o.ladder);
     const uint32_t comb_min = k.comb_min;
+    // (the LDS walk has fewer instructions but less independent work per lane than the masked scans: it wins once the call
+    //  keeps every SIMD busy -- single kernel, 4096 CMZ proofs 590 vs 370 us, 8192: 860 vs 690, 16384: 1300 vs 1390; pipelined
+    //  step: 4096 proofs -1 %, 8192 +1.6 %, 16384 +7 %, 524,288 +4.7 %)
+    const bool group_on = c->grouped_comb < 0 ? n_terms >= (k.throughput ? zkp_ctx::kWideCallTerms : zkp_ctx::kGroupedCombTerms) : c->grouped_comb != 0;
+    const uint32_t group_min = (flags == ZKP_CT && k.teeth == 16 && group_on && k.max_tables) ? GROUP_MIN_USES : 0xffffffffu;
+    uint32_t* gstart = reinterpret_cast<uint32_t*>(base + o.gstart);
+    uint32_t* gfill = reinterpret_cast<uint32_t*>(base + o.gfill);
     if (phase & PH_POINTS) {
     HIP_TRY(hipMemsetAsync(cls, 0, 512 * 4, c->stream));
     HIP_TRY(hipMemsetAsync(needs, 0, (size_t)n_points * 4, c->stream));
@@ -1140,17 +1158,20 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     else
       HIP_TRY(hipMemsetAsync(hotmap, 0xff, (size_t)n_points * 4, c->stream));
     hipLaunchKernelGGL(k_use_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs);
-    hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, class_cnt);
+    hipLaunchKernelGGL(k_class_count, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, group_min, class_cnt);
     prof_mark(c, ZKP_K_SORT);
     // decode: every point when the caller's semantics ask for it (a verifier rejects any allocated point that does not
     // decompress, verifier.rs:87-92), otherwise only the points whose coordinates this call uses
     hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, decode_all ? (const uint32_t*)nullptr : needs);
     prof_mark(c, ZKP_K_DECODE);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor, blk_start);
-    hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, cursor, list);
+    if (group_min != 0xffffffffu) HIP_TRY(hipMemsetAsync(gfill, 0, (size_t)n_points * 4, c->stream));
+    if (k.max_tables)                  // table slots, and the list ranges of the grouped points (before the scatter that fills them)
+      hipLaunchKernelGGL(k_comb_slots, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, group_min, k.max_tables, n_slots, slot_of, slot_pt, gstart, pts);
+    hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, group_min, class_start, gstart, gfill,
+                       cursor, list);
     prof_mark(c, ZKP_K_SORT);          // path A: term classification
     if (k.max_tables) {
-      hipLaunchKernelGGL(k_comb_slots, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, k.max_tables, n_slots, slot_of, slot_pt, pts);
       if (k.throughput) {
         if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables_lane<16>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
         else hipLaunchKernelGGL(k_comb_tables_lane<4>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
@@ -1161,7 +1182,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     }
     prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
     }
-    const dim3 grid((unsigned)((n_terms + 255) / 256 + 3 + HOT_SLOTS));     // every fixed-base class starts a new block
+    const dim3 grid((unsigned)((n_terms + 255) / 256 + 4 + HOT_SLOTS));     // every class starts a new block
     // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l
     if (batched_encode) {
       uint8_t* d_half = reinterpret_cast<uint8_t*>(base + o.half);
@@ -1412,6 +1433,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
     case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_single_use_tables = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_DEV_OVERLAP: c->dev_overlap = value != 0; return ZKP_OK;
+    case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_TRANSCRIPT_LANES:
       if (value != ~0ull && value != 1 && value != 2) return fail(ZKP_ERR_ARG, "ZKP_OPT_TRANSCRIPT_LANES: 1, 2 or UINT64_MAX");
       c->tr_lanes = value == ~0ull ? -1 : (int)value;

@@ -958,6 +958,7 @@ struct zkp_ctx {
   // caller sees, give single-use points a table; the asynchronous _dev entry points, whose callers keep many calls in flight
   // and are bound by instruction issue, take the ladder.  -1 = that rule (default), 0 = ladder, 1 = tables.
   int ct_single_use_tables = -1;
+  int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
   static constexpr size_t kGroupedCombTerms = 400000;
   bool dev_overlap = false;          // ZKP_OPT_DEV_OVERLAP: the _dev flows fork their scalar-independent half onto the side stream too
@@ -1172,7 +1173,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
                        cursor, list);
     prof_mark(c, ZKP_K_SORT);          // path A: term classification
     if (k.max_tables) {
-      if (k.throughput) {
+      if (c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) {
         if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables_lane<16>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
         else hipLaunchKernelGGL(k_comb_tables_lane<4>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       } else {
@@ -1433,6 +1434,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
     case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_single_use_tables = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_DEV_OVERLAP: c->dev_overlap = value != 0; return ZKP_OK;
+    case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_TRANSCRIPT_LANES:
       if (value != ~0ull && value != 1 && value != 2) return fail(ZKP_ERR_ARG, "ZKP_OPT_TRANSCRIPT_LANES: 1, 2 or UINT64_MAX");

@@ -49,9 +49,9 @@ BASE = bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e0
 DEFAULT_PMC = os.path.join("profiles", "r02_pmc_counters.json")
 # what the HIP-event timing kinds of zkp_ctx_last_timing are, per flow (kernel names as rocprofv3 prints them)
 KERNELS = {
-    ("prove", "transcript"): "k_transcript_run (2 launches)", ("prove", "tables"): "k_comb_slots + k_comb_tables_lane<16>",
-    ("prove", "terms"): "k_terms_split<true, 16, true>", ("prove", "reduce"): "k_encode_prepare + k_encode_invert + k_encode_finish",
-    ("prove", "sort"): "k_hot_match + k_use_count + k_class_count/scan/scatter", ("prove", "decode"): "k_decode_affine",
+    ("prove", "transcript"): "k_transcript_run (2 launches)", ("prove", "tables"): "k_comb_tables_lane<16>",
+    ("prove", "terms"): "k_terms_split<true, 16, false>", ("prove", "reduce"): "k_encode_prepare + k_encode_invert + k_encode_finish",
+    ("prove", "sort"): "k_hot_match + k_use_count + k_class_count/scan + k_comb_slots + k_class_scatter", ("prove", "decode"): "k_decode_affine",
     ("prove", "scalars"): "k_wide_reduce + k_stmt_scalars + k_halve_scalars + k_responses",
     ("batch_verify", "transcript"): "k_transcript_run", ("batch_verify", "decode"): "k_pip_prepare<c>",
     ("batch_verify", "sort"): "k_pip_tile_hist/total/scan/base/scatter", ("batch_verify", "bucket"): "k_pip_vmap + k_pip_bucket_part + k_pip_bucket_merge",
@@ -517,6 +517,11 @@ def main():
     shares = [(kms[f][k], f, k) for f in step_flows for k in kms[f] if k != "total" and kms[f][k] > 0]
     t_all = sum(s[0] for s in shares)
     names = dict(KERNELS)
+    if args.config in ("2", "4share") and n * 31 >= 250000:      # a call that fills the chip on its own: ladder for Q, one transcript lane per proof
+        names[("prove", "terms")] = "k_terms_split<true, 16, true>"
+    if n >= 8192:
+        names[("prove", "transcript")] = "k_transcript_run1 (2 launches)"
+        names[("batch_verify", "transcript")] = "k_transcript_run1"
     if args.config == "5share":                 # every point of the wide statement is a common generator: fixed-base blocks only, no ladder blocks
         names[("prove", "terms")] = "k_terms_split<true, T, false> (fixed-base blocks only)"
     by_kernel = [{"flow": f, "kind": k, "kernels": names.get((f, k), k), "ms": ms, "share": ms / t_all, "GB/s": algo[f] / (ms * 1e-3) / 1e9}

@@ -267,3 +267,38 @@ def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_ta
     want, wst = C.msm_many(off3, sc2[:1100], np.arange(1100, dtype=np.uint32), table[1:1101], 1)
     assert (st == wst).all() and (got == want).all()
     e.close()
+
+
+@pytest.mark.parametrize("single_use_tables", [0, 1])
+def test_grouped_comb_walk_with_mixed_group_sizes(single_use_tables):
+    """ZKP_OPT_GROUPED_COMB at its edges: points with exactly 8 and 9 uses (three tables in one 16-lane column), large groups that
+    span columns and blocks, points below the threshold (2..7 uses: masked scans) and single-use points in the same constant-time
+    call, an undecodable point inside a group, terms in shuffled order -- against the oracle, byte for byte."""
+    from zkp_amd.engine import Engine
+    rng = np.random.default_rng(77)
+    uses = np.array([8, 9, 10, 23, 1, 2, 7, 8, 16, 8, 8, 9, 300, 1, 5] * 24, np.int64)
+    n_pts = len(uses)
+    ks = rng.integers(0, 256, size=(n_pts, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x0f
+    base = np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32)
+    pts, _ = C.msm_many(np.arange(n_pts + 1, dtype=np.uint32), ks, np.zeros(n_pts, np.uint32), base, 0)
+    pts = pts.copy()
+    pts[7] = 0xff                                                        # a point of a group of 8 that does not decode
+    pidx = np.repeat(np.arange(n_pts, dtype=np.uint32), uses)
+    rng.shuffle(pidx)
+    n_terms = len(pidx)
+    cuts = np.sort(rng.choice(np.arange(1, n_terms), size=n_terms // 3, replace=False))
+    off = np.concatenate([[0], cuts, [n_terms]]).astype(np.uint32)       # MSMs of 1 .. ~10 terms
+    sc = rng.integers(0, 256, size=(n_terms, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x0f
+    sc[3] = 0; sc[4] = 0xff
+    want, wst = C.msm_many(off, sc, pidx, pts, 1)
+    assert wst.any() and not wst.all()
+    e = Engine(0)
+    e.prepare_fixed_points(pts[[3, 12]])                                 # two of the points are fixed-base points as well
+    e.set_option(3, single_use_tables)
+    for grouped in (1, 0):
+        e.set_option(6, grouped)
+        got, st = e.msm_many(off, sc, pidx, pts, 1)
+        assert (st == wst).all() and (got[wst == 0] == want[wst == 0]).all(), grouped
+    e.close()

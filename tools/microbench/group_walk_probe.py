@@ -18,6 +18,8 @@ eng.prepare_fixed_points(pts[:11])
 sc = rng.integers(0, 256, size=(31 * n, 32), dtype=np.uint8)
 sc[:, 31] &= 0x0f
 ref = None
+if os.environ.get('PROBE_OPT3'):
+    eng.set_option(3, int(os.environ['PROBE_OPT3']))
 for grouped in (1, 0, 1, 0, 1, 0):
     eng.set_option(6, grouped)
     out, st = eng.msm_many(off, sc, pidx, pts, ZKP_CT)

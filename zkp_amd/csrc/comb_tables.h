@@ -386,15 +386,23 @@ __device__ __forceinline__ void comb_group_block(uint32_t i0, uint32_t n_g, cons
   ge_p3 acc;
   ge_identity(acc);
   issue(0);
+#ifdef ZKP_PROBE_TIMING
+  uint64_t tp[6] = {0, 0, 0, 0, 0, 0}, t0 = __builtin_readcyclecounter();
+#define ZKP_TP(i) { const uint64_t now_ = __builtin_readcyclecounter(); tp[i] += now_ - t0; t0 = now_; }
+#else
+#define ZKP_TP(i)
+#endif
 #pragma unroll 1
   for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
     if (live && w != cfg::WINDOWS - 1) ge_double4(acc);            // (the accumulator is still the identity in the first window)
+    ZKP_TP(5)
     uint32_t clo = dlo[0], chi = dhi[0];
 #pragma unroll
     for (int q = 1; q < cfg::WINDOWS; ++q) { clo = (w == q) ? dlo[q] : clo; chi = (w == q) ? dhi[q] : chi; }
 #pragma unroll 1
     for (int j = 0; j < 16; ++j) {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // this step's rows have landed, for every wavefront's part
+      ZKP_TP(0)
       ge_cached sel;
       uint32_t neg = 0;
       if (live) {
@@ -413,14 +421,26 @@ __device__ __forceinline__ void comb_group_block(uint32_t i0, uint32_t n_g, cons
         }
         fe_set(sel.YmX, wd); fe_set(sel.YpX, wd + 9); fe_set(sel.Z2, wd + 18); fe_set(sel.T2d, wd + 27);
       }
+      ZKP_TP(1)
       lds_barrier();                                               // every lane holds its entry: the rows may be replaced
+      ZKP_TP(2)
       if (w != 0 || j != 15) issue((uint32_t)((j + 1) & 15));      // next step's rows arrive during the addition
+      ZKP_TP(3)
       if (live) {
         ge_cached_cneg(sel, neg);
         ge_add_cached(acc, acc, sel);
       }
+#ifdef ZKP_PROBE_TIMING
+      asm volatile("" : "+v"(acc.X.v[0]));
+#endif
+      ZKP_TP(4)
     }
   }
+#ifdef ZKP_PROBE_TIMING
+  if (i0 == 0 && tid == 0)
+    printf("[group walk probe] cycles: wait rows %llu | look-up %llu | read barrier %llu | issue DMA %llu | cneg + add %llu | doublings %llu\n",
+           (unsigned long long)tp[0], (unsigned long long)tp[1], (unsigned long long)tp[2], (unsigned long long)tp[3], (unsigned long long)tp[4], (unsigned long long)tp[5]);
+#endif
   if (live) {
     ge_cached sel, c;
     ge_cached_identity(sel);

@@ -80,10 +80,15 @@ const char* zkp_version(void);
  *     calls: 250,000).
  *   ZKP_OPT_TABLES_LANE: comb tables are built by one lane per point (1: half the instructions) or by four lanes per point
  *     (0: a quarter of the latency); UINT64_MAX = default: 1 in the asynchronous _dev entry points, 0 in the synchronous ones.
+ *   ZKP_OPT_FUSE_TABLES_TRANSCRIPT: 1 = zkp_fused_prove_dev / _verify_compact_dev run their first transcript program in the same
+ *     launch as the comb-table construction (both are long dependent chains on few wavefronts, independent of each other): a
+ *     lone call of 4096 CMZ proofs takes 1.47 instead of 1.99 ms, while pipelined callers lose 7 % (the transcript
+ *     wavefronts then carry the table builder's 212 registers instead of their own 118).  Default 0.
  *   ZKP_OPT_TRANSCRIPT_LANES: lanes per proof in the Merlin transcript kernel of the fused flows.  2 = a lane pair per proof
  *     (each lane holds one 32-bit half of every STROBE word: half the latency), 1 = one lane per proof (23 % fewer
  *     instructions per Keccak-f), UINT64_MAX = default: 1 in asynchronous _dev calls of 8192 proofs or more, 2 otherwise. */
-enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7 };
+enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
+       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~75 short kernels; enqueueing them one by one costs the host ~0.15 ms per

@@ -64,12 +64,15 @@ def test_msm_many_dev_equals_host_entry_and_oracle(eng, flags):
     assert (want == exp).all()
 
 
-@pytest.mark.parametrize("n,wide", [(40, False), (1500, False), (40, True), (1500, True)])
+@pytest.mark.parametrize("n,wide", [(40, False), (1500, False), (40, True), (1500, True), (40, "fuse"), (1500, "fuse")])
 def test_fused_dev_flows_equal_host_pointer_flows(eng, n, wide):
     """zkp_fused_prove_dev / _verify_compact_dev / _batch_verify_dev against zkp_fused_prove / ... (through the toolbox).
     wide: with the variants the _dev entry points pick for calls that fill the chip on their own (one transcript lane per
-    proof, constant-time ladder for single-use points), forced here at a small batch size."""
-    if wide:
+    proof, constant-time ladder for single-use points), forced here at a small batch size; "fuse": with
+    ZKP_OPT_FUSE_TABLES_TRANSCRIPT."""
+    if wide == "fuse":
+        eng.set_option(8, 1)            # ZKP_OPT_FUSE_TABLES_TRANSCRIPT: program A in the comb tables' launch
+    elif wide:
         eng.set_option(4, 1)            # ZKP_OPT_TRANSCRIPT_LANES
         eng.set_option(3, 0)            # ZKP_OPT_CT_SINGLE_USE_TABLES
     try:
@@ -77,6 +80,7 @@ def test_fused_dev_flows_equal_host_pointer_flows(eng, n, wide):
     finally:
         eng.set_option(4, 2**64 - 1)
         eng.set_option(3, 2**64 - 1)
+        eng.set_option(8, 0)
 
 
 def _fused_dev_flows(eng, n):

@@ -141,11 +141,9 @@ __device__ __forceinline__ void store_comb_entry(dev_ext* dst, const ge_cached& 
   store_vec<9>(dst, w);
 }
 template <int TEETH>
-__global__ void __launch_bounds__(256, 2)
-k_comb_tables_lane(const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
-                   const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
+__device__ __forceinline__ void comb_table_lane(uint32_t slot, const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
+                                                const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
   using cfg = comb_cfg<TEETH>;
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t ns = min(*n_slots, max_tables);
   if (slot >= ns) return;
   ge_p3 base;
@@ -178,6 +176,12 @@ k_comb_tables_lane(const uint32_t* __restrict__ n_slots, uint32_t max_tables, co
   ge_cached c;
   ge_to_cached(c, base);                                                   // 2^256 * P
   store_comb_entry(tbl + 8 * TEETH, c);
+}
+template <int TEETH>
+__global__ void __launch_bounds__(256, 2)
+k_comb_tables_lane(const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
+                   const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
+  comb_table_lane<TEETH>(blockIdx.x * blockDim.x + threadIdx.x, n_slots, max_tables, slot_pt, pts, comb);
 }
 
 __device__ __forceinline__ void load_comb_entry(ge_cached& c, const dev_ext* src) {

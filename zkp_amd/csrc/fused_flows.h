@@ -8,181 +8,9 @@
 //   zkp_fused_batch_verify    macros.rs:336-370 ; batch_verifier.rs:67-235
 #pragma once
 #include "merlin_prog.h"
+#include "transcript_kernels.h"
 
 namespace zkp {
-
-// ---- the transcript interpreter on the GPU ---------------------------------------------------------------------------
-// A lone wavefront issues one VALU instruction every 4 cycles, and a batch of a few thousand proofs is only a few dozen
-// wavefronts: the kernel is latency-bound, so each proof is spread over a PAIR of lanes.  Lane h of the pair holds the
-// h-th 32-bit half of every 64-bit STROBE word (LDS columns of uint32: dynamic word index without scratch).  XOR / AND /
-// NOT are half-local; a 64-bit rotation takes the partner's half with one DPP quad_perm move and one v_alignbit_b32:
-// ~160 full-rate VALU operations per Keccak round per lane instead of 264.  Semantics = tr_run_one (merlin_prog.h).
-__device__ __forceinline__ uint32_t pair_swap(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
-}
-// half of rotl64 by R that this lane keeps (mine / partner = this lane's and the other lane's half of the word)
-__device__ __forceinline__ uint32_t rotl_half(uint32_t mine, uint32_t partner, int R) {
-  const int n = R & 31;
-  if (R & 32) return n ? __builtin_amdgcn_alignbit(partner, mine, 32 - n) : partner;
-  return n ? __builtin_amdgcn_alignbit(mine, partner, 32 - n) : mine;
-}
-__device__ __forceinline__ uint32_t half_of(uint64_t v, uint32_t h) { return h ? (uint32_t)(v >> 32) : (uint32_t)v; }
-
-__device__ __forceinline__ void keccak_f1600_split(uint32_t a[25], uint32_t h) {
-  static const uint64_t RC[24] = {
-      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
-      0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
-      0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
-      0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-  constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};   // [x + 5 y]
-#pragma unroll 1
-  for (int round = 0; round < 24; ++round) {
-    uint32_t c[5], b[25];
-#pragma unroll
-    for (int x = 0; x < 5; ++x) c[x] = tr_xor5_32(a[x], a[x + 5], a[x + 10], a[x + 15], a[x + 20]);
-#pragma unroll
-    for (int x = 0; x < 5; ++x) {                       // theta: D[x] = C[x-1] ^ rotl(C[x+1], 1)
-      const uint32_t cn = c[(x + 1) % 5];
-      const uint32_t d = c[(x + 4) % 5] ^ rotl_half(cn, pair_swap(cn), 1);
-#pragma unroll
-      for (int y = 0; y < 5; ++y) a[x + 5 * y] ^= d;
-    }
-#pragma unroll
-    for (int y = 0; y < 5; ++y)                         // rho + pi: B[y][2x+3y] = rotl(A[x][y], r[x][y])
-#pragma unroll
-      for (int x = 0; x < 5; ++x) {
-        const uint32_t v = a[x + 5 * y];
-        b[y + 5 * ((2 * x + 3 * y) % 5)] = RHO[x + 5 * y] ? rotl_half(v, pair_swap(v), RHO[x + 5 * y]) : v;
-      }
-#pragma unroll
-    for (int y = 0; y < 5; ++y)                         // chi
-#pragma unroll
-      for (int x = 0; x < 5; ++x) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-    a[0] ^= half_of(RC[round], h);                      // iota
-  }
-}
-
-constexpr int TR_BLOCK = 64;       // lanes per workgroup (one wavefront) = 32 proofs
-// The operation list is fetched 64 operations at a time: lane i loads operation base + i (one coalesced 1 KiB load), and
-// the wavefront then walks them with v_readlane -- no scalar-memory latency inside the loop (an s_load per operation
-// would be waited for at every LDS access, since both count on lgkmcnt).
-__global__ void __launch_bounds__(TR_BLOCK)
-k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t* __restrict__ tables, uint32_t N, const tr_bufs bufs,
-                 uint8_t* __restrict__ ts, uint32_t* __restrict__ saved /*[25][2N]*/, uint32_t* __restrict__ failed, uint32_t tail) {
-  __shared__ uint32_t S[25 * TR_BLOCK];
-  const uint32_t lane = threadIdx.x, h = lane & 1;
-  const uint32_t j_raw = blockIdx.x * (TR_BLOCK / 2) + (lane >> 1);
-  const bool live = j_raw < N;                          // lanes past the end shadow the last proof (they must stay in the
-  const uint32_t j = live ? j_raw : N - 1;              // wavefront: they carry operations for v_readlane) and store nothing
-  uint32_t* col = S + lane;
-  uint32_t* blob = reinterpret_cast<uint32_t*>(ts + 208 * (size_t)j);
-#pragma unroll
-  for (int i = 0; i < 25; ++i) col[TR_BLOCK * i] = blob[2 * i + h];
-  uint32_t* sv = saved + 2 * (size_t)j + h;
-  const size_t sv_stride = 2 * (size_t)N;
-  uint32_t bad = 0;
-  for (uint32_t base = 0; base < n_ops; base += TR_BLOCK) {
-    const uint32_t cnt = n_ops - base < TR_BLOCK ? n_ops - base : TR_BLOCK;
-    uint4 mine = make_uint4(0, 0, 0, 0);
-    if (lane < cnt) mine = reinterpret_cast<const uint4*>(prog)[base + lane];
-    for (uint32_t i = 0; i < cnt; ++i) {
-      const uint32_t o_ctl = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)i);
-      const uint32_t o_stride = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)i);
-      const uint64_t o_off = (uint32_t)__builtin_amdgcn_readlane((int)mine.z, (int)i) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mine.w, (int)i) << 32;
-      const tr_fields op = tr_unpack(o_ctl, o_stride, o_off);
-      if (op.flags & TR_RESTORE) {
-#pragma unroll
-        for (int k = 0; k < 25; ++k) col[TR_BLOCK * k] = sv[k * sv_stride];
-      }
-      if (op.flags & TR_CHECK_NONZERO) {
-        const uint4* p = reinterpret_cast<const uint4*>(tr_src_ptr(bufs, op.src_buf - 1u) + (size_t)j * op.stride + op.off);
-        const uint4 lo = p[0], hi = p[1];
-        if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) bad = 1;
-      }
-      if (op.dst_buf) {                                 // PRF output: the bytes of word w that live in this half
-        uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + (size_t)j * op.stride + op.off;
-        // this half holds bytes [4h, 4h + 4) of the word; its share of [dlb, dlb + dnb) is one run: a whole half goes
-        // out as one (possibly unaligned) 32-bit store
-        const uint32_t lo = op.dlb > 4 * h ? op.dlb : 4 * h;
-        const uint32_t hi = op.dlb + op.dnb < 4 * h + 4 ? op.dlb + op.dnb : 4 * h + 4;
-        if (hi > lo && live) {
-          const uint32_t v = col[TR_BLOCK * op.w] >> (8 * (lo - 4 * h));
-          uint8_t* dp = d + (lo - op.dlb);
-          if (hi - lo == 4) {
-            __builtin_memcpy(dp, &v, 4);
-          } else {
-            for (uint32_t k = 0; k < hi - lo; ++k) dp[k] = (uint8_t)(v >> (8 * k));
-          }
-        }
-      }
-      if (op.src_buf && !(op.flags & TR_CHECK_NONZERO)) {
-        const uint64_t addr = (uint64_t)j * op.stride + op.off;
-        const uint32_t sh = (uint32_t)(addr & 7);
-        const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
-        uint64_t x = p[0] >> (8 * sh);
-        if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
-        x = (x & tr_bytemask(op.nb)) << (8 * op.lb);
-        col[TR_BLOCK * op.w] = (col[TR_BLOCK * op.w] & half_of(op.keep, h)) ^ half_of(x, h);
-      }
-      if (op.flags & TR_APPLY) {
-        const uint64_t* tbl = tables + (size_t)TR_TABLE_WORDS * op.off;
-        uint32_t a[25];
-#pragma unroll
-        for (int k = 0; k < 25; ++k) a[k] = col[TR_BLOCK * k];
-#pragma unroll
-        for (int k = 0; k < 21; ++k) a[k] = (a[k] & half_of(tbl[k], h)) ^ half_of(tbl[21 + k], h);
-        if (op.flags & TR_PERMUTE) keccak_f1600_split(a, h);
-#pragma unroll
-        for (int k = 0; k < 25; ++k) col[TR_BLOCK * k] = a[k];
-      }
-      if ((op.flags & TR_SAVE) && live) {
-#pragma unroll
-        for (int k = 0; k < 25; ++k) sv[k * sv_stride] = col[TR_BLOCK * k];
-      }
-    }
-  }
-  if (!live) return;
-#pragma unroll
-  for (int i = 0; i < 25; ++i) blob[2 * i + h] = col[TR_BLOCK * i];
-  if (h == 0) { blob[50] = tail; blob[51] = 0; }
-  if (bad && h == 0) failed[j] = 1;
-}
-
-// The same interpreter with ONE lane per proof (64-bit words, tr_exec_op): 208 instead of 2 x 135 VALU operations per Keccak
-// round and proof, and twice the latency -- the choice of the asynchronous _dev entry points, whose callers keep calls in
-// flight (ZKP_OPT_TRANSCRIPT_LANES).  State in LDS columns of uint64 (dynamic word index without scratch); the clone slots
-// have the pair kernel's layout.
-__global__ void __launch_bounds__(TR_BLOCK)
-k_transcript_run1(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t* __restrict__ tables, uint32_t N, const tr_bufs bufs,
-                  uint8_t* __restrict__ ts, uint64_t* __restrict__ saved /*[25][N]*/, uint32_t* __restrict__ failed, uint32_t tail) {
-  __shared__ uint64_t S[25 * TR_BLOCK];
-  const uint32_t lane = threadIdx.x;
-  const uint32_t j_raw = blockIdx.x * TR_BLOCK + lane;
-  const bool live = j_raw < N;                          // lanes past the end shadow the last proof and store nothing
-  const uint32_t j = live ? j_raw : N - 1;
-  uint64_t* col = S + lane;
-  uint64_t* blob = reinterpret_cast<uint64_t*>(ts + 208 * (size_t)j);
-#pragma unroll
-  for (int i = 0; i < 25; ++i) col[TR_BLOCK * i] = blob[i];
-  uint32_t bad = 0;
-  for (uint32_t base = 0; base < n_ops; base += TR_BLOCK) {
-    const uint32_t cnt = n_ops - base < TR_BLOCK ? n_ops - base : TR_BLOCK;
-    uint4 mine = make_uint4(0, 0, 0, 0);
-    if (lane < cnt) mine = reinterpret_cast<const uint4*>(prog)[base + lane];
-    for (uint32_t i = 0; i < cnt; ++i) {
-      const uint32_t o_ctl = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)i);
-      const uint32_t o_stride = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)i);
-      const uint64_t o_off = (uint32_t)__builtin_amdgcn_readlane((int)mine.z, (int)i) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mine.w, (int)i) << 32;
-      tr_exec_op(tr_unpack(o_ctl, o_stride, o_off), tables, j, bufs, col, TR_BLOCK, saved + j, N, &bad, live);
-    }
-  }
-  if (!live) return;
-#pragma unroll
-  for (int i = 0; i < 25; ++i) blob[i] = col[TR_BLOCK * i];
-  blob[25] = tail;
-  if (bad) failed[j] = 1;
-}
 
 // Scalar::from_bytes_mod_order_wide over n 64-byte strings
 __global__ void __launch_bounds__(256)
@@ -669,17 +497,32 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   return ZKP_OK;
 }
 
-// throughput = the caller keeps calls in flight (_dev entry points): one lane per proof; otherwise a lane pair per proof
+// throughput = the caller keeps calls in flight (_dev entry points): one lane per proof when the call is wide; otherwise a lane
+// pair per proof
+bool transcript_single_lane(const zkp_ctx* c, uint32_t N, bool throughput) {
+  return c->tr_lanes < 0 ? (throughput && N >= zkp_ctx::kWideCallProofs) : c->tr_lanes == 1;
+}
 void run_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput) {
   if (!p.n) return;
-  const bool single = c->tr_lanes < 0 ? (throughput && N >= zkp_ctx::kWideCallProofs) : c->tr_lanes == 1;
-  if (single) {
+  if (transcript_single_lane(c, N, throughput)) {
     hipLaunchKernelGGL(k_transcript_run1, dim3((N + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, c->stream, p.ops, p.n, p.tables, N, bufs, d_ts, d_saved, d_failed, p.tail);
   } else {
     constexpr uint32_t per_block = TR_BLOCK / 2;
     hipLaunchKernelGGL(k_transcript_run, dim3((N + per_block - 1) / per_block), dim3(TR_BLOCK), 0, c->stream, p.ops, p.n, p.tables, N, bufs, d_ts,
                        reinterpret_cast<uint32_t*>(d_saved), d_failed, p.tail);
   }
+}
+// Offer the program to the point phase of the term path that follows (it runs with the comb-table construction if there is
+// one: k_tables_transcript); run_program_pending() afterwards runs it on its own if nobody took it.
+void offer_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput, bool overlap) {
+  auto& t = c->pending_tr;
+  t.offered = t.active = c->fuse_tables_transcript && p.n != 0 && throughput && !overlap && !transcript_single_lane(c, N, throughput);
+  t.ops = p.ops; t.n_ops = p.n; t.tables = p.tables; t.N = N; t.bufs = bufs; t.ts = d_ts; t.saved = reinterpret_cast<uint32_t*>(d_saved); t.failed = d_failed; t.tail = p.tail;
+}
+void run_program_pending(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput) {
+  const bool taken = c->pending_tr.offered && !c->pending_tr.active;      // the term path launched it with its tables
+  c->pending_tr.offered = c->pending_tr.active = false;
+  if (!taken) run_program(c, p, N, bufs, d_ts, d_saved, d_failed, throughput);
 }
 
 // ---- side stream: the scalar-independent half of path A runs next to the transcripts -------------------------------------
@@ -750,16 +593,17 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   terms_cfg tk = cfg_from_terms(pl.tpt.data(), T, pl.s.ns, pl.s.np, N, c->ct_comb_min(throughput, (size_t)N * T));
   tk.throughput = throughput;
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
+  offer_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput, overlap);
   {   // side stream: operand indices, decode, classification, comb tables (nothing here depends on the blindings)
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
-    if (rc) return rc;
+    if (rc) { c->pending_tr.offered = c->pending_tr.active = false; return rc; }
     hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T, w.u32(o.off), w.u32(o.pidx));
     if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_POINTS, tk);
     const int rc2 = side_end(c, main, overlap);
-    if (rc || rc2) return rc ? rc : rc2;
+    if (rc || rc2) { c->pending_tr.offered = c->pending_tr.active = false; return rc ? rc : rc2; }
   }
-  run_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput);
+  run_program_pending(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   if (m) hipLaunchKernelGGL(k_wide_reduce, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N * m, w.u8(o.wide), w.u8(o.blind));
   // the blindings are canonical (k_wide_reduce), so the halving the batched encoder wants is three instructions per limb here
@@ -815,17 +659,18 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   terms_cfg tk = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2);
   tk.throughput = throughput;
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
+  offer_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, overlap);
   {   // side stream: operand indices and the point phase.  With no constraints there is no MSM, but every allocated
       // point must still decode (verifier.rs:87-92)
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
-    if (rc) return rc;
+    if (rc) { c->pending_tr.offered = c->pending_tr.active = false; return rc; }
     hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T1, w.u32(o.off), w.u32(o.pidx));
     rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_POINTS, tk);
     const int rc2 = side_end(c, main, overlap);
-    if (rc || rc2) return rc ? rc : rc2;
+    if (rc || rc2) { c->pending_tr.offered = c->pending_tr.active = false; return rc ? rc : rc2; }
   }
-  run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput);
+  run_program_pending(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, d_claim, w.u8(o.mc));
   if (T1) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T1, 256), dim3(256), 0, c->stream, N, T1, m, pl.d_tarr + nc + 1, d_resp, w.u8(o.mc), w.u8(o.sc), 0u);

@@ -61,6 +61,7 @@ __device__ __forceinline__ uint32_t sel8(const uint32_t w[8], int j) {
 #include "quad.h"
 #include "comb_tables.h"
 #include "sc25519.h"
+#include "transcript_kernels.h"
 
 // =============================================================================================
 // (A) small-MSM path
@@ -958,6 +959,11 @@ struct zkp_ctx {
   // caller sees, give single-use points a table; the asynchronous _dev entry points, whose callers keep many calls in flight
   // and are bound by instruction issue, take the ladder.  -1 = that rule (default), 0 = ladder, 1 = tables.
   int ct_single_use_tables = -1;
+  // a transcript program the flow wants run next to the comb-table construction of the term path's point phase (one launch:
+  // k_tables_transcript); consumed by msm_terms_path if it builds tables with one lane per point, else run by the flow itself
+  struct { bool offered = false, active = false; const tr_op* ops = nullptr; uint32_t n_ops = 0; const uint64_t* tables = nullptr; uint32_t N = 0; tr_bufs bufs{};
+           uint8_t* ts = nullptr; uint32_t* saved = nullptr; uint32_t* failed = nullptr; uint32_t tail = 0; } pending_tr;
+  bool fuse_tables_transcript = false;   // ZKP_OPT_FUSE_TABLES_TRANSCRIPT
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
   static constexpr size_t kGroupedCombTerms = 400000;
@@ -1174,7 +1180,13 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     prof_mark(c, ZKP_K_SORT);          // path A: term classification
     if (k.max_tables) {
       if (c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) {
-        if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables_lane<16>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
+        if (k.teeth == 16 && c->pending_tr.active) {               // the flow's transcript program shares the launch
+          const auto& t = c->pending_tr;
+          const uint32_t tr_blocks = (t.N + TR_BLOCK / 2 - 1) / (TR_BLOCK / 2);
+          hipLaunchKernelGGL(k_tables_transcript<16>, dim3(tr_blocks + (k.max_tables + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, c->stream, tr_blocks, t.ops, t.n_ops,
+                             t.tables, t.N, t.bufs, t.ts, t.saved, t.failed, t.tail, n_slots, k.max_tables, slot_pt, pts, comb);
+          c->pending_tr.active = false;
+        } else if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables_lane<16>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
         else hipLaunchKernelGGL(k_comb_tables_lane<4>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       } else {
         if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables<16>, grid1((size_t)k.max_tables * 4, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
@@ -1434,6 +1446,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
     case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_single_use_tables = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_DEV_OVERLAP: c->dev_overlap = value != 0; return ZKP_OK;
+    case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value != 0; return ZKP_OK;
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_TRANSCRIPT_LANES:

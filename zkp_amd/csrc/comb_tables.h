@@ -235,7 +235,7 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
 #pragma unroll 1
     for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
       if (w != cfg::WINDOWS - 1) {                              // (the accumulator is still the identity in the first window)
-        ge_double4(acc);
+        ge_double4_flat(acc);
       }
 #pragma unroll 1
       for (int j = 0; j < TEETH; ++j) {

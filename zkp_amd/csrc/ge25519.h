@@ -171,6 +171,13 @@ ZKP_HD void ge_double4(ge_p3& acc) {
   ge_double<true>(acc, acc);
 }
 
+ZKP_HD void ge_double4_flat(ge_p3& acc) {
+  ge_double<false>(acc, acc);
+  ge_double<false>(acc, acc);
+  ge_double<false>(acc, acc);
+  ge_double<true>(acc, acc);
+}
+
 ZKP_HD void ge_neg(ge_p3& r, const ge_p3& p) {
   fe t;
   fe_neg(t, p.X);

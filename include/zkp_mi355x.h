@@ -110,8 +110,8 @@ void zkp_graph_destroy(zkp_graph* graph);
  * will reference -- in the reference's vocabulary the statement's COMMON variables (define_proof!,
  * macros.rs:84,236-242) / BatchVerifier's static points (batch_verifier.rs:100-112), e.g. the issuer
  * parameters X_1..X_10, A of the CMZ'13 statement.  The engine builds fixed-base window tables for them once
- * (64 slots, least-recently-used replacement) and then serves every term on such a point with 65 mixed
- * additions and no doublings.  encodings = HOST pointer [n][32]; synchronous. */
+ * (64 slots, least-recently-used replacement) and then serves every term on such a point with 43 mixed
+ * additions and no doublings (154 KB of table per point).  encodings = HOST pointer [n][32]; synchronous. */
 int zkp_ctx_prepare_fixed_points(zkp_ctx* ctx, uint32_t n, const uint8_t* encodings);
 
 /* (1) Many small multiscalar multiplications in CSR form, fused with compression.

@@ -130,8 +130,9 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
 }
 
 // Classified terms in ONE launch, longest first: ladder terms (points with a single cold use of a variable-time call: 321
-// point operations per lane), terms on per-proof points with a comb table (BITS - 4 + 65 point operations), and the
-// fixed-base terms (65 mixed additions), which fill the SIMDs the others leave idle.
+// point operations per lane), terms on per-proof points with a comb table (BITS - 4 + 65 point operations; masked scans, or --
+// points with many uses in large constant-time calls -- rows through LDS: comb_group_block), and the fixed-base terms (43 mixed
+// additions, entries read from replicated LDS rows), which fill the SIMDs the others leave idle.
 // LADDER = false (every cold point of the call has a table: constant-time calls) only leaves the ladder's code out.
 // (Measured and dropped: the same kernel capped at 168 VGPRs for a third wavefront per SIMD needs 39 spills and is no
 // faster, 4.51 vs 4.51 M proofs/s pipelined; three separate kernels -- comb 154, fixed-base 161 VGPRs without spills, 3 per

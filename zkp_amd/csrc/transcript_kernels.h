@@ -140,8 +140,9 @@ __device__ __forceinline__ void transcript_pair_block(uint32_t bid, uint32_t* S 
   if (!live) return;
 #pragma unroll
   for (int i = 0; i < 25; ++i) blob[2 * i + h] = col[TR_BLOCK * i];
-  if (h == 0) { blob[50] = tail; blob[51] = 0; }
-  if (bad && h == 0) failed[j] = 1;
+  if (h == 0) { blob[50] = tail & 0xffffffu; blob[51] = 0; }
+  // bit 31 of `tail`: this program owns the rejection flags (it writes 0 too, so that nobody has to clear them first)
+  if (h == 0 && (bad || (tail >> 31))) failed[j] = bad;
 }
 
 __global__ void __launch_bounds__(TR_BLOCK)
@@ -197,8 +198,8 @@ k_transcript_run1(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t
   if (!live) return;
 #pragma unroll
   for (int i = 0; i < 25; ++i) blob[i] = col[TR_BLOCK * i];
-  blob[25] = tail;
-  if (bad) failed[j] = 1;
+  blob[25] = tail & 0xffffffu;
+  if (bad || (tail >> 31)) failed[j] = bad;
 }
 
 }  // namespace zkp

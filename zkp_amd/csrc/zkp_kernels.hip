@@ -964,6 +964,7 @@ struct zkp_ctx {
   // k_tables_transcript); consumed by msm_terms_path if it builds tables with one lane per point, else run by the flow itself
   struct { bool offered = false, active = false; const tr_op* ops = nullptr; uint32_t n_ops = 0; const uint64_t* tables = nullptr; uint32_t N = 0; tr_bufs bufs{};
            uint8_t* ts = nullptr; uint32_t* saved = nullptr; uint32_t* failed = nullptr; uint32_t tail = 0; } pending_tr;
+  int debug_dummy_launches = 0;      // option 9 (measurement only): empty kernels added to every prove call
   bool fuse_tables_transcript = false;   // ZKP_OPT_FUSE_TABLES_TRANSCRIPT
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
@@ -1083,13 +1084,13 @@ terms_layout terms_carve(size_t start, uint32_t n_points, uint32_t n_terms, uint
   o.pts = cv.take((size_t)n_points * sizeof(dev_affine));
   o.part = cv.take((size_t)n_terms * sizeof(dev_ext));
   o.hot = cv.take((size_t)n_points * 4);
-  o.cls = cv.take(512 * 4);
-  o.list = cv.take((size_t)n_terms * 4);
+  o.cls = cv.take(512 * 4);                                        // cls | needs | gfill are cleared by ONE memset per call
   o.needs = cv.take((size_t)n_points * 4);
+  o.gfill = cv.take(split ? (size_t)n_points * 4 : 0);             // grouped comb terms: fill cursor of a point's list range
+  o.list = cv.take((size_t)n_terms * 4);
   o.slot_of = cv.take(split ? (size_t)n_points * 4 : 0);
   o.slot_pt = cv.take(split ? (size_t)k.max_tables * 4 : 0);
-  o.gstart = cv.take(split ? (size_t)n_points * 4 : 0);            // grouped comb terms: list range of a point, fill cursor
-  o.gfill = cv.take(split ? (size_t)n_points * 4 : 0);
+  o.gstart = cv.take(split ? (size_t)n_points * 4 : 0);            // grouped comb terms: list range of a point
   o.comb = cv.take(split ? (size_t)k.max_tables * comb_entries(k.teeth) * sizeof(dev_ext) : 0);
   o.ladder = cv.take(split ? (size_t)k.max_ladder * LADDER_ENTRIES * sizeof(dev_ext) : 0);
   const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
@@ -1159,8 +1160,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     uint32_t* gstart = reinterpret_cast<uint32_t*>(base + o.gstart);
     uint32_t* gfill = reinterpret_cast<uint32_t*>(base + o.gfill);
     if (phase & PH_POINTS) {
-    HIP_TRY(hipMemsetAsync(cls, 0, 512 * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(needs, 0, (size_t)n_points * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(cls, 0, o.list - o.cls, c->stream));     // class counters, use counts, group cursors
     if (c->hot_nreg)
       hipLaunchKernelGGL(k_hot_match, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, c->hot_nreg, c->hot_reg_words, c->hot_reg_slot, hotmap, any_hot);
     else
@@ -1173,7 +1173,6 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, decode_all ? (const uint32_t*)nullptr : needs);
     prof_mark(c, ZKP_K_DECODE);
     hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, c->stream, class_cnt, class_start, cursor, blk_start);
-    if (group_min != 0xffffffffu) HIP_TRY(hipMemsetAsync(gfill, 0, (size_t)n_points * 4, c->stream));
     if (k.max_tables)                  // table slots, and the list ranges of the grouped points (before the scatter that fills them)
       hipLaunchKernelGGL(k_comb_slots, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, needs, comb_min, group_min, k.max_tables, n_slots, slot_of, slot_pt, gstart, pts);
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, group_min, class_start, gstart, gfill,
@@ -1447,6 +1446,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
     case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_single_use_tables = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_DEV_OVERLAP: c->dev_overlap = value != 0; return ZKP_OK;
+    case 9: c->debug_dummy_launches = (int)std::min<uint64_t>(value, 1000); return ZKP_OK;
     case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value != 0; return ZKP_OK;
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;

@@ -268,15 +268,11 @@ void launch_coeff_build(zkp_ctx* c, const fused_shape& s, uint32_t N, const uint
   const uint32_t* d_inc_k = d_inc + s.inc_off.size();
   const uint32_t* d_inc_sc = d_inc_k + s.inc_k.size();
   const uint32_t nblk = (N + 255) / 256, rows = s.ni + s.nc;
-  if (N && rows)
-    hipLaunchKernelGGL(k_coeff_matrix, dim3(nblk, rows), dim3(256), 0, c->stream, N, s.m, s.ns, s.ni, s.nc, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, d_sc);
-  if (s.ns) {
-    if (N) {
-      hipLaunchKernelGGL(k_coeff_static_partial, dim3(nblk, s.ns), dim3(256), 0, c->stream, N, s.m, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, d_part);
-      hipLaunchKernelGGL(k_coeff_static_final, dim3(s.ns), dim3(64), 0, c->stream, nblk, d_part, d_sc);
-    } else {
-      hipMemsetAsync(d_sc, 0, (size_t)s.ns * 32, c->stream);
-    }
+  if (N && (rows || s.ns)) {
+    hipLaunchKernelGGL(k_coeff_build, dim3(nblk, rows + s.ns), dim3(256), 0, c->stream, N, s.m, s.ns, s.ni, s.nc, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, d_sc, d_part);
+    if (s.ns) hipLaunchKernelGGL(k_coeff_static_final, dim3(s.ns), dim3(64), 0, c->stream, nblk, d_part, d_sc);
+  } else if (s.ns) {
+    hipMemsetAsync(d_sc, 0, (size_t)s.ns * 32, c->stream);
   }
 }
 size_t optional_ws(uint64_t total) {

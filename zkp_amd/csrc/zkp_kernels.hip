@@ -312,6 +312,32 @@ __device__ __forceinline__ uint32_t msm_sum(ge_p3& acc, uint32_t i, const uint32
   return bad;
 }
 
+// pass 2: inverses of up to 256 block products per block (one field inversion each)
+__device__ __forceinline__ void encode_invert_block(enc_tree& tree, int tid, uint32_t b, uint32_t n_blocks, const uint32_t* __restrict__ bprod,
+                                                    uint32_t* __restrict__ binv) {
+  fe x;
+  fe_1(x);
+  if (b < n_blocks) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x.v[k] = bprod[(size_t)b * 9 + k];
+    FE_TRACK(fe_set_ub_tight(x));
+  }
+  tree_put(tree, ENC_BLOCK + tid, x);
+  __syncthreads();
+  tree_up(tree, tid);
+  if (tid == 0) {
+    fe r, inv;
+    tree_get(r, tree, 1);
+    fe_invert(inv, r);
+    tree_put(tree, 1, inv);
+  }
+  __syncthreads();
+  tree_down(tree, tid);
+  if (b < n_blocks) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) binv[(size_t)b * 9 + k] = tree.node[ENC_BLOCK + tid][k];
+  }
+}
 // pass 1: per MSM the sum of its partials, the decode status, the encoding state; per block the product of the x's
 template <typename STATUS_T>
 __global__ void __launch_bounds__(ENC_BLOCK, 2)
@@ -347,34 +373,12 @@ k_encode_prepare(uint32_t n_msm, const uint32_t* __restrict__ off, const uint32_
   if (tid < 9) bprod[(size_t)blockIdx.x * 9 + tid] = tree.node[1][tid];
 }
 
-// pass 2: inverses of up to 256 block products per block (one field inversion each)
+// pass 2 (a kernel of its own: letting the last block of pass 1 do it needs a device-scope fence per block, i.e. an L2
+// write-back / invalidate across the eight XCDs, and cost 4 % of the pipelined step)
 __global__ void __launch_bounds__(ENC_BLOCK)
 k_encode_invert(uint32_t n_blocks, const uint32_t* __restrict__ bprod, uint32_t* __restrict__ binv) {
   __shared__ enc_tree tree;
-  const int tid = threadIdx.x;
-  const uint32_t b = blockIdx.x * ENC_BLOCK + tid;
-  fe x;
-  fe_1(x);
-  if (b < n_blocks) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) x.v[k] = bprod[(size_t)b * 9 + k];
-    FE_TRACK(fe_set_ub_tight(x));
-  }
-  tree_put(tree, ENC_BLOCK + tid, x);
-  __syncthreads();
-  tree_up(tree, tid);
-  if (tid == 0) {
-    fe r, inv;
-    tree_get(r, tree, 1);
-    fe_invert(inv, r);
-    tree_put(tree, 1, inv);
-  }
-  __syncthreads();
-  tree_down(tree, tid);
-  if (b < n_blocks) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) binv[(size_t)b * 9 + k] = tree.node[ENC_BLOCK + tid][k];
-  }
+  encode_invert_block(tree, threadIdx.x, blockIdx.x * ENC_BLOCK + threadIdx.x, n_blocks, bprod, binv);
 }
 
 // pass 3: per-output inverses from the block inverse, then the 32 bytes
@@ -701,14 +705,9 @@ k_pip_bucket_merge(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t*
 // Invariant before a level:  T = sum_j ( A_j + M * j * R_j ),  A absent (= 0) and M = 1 at level 0.
 // A quad folds m <= 8 consecutive inputs j = m j' + i:   R' = sum_i R_i,  A' = sum_i A_i + M * sum_i i R_i,  M' = M m.
 // (M = 2^shift; chunk sizes: 8 everywhere except a first level of 2 or 4 when log2 B is not a multiple of 3.)
-__global__ void __launch_bounds__(256, 2)
-k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t out_stride, int level, int m, int shift,
-                 const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
-                 dev_ext* __restrict__ A_out, dev_ext* __restrict__ R_out) {
-  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t g = gt >> 2;                        // one quad of lanes per output (quad.h)
-  const int q = (int)(gt & 3u);
-  if (g >= total) return;
+__device__ __forceinline__ void pip_reduce_quad(uint32_t g, int q, uint32_t n_out, uint32_t in_stride, uint32_t out_stride, int level, int m, int shift,
+                                                const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
+                                                dev_ext* __restrict__ A_out, dev_ext* __restrict__ R_out) {
   const uint32_t w = g / n_out, j = g - w * n_out;
   const dev_ext* rin = R_in + (size_t)w * in_stride + (size_t)m * j;
   qpt run, U, t;
@@ -739,13 +738,29 @@ k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t ou
     }
   }
   q_store_ext(A_out + (size_t)w * out_stride + j, U, q);
-  q_store_ext(R_out + (size_t)w * out_stride + j, run, q);
+  if (R_out) q_store_ext(R_out + (size_t)w * out_stride + j, run, q);
+}
+__global__ void __launch_bounds__(256, 2)
+k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t out_stride, int level, int m, int shift,
+                 const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
+                 dev_ext* __restrict__ A_out, dev_ext* __restrict__ R_out) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = gt >> 2;                        // one quad of lanes per output (quad.h)
+  const int q = (int)(gt & 3u);
+  if (g >= total) return;
+  pip_reduce_quad(g, q, n_out, in_stride, out_stride, level, m, shift, A_in, R_in, A_out, R_out);
 }
 
-// result = sum_w 2^(C w) T_w  (Horner, one lane: 256 inherently sequential doublings);  encode.
-__global__ void __launch_bounds__(64)
-k_pip_combine(int W1, int C, const dev_ext* __restrict__ T, const uint32_t* __restrict__ invalid,
-              uint8_t* __restrict__ out_point, uint32_t* __restrict__ status) {
+// The last tree level (one output per window: W1 quads of this one block), then
+// result = sum_w 2^(C w) T_w  (Horner, one quad: 256 inherently sequential doublings);  encode.
+__global__ void __launch_bounds__(256)
+k_pip_combine(int W1, int C, uint32_t in_stride, int level, int m, int shift, const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
+              dev_ext* __restrict__ T, const uint32_t* __restrict__ invalid, uint8_t* __restrict__ out_point, uint32_t* __restrict__ status) {
+  {
+    const uint32_t g = threadIdx.x >> 2;
+    if (g < (uint32_t)W1) pip_reduce_quad(g, (int)(threadIdx.x & 3u), 1u, in_stride, 1u, level, m, shift, A_in, R_in, T, nullptr);
+  }
+  __syncthreads();                                 // (T is written and read by this block only)
   if (threadIdx.x >= 4) return;                    // one quad of lanes (quad.h)
   const int q = (int)threadIdx.x;
   qpt acc, t;
@@ -829,35 +844,32 @@ __device__ __forceinline__ void coeff_of_point(sc& acc, uint32_t p, uint32_t j, 
   }
 }
 
-// instance rows and commitment rows of the coefficient matrix: lane (row, proof)
+// The whole coefficient build in one launch, grid (ceil(N / 256), ni + nc + ns):
+//   blockIdx.y <  ni + nc : instance rows and commitment rows of the coefficient matrix, lane (row, proof)
+//   blockIdx.y >= ni + nc : static coefficients -- block-level partial sums over the proofs (k_coeff_static_final adds them up)
 __global__ void __launch_bounds__(256)
-k_coeff_matrix(uint32_t N, uint32_t m, uint32_t ns, uint32_t ni, uint32_t nc, const uint32_t* __restrict__ inc_off,
-               const uint32_t* __restrict__ inc_k, const uint32_t* __restrict__ inc_sc, const uint8_t* __restrict__ minus_c,
-               const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16, uint8_t* __restrict__ scalars) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t row = blockIdx.y;
-  if (j >= N) return;
-  sc acc;
-  if (row < ni) {
-    coeff_of_point(acc, ns + row, j, N, m, inc_off, inc_k, inc_sc, minus_c, responses, weights16);
-  } else {
-    sc r;
-    sc_zero(r);
-    load_vec<1>(r.v, weights16 + 16 * ((size_t)(row - ni) * N + j));
-    sc_neg(acc, r);                                                // batch_verifier.rs:183
-  }
-  store_vec<2>(scalars + 32 * ((size_t)ns + (size_t)row * N + j), acc.v);
-}
-
-// static coefficients: block-level partial sums over proofs, then one block per static point
-__global__ void __launch_bounds__(256)
-k_coeff_static_partial(uint32_t N, uint32_t m, const uint32_t* __restrict__ inc_off, const uint32_t* __restrict__ inc_k,
-                       const uint32_t* __restrict__ inc_sc, const uint8_t* __restrict__ minus_c,
-                       const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16,
-                       uint32_t* __restrict__ partial /*[ns][gridDim.x][8]*/) {
+k_coeff_build(uint32_t N, uint32_t m, uint32_t ns, uint32_t ni, uint32_t nc, const uint32_t* __restrict__ inc_off,
+              const uint32_t* __restrict__ inc_k, const uint32_t* __restrict__ inc_sc, const uint8_t* __restrict__ minus_c,
+              const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16, uint8_t* __restrict__ scalars,
+              uint32_t* __restrict__ partial /*[ns][gridDim.x][8]*/) {
   __shared__ uint32_t red[256][8];
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t s = blockIdx.y;
+  const uint32_t row = blockIdx.y;
+  if (row < ni + nc) {
+    if (j >= N) return;
+    sc acc;
+    if (row < ni) {
+      coeff_of_point(acc, ns + row, j, N, m, inc_off, inc_k, inc_sc, minus_c, responses, weights16);
+    } else {
+      sc r;
+      sc_zero(r);
+      load_vec<1>(r.v, weights16 + 16 * ((size_t)(row - ni) * N + j));
+      sc_neg(acc, r);                                                // batch_verifier.rs:183
+    }
+    store_vec<2>(scalars + 32 * ((size_t)ns + (size_t)row * N + j), acc.v);
+    return;
+  }
+  const uint32_t s = row - ni - nc;
   sc acc;
   sc_zero(acc);
   if (j < N) coeff_of_point(acc, s, j, N, m, inc_off, inc_k, inc_sc, minus_c, responses, weights16);
@@ -1318,8 +1330,8 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   uint32_t in_stride = cfg::B1, n_in = cfg::B;
   size_t lvl_off = 0;
   int level = 0;
-  const dev_ext* Afinal = nullptr;
   int shift = 0;
+  static_assert(cfg::W1 <= 64, "k_pip_combine runs the last tree level with one quad per window in one 256-lane block");
   while (n_in > 1) {
     int lg = 0;
     while ((1u << lg) < n_in) ++lg;
@@ -1328,6 +1340,10 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
     dev_ext* Aout = lvlA + lvl_off;
     dev_ext* Rout = lvlR + lvl_off;
     const uint32_t total = cfg::W1 * n_out;
+    if (n_out == 1) {                                                 // the last level shares the launch of the Horner tail
+      hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(256), 0, c->stream, cfg::W1, C, in_stride, level, (int)m, shift, Ain, Rin, Aout, invalid, d_out, d_status);
+      break;
+    }
     hipLaunchKernelGGL(k_pip_reduce_lvl, grid1((size_t)total * 4, 256), dim3(256), 0, c->stream, n_out, total, in_stride, n_out, level, (int)m, shift,
                        Ain, Rin, Aout, Rout);
     Ain = Aout;
@@ -1335,11 +1351,9 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
     in_stride = n_out;
     n_in = n_out;
     lvl_off += total;
-    Afinal = Aout;
     shift += mbits;
     ++level;
   }
-  hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(64), 0, c->stream, cfg::W1, C, Afinal, invalid, d_out, d_status);
   prof_mark(c, ZKP_K_COMBINE);
   HIP_TRY(hipGetLastError());
   return ZKP_OK;

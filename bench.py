@@ -52,10 +52,11 @@ KERNELS = {
     ("prove", "transcript"): "k_transcript_run (2 launches)", ("prove", "tables"): "k_comb_tables_lane<16>",
     ("prove", "terms"): "k_terms_split<true, 16, false>", ("prove", "reduce"): "k_encode_prepare + k_encode_invert + k_encode_finish",
     ("prove", "sort"): "k_hot_match + k_use_count + k_class_count/scan + k_comb_slots + k_class_scatter", ("prove", "decode"): "k_decode_affine",
-    ("prove", "scalars"): "k_wide_reduce + k_stmt_scalars + k_halve_scalars + k_responses",
+    ("prove", "scalars"): "k_blind_scalars + k_responses",
     ("batch_verify", "transcript"): "k_transcript_run", ("batch_verify", "decode"): "k_pip_prepare<c>",
     ("batch_verify", "sort"): "k_pip_tile_hist/total/scan/base/scatter", ("batch_verify", "bucket"): "k_pip_vmap + k_pip_bucket_part + k_pip_bucket_merge",
-    ("batch_verify", "combine"): "k_pip_reduce_lvl x levels + k_pip_combine", ("batch_verify", "scalars"): "k_wide/neg_reduce + k_coeff_*",
+    ("batch_verify", "combine"): "k_pip_reduce_lvl x levels + k_pip_combine (last level + Horner)",
+    ("batch_verify", "scalars"): "k_batch_after_transcript + k_coeff_build + k_coeff_static_final",
 }
 
 

@@ -67,51 +67,81 @@ k_stmt_scalars(uint32_t N, uint32_t T, uint32_t m, const uint32_t* __restrict__ 
   store_vec<2>(scalars + 32 * g, a.v);
 }
 // The prover's version in one launch: blindings = the transcript rng's 64-byte strings mod l (prover.rs:86-92), written for
-// k_responses, and the term operands straight from the same strings (a term reduces its own copy: 31 reductions per CMZ proof
-// instead of 21, one launch instead of two)
+// k_responses, and the term operands from them.  A block takes P = 256 / max(m, T) whole proofs: first its lanes reduce the
+// P m strings (into LDS and to `blind`), then they assemble the P T operands from LDS -- every string is reduced once.
 __global__ void __launch_bounds__(256)
-k_blind_scalars(uint32_t N, uint32_t T, uint32_t m, const uint32_t* __restrict__ tsc, const uint8_t* __restrict__ wide, uint8_t* __restrict__ blind,
+k_blind_scalars(uint32_t N, uint32_t T, uint32_t m, uint32_t P, const uint32_t* __restrict__ tsc, const uint8_t* __restrict__ wide, uint8_t* __restrict__ blind,
                 uint8_t* __restrict__ scalars, uint32_t halve_canonical) {
-  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < (size_t)N * m) {
+  __shared__ uint32_t red[256][8];
+  const uint32_t j0 = blockIdx.x * P, tid = threadIdx.x;
+  const uint32_t np = min(P, N - j0);                              // proofs of this block (j0 < N by the grid size)
+  if (tid < np * m) {
+    const size_t v = (size_t)j0 * m + tid;
     sc lo, hi, r;
-    load_vec<2>(lo.v, wide + 64 * g);
-    load_vec<2>(hi.v, wide + 64 * g + 32);
-    sc_from_wide(r, lo, hi);
-    store_vec<2>(blind + 32 * g, r.v);
-  }
-  if (g < (size_t)N * T) {
-    const uint32_t j = (uint32_t)(g / T), s = tsc[g % T];
-    const size_t v = (size_t)j * m + s;
-    sc lo, hi, a;
     load_vec<2>(lo.v, wide + 64 * v);
     load_vec<2>(hi.v, wide + 64 * v + 32);
-    sc_from_wide(a, lo, hi);
-    if (halve_canonical) {
+    sc_from_wide(r, lo, hi);
+    store_vec<2>(blind + 32 * v, r.v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[tid][i] = r.v[i];
+  }
+  __syncthreads();
+  if (tid < np * T) {
+    const uint32_t jl = tid / T, k = tid - jl * T;
+    sc a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.v[i] = red[jl * m + tsc[k]][i];
+    if (halve_canonical) {           // the term path will encode 2 * H (batched encoder): hand it s / 2
       sc h;
       sc_halve_canonical(h, a);
       a = h;
     }
-    store_vec<2>(scalars + 32 * g, a.v);
+    store_vec<2>(scalars + 32 * ((size_t)(j0 + jl) * T + k), a.v);
   }
 }
 
-// responses  s * c + b  (prover.rs:107-109); c = the 64 challenge bytes mod l (mod.rs:222-227), reduced by every lane of the proof
-// (one launch instead of two) and written out by the first
+// responses  s * c + b  (prover.rs:107-109); c = the 64 challenge bytes mod l (mod.rs:222-227).  A block takes P = 256 / m whole
+// proofs: P lanes reduce the challenges (into LDS and to `chal`), then P m lanes compute the responses.
 __global__ void __launch_bounds__(256)
-k_responses(uint32_t N, uint32_t m, const uint8_t* __restrict__ secrets, const uint8_t* __restrict__ wchal, uint8_t* __restrict__ chal,
+k_responses(uint32_t N, uint32_t m, uint32_t P, const uint8_t* __restrict__ secrets, const uint8_t* __restrict__ wchal, uint8_t* __restrict__ chal,
             const uint8_t* __restrict__ blind, uint8_t* __restrict__ resp) {
-  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (size_t)N * m) return;
-  const size_t j = g / m;
-  sc s, c, b, r, lo, hi;
-  load_vec<2>(lo.v, wchal + 64 * j);
-  load_vec<2>(hi.v, wchal + 64 * j + 32);
-  sc_from_wide(c, lo, hi);
-  if (g == j * m) store_vec<2>(chal + 32 * j, c.v);
+  __shared__ uint32_t cs[256][8];
+  const uint32_t j0 = blockIdx.x * P, tid = threadIdx.x;
+  const uint32_t np = min(P, N - j0);
+  if (tid < np) {
+    const size_t j = (size_t)j0 + tid;
+    sc lo, hi, c;
+    load_vec<2>(lo.v, wchal + 64 * j);
+    load_vec<2>(hi.v, wchal + 64 * j + 32);
+    sc_from_wide(c, lo, hi);
+    store_vec<2>(chal + 32 * j, c.v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cs[tid][i] = c.v[i];
+  }
+  __syncthreads();
+  if (tid >= np * m) return;
+  const size_t g = (size_t)j0 * m + tid;
+  sc s, c, b, r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c.v[i] = cs[tid / m][i];
   load_vec<2>(s.v, secrets + 32 * g);
   load_vec<2>(b.v, blind + 32 * g);
   sc_mul(r, s, c);                      // s may be any 256-bit value (first operand), c and b are canonical
+  sc_add(r, r, b);
+  store_vec<2>(resp + 32 * g, r.v);
+}
+
+// (statements with more than 256 secrets: the challenges come reduced from k_wide_reduce)
+__global__ void __launch_bounds__(256)
+k_responses_wide(uint32_t N, uint32_t m, const uint8_t* __restrict__ secrets, const uint8_t* __restrict__ chal, const uint8_t* __restrict__ blind,
+                 uint8_t* __restrict__ resp) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)N * m) return;
+  sc s, c, b, r;
+  load_vec<2>(s.v, secrets + 32 * g);
+  load_vec<2>(c.v, chal + 32 * (g / m));
+  load_vec<2>(b.v, blind + 32 * g);
+  sc_mul(r, s, c);
   sc_add(r, r, b);
   store_vec<2>(resp + 32 * g, r.v);
 }
@@ -667,8 +697,15 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   // the blindings are canonical (k_wide_reduce), so the halving the batched encoder wants is three instructions per limb here
   // instead of a kernel with a reduction of its own
   tk.prehalved = nc && terms_batched_encode(c, N * T, N * nc, tk.throughput);
-  if (m) hipLaunchKernelGGL(k_blind_scalars, grid1(std::max<size_t>((size_t)N * T, (size_t)N * m), 256), dim3(256), 0, c->stream, N, T, m, pl.d_tarr + nc + 1, w.u8(o.wide),
-                            w.u8(o.blind), w.u8(o.sc), tk.prehalved ? 1u : 0u);
+  if (m && std::max(m, T) <= 256) {                     // (one launch; every 64-byte string reduced once)
+    const uint32_t P = 256 / std::max(m, T);
+    hipLaunchKernelGGL(k_blind_scalars, dim3((N + P - 1) / P), dim3(256), 0, c->stream, N, T, m, P, pl.d_tarr + nc + 1, w.u8(o.wide), w.u8(o.blind), w.u8(o.sc),
+                       tk.prehalved ? 1u : 0u);
+  } else if (m) {
+    hipLaunchKernelGGL(k_wide_reduce, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N * m, w.u8(o.wide), w.u8(o.blind));
+    if (T) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T, 256), dim3(256), 0, c->stream, N, T, m, pl.d_tarr + nc + 1, w.u8(o.blind), (const uint8_t*)nullptr, w.u8(o.sc),
+                              tk.prehalved ? 1u : 0u);
+  }
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
   {
@@ -679,8 +716,13 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   }
   run_program(c, pl.b, N, hb, d_ts, d_saved, w.u32(o.failed), throughput);
   prof_mark(c, ZKP_K_TRANSCRIPT);
-  if (m) hipLaunchKernelGGL(k_responses, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N, m, d_sec, w.u8(o.wchal), d_chal, w.u8(o.blind), d_resp);
-  else hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), d_chal);
+  if (m && m <= 256) {
+    const uint32_t P = 256 / m;
+    hipLaunchKernelGGL(k_responses, dim3((N + P - 1) / P), dim3(256), 0, c->stream, N, m, P, d_sec, w.u8(o.wchal), d_chal, w.u8(o.blind), d_resp);
+  } else {
+    hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), d_chal);
+    if (m) hipLaunchKernelGGL(k_responses_wide, grid1((size_t)N * m, 256), dim3(256), 0, c->stream, N, m, d_sec, d_chal, w.u8(o.blind), d_resp);
+  }
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
   return ZKP_OK;

@@ -31,6 +31,11 @@ pub const ZKP_CT: c_int = 1; //      RistrettoPoint::multiscalar_mul (prover.rs:
 pub const ZKP_OPT_BATCH_ENCODE_MIN: c_int = 1;
 pub const ZKP_OPT_COMB_TEETH: c_int = 2;
 pub const ZKP_OPT_CT_SINGLE_USE_TABLES: c_int = 3;
+pub const ZKP_OPT_TRANSCRIPT_LANES: c_int = 4;
+pub const ZKP_OPT_DEV_OVERLAP: c_int = 5;
+pub const ZKP_OPT_GROUPED_COMB: c_int = 6;
+pub const ZKP_OPT_TABLES_LANE: c_int = 7;
+pub const ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c_int = 8;
 
 pub const ZKP_TB_OK: c_int = 0;
 pub const ZKP_TB_VERIFICATION_FAILURE: c_int = 1; // ProofError::VerificationFailure (errors.rs:6)

@@ -680,13 +680,17 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   terms_cfg tk = cfg_from_terms(pl.tpt.data(), T, pl.s.ns, pl.s.np, N, c->ct_comb_min(throughput, (size_t)N * T));
   tk.throughput = throughput;
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
+  tk.stmt.toff = pl.d_tarr; tk.stmt.tpt = pl.d_tarr + nc + 1 + T; tk.stmt.N = N; tk.stmt.T = T; tk.stmt.nc = nc; tk.stmt.ns = pl.s.ns; tk.stmt.np = pl.s.np;
+  tk.stmt.off = w.u32(o.off); tk.stmt.pidx = w.u32(o.pidx); tk.stmt.on = c->stmt_classify;
   for (int q = 0; q < c->debug_dummy_launches; ++q) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, c->stream, (uint32_t*)nullptr);   // (launch-count sensitivity probe)
   offer_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput, overlap);
   {   // side stream: operand indices, decode, classification, comb tables (nothing here depends on the blindings)
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
     if (rc) { c->pending_tr.offered = c->pending_tr.active = false; return rc; }
-    hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T, w.u32(o.off), w.u32(o.pidx));
+    // (with constraints the term path's classifier writes the CSR offsets and point indices too: k_stmt_classify)
+    if (!(nc && stmt_classify_applies(tk, N * T)))
+      hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T, w.u32(o.off), w.u32(o.pidx));
     if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_POINTS, tk);
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) { c->pending_tr.offered = c->pending_tr.active = false; return rc ? rc : rc2; }
@@ -759,13 +763,16 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   terms_cfg tk = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2);
   tk.throughput = throughput;
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
+  tk.stmt.toff = pl.d_tarr; tk.stmt.tpt = pl.d_tarr + nc + 1 + T1; tk.stmt.N = N; tk.stmt.T = T1; tk.stmt.nc = nc; tk.stmt.ns = pl.s.ns; tk.stmt.np = pl.s.np;
+  tk.stmt.off = w.u32(o.off); tk.stmt.pidx = w.u32(o.pidx); tk.stmt.on = c->stmt_classify;
   offer_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, overlap);
   {   // side stream: operand indices and the point phase.  With no constraints there is no MSM, but every allocated
       // point must still decode (verifier.rs:87-92)
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
     if (rc) { c->pending_tr.offered = c->pending_tr.active = false; return rc; }
-    hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T1, w.u32(o.off), w.u32(o.pidx));
+    if (!stmt_classify_applies(tk, N * T1))
+      hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T1, w.u32(o.off), w.u32(o.pidx));
     rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_POINTS, tk);
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) { c->pending_tr.offered = c->pending_tr.active = false; return rc ? rc : rc2; }

@@ -250,6 +250,140 @@ k_class_scatter(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_
   }
 }
 
+// ---- the classifier of the fused flows: one launch ------------------------------------------------------------------------
+// When the caller is a statement flow (fused_flows.h) every proof of the batch has the same T terms on the same np point ids
+// (ids < ns: common to the batch, the others one point per proof), so everything the kernels above find out with atomics is
+// arithmetic: use counts, classes, class sizes and block starts, list positions (grouped classes point by point), table slots,
+// and the CSR offsets / point indices themselves (k_stmt_index).  Only the fixed-base registry has to be looked at (which common
+// points are hot).  Replaces memset + k_stmt_index + k_hot_match + k_use_count + k_class_count + k_class_scan + k_comb_slots +
+// k_class_scatter: seven launches fewer per flow, each worth ~1.4 us of a pipelined caller's step.
+// Per-proof points are never treated as hot here (one that happens to equal a registered encoding takes the comb path: same result).
+constexpr uint32_t STMT_MAX_TERMS = 1024, STMT_MAX_POINTS = 1024;
+struct stmt_job {                      // device arrays of the plan + the shape
+  const uint32_t* toff = nullptr;      // [nc + 1] term offsets of the constraints
+  const uint32_t* tpt = nullptr;       // [T] point id of statement term k
+  uint32_t N = 0, T = 0, nc = 0, ns = 0, np = 0;
+  uint32_t* off = nullptr;             // out: [N nc + 1]
+  uint32_t* pidx = nullptr;            // out: [N T]
+  bool on = false;
+};
+__global__ void __launch_bounds__(256)
+k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t nreg, const uint32_t* __restrict__ reg_words, const int32_t* __restrict__ reg_slot,
+                uint32_t comb_min, uint32_t group_min, uint32_t max_tables, uint32_t* __restrict__ uses, uint32_t* __restrict__ class_start,
+                uint32_t* __restrict__ blk_start, uint32_t* __restrict__ n_slots, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ slot_pt,
+                uint32_t* __restrict__ list) {
+  __shared__ uint32_t cnt[STMT_MAX_POINTS];            // terms of the statement on point id p
+  __shared__ int32_t cls_p[STMT_MAX_POINTS];           // class of the terms on p
+  __shared__ uint32_t rank_p[STMT_MAX_POINTS];         // table rank (static: among static table points; instance: among instance ones), or NONE
+  __shared__ uint32_t goff_p[STMT_MAX_POINTS];         // grouped points: offset of p's group (static: in the static part; instance: inside a proof's part)
+  __shared__ uint32_t pos_k[STMT_MAX_TERMS];           // term k: rank among the statement terms of its class (grouped: among the terms of its point)
+  __shared__ uint32_t cstart[HOT_CLASSES + 1];
+  __shared__ uint32_t cc[HOT_CLASSES];                 // statement terms per class
+  __shared__ uint32_t sh[4];                           // n_static_tab | n_inst_tab | SG (static grouped terms per proof) | UG (instance grouped terms per proof)
+  constexpr uint32_t NONE = 0xffffffffu;
+  const uint32_t tid = threadIdx.x, N = sj.N, T = sj.T, ns = sj.ns, np = sj.np;
+  for (uint32_t p = tid; p < np; p += 256) cnt[p] = 0;
+  if (tid < HOT_CLASSES) cc[tid] = 0;
+  __syncthreads();
+  for (uint32_t k = tid; k < T; k += 256) atomicAdd(&cnt[sj.tpt[k]], 1u);
+  __syncthreads();
+  for (uint32_t p = tid; p < np; p += 256) {           // class of every point id; common points: fixed-base registry first
+    int32_t c = -1;
+    if (p < ns && nreg) {
+      uint32_t w[8];
+      load_vec<2>(w, points + 32 * (size_t)p);
+      for (uint32_t r = 0; r < nreg; ++r) {
+        const uint32_t* q = reg_words + 8 * r;
+        bool eq = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) eq &= q[i] == w[i];
+        if (eq) c = reg_slot[r];
+      }
+    }
+    if (c < 0) {
+      const uint64_t u = p < ns ? (uint64_t)cnt[p] * N : cnt[p];
+      c = u >= group_min ? CLASS_GROUP : (u >= comb_min ? CLASS_COMB : CLASS_LADDER);
+    }
+    cls_p[p] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {                                      // the sequential part: ranks and offsets (np + T + 67 steps)
+    uint32_t n_stab = 0, n_itab = 0, SG = 0, UG = 0;
+    for (uint32_t p = 0; p < np; ++p) {
+      const int32_t c = cls_p[p];
+      const bool table = cnt[p] && (c == CLASS_GROUP || c == CLASS_COMB);
+      rank_p[p] = table ? (p < ns ? n_stab++ : n_itab++) : NONE;
+      goff_p[p] = 0;
+      if (cnt[p] && c == CLASS_GROUP) {
+        if (p < ns) { goff_p[p] = SG; SG += cnt[p]; } else { goff_p[p] = UG; UG += cnt[p]; }
+      }
+    }
+    sh[0] = n_stab; sh[1] = n_itab; sh[2] = SG; sh[3] = UG;
+    // per-term ranks
+    for (uint32_t k = 0; k < T; ++k) {
+      const uint32_t p = sj.tpt[k];
+      const int32_t c = cls_p[p];
+      if (c == CLASS_GROUP) {
+        uint32_t r = 0;                                              // rank among the terms of p (T^2 in the worst case, T <= 1024: once per block)
+        for (uint32_t k2 = 0; k2 < k; ++k2) r += sj.tpt[k2] == p;
+        pos_k[k] = r;
+      } else {
+        pos_k[k] = cc[c];
+      }
+      ++cc[c];
+    }
+    uint32_t run = 0, blk = 0;
+    for (int c = 0; c < HOT_CLASSES; ++c) {
+      cstart[c] = run;
+      const uint32_t n_c = cc[c] * N;
+      if (blockIdx.x == 0) {
+        class_start[c] = run;
+        if (c < HOT_SLOTS) { blk_start[c] = blk; blk += (n_c + 255u) / 256u; }
+      }
+      run += n_c;
+    }
+    cstart[HOT_CLASSES] = run;
+    if (blockIdx.x == 0) {
+      class_start[HOT_CLASSES] = run;
+      blk_start[HOT_SLOTS] = blk;
+      *n_slots = n_stab + n_itab * N;
+    }
+  }
+  __syncthreads();
+  const size_t g = (size_t)blockIdx.x * 256 + tid;
+  const size_t n_points = (size_t)ns + (size_t)(np - ns) * N, n_terms = (size_t)N * T;
+  if (g < n_points) {                                   // per point: cold use count (what k_decode_affine looks at), table slot
+    const uint32_t p = g < ns ? (uint32_t)g : ns + (uint32_t)((g - ns) / N);
+    const uint32_t j = g < ns ? 0u : (uint32_t)((g - ns) % N);
+    const int32_t c = cls_p[p];
+    const bool cold = c >= HOT_SLOTS;
+    const uint64_t u = cold ? (p < ns ? (uint64_t)cnt[p] * N : cnt[p]) : 0;
+    uses[g] = (uint32_t)(u > 0xffffffffull ? 0xffffffffull : u);
+    uint32_t slot = NONE;
+    if (rank_p[p] != NONE) slot = p < ns ? rank_p[p] : sh[0] + rank_p[p] * N + j;
+    if (slot != NONE && slot >= max_tables) slot = NONE;   // (cannot happen: max_tables counts every common point as cold)
+    slot_of[g] = slot;
+    if (slot != NONE) slot_pt[slot] = (uint32_t)g;
+  }
+  if (g < (size_t)N * sj.nc) sj.off[g] = (uint32_t)((g / sj.nc) * T + sj.toff[g % sj.nc]);
+  if (g == 0) sj.off[(size_t)N * sj.nc] = N * T;
+  if (g < n_terms) {
+    const uint32_t j = (uint32_t)(g / T), k = (uint32_t)(g % T);
+    const uint32_t p = sj.tpt[k];
+    sj.pidx[g] = p < ns ? p : ns + (p - ns) * N + j;
+    const int32_t c = cls_p[p];
+    size_t pos;
+    if (c == CLASS_GROUP) {
+      // common grouped points first (all N cnt[p] terms of a point together), then proof by proof
+      pos = p < ns ? (size_t)goff_p[p] * N + (size_t)j * cnt[p] + pos_k[k]
+                   : (size_t)sh[2] * N + (size_t)j * sh[3] + goff_p[p] + pos_k[k];
+    } else {
+      pos = (size_t)j * cc[c] + pos_k[k];
+    }
+    list[cstart[c] + pos] = (uint32_t)g;
+  }
+}
+
 // ---- the fixed-base terms of one block (256 lanes, one table) ----------------------------------------------------------
 // rep = HOT_ROW_CHUNKS * HOT_COPIES uint4 of LDS; rows = the table in HBM/L2.  Per window: the row (fetched one window ahead,
 // one chunk per lane) goes to LDS in HOT_COPIES copies, the lanes read their entry from their own copy, one mixed addition.

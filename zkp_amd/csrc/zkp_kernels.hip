@@ -977,6 +977,7 @@ struct zkp_ctx {
   struct { bool offered = false, active = false; const tr_op* ops = nullptr; uint32_t n_ops = 0; const uint64_t* tables = nullptr; uint32_t N = 0; tr_bufs bufs{};
            uint8_t* ts = nullptr; uint32_t* saved = nullptr; uint32_t* failed = nullptr; uint32_t tail = 0; } pending_tr;
   int debug_dummy_launches = 0;      // option 9 (measurement only): empty kernels added to every prove call
+  bool stmt_classify = true;         // option 10 (A/B): the fused flows' one-launch term classifier
   bool fuse_tables_transcript = false;   // ZKP_OPT_FUSE_TABLES_TRANSCRIPT
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
@@ -1068,7 +1069,11 @@ struct terms_cfg {
   uint32_t comb_min = 2;
   msm_map map;                     // lane -> MSM assignment of the reduce / encode kernels (fused flows: constraints by length)
   bool prehalved = false;          // the caller already wrote s / 2 mod l where the batched encoder is used (terms_batched_encode)
+  stmt_job stmt;                   // fused flows: the statement's term structure (one-launch classifier, k_stmt_classify)
 };
+inline bool stmt_classify_applies(const terms_cfg& k, uint32_t n_terms) {
+  return k.stmt.on && n_terms >= 1024 && k.stmt.T <= STMT_MAX_TERMS && k.stmt.np <= STMT_MAX_POINTS && k.stmt.T && k.stmt.N;
+}
 // (whether a constant-time call lists the terms of points with >= GROUP_MIN_USES uses together and walks their tables through
 //  LDS is the context's choice: zkp_ctx::grouped_comb)
 inline terms_cfg terms_cfg_clamped(terms_cfg k, uint32_t n_points, uint32_t n_terms) {
@@ -1171,7 +1176,15 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     const uint32_t group_min = (flags == ZKP_CT && k.teeth == 16 && group_on && k.max_tables) ? GROUP_MIN_USES : 0xffffffffu;
     uint32_t* gstart = reinterpret_cast<uint32_t*>(base + o.gstart);
     uint32_t* gfill = reinterpret_cast<uint32_t*>(base + o.gfill);
-    if (phase & PH_POINTS) {
+    if ((phase & PH_POINTS) && stmt_classify_applies(k, n_terms)) {
+      // the statement's structure gives classes, list positions and table slots arithmetically: one launch
+      const size_t lanes = std::max<size_t>(std::max<size_t>(n_terms, n_points), (size_t)k.stmt.N * k.stmt.nc + 1);
+      hipLaunchKernelGGL(k_stmt_classify, grid1(lanes, 256), dim3(256), 0, c->stream, k.stmt, d_points, c->hot_nreg, c->hot_reg_words, c->hot_reg_slot, comb_min, group_min,
+                         k.max_tables, needs, class_start, blk_start, n_slots, slot_of, slot_pt, list);
+      prof_mark(c, ZKP_K_SORT);
+      hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, decode_all ? (const uint32_t*)nullptr : needs);
+      prof_mark(c, ZKP_K_DECODE);
+    } else if (phase & PH_POINTS) {
     HIP_TRY(hipMemsetAsync(cls, 0, o.list - o.cls, c->stream));     // class counters, use counts, group cursors
     if (c->hot_nreg)
       hipLaunchKernelGGL(k_hot_match, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, c->hot_nreg, c->hot_reg_words, c->hot_reg_slot, hotmap, any_hot);
@@ -1190,7 +1203,8 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     hipLaunchKernelGGL(k_class_scatter, grid1(n_terms, 256), dim3(256), 0, c->stream, n_terms, d_pidx, n_points, hotmap, needs, comb_min, group_min, class_start, gstart, gfill,
                        cursor, list);
     prof_mark(c, ZKP_K_SORT);          // path A: term classification
-    if (k.max_tables) {
+    }
+    if ((phase & PH_POINTS) && k.max_tables) {
       if (c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) {
         if (k.teeth == 16 && c->pending_tr.active) {               // the flow's transcript program shares the launch
           const auto& t = c->pending_tr;
@@ -1205,8 +1219,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
         else hipLaunchKernelGGL(k_comb_tables<4>, grid1((size_t)k.max_tables * 4, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       }
     }
-    prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
-    }
+    if (phase & PH_POINTS) prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 4 + HOT_SLOTS));     // every class starts a new block
     // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l
     if (batched_encode) {
@@ -1460,6 +1473,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
     case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_single_use_tables = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_DEV_OVERLAP: c->dev_overlap = value != 0; return ZKP_OK;
+    case 10: c->stmt_classify = value != 0; return ZKP_OK;
     case 9: c->debug_dummy_launches = (int)std::min<uint64_t>(value, 1000); return ZKP_OK;
     case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value != 0; return ZKP_OK;
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;

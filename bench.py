@@ -51,7 +51,7 @@ DEFAULT_PMC = os.path.join("profiles", "r02_pmc_counters.json")
 KERNELS = {
     ("prove", "transcript"): "k_transcript_run (2 launches)", ("prove", "tables"): "k_comb_tables_lane<16>",
     ("prove", "terms"): "k_terms_split<true, 16, false>", ("prove", "reduce"): "k_encode_prepare + k_encode_invert + k_encode_finish",
-    ("prove", "sort"): "k_hot_match + k_use_count + k_class_count/scan + k_comb_slots + k_class_scatter", ("prove", "decode"): "k_decode_affine",
+    ("prove", "sort"): "k_stmt_classify", ("prove", "decode"): "k_decode_affine",
     ("prove", "scalars"): "k_blind_scalars + k_responses",
     ("batch_verify", "transcript"): "k_transcript_run", ("batch_verify", "decode"): "k_pip_prepare<c>",
     ("batch_verify", "sort"): "k_pip_tile_hist/total/scan/base/scatter", ("batch_verify", "bucket"): "k_pip_vmap + k_pip_bucket_part + k_pip_bucket_merge",

@@ -222,11 +222,11 @@ k_each_finish(uint32_t N, const uint8_t* __restrict__ out, const uint8_t* __rest
 // Batch verification, after the transcripts, in one launch: any rejected proof -> *any; -c mod l from the 64 challenge bytes;
 // commitment rows of the operand list (rows[k][j] = commitments[j][k], batch_verifier.rs:208-212)
 __global__ void __launch_bounds__(256)
-k_batch_after_transcript(uint32_t N, uint32_t nc, const uint32_t* __restrict__ failed, uint32_t* __restrict__ any, const uint8_t* __restrict__ wchal,
+k_batch_after_transcript(uint32_t N, uint32_t nc, const uint32_t* __restrict__ failed, uint32_t* __restrict__ any, uint32_t any_bit, const uint8_t* __restrict__ wchal,
                          uint8_t* __restrict__ minus_c, const uint8_t* __restrict__ coms, uint8_t* __restrict__ rows) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < N) {
-    if (failed[g]) *any = 1;
+    if (failed[g]) atomicOr(any, any_bit);
     sc lo, hi, r;
     load_vec<2>(lo.v, wchal + 64 * g);
     load_vec<2>(hi.v, wchal + 64 * g + 32);
@@ -819,7 +819,11 @@ int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* 
   const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni;
   const size_t total = (size_t)ns + ((size_t)ni + nc) * N;
   const ws_view w{static_cast<char*>(c->ws)};
-  HIP_TRY(hipMemsetAsync(d_status, 0, 8, c->stream));
+  // Status words without memsets: the transcript kernel zeroes the spare word behind its rejection flags, k_batch_after_transcript
+  // sets bit 1 of it if a proof was rejected, the MSM sets bit 0 on a decode failure, and the MSM's last kernel writes both
+  // status words (Pippenger sizes; tiny batches keep the two memsets)
+  uint32_t* shared = (N && total > kSmallOptional && pl.a.n) ? w.u32(o.failed) + N : nullptr;
+  if (!shared) HIP_TRY(hipMemsetAsync(d_status, 0, 8, c->stream));
   prof_begin(c);
   if (N) {
     tr_bufs hb{};
@@ -827,13 +831,13 @@ int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* 
     hb.dst[DST_CHAL] = w.u8(o.wchal);
     run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, /*owns_failed=*/true);
     prof_mark(c, ZKP_K_TRANSCRIPT);
-    hipLaunchKernelGGL(k_batch_after_transcript, grid1(std::max<size_t>(N, (size_t)N * nc), 256), dim3(256), 0, c->stream, N, nc, w.u32(o.failed), d_status + 1,
-                       w.u8(o.wchal), w.u8(o.mc), d_coms, d_pts + 32 * ((size_t)ns + (size_t)ni * N));
+    hipLaunchKernelGGL(k_batch_after_transcript, grid1(std::max<size_t>(N, (size_t)N * nc), 256), dim3(256), 0, c->stream, N, nc, w.u32(o.failed),
+                       shared ? shared : d_status + 1, shared ? 2u : 1u, w.u8(o.wchal), w.u8(o.mc), d_coms, d_pts + 32 * ((size_t)ns + (size_t)ni * N));
   }
   launch_coeff_build(c, pl.s, N, pl.d_inc, w.u8(o.mc), d_resp, d_w, w.u8(o.sc), w.u32(o.part));
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
-  return msm_optional_impl(c, total, w.u8(o.sc), d_pts, d_out, d_status, o.end);
+  return msm_optional_impl(c, total, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared);
 }
 
 // d_tbl = [ns + ni N + N nc][32]: common || instance rows || commitments [N][nc] (the last part doubles as the

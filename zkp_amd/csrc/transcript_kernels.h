@@ -143,6 +143,7 @@ __device__ __forceinline__ void transcript_pair_block(uint32_t bid, uint32_t* S 
   if (h == 0) { blob[50] = tail & 0xffffffu; blob[51] = 0; }
   // bit 31 of `tail`: this program owns the rejection flags (it writes 0 too, so that nobody has to clear them first)
   if (h == 0 && (bad || (tail >> 31))) failed[j] = bad;
+  if ((tail >> 31) && j_raw == 0 && h == 0) failed[N] = 0;      // the spare word behind the flags: the flow's shared status bits
 }
 
 __global__ void __launch_bounds__(TR_BLOCK)
@@ -200,6 +201,7 @@ k_transcript_run1(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t
   for (int i = 0; i < 25; ++i) blob[i] = col[TR_BLOCK * i];
   blob[25] = tail & 0xffffffu;
   if (bad || (tail >> 31)) failed[j] = bad;
+  if ((tail >> 31) && j_raw == 0) failed[N] = 0;
 }
 
 }  // namespace zkp

@@ -755,7 +755,8 @@ k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t ou
 // result = sum_w 2^(C w) T_w  (Horner, one quad: 256 inherently sequential doublings);  encode.
 __global__ void __launch_bounds__(256)
 k_pip_combine(int W1, int C, uint32_t in_stride, int level, int m, int shift, const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
-              dev_ext* __restrict__ T, const uint32_t* __restrict__ invalid, uint8_t* __restrict__ out_point, uint32_t* __restrict__ status) {
+              dev_ext* __restrict__ T, const uint32_t* __restrict__ invalid, uint8_t* __restrict__ out_point, uint32_t* __restrict__ status,
+              uint32_t shared_flags /*1: *invalid also carries bit 1 = "a transcript rejected a proof" -> status[1]*/) {
   {
     const uint32_t g = threadIdx.x >> 2;
     if (g < (uint32_t)W1) pip_reduce_quad(g, (int)(threadIdx.x & 3u), 1u, in_stride, 1u, level, m, shift, A_in, R_in, T, nullptr);
@@ -777,13 +778,15 @@ k_pip_combine(int W1, int C, uint32_t in_stride, int level, int m, int shift, co
   uint32_t o[8];
   ristretto_encode(o, full);
   if (q != 0) return;
-  const uint32_t bad = *invalid;
+  const uint32_t flags = *invalid;
+  const uint32_t bad = flags & 1u;
   if (bad) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = 0;
   }
   store_vec<2>(out_point, o);
-  *status = bad ? 1u : 0u;
+  status[0] = bad;
+  if (shared_flags) status[1] = (flags >> 1) & 1u;
 }
 
 // self-test hook for the 4-lane cooperative arithmetic: for pair i (P, Q): out[i] = enc(2P), enc(P+Q), enc(P+Q) via the
@@ -1297,7 +1300,7 @@ size_t pip_ws(uint64_t n) {
 
 template <int C>
 int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_points, uint8_t* d_out,
-            uint32_t* d_status, size_t ws_reserved) {
+            uint32_t* d_status, size_t ws_reserved, uint32_t* shared_flags) {
   using cfg = pip_cfg<C>;
   carve cv;
   cv.off = ws_reserved;
@@ -1317,13 +1320,14 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   dev_ext* parts = reinterpret_cast<dev_ext*>(base + cv.take((size_t)cfg::W1 * vmax * sizeof(dev_ext)));
   uint32_t* vmap = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * vmax * 4));
   uint32_t* invalid = reinterpret_cast<uint32_t*>(base + cv.take(256));
+  if (shared_flags) invalid = shared_flags;          // the caller's flag word, already zero (bit 0: ours; bit 1: the caller's, for status[1])
   dev_ext* buckets = reinterpret_cast<dev_ext*>(base + cv.take(nb * sizeof(dev_ext)));
   const size_t lvl_cap = (size_t)cfg::W1 * (cfg::B + 8);
   dev_ext* lvlA = reinterpret_cast<dev_ext*>(base + cv.take(lvl_cap * sizeof(dev_ext) * 2));
   dev_ext* lvlR = lvlA + lvl_cap;
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
 
-  HIP_TRY(hipMemsetAsync(invalid, 0, 4, c->stream));
+  if (!shared_flags) HIP_TRY(hipMemsetAsync(invalid, 0, 4, c->stream));
   hipLaunchKernelGGL(k_pip_prepare<C>, grid1(n, 256), dim3(256), 0, c->stream, n, d_scalars, d_points, niels, digits, invalid);
   prof_mark(c, ZKP_K_DECODE);
   hipLaunchKernelGGL(k_pip_tile_hist<C>, dim3(tiles, cfg::W1), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist);
@@ -1354,7 +1358,7 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
     dev_ext* Rout = lvlR + lvl_off;
     const uint32_t total = cfg::W1 * n_out;
     if (n_out == 1) {                                                 // the last level shares the launch of the Horner tail
-      hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(256), 0, c->stream, cfg::W1, C, in_stride, level, (int)m, shift, Ain, Rin, Aout, invalid, d_out, d_status);
+      hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(256), 0, c->stream, cfg::W1, C, in_stride, level, (int)m, shift, Ain, Rin, Aout, invalid, d_out, d_status, shared_flags ? 1u : 0u);
       break;
     }
     hipLaunchKernelGGL(k_pip_reduce_lvl, grid1((size_t)total * 4, 256), dim3(256), 0, c->stream, n_out, total, in_stride, n_out, level, (int)m, shift,
@@ -1717,9 +1721,12 @@ int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t*
   return ZKP_OK;
 }
 
+// shared_flags (optional, Pippenger sizes only): a zeroed device word that replaces the path's own decode-failure flag (bit 0) and
+// whose bit 1 the caller may have set; the last kernel then writes status[0] = bit 0 and status[1] = bit 1 (no memsets)
 static int msm_optional_impl(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, const uint8_t* d_points,
-                             uint8_t* d_out, uint32_t* d_status, size_t reserved) {
+                             uint8_t* d_out, uint32_t* d_status, size_t reserved, uint32_t* shared_flags = nullptr) {
   if (n <= kSmallOptional) {
+    if (shared_flags) return fail(ZKP_ERR_ARG, "internal: shared flags with a small MSM");
     carve cv;
     cv.off = reserved;
     const size_t o_pidx = cv.take((size_t)(n + 1) * 4);
@@ -1745,10 +1752,10 @@ static int msm_optional_impl(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, c
   int rc = ensure_ws(c, reserved + need);
   if (rc) return rc;
   switch (cbits) {
-    case 7: return pip_run<7>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
-    case 10: return pip_run<10>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
-    case 11: return pip_run<11>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
-    default: return pip_run<16>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved);
+    case 7: return pip_run<7>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags);
+    case 10: return pip_run<10>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags);
+    case 11: return pip_run<11>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags);
+    default: return pip_run<16>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags);
   }
 }
 

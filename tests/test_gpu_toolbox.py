@@ -560,3 +560,52 @@ def test_batch_verify_locate_names_the_bad_proofs(eng):
     with pytest.raises(T.BatchSizeMismatch):
         T.batch_verify_locate(eng, mod.statement, ts[:-1], inst, common, coms, resp)
     assert after_ok.shape == ts.shape
+
+
+@pytest.mark.parametrize("grouped", [0, 1])
+def test_statement_with_more_common_points_than_table_slots(eng, grouped):
+    """70 common generators: 64 get fixed-base tables, six stay cold and are shared by every proof of the batch -- comb tables
+    (masked scans), or with ZKP_OPT_GROUPED_COMB their terms walk through LDS as one group of N terms per point.  The fused
+    route (statement-aware one-launch classifier, k_stmt_classify) must produce the host-transcript route's bytes (generic
+    classifier), for proving and for both verifications."""
+    ng, n = 70, 48
+    xs = ["x_%d" % i for i in range(ng)]
+    gs = ["G_%d" % i for i in range(ng)]
+    wide = T.define_proof("wide70", b"W70", xs, ["Q"], gs, [("Q", [(x, g) for x, g in zip(xs, gs)])])
+    rng = np.random.default_rng(70)
+
+    def rs(k):
+        s = rng.integers(0, 256, size=(k, 32), dtype=np.uint8)
+        s[:, 31] &= 0x0f
+        return s
+
+    base = np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32)
+    common, _ = C.msm_many(np.arange(ng + 1, dtype=np.uint32), rs(ng), np.zeros(ng, np.uint32), base, 0)
+    secrets = rs(n * ng).reshape(n, ng, 32)
+    off = (ng * np.arange(n + 1)).astype(np.uint32)
+    q, st = C.msm_many(off, secrets.reshape(-1, 32), np.tile(np.arange(ng, dtype=np.uint32), n), common, 0)
+    assert not st.any()
+    inst = np.ascontiguousarray(q[None])                              # [1 instance point][n][32]
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    label = b"W70 test"
+    fresh = lambda: np.stack([T.Transcript(label).state] * n)
+    eng.set_option(6, grouped)
+    try:
+        results = []
+        for min_batch in (0, 10**9):                                  # fused route, then host transcripts + generic classifier
+            T.set_fused_min_batch(min_batch)
+            ts = fresh()
+            chal, resp, coms = T.prove_batch(eng, wide.statement, ts, secrets, inst, common, entropy)
+            res = T.verify_compact_batch(eng, wide.statement, fresh(), inst, common, chal, resp)
+            assert not res.any()
+            T.batch_verify(eng, wide.statement, fresh(), inst, common, coms, resp)
+            bad = resp.copy()
+            bad[5, 69, 0] ^= 1
+            res = T.verify_compact_batch(eng, wide.statement, fresh(), inst, common, chal, bad)
+            assert res[5] == 1 and res.sum() == 1
+            results.append((chal, resp, coms, ts))
+        for a, b in zip(results[0], results[1]):
+            assert (a == b).all()
+    finally:
+        T.set_fused_min_batch(32)
+        eng.set_option(6, 2**64 - 1)

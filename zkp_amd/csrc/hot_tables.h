@@ -277,12 +277,13 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
   __shared__ uint32_t rank_p[STMT_MAX_POINTS];         // table rank (static: among static table points; instance: among instance ones), or NONE
   __shared__ uint32_t goff_p[STMT_MAX_POINTS];         // grouped points: offset of p's group (static: in the static part; instance: inside a proof's part)
   __shared__ uint32_t pos_k[STMT_MAX_TERMS];           // term k: rank among the statement terms of its class (grouped: among the terms of its point)
+  __shared__ uint32_t seen_p[STMT_MAX_POINTS];         // (running count of the terms of p while the ranks are handed out)
   __shared__ uint32_t cstart[HOT_CLASSES + 1];
   __shared__ uint32_t cc[HOT_CLASSES];                 // statement terms per class
   __shared__ uint32_t sh[4];                           // n_static_tab | n_inst_tab | SG (static grouped terms per proof) | UG (instance grouped terms per proof)
   constexpr uint32_t NONE = 0xffffffffu;
   const uint32_t tid = threadIdx.x, N = sj.N, T = sj.T, ns = sj.ns, np = sj.np;
-  for (uint32_t p = tid; p < np; p += 256) cnt[p] = 0;
+  for (uint32_t p = tid; p < np; p += 256) { cnt[p] = 0; seen_p[p] = 0; }
   if (tid < HOT_CLASSES) cc[tid] = 0;
   __syncthreads();
   for (uint32_t k = tid; k < T; k += 256) atomicAdd(&cnt[sj.tpt[k]], 1u);
@@ -324,9 +325,7 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
       const uint32_t p = sj.tpt[k];
       const int32_t c = cls_p[p];
       if (c == CLASS_GROUP) {
-        uint32_t r = 0;                                              // rank among the terms of p (T^2 in the worst case, T <= 1024: once per block)
-        for (uint32_t k2 = 0; k2 < k; ++k2) r += sj.tpt[k2] == p;
-        pos_k[k] = r;
+        pos_k[k] = seen_p[p]++;                                      // rank among the terms of p
       } else {
         pos_k[k] = cc[c];
       }

@@ -86,12 +86,15 @@ const char* zkp_version(void);
  *     wavefronts then carry the table builder's 212 registers instead of their own 118).  Default 0.
  *   ZKP_OPT_TRANSCRIPT_LANES: lanes per proof in the Merlin transcript kernel of the fused flows.  2 = a lane pair per proof
  *     (each lane holds one 32-bit half of every STROBE word: half the latency), 1 = one lane per proof (23 % fewer
- *     instructions per Keccak-f), UINT64_MAX = default: 1 in asynchronous _dev calls of 8192 proofs or more, 2 otherwise. */
+ *     instructions per Keccak-f), UINT64_MAX = default: 1 in asynchronous _dev calls of 8192 proofs or more, 2 otherwise. 
+ *   (Measurement only, not part of the interface: option 9 = n empty kernels added to every zkp_fused_prove_dev call -- what a launch
+ *    costs a pipelined caller; option 10 = 0 sends the fused flows through the generic six-kernel term classifier instead of
+ *    k_stmt_classify.  profiles/r02_ab_experiments.txt, blocks o and p.) */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
        ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
-/* HIP graphs.  A batch of proofs is a chain of ~75 short kernels; enqueueing them one by one costs the host ~0.15 ms per
+/* HIP graphs.  A batch of proofs is a chain of ~35 short kernels (75 in round 1); enqueueing them one by one costs the host ~0.1 ms per
  * batch (measured: 0.14-0.17 ms against 0.9 ms of GPU time per pipelined batch; 0.025 ms as a graph), which matters for
  * short runs and for hosts busier than a benchmark loop.  Everything enqueued on the context's stream between _begin and
  * _end -- *_dev calls of this library and

@@ -191,7 +191,7 @@ def cmz_instance(eng, n, rng):
 
 
 def pick_streams(steps):
-    """Batches in flight.  A batch is a chain of ~75 kernels, several of them only a few dozen wavefronts wide, so the chip
+    """Batches in flight.  A batch is a chain of ~32 kernels, several of them only a few dozen wavefronts wide, so the chip
     is filled by running independent batches side by side (measured at 200 steps: 16 streams 4.61, 20 streams 4.85, 25 streams
     4.98, 28 streams 4.84, 32 streams 4.59, 40 streams 3.72 M proofs/s).  With K timed steps over S streams the last round of
     batches runs with K mod S streams busy; pick S in 12..25 that leaves the fewest idle slots (ties: more streams)."""
@@ -390,7 +390,7 @@ def main():
     barrier()
 
     def timed_loop(which, steps, warmup):
-        """K steps over the streams, each replaying the per-stream HIP graph of its chain (2 copies + ~75 kernels per flow pair):
+        """K steps over the streams, each replaying the per-stream HIP graph of its chain (2 copies + ~30 kernels per flow pair):
         barrier + synchronize on both sides; returns (elapsed, host time to enqueue)."""
         graphs = [None] * n_streams
         for k in range(n_streams):             # first pass: plans compiled, workspaces sized (nothing may allocate while capturing)

@@ -14,6 +14,19 @@ Inputs are synthetic (random witnesses, a consistent instance made by the engine
 RESIDENT IN HBM before the timed region; every step starts from fresh `Transcript::new(b"Benchmark")` states like the
 reference's bench loop.  value = proofs per second that went through the whole step.
 
+Batches per call (--batches-per-call K, config.batches_per_call): a server that proves / verifies batch after batch does not
+have to hand them to the GPU one by one.  K steps = K batches of N proofs travel in ONE call chain: the K N proofs are proven
+by one zkp_fused_prove_dev call (proving has no batch semantics) and verified by one zkp_fused_batch_verify_many_dev call --
+K independent batch verifications (own weights, own static-coefficient sums, own MSM, own verdict: K x
+batch_verifier.rs:137-235) through one transcript launch, one coefficient grid and one segmented Pippenger.  The narrow
+kernels of a single batch (transcripts, table chains, bucket tree, Horner) are then K times wider and a handful of streams
+fills the chip instead of 20 - 25.  K = 1 is the round-2 loop.  The timed region still covers exactly --steps batches.
+
+What `value` does NOT contain (the reference pays it on the host in every call): drawing the 32 bytes of thread_rng per proof
+(prover.rs:82) and the u128 weights (batch_verifier.rs:179) -- entropy and weights are fixed arrays resident in HBM, so every
+step re-proves the same proofs -- and host-side transcript work.  "e2e_host_buffers" in the line is the same flow through
+the host toolbox (host buffers in and out over PCIe, OS entropy + ChaCha20 for blindings and weights) for comparison.
+
 Other workloads (one JSON line each, same keys):
   --config 3       BASELINE configs[2]: BatchVerifier over 2^20 mixed DLEQ proofs -- 2^19 in define_proof! form (1 + 5 N
                    terms, benches/zkp.rs:49) + 2^19 in constraint-API form (static G, H: 2 + 4 N terms, benches/dleq.rs:188-241);
@@ -21,7 +34,7 @@ Other workloads (one JSON line each, same keys):
   --config 4share  one GPU's share of configs[3]: CMZ, 524,288 proofs per step (prove + batch verify)
   --config 5share  one GPU's share of configs[4]: the 64-term wide statement, 32,768 proofs per step (prove + batch verify)
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4share|5share] [--batch n] [--streams S]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4share|5share] [--batch n] [--batches-per-call K] [--streams S]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  Everything in it is measured in this run, except the PMC-derived fields (roofline.traffic,
@@ -46,17 +59,18 @@ VALU_PEAK = 34.5e12           # 4-cycle-class VALU lane-instructions / s (v_mad_
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
 LABEL = b"Benchmark"
 BASE = bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76")
-DEFAULT_PMC = os.path.join("profiles", "r02_pmc_counters.json")
-# what the HIP-event timing kinds of zkp_ctx_last_timing are, per flow (kernel names as rocprofv3 prints them)
+PMC_PATTERN = os.path.join("profiles", "r03_pmc_counters_cfg%s.json")      # one counter file per workload (tools/collect_profiles.sh)
+# what the HIP-event timing kinds of zkp_ctx_last_timing are, per flow: (kernel names as rocprofv3 prints them, launches per call).
+# roofline.kernel is chosen among the GROUPS below by kernel name, summed across flows (k_transcript_run* = 3 launches per step).
 KERNELS = {
-    ("prove", "transcript"): "k_transcript_run (2 launches)", ("prove", "tables"): "k_comb_tables_lane<16>",
-    ("prove", "terms"): "k_terms_split<true, 16, false>", ("prove", "reduce"): "k_encode_prepare + k_encode_invert + k_encode_finish",
-    ("prove", "sort"): "k_stmt_classify", ("prove", "decode"): "k_decode_affine",
-    ("prove", "scalars"): "k_blind_scalars + k_responses",
-    ("batch_verify", "transcript"): "k_transcript_run", ("batch_verify", "decode"): "k_pip_prepare<c>",
-    ("batch_verify", "sort"): "k_pip_tile_hist/total/scan/base/scatter", ("batch_verify", "bucket"): "k_pip_vmap + k_pip_bucket_part + k_pip_bucket_merge",
-    ("batch_verify", "combine"): "k_pip_reduce_lvl x levels + k_pip_combine (last level + Horner)",
-    ("batch_verify", "scalars"): "k_batch_after_transcript + k_coeff_build + k_coeff_static_final",
+    ("prove", "transcript"): ("k_transcript_run", 2), ("prove", "tables"): ("k_comb_tables_lane<16>", 1),
+    ("prove", "terms"): ("k_terms_split<true, 16, false>", 1), ("prove", "reduce"): ("k_encode_prepare + k_encode_invert + k_encode_finish", 3),
+    ("prove", "sort"): ("k_stmt_classify", 1), ("prove", "decode"): ("k_decode_affine", 1),
+    ("prove", "scalars"): ("k_blind_scalars + k_responses", 2),
+    ("batch_verify", "transcript"): ("k_transcript_run", 1), ("batch_verify", "decode"): ("k_pip_prepare<c>", 1),
+    ("batch_verify", "sort"): ("k_pip_tile_hist/total/scan/base/scatter", 5), ("batch_verify", "bucket"): ("k_pip_vmap + k_pip_bucket_part + k_pip_bucket_merge", 3),
+    ("batch_verify", "combine"): ("k_pip_reduce_lvl x levels + k_pip_combine (last level + Horner)", 4),
+    ("batch_verify", "scalars"): ("k_batch_after_transcript + k_coeff_build + k_coeff_static_final", 3),
 }
 
 
@@ -123,6 +137,7 @@ def w64_statement():
 
 WORKLOADS = {
     # name: (description, [(statement label, statement fn, share of the batch, flows)], default batch, default streams (0 = auto), default steps)
+    # (--config 2 packs K batches into one call chain: pick_call_shape)
     "2": ("CMZ'13 10-hidden-attribute credential, batch of %d proofs per GPU: complete proving (Merlin transcripts, blindings, 11 constant-time "
           "commitment MSMs / 31 terms per proof, challenges, responses) + complete batch verification of those proofs (transcripts, coefficient "
           "build, one MSM of 12 + 24 N terms)", [(b"CMZ cred show n=10", cmz_statement, 1.0, ("prove", "batch_verify"))], 4096, 0, 1000),
@@ -191,13 +206,41 @@ def cmz_instance(eng, n, rng):
 
 
 def pick_streams(steps):
-    """Batches in flight.  A batch is a chain of ~32 kernels, several of them only a few dozen wavefronts wide, so the chip
-    is filled by running independent batches side by side (measured at 200 steps: 16 streams 4.61, 20 streams 4.85, 25 streams
-    4.98, 28 streams 4.84, 32 streams 4.59, 40 streams 3.72 M proofs/s).  With K timed steps over S streams the last round of
-    batches runs with K mod S streams busy; pick S in 12..25 that leaves the fewest idle slots (ties: more streams)."""
+    """Round-2 loop (one batch per call, --batches-per-call 1): batches in flight.  A batch is a chain of ~32 kernels, several of
+    them only a few dozen wavefronts wide, so the chip is filled by running independent batches side by side (measured at 200
+    steps: 16 streams 4.61, 20 streams 4.85, 25 streams 4.98, 28 streams 4.84, 32 streams 4.59, 40 streams 3.72 M proofs/s).
+    With K timed steps over S streams the last round of batches runs with K mod S streams busy; pick S in 12..25 that leaves
+    the fewest idle slots (ties: more streams)."""
     if steps <= 25:
         return max(1, steps)
     return min(range(12, 26), key=lambda s: ((-steps) % s, -s))
+
+
+CALL_SHAPES = {}       # filled from measurements: steps -> (batches per call, streams); see pick_call_shape
+
+
+def pick_call_shape(steps, want_k=0, want_streams=0):
+    """(K, S) for --config 2: K batches per call chain, S call chains in flight.  K must divide --steps (exactly --steps batches
+    are timed).  Wide calls fill the chip on their own, so few streams are needed; two to four of them overlap one call's
+    remaining narrow kernels (the K Horner quads, the inversion of the batched encoder) with the others' wide ones.
+    Defaults: the largest divisor of steps that is <= 16 and leaves at least 4 calls (<= 40 steps: at least 2 calls)."""
+    if want_k > 0:
+        if steps % want_k:
+            raise SystemExit("--batches-per-call must divide --steps (exactly --steps batches are timed)")
+        k = want_k
+    elif steps in CALL_SHAPES:
+        k = CALL_SHAPES[steps][0]
+    else:
+        min_calls = 2 if steps <= 40 else 4
+        k = max([d for d in range(1, 17) if steps % d == 0 and steps // d >= min_calls] or [1])
+    calls = steps // k
+    if want_streams > 0:
+        s = want_streams
+    elif steps in CALL_SHAPES and not want_k:
+        s = CALL_SHAPES[steps][1]
+    else:
+        s = pick_streams(steps) if k == 1 else min(4, calls)
+    return k, max(1, min(s, calls))
 
 
 def source_sha256():
@@ -249,61 +292,29 @@ def init_distributed(world, rank, local_rank):
     return dist, group, info
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 1000 for --config 2 = 0.8 s, fewer for the large workloads)")
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="2", choices=sorted(WORKLOADS), help="BASELINE.json workload (2 = configs[1], the metric's configuration)")
-    ap.add_argument("--batch", type=int, default=None, help="proofs per GPU per step (default: the workload's)")
-    ap.add_argument("--streams", type=int, default=0, help="independent batches in flight, each on its own HIP stream / engine context "
-                                                            "(0 = automatic: 12..24 for --config 2, the count that splits --steps most evenly)")
-    ap.add_argument("--max-hw-queues", type=int, default=25, help="cap of GPU_MAX_HW_QUEUES (one hardware queue per stream up to this)")
-    ap.add_argument("--no-graphs", action="store_true", help="enqueue every kernel of every batch from the host instead of replaying one "
-                                                            "HIP graph per stream")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-flow-lines", action="store_true", help="skip the pipelined prove-only / batch-verify-only / verify_compact measurements")
-    ap.add_argument("--pmc-json", default=DEFAULT_PMC, help="rocprofv3 --pmc summary (tools/pmc_summary.py); used only if its source hash matches")
-    ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
-                    help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
-    args = ap.parse_args()
+class Ctx:
+    """what every workload of a run shares: the rank's device, the process groups"""
+    pass
 
-    if args.gpus > 1 and "RANK" not in os.environ:
-        # convenience: self-launch one process per GPU exactly as the driver would
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
 
-    desc, parts, def_batch, def_streams, def_steps = WORKLOADS[args.config]
-    if args.steps is None:
-        args.steps = def_steps
-    n = args.batch or def_batch
-    if args.streams <= 0:
-        args.streams = def_streams or pick_streams(args.steps)
-    args.streams = max(1, min(args.streams, max(1, args.steps)))
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(args.streams, args.max_hw_queues))))   # one hardware queue per stream (default is 4)
+def run_workload(cx, args, cfg, n, steps, warmup, K, n_streams, primary):
+    """One workload of WORKLOADS on this rank: set-up (untimed), the timed loop (barrier + synchronize on both sides, MAX over
+    ranks), and -- for the primary workload of the run -- the single-flow lines, per-kernel HIP-event timing and roofline.
+    A call = K steps = K batches of n proofs in one chain (K = 1 except --config 2).  Returns the result dictionary."""
     import numpy as np
     import torch
     from zkp_amd.engine import Engine, FusedStatement
     from zkp_amd import toolbox as T
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist, group, dinfo = None, None, {"collective": None, "backend_world_size": 1, "rccl_error": None}
-    if world > 1:
-        if os.environ.get("ZKP_BENCH_DRYRUN_ONE_GPU"):
-            local_rank = 0
-        else:
-            torch.cuda.set_device(local_rank)
-        dist, group, dinfo = init_distributed(world, rank, local_rank)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    n_streams = args.streams
-    engines = [Engine(local_rank) for _ in range(n_streams)]
+    desc, parts, _, _, _ = WORKLOADS[cfg]
+    dist, group, dev, rank, world = cx.dist, cx.group, cx.dev, cx.rank, cx.world
+    assert steps % K == 0
+    calls = steps // K
+    n_streams = max(1, min(n_streams, calls))
+    engines = [Engine(cx.local_rank) for _ in range(n_streams)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     for e_, s_ in zip(engines, streams):
-        e_.set_stream(s_.cuda_stream)          # engine work and the torch copies of one batch share one HIP stream
+        e_.set_stream(s_.cuda_stream)          # engine work and the torch copies of one call share one HIP stream
         for kv in args.engine_opt:
             e_.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     eng = engines[0]
@@ -320,14 +331,17 @@ def main():
     for label, st_fn, share, flows in parts:
         p = Part()
         p.st = st_fn()
-        p.n = max(1, int(round(n * share)))
+        p.n_each = max(1, int(round(n * share)))       # proofs of one batch (= one step)
+        p.K = K
+        p.n = p.n_each * K                             # proofs of one call
         p.flows = flows
         p.secrets, p.inst, p.common = make_instance(eng, p.st, p.n, rng)
         p.fst = FusedStatement(label, *p.st)
         p.m, p.nc = len(p.st[0]), len(p.st[2])
         p.ns, p.ni = len(p.common), len(p.inst)
         p.T = sum(len(lc) for _, lc in p.st[2])
-        p.n_bv = p.ns + (p.ni + p.nc) * p.n
+        p.n_bv_each = p.ns + (p.ni + p.nc) * p.n_each  # terms of one batch's MSM (batch_verifier.rs:219-228)
+        p.n_pts = p.ns + (p.ni + p.nc) * p.n
         p.d_ts0 = t(np.stack([t0s] * p.n))
         p.d_sec = t(p.secrets)
         p.d_tbl = t(np.concatenate([p.common, p.inst.reshape(-1, 32)]))        # common || inst rows: the prover's point table
@@ -336,7 +350,7 @@ def main():
         p.bufs = []
         for _ in engines:
             b = dict(ts=z8(p.n, 208), ts2=z8(p.n, 208), ts3=z8(p.n, 208), chal=z8(p.n, 32), resp=z8(p.n, p.m, 32), coms=z8(p.n, p.nc, 32),
-                     st=z8(p.n * p.nc), pts=z8(p.n_bv, 32), out=z8(32), bst=torch.ones(2, dtype=torch.int32, device=dev), res=z8(p.n))
+                     st=z8(p.n * p.nc), pts=z8(p.n_pts, 32), out=z8(K, 32), bst=torch.ones((K, 2), dtype=torch.int32, device=dev), res=z8(p.n))
             b["pts"][: p.ns + p.ni * p.n] = p.d_tbl
             p.bufs.append(b)
         ps.append(p)
@@ -350,14 +364,14 @@ def main():
                            b["resp"].data_ptr(), b["coms"].data_ptr(), b["st"].data_ptr())
 
     def batch_verify(e_, p, b):
-        e_.fused_batch_verify_dev(p.fst, p.n, pos, b["ts2"].data_ptr(), b["pts"].data_ptr(), b["coms"].data_ptr(), b["resp"].data_ptr(),
-                                  p.d_w.data_ptr(), b["out"].data_ptr(), b["bst"].data_ptr())
+        e_.fused_batch_verify_many_dev(p.fst, p.K, p.n_each, pos, b["ts2"].data_ptr(), b["pts"].data_ptr(), b["coms"].data_ptr(), b["resp"].data_ptr(),
+                                       p.d_w.data_ptr(), b["out"].data_ptr(), b["bst"].data_ptr())
 
     def verify_compact(e_, p, b):
         e_.fused_verify_compact_dev(p.fst, p.n, pos, b["ts3"].data_ptr(), p.d_tbl.data_ptr(), b["chal"].data_ptr(), b["resp"].data_ptr(), b["res"].data_ptr())
 
     def enqueue(k, which=None):
-        """one step on stream k: per part, fresh transcripts and its flows (or only the flow `which`)"""
+        """one call (= K steps) on stream k: per part, fresh transcripts and its flows (or only the flow `which`)"""
         e_ = engines[k]
         with torch.cuda.stream(streams[k]):
             for p in ps:
@@ -380,6 +394,9 @@ def main():
             e_.synchronize()
         torch.cuda.synchronize()
 
+    def batches_ok(b):
+        return int(b["bst"].abs().sum().item()) == 0 and not bool(b["out"].any().item())
+
     # proofs for the parts whose step only verifies: made once, untimed
     for k in range(n_streams):
         with torch.cuda.stream(streams[k]):
@@ -389,9 +406,9 @@ def main():
                     prove(engines[k], p, p.bufs[k])
     barrier()
 
-    def timed_loop(which, steps, warmup):
-        """K steps over the streams, each replaying the per-stream HIP graph of its chain (2 copies + ~30 kernels per flow pair):
-        barrier + synchronize on both sides; returns (elapsed, host time to enqueue)."""
+    def timed_loop(which, n_calls, warm):
+        """n_calls calls over the streams, each replaying the per-stream HIP graph of its chain: barrier + synchronize on both
+        sides; returns (elapsed, host time to enqueue, per-rank elapsed)."""
         graphs = [None] * n_streams
         for k in range(n_streams):             # first pass: plans compiled, workspaces sized (nothing may allocate while capturing)
             enqueue(k, which)
@@ -399,30 +416,32 @@ def main():
         if not args.no_graphs:
             for k in range(n_streams):
                 engines[k].capture_begin()
-                enqueue(k, which)
-                graphs[k] = engines[k].capture_end()
+                try:
+                    enqueue(k, which)
+                finally:
+                    graphs[k] = engines[k].capture_end()       # always ends the capture: a failed call must not leave the stream capturing
 
-        def step(i):
-            # consecutive batches go to different engine contexts = different HIP streams, so the narrow phases of one batch
-            # (transcripts, table chains, Horner) overlap with the wide kernels of the others
+        def call(i):
+            # consecutive calls go to different engine contexts = different HIP streams, so the narrow phases of one call
+            # (table chains, Horner quads, the encoder's inversion) overlap with the wide kernels of the others
             k = i % n_streams
             if graphs[k] is not None:
                 graphs[k].launch()
             else:
                 enqueue(k, which)
 
-        for i in range(max(warmup, 1) * n_streams):
-            step(i)
+        for i in range(max(warm, 1) * n_streams):
+            call(i)
         barrier()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
+        for i in range(n_calls):
+            call(i)
         t_enq = time.perf_counter() - t0
         if which is None and dist is not None:
             # the only cross-GPU exchange of the path: AND of the per-GPU verdict bits (int32 MIN all-reduce)
             for e_ in engines:
                 e_.synchronize()
-            ok_local = all(int(b["bst"].abs().sum().item()) == 0 and not bool(b["out"].any().item()) for p in ps for b in p.bufs)
+            ok_local = all(batches_ok(b) for p in ps if "batch_verify" in p.flows for b in p.bufs)
             verdict.fill_(1 if ok_local else 0)
             if group is not None:
                 dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)           # RCCL
@@ -431,7 +450,7 @@ def main():
                 dist.all_reduce(v, op=dist.ReduceOp.MIN)                              # gloo fallback
                 verdict.copy_(v)
         barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = own = time.perf_counter() - t0
         if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -439,48 +458,62 @@ def main():
         for g in graphs:
             if g is not None:
                 g.close()
-        return elapsed, t_enq
+        return elapsed, t_enq, own
 
-    elapsed, t_enqueued = timed_loop(None, args.steps, args.warmup)
+    elapsed, t_enqueued, own_elapsed = timed_loop(None, calls, warmup)
     if dist is not None:
         assert int(verdict.item()) == 1, "a rank reported a batch that did not verify"
     for p in ps:
         for b in p.bufs:
             assert not bool(b["st"].any().item()), "prover: an input point failed to decode"
-            assert int(b["bst"].abs().sum().item()) == 0 and not bool(b["out"].any().item()), "the batch of fresh proofs did not verify"
+            if "batch_verify" in p.flows:
+                assert batches_ok(b), "a batch of fresh proofs did not verify"
         assert all(bool((b["chal"] == p.bufs[0]["chal"]).all().item()) and bool((b["resp"] == p.bufs[0]["resp"]).all().item()) for b in p.bufs), "streams disagree"
-    # the proofs must be REAL proofs: a flipped response bit makes the batch check fail
+    # the proofs must be REAL proofs: a flipped response bit makes its batch check fail -- and only that one
     for p in ps:
+        if "batch_verify" not in p.flows:
+            continue
         b = p.bufs[0]
+        kb = p.K // 2
+        j = kb * p.n_each + p.n_each // 2
         with torch.cuda.stream(streams[0]):
-            b["resp"][p.n // 2, p.m // 2, 0] ^= 1
+            b["resp"][j, p.m // 2, 0] ^= 1
             b["ts2"].copy_(p.d_ts0)
             batch_verify(eng, p, b)
         eng.synchronize()
         torch.cuda.synchronize()
-        assert bool(b["out"].any().item()) or int(b["bst"].abs().sum().item()) != 0, "a corrupted proof passed the batch check"
+        bad = [i for i in range(p.K) if bool(b["out"][i].any().item()) or int(b["bst"][i].abs().sum().item()) != 0]
+        assert bad == [kb], "a corrupted proof must fail exactly its own batch: %r" % (bad,)
         with torch.cuda.stream(streams[0]):
-            b["resp"][p.n // 2, p.m // 2, 0] ^= 1
+            b["resp"][j, p.m // 2, 0] ^= 1
         torch.cuda.synchronize()
 
+    total_n = sum(p.n_each for p in ps)                # proofs per step
+    res = {"elapsed": elapsed, "own_elapsed": own_elapsed, "ms_per_step": elapsed * 1e3 / steps, "value": world * total_n * steps / elapsed,
+           "host_enqueue_ms_per_step": t_enqueued * 1e3 / steps, "streams": n_streams, "ps": ps, "total_n": total_n}
+    if not primary:
+        for e_ in engines:
+            e_.close()
+        return res
+
     # ---- pipelined single-flow lines (same loop, one flow) -------------------------------------------------------------
-    total_n = sum(p.n for p in ps)
     flow_lines = {}
     if not args.no_flow_lines:
         flows_present = sorted({f for p in ps for f in p.flows})
-        for which in flows_present + (["verify_compact"] if args.config != "3" else []):
+        for which in flows_present + (["verify_compact"] if cfg != "3" else []):
             if len(flows_present) == 1 and which == flows_present[0]:
                 continue                       # the step itself is that flow
-            el, _ = timed_loop(which, args.steps, 1)
-            flow_lines[which] = world * total_n * args.steps / el
+            el, _, _ = timed_loop(which, calls, 1)
+            flow_lines[which] = world * total_n * steps / el
         if "verify_compact" in flow_lines:
             assert all(not bool(b["res"].any().item()) for p in ps for b in p.bufs), "verify_compact rejected a fresh proof"
+    res["flow_lines"] = flow_lines
 
     # ---- per-kernel timing with HIP events on the engine's stream (separate, profiled passes on one stream) -------------
     eng.set_profiling(True)
-    reps = 5 if total_n <= (1 << 16) else 2
+    reps = 5 if total_n * K <= (1 << 16) else 2
     kms = {}
-    flows_timed = sorted({f for p in ps for f in p.flows}) + ([] if args.no_flow_lines or args.config == "3" else ["verify_compact"])
+    flows_timed = sorted({f for p in ps for f in p.flows}) + ([] if args.no_flow_lines or cfg == "3" else ["verify_compact"])
     with torch.cuda.stream(streams[0]):
         for _ in range(reps):
             for p in ps:
@@ -503,56 +536,196 @@ def main():
                         d[k] = d.get(k, 0.0) + v / reps
                     d["total"] = d.get("total", 0.0) + tot / reps
     eng.set_profiling(False)
+    res["kms"] = kms                           # ms per CALL (K steps) on a lone stream
+    res["engines"] = engines
+    return res
+
+
+def e2e_host_buffers(eng, n=4096, reps=3):
+    """The CMZ step THROUGH the host toolbox (include/zkp_toolbox.h): host buffers in and out over PCIe, the per-proof entropy
+    and the u128 weights drawn inside the call (getrandom + ChaCha20) -- what `value` leaves out.  Best of `reps`."""
+    import numpy as np
+    from zkp_amd import toolbox as T
+    mod = T.cmz_module(10)
+    rng = np.random.default_rng(77)
+    secrets, inst, common = make_instance(eng, cmz_statement(), n, rng)
+    best = None
+    for _ in range(reps + 1):
+        ts = np.stack([T.Transcript(LABEL).state] * n)
+        t0 = time.perf_counter()
+        chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, common)              # entropy = None: from the OS
+        t1 = time.perf_counter()
+        ts = np.stack([T.Transcript(LABEL).state] * n)
+        t1b = time.perf_counter()
+        T.batch_verify(eng, mod.statement, ts, inst, common, coms, resp)                             # weights = None: from the OS
+        t2 = time.perf_counter()
+        cur = (t1 - t0, t2 - t1b)
+        if best is None or sum(cur) < sum(best):
+            best = cur
+    return {"proofs": n, "prove_ms": best[0] * 1e3, "batch_verify_ms": best[1] * 1e3, "proofs_per_s": n / sum(best),
+            "note": "zkp_prove_batch + zkp_batch_verify (fused route) on host buffers: PCIe copies, OS entropy for the blindings (prover.rs:82) and "
+                    "ChaCha20 weights (batch_verifier.rs:179) included; one synchronous call each, nothing pipelined"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps = batches (default: 1000 for --config 2 = 0.7 s, fewer for the large workloads)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="2", choices=sorted(WORKLOADS), help="BASELINE.json workload (2 = configs[1], the metric's configuration)")
+    ap.add_argument("--batch", type=int, default=None, help="proofs per GPU per step (default: the workload's)")
+    ap.add_argument("--batches-per-call", type=int, default=0, help="--config 2: K steps (batches) travel in one call chain -- one wide prove call + "
+                                                                     "one K-batch verification; must divide --steps (0 = automatic, 1 = one batch per call)")
+    ap.add_argument("--streams", type=int, default=0, help="independent call chains in flight, each on its own HIP stream / engine context (0 = automatic)")
+    ap.add_argument("--max-hw-queues", type=int, default=8, help="cap of GPU_MAX_HW_QUEUES (one hardware queue per stream up to this)")
+    ap.add_argument("--no-graphs", action="store_true", help="enqueue every kernel of every call from the host instead of replaying one "
+                                                            "HIP graph per stream")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flow-lines", action="store_true", help="skip the pipelined prove-only / batch-verify-only / verify_compact measurements")
+    ap.add_argument("--no-multi-configs", action="store_true", help="--gpus > 1: skip the strong-scaling sub-records of BASELINE configs[3] / configs[4]")
+    ap.add_argument("--multi-total4", type=int, default=1 << 22, help="--gpus > 1: total proofs of the configs[3] sub-record (2^22 CMZ proofs over the GPUs)")
+    ap.add_argument("--multi-total5", type=int, default=1 << 18, help="--gpus > 1: total proofs of the configs[4] sub-record (2^18 W64 proofs over the GPUs)")
+    ap.add_argument("--pmc-json", default=None, help="rocprofv3 --pmc summary (tools/pmc_summary.py); default profiles/r03_pmc_counters_cfg<config>.json; "
+                                                     "used only if its source hash and workload shape match")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
+                    help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # convenience: self-launch one process per GPU exactly as the driver would
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    desc, parts, def_batch, def_streams, def_steps = WORKLOADS[args.config]
+    if args.steps is None:
+        args.steps = def_steps
+    n = args.batch or def_batch
+    if args.config == "2":
+        K, n_streams = pick_call_shape(args.steps, args.batches_per_call, args.streams)
+    else:
+        if args.batches_per_call > 1:
+            raise SystemExit("--batches-per-call applies to --config 2 (the other workloads are one wide batch per step)")
+        K, n_streams = 1, max(1, min(args.streams or def_streams or pick_streams(args.steps), max(1, args.steps)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(max(n_streams, 8 if args.gpus > 1 else 1), args.max_hw_queues))))   # default is 4
+    import numpy as np
+    import torch
+
+    cx = Ctx()
+    cx.rank = int(os.environ.get("RANK", "0"))
+    cx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    cx.dist, cx.group, dinfo = None, None, {"collective": None, "backend_world_size": 1, "rccl_error": None}
+    if cx.world > 1:
+        if os.environ.get("ZKP_BENCH_DRYRUN_ONE_GPU"):
+            cx.local_rank = 0
+        else:
+            torch.cuda.set_device(cx.local_rank)
+        cx.dist, cx.group, dinfo = init_distributed(cx.world, cx.rank, cx.local_rank)
+    cx.dev = torch.device("cuda", cx.local_rank)
+    torch.cuda.set_device(cx.dev)
+    rank, world, dist = cx.rank, cx.world, cx.dist
+
+    r = run_workload(cx, args, args.config, n, args.steps, args.warmup, K, n_streams, primary=True)
+    ps, kms, flow_lines, total_n = r["ps"], r["kms"], r["flow_lines"], r["total_n"]
+    eng = r["engines"][0]
+
+    # ---- BASELINE configs[3] and configs[4] are 8-GPU configurations: measured whenever the job spans several GPUs -----------
+    multi = None
+    e2e = None
+    if world == 1 and args.config == "2" and not args.no_flow_lines:
+        e2e = e2e_host_buffers(eng)
+    for e_ in r["engines"]:
+        e_.close()
+    if world > 1 and args.config == "2" and not args.no_multi_configs:
+        multi = {}
+        for key, cfg, total, cap, streams_cap in (("4", "4share", args.multi_total4, 1 << 19, 2), ("5", "5share", args.multi_total5, 1 << 15, 8)):
+            share = max(1, total // world)                  # strong scaling: the total is fixed, each rank takes a contiguous range of it
+            chunk = min(share, cap)                         # per call: at most the per-GPU share of the 8-GPU configuration (workspace ~ 40 GB at 2^19 CMZ proofs)
+            csteps = max(1, share // chunk)
+            torch.cuda.empty_cache()
+            rr = run_workload(cx, args, cfg, chunk, csteps, 1, 1, min(streams_cap, csteps), primary=False)
+            tmin = torch.tensor([rr["own_elapsed"]], dtype=torch.float64)
+            tmax = tmin.clone()
+            dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            multi[key] = {"workload": WORKLOADS[cfg][0] % chunk, "baseline_config": "configs[%d]" % (int(key) - 1), "proofs_total": world * chunk * csteps,
+                          "proofs_per_gpu": chunk * csteps, "proofs_per_call": chunk, "calls_per_gpu": csteps, "streams": rr["streams"],
+                          "value": world * chunk * csteps / rr["elapsed"], "unit": "proofs/s", "scaling": "strong", "elapsed_ms": rr["elapsed"] * 1e3,
+                          "ms_per_call": rr["elapsed"] * 1e3 / csteps, "per_rank_elapsed_ms": {"min": float(tmin.item()) * 1e3, "max": float(tmax.item()) * 1e3},
+                          "collective": dinfo["collective"], "verdict": "every batch of every rank verified (asserted)"}
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = world * total_n * args.steps / elapsed
-    # ---- roofline of the dominant kernel: the timing kind with the largest share of the step's kernel time (HIP events) --
+    ms_per_step = r["ms_per_step"]
+    value = r["value"]
+    # ---- roofline of the dominant kernel: the kernel (by name, summed over the flows that launch it) with the largest share of the
+    #      step's kernel time, HIP events on a lone stream -----------------------------------------------------------------------------
     algo = {"prove": sum((64.0 * p.T + 32.0 * p.nc) * p.n for p in ps if "prove" in p.flows),                 # SURVEY 8(d): 64 B per term in + 32 B per MSM out
-            "batch_verify": sum(64.0 * p.n_bv for p in ps if "batch_verify" in p.flows)}                      #              64 B per operand of the one MSM
+            "batch_verify": sum(64.0 * p.n_bv_each * p.K for p in ps if "batch_verify" in p.flows)}           #              64 B per operand of every MSM of the call
     step_flows = sorted({f for p in ps for f in p.flows})
-    shares = [(kms[f][k], f, k) for f in step_flows for k in kms[f] if k != "total" and kms[f][k] > 0]
-    t_all = sum(s[0] for s in shares)
     names = dict(KERNELS)
-    if args.config in ("2", "4share") and n * 31 >= 250000:      # a call that fills the chip on its own: ladder for Q, one transcript lane per proof
-        names[("prove", "terms")] = "k_terms_split<true, 16, true>"
-    if n >= 8192:
-        names[("prove", "transcript")] = "k_transcript_run1 (2 launches)"
-        names[("batch_verify", "transcript")] = "k_transcript_run1"
+    call_n = n * K
+    if args.config in ("2", "4share") and call_n * 31 >= 250000:      # a call that fills the chip on its own: ladder for Q, grouped comb walk
+        names[("prove", "terms")] = ("k_terms_split<true, 16, true>", 1)
+    if call_n >= 8192:                                                 # ... and one transcript lane per proof
+        names[("prove", "transcript")] = ("k_transcript_run1", 2)
+        names[("batch_verify", "transcript")] = ("k_transcript_run1", 1)
     if args.config == "5share":                 # every point of the wide statement is a common generator: fixed-base blocks only, no ladder blocks
-        names[("prove", "terms")] = "k_terms_split<true, T, false> (fixed-base blocks only)"
-    by_kernel = [{"flow": f, "kind": k, "kernels": names.get((f, k), k), "ms": ms, "share": ms / t_all, "GB/s": algo[f] / (ms * 1e-3) / 1e9}
-                 for ms, f, k in sorted(shares, reverse=True)]
+        names[("prove", "terms")] = ("k_terms_split<true, T, false> (fixed-base blocks only)", 1)
+    groups = {}
+    for f in step_flows:
+        for k, ms in kms[f].items():
+            if k == "total" or ms <= 0:
+                continue
+            nm, launches = names.get((f, k), (k, 1))
+            launches *= sum(1 for p in ps if f in p.flows)
+            g = groups.setdefault(nm, {"kernels": nm, "ms": 0.0, "launches": 0, "bytes": 0.0, "kinds": []})
+            g["ms"] += ms
+            g["launches"] += launches
+            g["bytes"] += algo[f] * launches
+            g["kinds"].append("%s/%s" % (f, k))
+    t_all = sum(g["ms"] for g in groups.values())
+    by_kernel = [{"kernels": g["kernels"], "timing_kinds": g["kinds"], "launches_per_call": g["launches"], "ms_per_call": g["ms"], "share": g["ms"] / t_all,
+                  "avg_launch_ms": g["ms"] / g["launches"], "GB/s": g["bytes"] / (g["ms"] * 1e-3) / 1e9}
+                 for g in sorted(groups.values(), key=lambda g: -g["ms"])]
     dom = by_kernel[0]
     achieved = dom["GB/s"]
-    roof = {"bound": "hbm", "kernel": "%s  (%s flow, %.0f %% of the step's kernel time on one stream)" % (dom["kernels"], dom["flow"], 100 * dom["share"]),
+    roof = {"bound": "hbm", "kernel": "%s  (%d launch%s per call of %d batch%s, %.0f %% of a call's kernel time on a lone stream)"
+                                      % (dom["kernels"], dom["launches_per_call"], "" if dom["launches_per_call"] == 1 else "es", K, "" if K == 1 else "es", 100 * dom["share"]),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes_per_launch": algo[dom["flow"]], "launch_ms": dom["ms"],
+            "algorithmic_bytes_per_launch": achieved * 1e9 * dom["avg_launch_ms"] * 1e-3, "launch_ms": dom["avg_launch_ms"],
             "note": "integer-VALU bound by construction (SURVEY.md 8(d)): algorithmic bytes = 64 B per (scalar, point) term + 32 B per output, "
                     "so the HBM fraction of ANY kernel of this path is ~1e-3; the binding roofline is step_valu / *_valu_issue_frac (PMC)",
             "by_kernel": by_kernel}
-    # ---- PMC-derived fields: only from a counter file collected from exactly these sources -----------------------------
+    # ---- PMC-derived fields: only from a counter file collected from exactly these sources and this call shape ---------------------------
     sha = source_sha256()
     pmc_source, step_valu = None, None
-    pmc_path = args.pmc_json if os.path.isabs(args.pmc_json) else os.path.join(ROOT, args.pmc_json)
-    if args.config == "2" and n == 4096 and os.path.exists(pmc_path):
+    pmc_rel = args.pmc_json or (PMC_PATTERN % args.config)
+    pmc_path = pmc_rel if os.path.isabs(pmc_rel) else os.path.join(ROOT, pmc_rel)
+    if os.path.exists(pmc_path):
         try:
             pj = json.load(open(pmc_path))
-            if pj.get("_source_sha256") == sha:
-                pmc_source = "%s: rocprofv3 --pmc passes of `python bench.py --steps 20` at kernel-source sha256 %s (tools/collect_profiles.sh)" % (args.pmc_json, sha[:12])
-                pmc_names = {"terms": "k_terms_split<true", "tables": "zkp::k_comb_tables_lane<16", "transcript": "zkp::k_transcript_run", "decode": "k_pip_prepare<11"}
-                kname = next((k for k in pj if dom["kind"] in pmc_names and k.startswith(pmc_names[dom["kind"]])), None)
+            shape = pj.get("_workload", {})
+            if pj.get("_source_sha256") == sha and shape.get("batch") == n and shape.get("batches_per_call") == K and shape.get("config") == args.config:
+                pmc_source = "%s: rocprofv3 --pmc passes of `python bench.py --config %s --steps %s` at kernel-source sha256 %s (tools/collect_profiles.sh)" % (
+                    pmc_rel, args.config, shape.get("steps"), sha[:12])
+                pmc_prefix = {"k_terms_split": "k_terms_split<true", "k_comb_tables_lane": "zkp::k_comb_tables_lane<16", "k_transcript_run1": "zkp::k_transcript_run1",
+                              "k_transcript_run": "zkp::k_transcript_run", "k_pip_prepare": "k_pip_prepare<", "k_pip_vmap": "k_pip_bucket_part",
+                              "k_encode_prepare": "k_encode_prepare"}
+                key = next((v for k_, v in sorted(pmc_prefix.items(), key=lambda kv: -len(kv[0])) if dom["kernels"].startswith(k_)), None)
+                kname = next((k_ for k_ in pj if key and k_.startswith(key)), None)
                 if kname:
                     roof["traffic"] = pj[kname].get("hbm_bytes_per_launch")
-                    roof["dominant_kernel_valu_issue_frac"] = pj[kname]["SQ_INSTS_VALU"] * 64.0 / (dom["ms"] * 1e-3) / VALU_PEAK * (2 if (dom["kind"], dom["flow"]) == ("transcript", "prove") else 1)
-                tname = next((k for k in pj if k.startswith("k_terms_split<true")), None)
+                    roof["dominant_kernel_valu_issue_frac"] = pj[kname]["SQ_INSTS_VALU"] * 64.0 / (dom["avg_launch_ms"] * 1e-3) / VALU_PEAK
+                tname = next((k_ for k_ in pj if k_.startswith("k_terms_split<true")), None)
                 if tname and kms.get("prove", {}).get("terms"):
                     roof["terms_kernel_valu_issue_frac"] = pj[tname]["SQ_INSTS_VALU"] * 64.0 / (kms["prove"]["terms"] * 1e-3) / VALU_PEAK
                     roof["terms_kernel_traffic"] = pj[tname].get("hbm_bytes_per_launch")
+                    roof["terms_kernel_algorithmic_bytes"] = algo["prove"]
                 tot = pj.get("_step_totals", {}).get("valu_wave_instructions_per_step")
                 if tot:
                     lane = tot * 64.0
@@ -566,20 +739,42 @@ def main():
         "metric": METRIC, "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
         "data": "synthetic", "seed": 1000,                                      # numpy default_rng(seed + rank) drives every witness, point, entropy and weight
-        "config": {"workload": desc % n, "baseline_config": args.config, "batch_per_gpu": n, "streams": n_streams, "hip_graphs": not args.no_graphs,
+        "config": {"workload": desc % n, "baseline_config": args.config, "batch_per_gpu": n, "batches_per_call": K, "calls": args.steps // K,
+                   "streams": r["streams"], "hip_graphs": not args.no_graphs,
                    "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "sharding": "independent proof ranges per GPU, AND of verdict bits",
-                   "collective": dinfo["collective"], "backend_world_size": dinfo["backend_world_size"]},
-        "host_enqueue_ms_per_step": t_enqueued * 1e3 / args.steps,
+                   "collective": dinfo["collective"], "backend_world_size": dinfo["backend_world_size"],
+                   "excluded_from_value": "per-proof entropy (prover.rs:82 thread_rng) and batch weights (batch_verifier.rs:179) are fixed arrays resident in HBM, "
+                                          "so every step re-proves the same proofs; host-side RNG / weight generation is not timed (see e2e_host_buffers)"},
+        "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"],
         "pipelined_proofs_per_s": flow_lines,                                   # same loop, one flow only
-        "single_stream_proofs_per_s": {f: world * sum(p.n for p in ps if f == "verify_compact" or f in p.flows) / (kms[f]["total"] * 1e-3) for f in kms},
-        "kernel_ms": kms, "roofline": roof, "pmc_source": pmc_source, "source_sha256": sha,
+        "single_stream_proofs_per_s": {f: world * K * sum(p.n_each for p in ps if f == "verify_compact" or f in p.flows) / (kms[f]["total"] * 1e-3) for f in kms},
+        "kernel_ms_per_call": kms, "roofline": roof, "pmc_source": pmc_source, "source_sha256": sha,
     }
     if dinfo.get("rccl_error"):
         out["config"]["rccl_error"] = dinfo["rccl_error"]
     if step_valu:
         out["step_valu"] = step_valu
+    if multi is not None:
+        out["configs"] = multi
+    if e2e is not None:
+        out["e2e_host_buffers"] = e2e
     if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (rank 0's host cores)
-        out["cpu_baseline"] = cpu_baseline(ps, LABEL, 4096 if args.config == "2" else 1024)
+        sample = 4096 if args.config == "2" else 1024
+        base, oracle_proofs = cpu_baseline(ps, LABEL, sample)
+        out["cpu_baseline"] = base
+        # every proof the CPU leg recomputed (same secrets, same entropy) against what the TIMED steps left in stream 0's buffers
+        checked, equal = 0, True
+        for p, (o_chal, o_resp, o_coms) in zip(ps, oracle_proofs):
+            mm = len(o_resp)
+            b = p.bufs[0]
+            g_resp, g_coms = b["resp"][:mm].cpu().numpy(), b["coms"][:mm].cpu().numpy()
+            equal = equal and bool((g_resp == o_resp).all()) and bool((g_coms == o_coms).all())
+            if "prove" in p.flows:
+                equal = equal and bool((b["chal"][:mm].cpu().numpy() == o_chal).all())
+            checked += mm
+        out["parity_checked"] = {"proofs": checked, "fields": "challenges, responses, commitments of the proofs the timed steps produced (stream 0) vs the oracle's "
+                                 "prover on the same secrets and entropy", "equal": equal}
+        assert equal, "GPU proofs differ from the oracle's"
         if args.config == "2":
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
     print(json.dumps(out))
@@ -598,6 +793,7 @@ def cpu_baseline(ps, label, sample):
     t_prove = t_bv = 0.0
     n_done = 0
     notes = []
+    proofs = []                                # per part: (challenges, responses, commitments) the oracle made -- bench.py's parity check
     for p in ps:
         m = min(p.n, sample)
         secrets_l, points, cons = p.st
@@ -609,13 +805,14 @@ def cpu_baseline(ps, label, sample):
             (com_rank if c else inst_rank)[i] = len(com_rank if c else inst_rank)
         coms = np.zeros((m, p.nc, 32), np.uint8)
         resp = np.zeros((m, p.m, 32), np.uint8)
+        chal = np.zeros((m, 32), np.uint8)
         ent = p.d_ent[:m].cpu().numpy()
         w = np.ascontiguousarray(p.d_w[:, :m].cpu().numpy())
         t0 = time.perf_counter()
         for j in range(m):
             pts = np.stack([p.common[com_rank[i]] if i in com_rank else p.inst[inst_rank[i], j] for i in range(len(points))])
-            _, er, ek, _ = C.prove(cst, label, p.secrets[j], pts, ent[j].tobytes())
-            coms[j], resp[j] = ek, er
+            ec, er, ek, _ = C.prove(cst, label, p.secrets[j], pts, ent[j].tobytes())
+            coms[j], resp[j], chal[j] = ek, er, ec
         t1 = time.perf_counter()
         rc = C.batch_verify(cst, label, m, np.ascontiguousarray(p.inst[:, :m]), p.common, coms, resp, w)
         t2 = time.perf_counter()
@@ -624,14 +821,17 @@ def cpu_baseline(ps, label, sample):
             t_prove += t1 - t0
         t_bv += t2 - t1
         n_done += m
+        proofs.append((chal, resp, coms))
         notes.append("%d proofs of \"%s\": proven one by one %.3f s%s, one batch verification %.3f s (%d-term Pippenger incl. decompression)"
                      % (m, p.fst._label.decode(), t1 - t0, "" if "prove" in p.flows else " (set-up, not counted)", t2 - t1, p.ns + (p.ni + p.nc) * m))
     outd = {"value": n_done / (t_prove + t_bv), "unit": "proofs/s", "cores": 1, "kind": "port",
             "sample": "; ".join(notes) + "; Merlin + radix-16 constant-time Straus + responses / Merlin + coefficients + Pippenger; gcc -O3 -march=native, 5x51-bit limbs",
-            "batch_verifies_per_s": n_done / t_bv}
+            "batch_verifies_per_s": n_done / t_bv,
+            "note": "scalar u64-style port of the reference's flows (dalek's u64_backend algorithms); the reference's own Rust cannot be built on this box, and its "
+                    "simd_backend (AVX2 / IFMA, Cargo.toml:37-40) is ~1.5-2x faster per core [RECALL, BASELINE.md section 3] -- not obtainable here"}
     if t_prove:
         outd["prove_proofs_per_s"] = n_done / t_prove
-    return outd
+    return outd, proofs
 
 
 def cpu_baseline_all_cores():
@@ -640,7 +840,9 @@ def cpu_baseline_all_cores():
     batch-verifying 1024 CMZ presentations (about 1 s of work per worker)."""
     try:
         outp = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--per", "1024"], cwd=ROOT, capture_output=True, text=True, timeout=240)
-        return json.loads(outp.stdout.strip().splitlines()[-1])
+        j = json.loads(outp.stdout.strip().splitlines()[-1])
+        j["note"] = "same scalar port on every usable host thread; dalek's simd_backend would be ~1.5-2x faster per core [RECALL], not obtainable here"
+        return j
     except Exception as e:      # a reported baseline, never the measurement: do not fail the bench line over it
         return {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
 

@@ -208,6 +208,21 @@ int zkp_fused_batch_verify(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t
                            const uint8_t* inst, const uint8_t* common, const uint8_t* commitments,
                            const uint8_t* responses, const uint8_t* weights16, int* verdict, uint8_t* debug_scalars);
 
+/* K independent batch verifications in ONE pass (K x batch_verifier.rs:67-235), for servers that collect more proofs than
+ * they want to tie to one verdict: the K * N_each proofs lie next to each other in every array, batch b = proofs
+ * [b * N_each, (b + 1) * N_each).  Each batch gets what BatchVerifier::verify_batchable gives it: its own weights, its own
+ * sums of the static-point coefficients (:187, :198), its own MSM of n_static + (n_instance + n_constraints) * N_each terms
+ * (:219-228) and its own verdict -- a bad proof, a rejected point or an undecodable point in batch b changes verdict b only.
+ * One transcript launch, one coefficient grid and one "segmented" Pippenger (sort key = (batch, window, digit)) serve all K
+ * batches, so the narrow tails of a single batch check (bucket tree, Horner) are K times wider.
+ * Layouts as in zkp_fused_batch_verify with N = K * N_each: transcripts [N][208], inst [n_instance][N][32], commitments
+ * [N][n_constraints][32], responses [N][n_secrets][32], weights16 [n_constraints][N][16].  verdicts [K]: 0 = batch b verifies.
+ * debug_scalars (NULL or [K * n_static + (n_instance + n_constraints) * N][32]): static coefficients batch by batch, then the
+ * coefficient matrix row-major over all N proofs.  K = 1 is zkp_fused_batch_verify. */
+int zkp_fused_batch_verify_many(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t n_batches, uint32_t N_each, uint8_t* transcripts,
+                                const uint8_t* inst, const uint8_t* common, const uint8_t* commitments, const uint8_t* responses,
+                                const uint8_t* weights16, int* verdicts, uint8_t* debug_scalars);
+
 /* N x { build_verifier ; Verifier::verify_batchable (verifier.rs:123-173) }: one MSM of (points + commitments) terms per
  * proof, folded with the 128-bit weights16 [N][n_constraints][16] (verifier.rs:153).  results[j]: 0 = accepted.  This is
  * the per-proof check that localises a bad proof after a failed batch verification. */
@@ -241,6 +256,14 @@ int zkp_fused_batch_verify_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint
                                uint8_t* d_transcripts, uint8_t* d_points, const uint8_t* d_commitments,
                                const uint8_t* d_responses, const uint8_t* d_weights16, uint8_t* d_out_point,
                                uint32_t* d_status);
+
+/* zkp_fused_batch_verify_many on device buffers: d_points [n_static + (n_instance + n_constraints) * N][32] (N = n_batches *
+ * N_each; static points and instance rows filled in, commitment rows written by the call), d_out_points [n_batches][32],
+ * d_status [n_batches][2] words (decode failure in batch b's MSM | a point, commitment or response of batch b rejected):
+ * batch b verifies iff both are 0 and d_out_points[b] is 32 zero bytes. */
+int zkp_fused_batch_verify_many_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t n_batches, uint32_t N_each, uint32_t strobe_pos,
+                                    uint8_t* d_transcripts, uint8_t* d_points, const uint8_t* d_commitments, const uint8_t* d_responses,
+                                    const uint8_t* d_weights16, uint8_t* d_out_points, uint32_t* d_status);
 
 /* (3) Stand-alone decode / validity check, batched.  Replaces the
  *     `.map(|pt| pt.decompress()).collect::<Option<Vec<_>>>()` of verifier.rs:87-92.

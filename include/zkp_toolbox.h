@@ -33,12 +33,17 @@ extern "C" {
 #define ZKP_TB_BAD_STATEMENT (-10)      /* malformed statement descriptor / NULL argument  */
 #define ZKP_TB_INVALID_POINT (-11)      /* prover was handed an encoding that does not decode */
 #define ZKP_TB_NO_ENTROPY (-12)         /* entropy / weights16 == NULL and the operating system's getrandom() failed */
+#define ZKP_TB_TOO_LONG (-14)           /* a transcript message, output or label longer than UINT32_MAX bytes (merlin asserts) */
 
 /* ---- Merlin transcripts (merlin::Transcript, re-exported by the reference at lib.rs:35) ----------- */
 #define ZKP_TRANSCRIPT_BYTES 208        /* opaque, plain-old-data: memcpy = Clone */
 void zkp_transcript_init(uint8_t t[ZKP_TRANSCRIPT_BYTES], const uint8_t* label, size_t label_len);
-void zkp_transcript_append_message(uint8_t t[ZKP_TRANSCRIPT_BYTES], const char* label, const uint8_t* msg, size_t len);
-void zkp_transcript_challenge_bytes(uint8_t t[ZKP_TRANSCRIPT_BYTES], const char* label, uint8_t* out, size_t len);
+/* Merlin frames every message / output with its length as a u32 and asserts that the length fits (merlin 2.x
+ * `encode_usize_as_u32`; the reference's tests/sig_and_vrf_example.rs:224-241 is the `#[ignore]`d > 4 GiB case): a `len`
+ * above UINT32_MAX -- or a label longer than that -- is ZKP_TB_TOO_LONG and leaves the transcript untouched, never a
+ * silently truncated length prefix.  Returns ZKP_TB_OK otherwise. */
+int zkp_transcript_append_message(uint8_t t[ZKP_TRANSCRIPT_BYTES], const char* label, const uint8_t* msg, size_t len);
+int zkp_transcript_challenge_bytes(uint8_t t[ZKP_TRANSCRIPT_BYTES], const char* label, uint8_t* out, size_t len);
 
 /* ---- scalars mod l (curve25519_dalek::scalar::Scalar) -------------------------------------------- */
 void zkp_scalar_from_wide(uint8_t out[32], const uint8_t in[64]);   /* from_bytes_mod_order_wide */
@@ -70,6 +75,11 @@ uint32_t zkp_statement_num_constraints(const zkp_statement* st);
  *   common_points [ns][32]
  *   challenges    [N][32]   responses [N][m][32]   commitments [N][nc][32]
  *   results       [N]       0 = Ok(()), 1 = Err(VerificationFailure)
+ * Canonical-scalar rule: the verify calls take proofs as raw 32-byte fields, i.e. where the reference has
+ * `bincode::deserialize` in front of its verifiers (tests/zkp.rs:54, :97).  dalek's Deserialize refuses a Scalar whose
+ * value is >= l (proofs.rs:14-32), so such a proof never verifies there; here a response (or compact challenge) >= l is
+ * Err(VerificationFailure) for that proof -- for the whole batch in zkp_batch_verify*.  (The wire codec below applies the
+ * same rule when it parses.)
  */
 
 /* Prove N statements.  entropy = [N][32] bytes replacing the thread_rng contribution of prover.rs:82, or
@@ -94,6 +104,18 @@ int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* st, uint32_t N,
 int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* transcripts,
                      const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
                      const uint8_t* responses, const uint8_t* weights16, int n_threads);
+
+/* K batch verifications in one call: the N = n_batches * N_each proofs lie next to each other in every array (layouts as in
+ * zkp_batch_verify with that N), batch b = proofs [b * N_each, (b + 1) * N_each); verdicts [n_batches]: ZKP_TB_OK or
+ * ZKP_TB_VERIFICATION_FAILURE per batch, each exactly what zkp_batch_verify returns for that batch alone (its own weights,
+ * its own sums of the static coefficients, its own MSM: K x batch_verifier.rs:137-235).  On the device this is one
+ * transcript launch, one coefficient grid and one segmented Pippenger for all batches (zkp_fused_batch_verify_many);
+ * batches whose transcripts do not stand at one STROBE position, or below the fused threshold, are verified one by one.
+ * Returns ZKP_TB_OK when every verdict was computed (look at verdicts[]), ZKP_TB_BATCH_SIZE_MISMATCH if n_transcripts !=
+ * N, negative on infrastructure failure. */
+int zkp_batch_verify_many(zkp_ctx* ctx, const zkp_statement* st, uint32_t n_batches, uint32_t N_each, uint32_t n_transcripts,
+                          uint8_t* transcripts, const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
+                          const uint8_t* responses, const uint8_t* weights16, int n_threads, int* verdicts);
 
 /* zkp_batch_verify with bad-proof localisation.  The reference's batch verifier can only say that
  * SOME proof of the batch is wrong (batch_verifier.rs:233); finding it means verifying one by one.  This call runs the batch

@@ -42,6 +42,7 @@ void orc_ge_basepoint(ge_ext* r);
 
 void orc_sc_from_wide(uint8_t out[32], const uint8_t in[64]);           /* Scalar::from_bytes_mod_order_wide */
 void orc_sc_reduce32(uint8_t out[32], const uint8_t in[32]);
+int  orc_sc_is_canonical(const uint8_t in[32]);                            /* 1 = value < l (what serde lets through as a Scalar) */
 void orc_sc_muladd(uint8_t out[32], const uint8_t a[32], const uint8_t b[32], const uint8_t c[32]); /* a*b+c */
 void orc_sc_neg(uint8_t out[32], const uint8_t a[32]);
 void orc_sc_add(uint8_t out[32], const uint8_t a[32], const uint8_t b[32]);
@@ -99,6 +100,9 @@ typedef struct {
 int orc_prove(const orc_statement* st, const uint8_t* transcript_label, size_t tl_len,
               const uint8_t* secrets, const uint8_t* points, const uint8_t entropy32[32],
               uint8_t challenge[32], uint8_t* responses, uint8_t* commitments, uint8_t* blindings_out);
+/* The verifier entry points take proofs as BYTES, i.e. where the reference has `bincode::deserialize` (tests/zkp.rs:54, :97)
+ * in front of the verifier: a challenge or response that is not a canonical scalar (>= l) fails deserialisation there
+ * (proofs.rs:14-32 over dalek's Deserialize [RECALL]) and is a VerificationFailure (1) here, for the proof / the whole batch. */
 /* Verifier::verify_compact (verifier.rs:80-120): 0 = Ok, 1 = VerificationFailure */
 int orc_verify_compact(const orc_statement* st, const uint8_t* transcript_label, size_t tl_len,
                        const uint8_t* points, const uint8_t challenge[32], const uint8_t* responses);

@@ -79,6 +79,14 @@ void orc_sc_from_wide(uint8_t out[32], const uint8_t in[64]) {
   sc_reduce512(r, x);
   memcpy(out, r, 32);
 }
+/* Scalar::from_canonical_bytes / dalek's serde Deserialize for Scalar [RECALL: curve25519-dalek 2.x src/scalar.rs]: a 32-byte
+ * string is a Scalar only if its value is < l.  The reference's proofs reach a verifier through serde (proofs.rs:14-32,
+ * tests/zkp.rs:53-54), so a challenge or response >= l can never arrive there.  1 = canonical. */
+int orc_sc_is_canonical(const uint8_t in[32]) {
+  uint64_t x[4];
+  memcpy(x, in, 32);
+  return bn_ge(x, L_LIMBS, 4) ? 0 : 1;
+}
 void orc_sc_reduce32(uint8_t out[32], const uint8_t in[32]) {
   uint8_t wide[64] = {0};
   memcpy(wide, in, 32);

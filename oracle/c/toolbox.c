@@ -89,6 +89,8 @@ static int build_verifier(orc_transcript* t, const orc_statement* st, const uint
 int orc_verify_compact(const orc_statement* st, const uint8_t* tl, size_t tl_len, const uint8_t* points,
                        const uint8_t challenge[32], const uint8_t* responses) {
   const uint32_t np = st->n_inst + st->n_common;
+  if (!orc_sc_is_canonical(challenge)) return 1;                                    /* proofs.rs:15-20 through serde: Scalars are canonical */
+  for (uint32_t i = 0; i < st->n_secrets; ++i) if (!orc_sc_is_canonical(responses + 32 * i)) return 1;
   orc_transcript t;
   if (build_verifier(&t, st, tl, tl_len, points)) return 1;
   ge_ext* P = (ge_ext*)malloc(sizeof(ge_ext) * (np ? np : 1));
@@ -122,6 +124,7 @@ static void sc_from_u128(uint8_t out[32], const uint8_t w16[16]) { memset(out, 0
 int orc_verify_batchable(const orc_statement* st, const uint8_t* tl, size_t tl_len, const uint8_t* points,
                          const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16) {
   const uint32_t np = st->n_inst + st->n_common, nc = st->n_cons;
+  for (uint32_t i = 0; i < st->n_secrets; ++i) if (!orc_sc_is_canonical(responses + 32 * i)) return 1;   /* proofs.rs:27-32 through serde */
   orc_transcript t;
   if (build_verifier(&t, st, tl, tl_len, points)) return 1;
   for (uint32_t k = 0; k < nc; ++k)                                                 /* verifier.rs:134-140 */
@@ -156,6 +159,7 @@ int orc_batch_verify(const orc_statement* st, const uint8_t* tl, size_t tl_len, 
                      const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
                      const uint8_t* responses, const uint8_t* weights16, uint8_t* msm_scalars, uint8_t* msm_points) {
   const uint32_t ni = st->n_inst, ns = st->n_common, nc = st->n_cons, m = st->n_secrets, np = ni + ns;
+  for (size_t i = 0; i < (size_t)N * m; ++i) if (!orc_sc_is_canonical(responses + 32 * i)) return 1;   /* proofs.rs:27-32 through serde */
   /* kind / rank of every point variable in allocation order */
   uint8_t* is_common = (uint8_t*)malloc(np ? np : 1);
   uint32_t* rank = (uint32_t*)malloc(4 * (np ? np : 1));

@@ -105,6 +105,9 @@ extern "C" {
     pub fn zkp_fused_batch_verify(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, transcripts: *mut u8, inst: *const u8,
                                   common: *const u8, commitments: *const u8, responses: *const u8, weights16: *const u8,
                                   verdict: *mut c_int, debug_scalars: *mut u8) -> c_int;
+    pub fn zkp_fused_batch_verify_many(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n_batches: u32, n_each: u32, transcripts: *mut u8,
+                                       inst: *const u8, common: *const u8, commitments: *const u8, responses: *const u8,
+                                       weights16: *const u8, verdicts: *mut c_int, debug_scalars: *mut u8) -> c_int;
     pub fn zkp_fused_verify_batchable(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, transcripts: *mut u8, inst: *const u8,
                                       common: *const u8, commitments: *const u8, responses: *const u8, weights16: *const u8,
                                       results: *mut u8) -> c_int;
@@ -120,6 +123,9 @@ extern "C" {
     pub fn zkp_fused_batch_verify_dev(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, strobe_pos: u32,
                                       d_transcripts: *mut u8, d_points: *mut u8, d_commitments: *const u8, d_responses: *const u8,
                                       d_weights16: *const u8, d_out_point: *mut u8, d_status: *mut u32) -> c_int;
+    pub fn zkp_fused_batch_verify_many_dev(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n_batches: u32, n_each: u32, strobe_pos: u32,
+                                           d_transcripts: *mut u8, d_points: *mut u8, d_commitments: *const u8, d_responses: *const u8,
+                                           d_weights16: *const u8, d_out_points: *mut u8, d_status: *mut u32) -> c_int;
     // ---- (3), (4) stand-alone codec: verifier.rs:87-92, mod.rs:180 -------------------------------------------------------
     pub fn zkp_decode_check(ctx: *mut zkp_ctx, n: u64, points: *const u8, status: *mut u8, xyzt: *mut u8) -> c_int;
     pub fn zkp_encode_many(ctx: *mut zkp_ctx, n: u64, xyzt: *const u8, out: *mut u8) -> c_int;
@@ -129,8 +135,8 @@ extern "C" {
 
     // ---- zkp_toolbox.h: Merlin transcripts, scalars ---------------------------------------------------------------------
     pub fn zkp_transcript_init(t: *mut u8, label: *const u8, label_len: usize);
-    pub fn zkp_transcript_append_message(t: *mut u8, label: *const c_char, msg: *const u8, len: usize);
-    pub fn zkp_transcript_challenge_bytes(t: *mut u8, label: *const c_char, out: *mut u8, len: usize);
+    pub fn zkp_transcript_append_message(t: *mut u8, label: *const c_char, msg: *const u8, len: usize) -> c_int;
+    pub fn zkp_transcript_challenge_bytes(t: *mut u8, label: *const c_char, out: *mut u8, len: usize) -> c_int;
     pub fn zkp_scalar_from_wide(out: *mut u8, input: *const u8);
     pub fn zkp_scalar_muladd(out: *mut u8, a: *const u8, b: *const u8, c: *const u8);
     pub fn zkp_scalar_neg(out: *mut u8, a: *const u8);
@@ -161,6 +167,9 @@ extern "C" {
     pub fn zkp_batch_verify_coeffs(ctx: *mut zkp_ctx, st: *const zkp_statement, n: u32, n_transcripts: u32, transcripts: *mut u8,
                                    inst_points: *const u8, common_points: *const u8, commitments: *const u8, responses: *const u8,
                                    weights16: *const u8, n_threads: c_int, coeffs: *mut u8) -> c_int;
+    pub fn zkp_batch_verify_many(ctx: *mut zkp_ctx, st: *const zkp_statement, n_batches: u32, n_each: u32, n_transcripts: u32,
+                                 transcripts: *mut u8, inst_points: *const u8, common_points: *const u8, commitments: *const u8,
+                                 responses: *const u8, weights16: *const u8, n_threads: c_int, verdicts: *mut c_int) -> c_int;
     pub fn zkp_batch_verify_locate(ctx: *mut zkp_ctx, st: *const zkp_statement, n: u32, n_transcripts: u32, transcripts: *mut u8,
                                    inst_points: *const u8, common_points: *const u8, commitments: *const u8, responses: *const u8,
                                    weights16: *const u8, n_threads: c_int, results: *mut u8) -> c_int;

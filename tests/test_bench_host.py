@@ -53,6 +53,17 @@ def test_stream_picker_and_source_hash():
     assert len(h) == 64 and h == bench.source_sha256()
 
 
+def test_call_shape_picker():
+    """--config 2 packs K batches into one call chain: K divides --steps (exactly --steps batches are timed)"""
+    for steps in (1, 4, 7, 20, 40, 100, 1000):
+        k, s = bench.pick_call_shape(steps)
+        assert steps % k == 0 and 1 <= s <= steps // k and k <= 16
+    assert bench.pick_call_shape(20, want_k=5, want_streams=3) == (5, 3)
+    assert bench.pick_call_shape(20, want_k=1) == (1, 20)
+    with pytest.raises(SystemExit):
+        bench.pick_call_shape(20, want_k=3)
+
+
 def test_workload_table_is_consistent():
     for name, (desc, parts, batch, streams, steps) in bench.WORKLOADS.items():
         assert "%d" in desc and abs(sum(share for _, _, share, _ in parts) - 1.0) < 1e-9 and batch > 0 and steps > 0

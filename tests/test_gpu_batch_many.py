@@ -1,0 +1,265 @@
+"""zkp_fused_batch_verify_many / zkp_batch_verify_many: K independent BatchVerifier::verify_batchable runs
+(batch_verifier.rs:137-235) in ONE pass over the device -- one transcript launch, one coefficient grid, one segmented
+Pippenger (sort key = (batch, window, digit)).  Every batch must get exactly what a call of its own gives it: the same
+coefficient vector (its own weights, its own sums of the static coefficients), the same verdict, and a defect in batch k
+(a tampered proof, a rejected or undecodable point, a non-canonical response) must change verdict k only.  Verdicts are also
+checked against the C oracle's BatchVerifier run batch by batch."""
+import numpy as np
+import pytest
+
+from oracle import cbind as C
+from oracle import model as M
+from zkp_amd import toolbox as T
+from tests.test_gpu_toolbox import _cmz_batch
+from tests.test_gpu_fused import _dleq_batch
+
+pytestmark = pytest.mark.gpu
+NEVER = 0xFFFFFFFF
+JUNK = np.frombuffer(bytes([1] + [0] * 31), np.uint8)          # s = 1: not a valid ristretto255 encoding
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zkp_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+    T.set_fused_min_batch(32)
+
+
+def _fused_statement(st):
+    from zkp_amd.engine import FusedStatement
+    return FusedStatement(st.proof_label, st.secrets, st.points, st.constraints)
+
+
+def _prove(eng, st, label, secrets, inst, common, seed):
+    n = len(secrets)
+    entropy = np.random.default_rng(seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ts = np.stack([T.Transcript(label).state] * n)
+    return T.prove_batch(eng, st, ts, secrets, inst, common, entropy)
+
+
+def _separate(eng, st, label, K, n_each, inst, common, coms, resp, w):
+    """verdicts and coefficient vectors of K calls of the single-batch entry point, each on its own slice"""
+    verdicts, coeffs = [], []
+    for b in range(K):
+        sl = slice(b * n_each, (b + 1) * n_each)
+        ts = np.stack([T.Transcript(label).state] * n_each)
+        ok, co = T.batch_verify_coeffs(eng, st, ts, np.ascontiguousarray(inst[:, sl]), common, coms[sl], resp[sl], np.ascontiguousarray(w[:, sl]))
+        verdicts.append(0 if ok else 1)
+        coeffs.append(co)
+    return np.array(verdicts), coeffs
+
+
+def _many_layout(coeffs, K, ns, rows, n_each):
+    """the K per-batch coefficient vectors (static [ns] || rows [rows][n_each]) in the layout of the many call:
+    static [K][ns] || rows [rows][K * n_each]"""
+    stat = np.concatenate([c[:ns] for c in coeffs])
+    mat = np.concatenate([c[ns:].reshape(rows, n_each, 32) for c in coeffs], axis=1).reshape(-1, 32)
+    return np.concatenate([stat, mat])
+
+
+@pytest.mark.parametrize("K,n_each", [(3, 1), (3, 5), (4, 64), (2, 700), (5, 333)])
+def test_many_equals_separate_calls_and_oracle(eng, K, n_each):
+    n = K * n_each
+    mod, secrets, inst, common = _cmz_batch(n, 100 + n)
+    st, fst = mod.statement, _fused_statement(mod.statement)
+    label = b"many"
+    chal, resp, coms = _prove(eng, st, label, secrets, inst, common, n)
+    w = np.random.default_rng(n + 1).integers(0, 256, size=(st.nc, n, 16), dtype=np.uint8)
+    T.set_fused_min_batch(0)
+    try:
+        want_v, want_co = _separate(eng, st, label, K, n_each, inst, common, coms, resp, w)
+        assert not want_v.any()
+        ts = np.stack([T.Transcript(label).state] * n)
+        v, co = eng.fused_batch_verify_many(fst, K, ts, inst, common, coms, resp, w, want_coeffs=True)
+        assert (v == 0).all()
+        assert (co == _many_layout(want_co, K, st.ns, st.ni + st.nc, n_each)).all()
+        # the transcripts are left exactly as K separate batch verifiers leave them
+        ts1 = np.stack([T.Transcript(label).state] * n_each)
+        T.batch_verify(eng, st, ts1, np.ascontiguousarray(inst[:, :n_each]), common, coms[:n_each], resp[:n_each], np.ascontiguousarray(w[:, :n_each]))
+        assert (ts[:n_each, :203] == ts1[:, :203]).all()
+        # defects in ONE batch: only that verdict changes, and the oracle agrees batch by batch
+        cst = C.Statement.from_model(M.cmz_statement(10))
+        kb = K - 2 if K > 2 else K - 1
+        j = kb * n_each + n_each // 2
+        cases = {}
+        bad = resp.copy(); bad[j, 7, 3] ^= 0x20
+        cases["tampered response"] = dict(resp=bad)
+        ident = inst.copy(); ident[1, j] = 0
+        cases["identity instance point"] = dict(inst=ident)
+        junk = inst.copy(); junk[11, j] = JUNK
+        cases["undecodable instance point"] = dict(inst=junk)
+        zc = coms.copy(); zc[j, 4] = 0
+        cases["identity commitment"] = dict(coms=zc)
+        jc = coms.copy(); jc[j, 10] = JUNK
+        cases["undecodable commitment"] = dict(coms=jc)
+        big = resp.copy()
+        big[j, 20] = np.frombuffer((int.from_bytes(resp[j, 20].tobytes(), "little") + M.L).to_bytes(32, "little"), np.uint8)
+        cases["response + l"] = dict(resp=big)
+        swap = coms.copy(); swap[j, 0] = coms[j, 1]
+        cases["wrong (valid) commitment"] = dict(coms=swap)
+        for name, kw in cases.items():
+            a = dict(inst=inst, coms=coms, resp=resp)
+            a.update(kw)
+            ts = np.stack([T.Transcript(label).state] * n)
+            v = eng.fused_batch_verify_many(fst, K, ts, a["inst"], common, a["coms"], a["resp"], w)
+            expect = np.zeros(K, np.int32); expect[kb] = 1
+            assert (v == expect).all(), name
+            for b in range(K):
+                sl = slice(b * n_each, (b + 1) * n_each)
+                rc = C.batch_verify(cst, label, n_each, np.ascontiguousarray(a["inst"][:, sl]), common, a["coms"][sl], a["resp"][sl], np.ascontiguousarray(w[:, sl]))
+                assert rc == expect[b], (name, b)
+        # a defect of a COMMON point hits every batch
+        badc = common.copy(); badc[11] = JUNK                        # `B`: in no constraint, every batch check still decompresses it
+        ts = np.stack([T.Transcript(label).state] * n)
+        assert eng.fused_batch_verify_many(fst, K, ts, inst, badc, coms, resp, w).all()
+        # two defective batches
+        if K >= 3:
+            two = resp.copy(); two[0, 0, 0] ^= 1; two[n - 1, 20, 31] ^= 1
+            ts = np.stack([T.Transcript(label).state] * n)
+            v = eng.fused_batch_verify_many(fst, K, ts, inst, common, coms, two, w)
+            assert v[0] == 1 and v[K - 1] == 1 and v.sum() == 2
+    finally:
+        T.set_fused_min_batch(32)
+
+
+def test_many_through_the_toolbox_both_routes(eng):
+    """zkp_batch_verify_many: the fused route (one pass) and the host-transcript route (batch by batch) give the same
+    verdicts; shape errors are the reference's (batch_verifier.rs:72-74)."""
+    K, n_each = 4, 48
+    n = K * n_each
+    mod, secrets, inst, common = _cmz_batch(n, 5)
+    st = mod.statement
+    label = b"many-tb"
+    chal, resp, coms = _prove(eng, st, label, secrets, inst, common, 6)
+    w = np.random.default_rng(7).integers(0, 256, size=(st.nc, n, 16), dtype=np.uint8)
+    bad = resp.copy(); bad[2 * n_each + 3, 0, 0] ^= 1
+    out = {}
+    for route, thr in (("host", NEVER), ("fused", 0)):
+        T.set_fused_min_batch(thr)
+        try:
+            ts = np.stack([T.Transcript(label).state] * n)
+            v_ok = T.batch_verify_many(eng, st, K, ts, inst, common, coms, resp, w)
+            ts_ok = ts.copy()
+            ts = np.stack([T.Transcript(label).state] * n)
+            v_bad = T.batch_verify_many(eng, st, K, ts, inst, common, coms, bad, w)
+            ts = np.stack([T.Transcript(label).state] * n)
+            v_rand = T.batch_verify_many(eng, st, K, ts, inst, common, coms, resp)          # weights from the OS
+            out[route] = (v_ok, v_bad, v_rand, ts_ok)
+        finally:
+            T.set_fused_min_batch(32)
+    for route in out:
+        v_ok, v_bad, v_rand, _ = out[route]
+        assert not v_ok.any() and not v_rand.any(), route
+        assert v_bad.tolist() == [0, 0, 1, 0], route
+    assert (out["host"][3][:, :203] == out["fused"][3][:, :203]).all()
+    with pytest.raises(T.BatchSizeMismatch):
+        ts = np.stack([T.Transcript(label).state] * (n - 1))
+        T.batch_verify_many(eng, st, K, ts, inst, common, coms, resp, w)
+    with pytest.raises(ValueError):
+        T.batch_verify_many(eng, st, 5, np.stack([T.Transcript(label).state] * n), inst, common, coms, resp, w)
+
+
+def test_many_dleq_statement_without_static_sums(eng):
+    """define_proof!'s DLEQ: one common point (G) whose coefficient is a sum over the batch -- per batch here."""
+    K, n_each = 6, 40
+    n = K * n_each
+    mod, x, A, B, H = _dleq_batch(n, 3)
+    st, fst = mod.statement, _fused_statement(mod.statement)
+    inst = np.ascontiguousarray(np.stack([A, B, H]))
+    common = np.frombuffer(bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"), np.uint8).reshape(1, 32).copy()
+    label = b"many-dleq"
+    chal, resp, coms = _prove(eng, st, label, x, inst, common, 4)
+    w = np.random.default_rng(8).integers(0, 256, size=(st.nc, n, 16), dtype=np.uint8)
+    T.set_fused_min_batch(0)
+    try:
+        want_v, want_co = _separate(eng, st, label, K, n_each, inst, common, coms, resp, w)
+        ts = np.stack([T.Transcript(label).state] * n)
+        v, co = eng.fused_batch_verify_many(fst, K, ts, inst, common, coms, resp, w, want_coeffs=True)
+        assert not v.any() and not want_v.any()
+        assert (co == _many_layout(want_co, K, st.ns, st.ni + st.nc, n_each)).all()
+        bad = resp.copy(); bad[3 * n_each, 0, 5] ^= 2
+        ts = np.stack([T.Transcript(label).state] * n)
+        assert eng.fused_batch_verify_many(fst, K, ts, inst, common, coms, bad, w).tolist() == [0, 0, 0, 1, 0, 0]
+    finally:
+        T.set_fused_min_batch(32)
+
+
+def test_many_dev_entry_equals_host_entry_and_graph_replay(eng):
+    """zkp_fused_batch_verify_many_dev on device-resident buffers (what bench.py times), directly and replayed from a HIP
+    graph, against the host-pointer entry point: 16 batches of 256 CMZ proofs proven in one wide zkp_fused_prove_dev call."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("torch cannot see the GPU in this process")
+    import bench
+    from zkp_amd.engine import FusedStatement
+    K, n_each = 16, 256
+    n = K * n_each
+    mod, secrets, inst, common = _cmz_batch(n, 9)
+    st = mod.statement
+    fst = FusedStatement(b"CMZ cred show n=10", *bench.cmz_statement())
+    rng = np.random.default_rng(10)
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    w = rng.integers(0, 256, size=(11, n, 16), dtype=np.uint8)
+    t0 = T.Transcript(b"many-dev").state
+    pos = int(t0[200]) | int(t0[201]) << 8 | int(t0[202]) << 16
+    ts0 = np.stack([t0] * n)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    z = lambda *s: torch.zeros(s, dtype=torch.uint8, device="cuda:0")
+    eng.prepare_fixed_points(common)
+    d_ts0, d_sec, d_tbl, d_ent, d_w = dev(ts0), dev(secrets), dev(np.concatenate([common, inst.reshape(-1, 32)])), dev(entropy), dev(w)
+    d_ts, d_chal, d_resp, d_coms, d_st = z(n, 208), z(n, 32), z(n, 21, 32), z(n, 11, 32), z(11 * n)
+    d_pts = z(12 + 24 * n, 32)
+    d_pts[: 12 + 13 * n] = d_tbl
+    d_out = torch.ones((K, 32), dtype=torch.uint8, device="cuda:0")
+    d_bst = torch.ones((K, 2), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    d_ts.copy_(d_ts0)
+    eng.fused_prove_dev(fst, n, pos, d_ts.data_ptr(), d_sec.data_ptr(), d_tbl.data_ptr(), d_ent.data_ptr(), d_chal.data_ptr(), d_resp.data_ptr(),
+                        d_coms.data_ptr(), d_st.data_ptr())
+    eng.synchronize()
+    assert not d_st.cpu().numpy().any()
+    resp, coms = d_resp.cpu().numpy(), d_coms.cpu().numpy()
+    cst = C.Statement.from_model(M.cmz_statement(10))              # the wide prove call against the oracle's prover, sampled
+    for j in (0, n_each, n - 1):
+        ec, er, ek, _ = C.prove(cst, b"many-dev", secrets[j], np.concatenate([inst[:, j], common]), entropy[j].tobytes())
+        assert (resp[j] == er).all() and (coms[j] == ek).all()
+
+    def run():
+        d_ts.copy_(d_ts0)
+        eng.fused_batch_verify_many_dev(fst, K, n_each, pos, d_ts.data_ptr(), d_pts.data_ptr(), d_coms.data_ptr(), d_resp.data_ptr(), d_w.data_ptr(),
+                                        d_out.data_ptr(), d_bst.data_ptr())
+    s = torch.cuda.Stream()
+    eng.set_stream(s.cuda_stream)
+    try:
+        with torch.cuda.stream(s):
+            run()
+            eng.synchronize()
+            assert not d_out.cpu().numpy().any() and not d_bst.cpu().numpy().any()
+            ts_direct = d_ts.cpu().numpy()
+            # host-pointer entry point on the same proofs
+            ts = ts0.copy()
+            v = eng.fused_batch_verify_many(fst, K, ts, inst, common, coms, resp, w)
+            assert not v.any() and (ts[:, :203] == ts_direct[:, :203]).all()
+            # tamper with batch 5 and batch 11 on the device; replay the same chain from a graph
+            d_resp[5 * n_each + 7, 3, 0] ^= 1
+            d_coms[11 * n_each, 2] = 0
+            run()
+            eng.synchronize()
+            eng.capture_begin()
+            try:
+                run()
+            finally:
+                g = eng.capture_end()
+            d_out.fill_(7); d_bst.fill_(7)
+            g.launch()
+            eng.synchronize()
+            out, bst = d_out.cpu().numpy(), d_bst.cpu().numpy()
+            bad = [b for b in range(K) if out[b].any() or bst[b].any()]
+            assert bad == [5, 11]
+            assert out[5].any() and not bst[5].any()               # a wrong response: the MSM is not the identity
+            assert bst[11, 1] == 1 and bst[11, 0] == 0             # an identity commitment: rejected by the transcript protocol
+            g.close()
+    finally:
+        eng.set_stream(0)

@@ -90,7 +90,7 @@ def test_bench_eight_rank_control_flow_on_one_gpu():
     env.pop("GPU_MAX_HW_QUEUES", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
-           "--batch", "256", "--streams", "2", "--no-flow-lines"]
+           "--batch", "256", "--streams", "2", "--no-flow-lines", "--multi-total4", "2048", "--multi-total5", "1024"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -100,3 +100,10 @@ def test_bench_eight_rank_control_flow_on_one_gpu():
     assert j["config"]["backend_world_size"] == 8 and j["config"]["collective"] == "gloo-fallback" and "dry run" in j["config"]["rccl_error"]
     assert abs(j["value"] - 8 * 256 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]
     assert "cpu_baseline" not in j                                  # reported at N = 1 only
+    assert j["config"]["batches_per_call"] == 2 and j["config"]["calls"] == 2          # 4 steps = 2 calls of 2 batches each
+    # BASELINE configs[3] / configs[4] (the 8-GPU configurations) ride along as strong-scaling sub-records of the same line
+    c4, c5 = j["configs"]["4"], j["configs"]["5"]
+    assert c4["proofs_total"] == 2048 and c4["proofs_per_gpu"] == 256 and c4["scaling"] == "strong" and c4["value"] > 0
+    assert c5["proofs_total"] == 1024 and c5["proofs_per_gpu"] == 128 and c5["value"] > 0
+    assert c4["per_rank_elapsed_ms"]["min"] <= c4["per_rank_elapsed_ms"]["max"] <= c4["elapsed_ms"] * 1.001 + 1e-6
+    assert c4["collective"] == "gloo-fallback"

@@ -298,12 +298,15 @@ def test_cmz_batch_prove_verify(eng, n):
     entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
     ts = np.stack([T.Transcript(label).state] * n)
     chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, common, entropy)
-    # the C oracle, run on a sample of the batch, must produce the same bytes
+    # the C oracle's prover must produce the same bytes for EVERY proof of the batch (4096 proofs: ~3 s of CPU), and its batch
+    # verifier must accept what the GPU made
     cst = C.Statement.from_model(M.cmz_statement(10))
-    for j in sorted(set([0, 1, n // 2, n - 1])):
+    for j in range(n):
         pts = np.concatenate([inst[:, j], common])
         ec, er, ek, _ = C.prove(cst, label, secrets[j], pts, entropy[j].tobytes())
         assert chal[j].tobytes() == ec.tobytes() and (resp[j] == er).all() and (coms[j] == ek).all(), j
+    w = rng.integers(0, 256, size=(11, n, 16), dtype=np.uint8)
+    assert C.batch_verify(cst, label, n, inst, common, coms, resp, w) == 0
     ts = np.stack([T.Transcript(label).state] * n)
     res = T.verify_compact_batch(eng, mod.statement, ts, inst, common, chal, resp)
     assert not res.any()
@@ -379,15 +382,26 @@ def test_gpu_coefficient_build_matches_host_and_oracle(eng, n):
         cst = C.Statement.from_model(M.cmz_statement(10))
         rc, osc, _ = C.batch_verify(cst, label, n, inst, common, coms, resp, w, want_msm_inputs=True)
         assert rc == 0 and (osc == got).all()
-    # non-canonical responses (>= l) are reduced like Scalar::from_bytes_mod_order would; verdict = failure or ok
-    # according to the value, coefficients still equal the host's
+    # a non-canonical response (s + l: the same residue, another byte string) never reaches the reference's verifier -- serde
+    # refuses it (proofs.rs:27-32 over dalek's Deserialize) -- so the batch fails here too, on both routes and in the oracle
     big = resp.copy()
     big[0, 0] = np.frombuffer(((int.from_bytes(resp[0, 0].tobytes(), "little") + M.L)).to_bytes(32, "little"), np.uint8)
+    for thr in (0xFFFFFFFF, 0):
+        T.set_fused_min_batch(thr)
+        try:
+            ts = np.stack([T.Transcript(label).state] * n)
+            ok, _ = T.batch_verify_coeffs(eng, mod.statement, ts, inst, common, coms, big, w)
+            assert not ok
+            ts = np.stack([T.Transcript(label).state] * n)
+            with pytest.raises(T.VerificationFailure):
+                T.batch_verify(eng, mod.statement, ts, inst, common, coms, big, w)
+        finally:
+            T.set_fused_min_batch(32)
+    if n <= 300:
+        assert C.batch_verify(C.Statement.from_model(M.cmz_statement(10)), label, n, inst, common, coms, big, w) == 1
     ts = np.stack([T.Transcript(label).state] * n)
-    want_sc, _ = T.batch_verify_build(mod.statement, ts, inst, common, coms, big, w)
-    ts = np.stack([T.Transcript(label).state] * n)
-    ok, got = T.batch_verify_coeffs(eng, mod.statement, ts, inst, common, coms, big, w)
-    assert ok and (got == want_sc).all()
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify_build(mod.statement, ts, inst, common, coms, big, w)
     # tampered response: coefficients still match the host's, verdict is failure
     bad = resp.copy()
     bad[n // 2, 3, 1] ^= 4
@@ -544,15 +558,15 @@ def test_batch_verify_locate_names_the_bad_proofs(eng):
     ts = np.stack([T.Transcript(label).state] * n)
     chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, common, entropy)
     ts = np.stack([T.Transcript(label).state] * n)
-    res = T.batch_verify_locate(eng, mod.statement, ts, inst, common, coms, resp)
-    assert not res.any()
+    ok, res = T.batch_verify_locate(eng, mod.statement, ts, inst, common, coms, resp)
+    assert ok and not res.any()
     after_ok = ts.copy()
     bad_resp, bad_coms = resp.copy(), coms.copy()
     bad_resp[41, 3, 7] ^= 0x10
     bad_coms[207, 10] = coms[206, 10]                              # a valid point, the wrong commitment
     ts = np.stack([T.Transcript(label).state] * n)
-    res = T.batch_verify_locate(eng, mod.statement, ts, inst, common, bad_coms, bad_resp)
-    assert sorted(np.nonzero(res)[0].tolist()) == [41, 207]
+    ok, res = T.batch_verify_locate(eng, mod.statement, ts, inst, common, bad_coms, bad_resp)
+    assert not ok and sorted(np.nonzero(res)[0].tolist()) == [41, 207]
     ts2 = np.stack([T.Transcript(label).state] * n)
     with pytest.raises(T.VerificationFailure):
         T.batch_verify(eng, mod.statement, ts2, inst, common, bad_coms, bad_resp)

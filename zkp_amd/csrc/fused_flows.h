@@ -36,6 +36,14 @@ k_neg_reduce(uint32_t n, const uint8_t* in, uint8_t* out) {       // in may equa
   store_vec<2>(out + 32 * (size_t)i, r.v);
 }
 
+// l <= the 256-bit little-endian value?  (Scalar::from_canonical_bytes / dalek's Deserialize accept only values < l.)
+__device__ __forceinline__ uint32_t sc_not_canonical(const uint32_t v[8]) {
+  uint64_t br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) br = (((uint64_t)v[i] - sc_l(i) - br) >> 63) & 1u;
+  return br ? 0u : 1u;                              // no borrow: v >= l
+}
+
 // The CSR multiscalar job of a batch of proofs of one statement: T terms per proof in nc MSMs.
 //   term t of proof j:  scalar = tsc[t] == ~0 ? special[j] : vals[j][tsc[t]];   point = table index of point id tpt[t]
 // (prover.rs:94-97 with vals = blindings; verifier.rs:97-106 with vals = responses, special = -c)
@@ -148,12 +156,17 @@ k_responses_wide(uint32_t N, uint32_t m, const uint8_t* __restrict__ secrets, co
 
 // verify_compact verdicts (verifier.rs:87-92, :113-119): 0 = accepted
 __global__ void __launch_bounds__(256)
-k_verify_finish(uint32_t N, uint32_t nc, uint32_t ns, const uint8_t* __restrict__ chal, const uint8_t* __restrict__ claimed,
-                const uint8_t* __restrict__ status8, const uint32_t* __restrict__ failed, const dev_affine* __restrict__ pts,
-                const uint32_t* __restrict__ unref, uint32_t n_unref, uint8_t* __restrict__ results) {
+k_verify_finish(uint32_t N, uint32_t nc, uint32_t ns, uint32_t m, const uint8_t* __restrict__ chal, const uint8_t* __restrict__ claimed,
+                const uint8_t* __restrict__ responses, const uint8_t* __restrict__ status8, const uint32_t* __restrict__ failed,
+                const dev_affine* __restrict__ pts, const uint32_t* __restrict__ unref, uint32_t n_unref, uint8_t* __restrict__ results) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= N) return;
   uint32_t bad = failed[j];
+  for (uint32_t i = 0; i < m; ++i) {              // a response >= l never reaches the reference's verifier (serde rejects it, proofs.rs:14-20)
+    uint32_t r[8];
+    load_vec<2>(r, responses + 32 * ((size_t)j * m + i));
+    bad |= sc_not_canonical(r);
+  }
   for (uint32_t k = 0; k < nc; ++k) bad |= status8[(size_t)j * nc + k];
   for (uint32_t u = 0; u < n_unref; ++u) {
     const uint32_t p = unref[u];
@@ -207,26 +220,34 @@ k_each_coeffs(uint32_t N, uint32_t m, uint32_t ns, uint32_t ni, uint32_t nc, con
 // verdicts of verify_batchable: accepted iff no rejection by the transcript protocol, every point decoded and the MSM
 // is the identity (verifier.rs:134-140, :162-172)
 __global__ void __launch_bounds__(256)
-k_each_finish(uint32_t N, const uint8_t* __restrict__ out, const uint8_t* __restrict__ status8, const uint32_t* __restrict__ failed,
-              uint8_t* __restrict__ results) {
+k_each_finish(uint32_t N, uint32_t m, const uint8_t* __restrict__ out, const uint8_t* __restrict__ status8, const uint32_t* __restrict__ failed,
+              const uint8_t* __restrict__ responses, uint8_t* __restrict__ results) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= N) return;
   uint32_t w[8];
   load_vec<2>(w, out + 32 * (size_t)j);
   uint32_t d = failed[j] | status8[j];
+  for (uint32_t i = 0; i < m; ++i) {              // canonical-scalar rule of the proof format (proofs.rs:27-32 under serde)
+    uint32_t r[8];
+    load_vec<2>(r, responses + 32 * ((size_t)j * m + i));
+    d |= sc_not_canonical(r);
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) d |= w[i];
   results[j] = d ? 1 : 0;
 }
 
-// Batch verification, after the transcripts, in one launch: any rejected proof -> *any; -c mod l from the 64 challenge bytes;
-// commitment rows of the operand list (rows[k][j] = commitments[j][k], batch_verifier.rs:208-212)
+// Batch verification, after the transcripts, in one launch: any rejected proof of batch b -> any[b * any_stride] |= any_bit; -c mod l
+// from the 64 challenge bytes; commitment rows of the operand list (rows[k][j] = commitments[j][k], batch_verifier.rs:208-212).
+// A response that is not a canonical scalar rejects its batch too: the reference can only receive responses through serde,
+// and dalek's Deserialize refuses s >= l (proofs.rs:14-32; SURVEY 8(a) semantic 5).  N = all proofs of the call, batches of N_each.
 __global__ void __launch_bounds__(256)
-k_batch_after_transcript(uint32_t N, uint32_t nc, const uint32_t* __restrict__ failed, uint32_t* __restrict__ any, uint32_t any_bit, const uint8_t* __restrict__ wchal,
-                         uint8_t* __restrict__ minus_c, const uint8_t* __restrict__ coms, uint8_t* __restrict__ rows) {
+k_batch_after_transcript(uint32_t N, uint32_t N_each, uint32_t nc, uint32_t m, const uint32_t* __restrict__ failed, uint32_t* __restrict__ any, uint32_t any_stride,
+                         uint32_t any_bit, const uint8_t* __restrict__ wchal, uint8_t* __restrict__ minus_c, const uint8_t* __restrict__ coms,
+                         uint8_t* __restrict__ rows, const uint8_t* __restrict__ responses) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < N) {
-    if (failed[g]) atomicOr(any, any_bit);
+    if (failed[g]) atomicOr(any + (g / N_each) * any_stride, any_bit);
     sc lo, hi, r;
     load_vec<2>(lo.v, wchal + 64 * g);
     load_vec<2>(hi.v, wchal + 64 * g + 32);
@@ -239,6 +260,11 @@ k_batch_after_transcript(uint32_t N, uint32_t nc, const uint32_t* __restrict__ f
     uint32_t w[8];
     load_vec<2>(w, coms + 32 * g);
     store_vec<2>(rows + 32 * (k * N + j), w);
+  }
+  if (g < (size_t)N * m) {
+    uint32_t w[8];
+    load_vec<2>(w, responses + 32 * g);
+    if (sc_not_canonical(w)) atomicOr(any + ((g / m) / N_each) * any_stride, any_bit);
   }
 }
 
@@ -291,18 +317,20 @@ std::vector<uint32_t> incidence_words(const fused_shape& s) {
   return w;
 }
 
-// batch_verifier.rs:173-206 on device buffers; d_inc = inc_off | inc_k | inc_sc
-void launch_coeff_build(zkp_ctx* c, const fused_shape& s, uint32_t N, const uint32_t* d_inc, const uint8_t* d_mc,
-                        const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_sc, uint32_t* d_part) {
+// batch_verifier.rs:173-206 on device buffers; d_inc = inc_off | inc_k | inc_sc.  K batches of N_each proofs (K = 1: one batch of N):
+// d_sc = static coefficients [K][ns] || Matrix rows [ni + nc][K * N_each];  d_part holds ns * K * ceil(N_each / 256) partial sums
+void launch_coeff_build(zkp_ctx* c, const fused_shape& s, uint32_t N_each, const uint32_t* d_inc, const uint8_t* d_mc,
+                        const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_sc, uint32_t* d_part, uint32_t K = 1) {
   const uint32_t* d_inc_off = d_inc;
   const uint32_t* d_inc_k = d_inc + s.inc_off.size();
   const uint32_t* d_inc_sc = d_inc_k + s.inc_k.size();
-  const uint32_t nblk = (N + 255) / 256, rows = s.ni + s.nc;
+  const uint32_t nblk = (N_each + 255) / 256, rows = s.ni + s.nc, N = K * N_each;
   if (N && (rows || s.ns)) {
-    hipLaunchKernelGGL(k_coeff_build, dim3(nblk, rows + s.ns), dim3(256), 0, c->stream, N, s.m, s.ns, s.ni, s.nc, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w, d_sc, d_part);
-    if (s.ns) hipLaunchKernelGGL(k_coeff_static_final, dim3(s.ns), dim3(64), 0, c->stream, nblk, d_part, d_sc);
+    hipLaunchKernelGGL(k_coeff_build, dim3(K * nblk, rows + s.ns), dim3(256), 0, c->stream, N, N_each, nblk, K, s.m, s.ns, s.ni, s.nc, d_inc_off, d_inc_k, d_inc_sc, d_mc, d_resp, d_w,
+                       d_sc, d_part);
+    if (s.ns) hipLaunchKernelGGL(k_coeff_static_final, dim3(s.ns, K), dim3(64), 0, c->stream, nblk, s.ns, d_part, d_sc);
   } else if (s.ns) {
-    hipMemsetAsync(d_sc, 0, (size_t)s.ns * 32, c->stream);
+    hipMemsetAsync(d_sc, 0, (size_t)K * s.ns * 32, c->stream);
   }
 }
 size_t optional_ws(uint64_t total) {
@@ -791,38 +819,55 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.chal));
   // the decoded point table is the first thing msm_terms_path carves after its reserved prefix
-  hipLaunchKernelGGL(k_verify_finish, grid1(N, 256), dim3(256), 0, c->stream, N, nc, pl.s.ns, w.u8(o.chal), d_claim, w.u8(o.st8), w.u32(o.failed),
+  hipLaunchKernelGGL(k_verify_finish, grid1(N, 256), dim3(256), 0, c->stream, N, nc, pl.s.ns, m, w.u8(o.chal), d_claim, d_resp, w.u8(o.st8), w.u32(o.failed),
                      reinterpret_cast<const dev_affine*>(w.base + o.end), pl.d_tarr + nc + 1 + 2 * (size_t)T1, (uint32_t)pl.s.unref.size(), d_results);
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
   return ZKP_OK;
 }
 
+// K batch verifications of N_each = pl.N / K proofs each in one pass (K = 1: zkp_fused_batch_verify).  The N = pl.N proofs of the
+// call lie next to each other, batch b = proofs [b N_each, (b + 1) N_each).
 // d_pts = [ns + (ni + nc) N][32] with static || instance rows filled in by the caller; the commitment rows are written here
-struct batch_inter { size_t sc, failed, wchal, mc, part, end; };
-batch_inter batch_carve(const fused_plan& pl, size_t start) {
-  const size_t N = pl.N, ns = pl.s.ns, total = ns + ((size_t)pl.s.ni + pl.s.nc) * N, nblk = (N + 255) / 256;
+struct batch_inter { size_t sc, failed, flags, wchal, mc, part, end; };
+batch_inter batch_carve(const fused_plan& pl, size_t start, uint32_t K = 1) {
+  const size_t N = pl.N, ns = pl.s.ns, N_each = N / (K ? K : 1), total = (size_t)K * ns + ((size_t)pl.s.ni + pl.s.nc) * N, nblk = (size_t)K * ((N_each + 255) / 256);
   carve cv;
   cv.off = start;
   batch_inter o;
   o.sc = cv.take(total * 32 + 32);
   o.failed = cv.take(N * 4 + 4);
+  o.flags = cv.take((size_t)K * 4);
   o.wchal = cv.take(N * 64 + 64);
   o.mc = cv.take(N * 32 + 32);
   o.part = cv.take((ns ? ns : 1) * (nblk ? nblk : 1) * 32);
   o.end = cv.off;
   return o;
 }
+size_t optional_many_ws(uint64_t n_each, uint32_t K) {
+  switch (pick_c(n_each)) {
+    case 7: return pip_ws<7>(n_each, K);
+    case 10: return pip_ws<10>(n_each, K);
+    case 11: return pip_ws<11>(n_each, K);
+    default: return pip_ws<16>(n_each, K);
+  }
+}
 int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* d_ts, uint8_t* d_pts, const uint8_t* d_coms,
-               const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_out, uint32_t* d_status /*[2]: MSM decode failure | transcript rejection*/,
-               bool throughput) {
-  const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni;
-  const size_t total = (size_t)ns + ((size_t)ni + nc) * N;
+               const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_out /*[K][32]*/,
+               uint32_t* d_status /*[K][2]: MSM decode failure | transcript rejection or non-canonical response*/, bool throughput, uint32_t K = 1) {
+  const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni, N_each = N / K;
+  const size_t n_each = (size_t)ns + ((size_t)ni + nc) * N_each;          // terms of one batch's MSM (batch_verifier.rs:219-228)
   const ws_view w{static_cast<char*>(c->ws)};
-  // Status words without memsets: the transcript kernel zeroes the spare word behind its rejection flags, k_batch_after_transcript
+  // Status words without memsets (K = 1): the transcript kernel zeroes the spare word behind its rejection flags, k_batch_after_transcript
   // sets bit 1 of it if a proof was rejected, the MSM sets bit 0 on a decode failure, and the MSM's last kernel writes both
-  // status words (Pippenger sizes; tiny batches keep the two memsets)
-  uint32_t* shared = (N && total > kSmallOptional && pl.a.n) ? w.u32(o.failed) + N : nullptr;
+  // status words (Pippenger sizes; tiny batches keep the two memsets).  K > 1: one flag word per batch, cleared by one memset.
+  uint32_t* shared = nullptr;
+  if (K > 1) {
+    shared = w.u32(o.flags);
+    HIP_TRY(hipMemsetAsync(shared, 0, (size_t)K * 4, c->stream));
+  } else if (N && n_each > kSmallOptional && pl.a.n) {
+    shared = w.u32(o.failed) + N;
+  }
   if (!shared) HIP_TRY(hipMemsetAsync(d_status, 0, 8, c->stream));
   prof_begin(c);
   if (N) {
@@ -831,13 +876,22 @@ int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* 
     hb.dst[DST_CHAL] = w.u8(o.wchal);
     run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, /*owns_failed=*/true);
     prof_mark(c, ZKP_K_TRANSCRIPT);
-    hipLaunchKernelGGL(k_batch_after_transcript, grid1(std::max<size_t>(N, (size_t)N * nc), 256), dim3(256), 0, c->stream, N, nc, w.u32(o.failed),
-                       shared ? shared : d_status + 1, shared ? 2u : 1u, w.u8(o.wchal), w.u8(o.mc), d_coms, d_pts + 32 * ((size_t)ns + (size_t)ni * N));
+    const size_t lanes = std::max<size_t>(std::max<size_t>(N, (size_t)N * nc), (size_t)N * pl.s.m);
+    hipLaunchKernelGGL(k_batch_after_transcript, grid1(lanes, 256), dim3(256), 0, c->stream, N, N_each, nc, pl.s.m, w.u32(o.failed),
+                       shared ? shared : d_status + 1, 1u, shared ? 2u : 1u, w.u8(o.wchal), w.u8(o.mc), d_coms, d_pts + 32 * ((size_t)ns + (size_t)ni * N), d_resp);
   }
-  launch_coeff_build(c, pl.s, N, pl.d_inc, w.u8(o.mc), d_resp, d_w, w.u8(o.sc), w.u32(o.part));
+  launch_coeff_build(c, pl.s, N_each, pl.d_inc, w.u8(o.mc), d_resp, d_w, w.u8(o.sc), w.u32(o.part), K);
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
-  return msm_optional_impl(c, total, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared);
+  if (K == 1) return msm_optional_impl(c, n_each, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared);
+  pip_seg seg;
+  seg.K = K; seg.ns = ns; seg.N_each = N_each;
+  switch (pick_c(n_each)) {
+    case 7: return pip_run<7>(c, (uint32_t)n_each, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared, seg);
+    case 10: return pip_run<10>(c, (uint32_t)n_each, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared, seg);
+    case 11: return pip_run<11>(c, (uint32_t)n_each, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared, seg);
+    default: return pip_run<16>(c, (uint32_t)n_each, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared, seg);
+  }
 }
 
 // d_tbl = [ns + ni N + N nc][32]: common || instance rows || commitments [N][nc] (the last part doubles as the
@@ -891,7 +945,7 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
   const int rc = msm_terms_path(c, N, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * K, ZKP_VARTIME, w.u8(o.out), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true,
                                 PH_ALL, each_terms_cfg(pl));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_each_finish, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.out), w.u8(o.st8), w.u32(o.failed), d_results);
+  hipLaunchKernelGGL(k_each_finish, grid1(N, 256), dim3(256), 0, c->stream, N, pl.s.m, w.u8(o.out), w.u8(o.st8), w.u32(o.failed), d_resp, d_results);
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
   return ZKP_OK;
@@ -1176,6 +1230,98 @@ int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N
   HIP_TRY(hipStreamSynchronize(c->stream));
   static const uint8_t zero[32] = {0};
   *verdict = (stv[0] == 0 && stv[1] == 0 && memcmp(out, zero, 32) == 0) ? 0 : 1;   // batch_verifier.rs:230-234
+  return ZKP_OK;
+}
+
+// ---- K batch verifications in one pass ------------------------------------------------------------------------------
+static int check_many(uint32_t K, uint32_t N_each, const fused_shape& s, uint64_t* n_each_out) {
+  if (K == 0 || N_each == 0) return fail(ZKP_ERR_ARG, "n_batches and N_each must be positive");
+  if ((uint64_t)K * N_each > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  const uint64_t n_each = (uint64_t)s.ns + ((uint64_t)s.ni + s.nc) * N_each;
+  if (n_each * K > 0x7fffffffull || (uint64_t)K * 65 > 65535) return fail(ZKP_ERR_ARG, "batch too large");
+  *n_each_out = n_each;
+  return ZKP_OK;
+}
+int zkp_fused_batch_verify_many_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t K, uint32_t N_each, uint32_t strobe_pos,
+                                    uint8_t* d_transcripts, uint8_t* d_points, const uint8_t* d_commitments, const uint8_t* d_responses,
+                                    const uint8_t* d_weights16, uint8_t* d_out_points, uint32_t* d_status) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  if (K == 1) return zkp_fused_batch_verify_dev(c, st, N_each, strobe_pos, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_points, d_status);
+  fused_shape s0;
+  int rc = check_fused_statement(st, s0);
+  if (rc) return rc;
+  uint64_t n_each = 0;
+  rc = check_many(K, N_each, s0, &n_each);
+  if (rc) return rc;
+  fused_plan* pl = nullptr;
+  rc = get_plan(c, FLOW_BATCH, st, K * N_each, strobe_pos, &pl);
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if (!d_out_points || !d_status || !d_transcripts || (s.nc && (!d_commitments || !d_weights16)) || (s.m && !d_responses) || !d_points)
+    return fail(ZKP_ERR_ARG, "NULL device pointer");
+  const batch_inter o = batch_carve(*pl, 0, K);
+  rc = ensure_ws(c, o.end + optional_many_ws(n_each, K));
+  if (rc) return rc;
+  return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_points, d_status, /*throughput=*/true, K);
+}
+
+int zkp_fused_batch_verify_many(zkp_ctx* c, const zkp_fused_statement* st, uint32_t K, uint32_t N_each, uint8_t* transcripts, const uint8_t* inst,
+                                const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
+                                int* verdicts, uint8_t* debug_scalars) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (!verdicts || !transcripts) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (K == 1) return zkp_fused_batch_verify(c, st, N_each, transcripts, inst, common, commitments, responses, weights16, verdicts, debug_scalars);
+  fused_shape s0;
+  int rc = check_fused_statement(st, s0);
+  if (rc) return rc;
+  uint64_t n_each = 0;
+  rc = check_many(K, N_each, s0, &n_each);
+  if (rc) return rc;
+  const uint32_t N = K * N_each;
+  uint32_t pos = 0;
+  rc = common_tail(transcripts, N, &pos);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  fused_plan* pl = nullptr;
+  rc = get_plan(c, FLOW_BATCH, st, N, pos, &pl);
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if ((s.nc && (!commitments || !weights16)) || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
+  const uint32_t m = s.m, nc = s.nc, ns = s.ns, ni = s.ni;
+  const size_t n_pts = (size_t)ns + ((size_t)ni + nc) * N, n_sc = (size_t)K * ns + ((size_t)ni + nc) * N;
+  carve cv;
+  const size_t o_pts = cv.take(n_pts * 32 + 32);
+  const size_t o_out = cv.take((size_t)K * 32);
+  const size_t o_st = cv.take((size_t)K * 8);
+  const size_t o_ts = cv.take((size_t)N * 208);
+  const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
+  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
+  const size_t o_w = cv.take((size_t)nc * N * 16 + 16);
+  const batch_inter o = batch_carve(*pl, cv.off, K);
+  rc = ensure_ws(c, o.end + optional_many_ws(n_each, K));
+  if (rc) return rc;
+  const ws_view w{static_cast<char*>(c->ws)};
+  if (ns) HIP_TRY(hipMemcpyAsync(w.base + o_pts, common, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
+  if (ni) HIP_TRY(hipMemcpyAsync(w.base + o_pts + 32 * (size_t)ns, inst, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
+  if (nc) {
+    HIP_TRY(hipMemcpyAsync(w.base + o_coms, commitments, (size_t)N * nc * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(w.base + o_w, weights16, (size_t)nc * N * 16, hipMemcpyHostToDevice, c->stream));
+  }
+  if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
+  rc = batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st), /*throughput=*/false, K);
+  if (rc) return rc;
+  std::vector<uint8_t> out((size_t)K * 32);
+  std::vector<uint32_t> stv((size_t)K * 2, 1u);
+  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, w.base + o.sc, n_sc * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(out.data(), w.base + o_out, out.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(stv.data(), w.base + o_st, stv.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  static const uint8_t zero[32] = {0};
+  for (uint32_t b = 0; b < K; ++b)                    // batch_verifier.rs:230-234, once per batch
+    verdicts[b] = (stv[2 * b] == 0 && stv[2 * b + 1] == 0 && memcmp(out.data() + 32 * (size_t)b, zero, 32) == 0) ? 0 : 1;
   return ZKP_OK;
 }
 

@@ -190,6 +190,28 @@ inline uint32_t table_index(const zkp_statement& st, uint32_t p, uint32_t j, uin
   return pt.common ? pt.rank : st.ns + pt.rank * N + j;
 }
 
+// Scalar::from_canonical_bytes: the value must be < l = 2^252 + 27742317777372353535851937790883648493.  The reference's proofs
+// reach its verifiers through serde (proofs.rs:14-32), and dalek's Deserialize refuses any other encoding of a Scalar; the
+// verify entry points below take proofs as raw bytes, so they apply the same rule: a response (or challenge) >= l is a
+// VerificationFailure for that proof / batch.
+inline bool scalar_is_canonical(const uint8_t s[32]) {
+  static const uint8_t L[32] = {0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
+                                0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10};
+  for (int i = 31; i >= 0; --i) {
+    if (s[i] < L[i]) return true;
+    if (s[i] > L[i]) return false;
+  }
+  return false;                                                      // == l
+}
+// proofs (of N) whose m responses are not all canonical -> flag[j] = 1; returns whether any is
+bool flag_noncanonical(uint32_t N, uint32_t m, const uint8_t* responses, uint8_t* flag) {
+  bool any = false;
+  for (uint32_t j = 0; j < N; ++j)
+    for (uint32_t i = 0; i < m; ++i)
+      if (!scalar_is_canonical(responses + 32 * ((size_t)j * m + i))) { if (flag) flag[j] = 1; any = true; break; }
+  return any;
+}
+
 bool all_transcripts_equal(const uint8_t* ts, uint32_t N) {
   for (uint32_t j = 1; j < N; ++j)
     if (std::memcmp(ts, ts + TB * (size_t)j, Transcript::kLiveBytes) != 0) return false;       // (the 5 padding bytes carry nothing)
@@ -308,15 +330,24 @@ uint32_t zkp_toolbox_get_fused_min_batch(void) { return g_fused_min_batch.load()
 
 // ---- transcripts / scalars -----------------------------------------------------------------------------
 void zkp_transcript_init(uint8_t* t, const uint8_t* label, size_t len) { Transcript(label, len).to_bytes(t); }
-void zkp_transcript_append_message(uint8_t* t, const char* label, const uint8_t* msg, size_t len) {
+// merlin's encode_usize_as_u32 asserts that lengths fit 32 bits (the > 4 GiB case of tests/sig_and_vrf_example.rs:224-241):
+// an error here, never a truncated length prefix
+static bool fits_u32(size_t n) { return (uint64_t)n <= 0xffffffffull; }
+int zkp_transcript_append_message(uint8_t* t, const char* label, const uint8_t* msg, size_t len) {
+  if (!t || !label || (len && !msg)) return ZKP_TB_BAD_STATEMENT;
+  if (!fits_u32(len) || !fits_u32(std::strlen(label))) return ZKP_TB_TOO_LONG;
   Transcript x = Transcript::from_bytes(t);
   x.append_message(label, msg, len);
   x.to_bytes(t);
+  return ZKP_TB_OK;
 }
-void zkp_transcript_challenge_bytes(uint8_t* t, const char* label, uint8_t* out, size_t len) {
+int zkp_transcript_challenge_bytes(uint8_t* t, const char* label, uint8_t* out, size_t len) {
+  if (!t || !label || (len && !out)) return ZKP_TB_BAD_STATEMENT;
+  if (!fits_u32(len) || !fits_u32(std::strlen(label))) return ZKP_TB_TOO_LONG;
   Transcript x = Transcript::from_bytes(t);
   x.challenge_bytes(label, out, len);
   x.to_bytes(t);
+  return ZKP_TB_OK;
 }
 void zkp_scalar_from_wide(uint8_t out[32], const uint8_t in[64]) { Scalar::from_bytes_mod_order_wide(in).to_bytes(out); }
 void zkp_scalar_muladd(uint8_t out[32], const uint8_t a[32], const uint8_t b[32], const uint8_t c[32]) {
@@ -328,16 +359,6 @@ void zkp_scalar_neg(uint8_t out[32], const uint8_t a[32]) { (-Scalar::from_bytes
 namespace {
 inline void put_u64le(uint8_t* out, uint64_t v) { for (int i = 0; i < 8; ++i) out[i] = (uint8_t)(v >> (8 * i)); }
 inline uint64_t get_u64le(const uint8_t* in) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v |= (uint64_t)in[i] << (8 * i); return v; }
-// Scalar::from_canonical_bytes: the value must be < l = 2^252 + 27742317777372353535851937790883648493
-inline bool scalar_is_canonical(const uint8_t s[32]) {
-  static const uint8_t L[32] = {0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
-                                0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10};
-  for (int i = 31; i >= 0; --i) {
-    if (s[i] < L[i]) return true;
-    if (s[i] > L[i]) return false;
-  }
-  return false;                                                      // == l
-}
 // u64 count + count x 32 bytes at in[pos..]; false = truncated / count larger than the remaining bytes
 inline bool read_vec32(const uint8_t* in, size_t len, size_t& pos, uint64_t& count) {
   if (len - pos < 8) return false;
@@ -567,6 +588,7 @@ int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N,
   }
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), T1 = st.terms + nc;
   std::memset(results, 0, N);
+  flag_noncanonical(N, m, responses, results);                         // proofs.rs:15-20 through serde: s >= l never reaches the verifier
   build_verifiers(st, N, ts, inst, common, n_threads, results);
   // verifier.rs:95-106: per constraint, responses over the rhs points and (-c) over the lhs point
   std::vector<uint8_t> scalars(32 * (size_t)N * T1), coms(32 * (size_t)N * nc), status((size_t)N * nc);
@@ -647,6 +669,7 @@ int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N
     return zkp_fused_verify_batchable(ctx, &fv.fs, N, ts, inst, common, commitments, responses, weights16, results);
   }
   std::memset(results, 0, N);
+  flag_noncanonical(N, m, responses, results);                         // proofs.rs:27-32 through serde
   build_verifiers(st, N, ts, inst, common, n_threads, results);
   // one (np + nc)-term MSM per proof over  points || commitments   (verifier.rs:144-166)
   const uint32_t K = np + nc;
@@ -705,6 +728,7 @@ int zkp_batch_verify_build(const zkp_statement* stp, uint32_t N, uint32_t n_tran
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), ni = st.ni, ns = st.ns;
   const size_t rows = (size_t)ni + nc;
   if (N == 0) { std::memset(msm_scalars, 0, 32 * (size_t)ns); if (ns) std::memcpy(msm_points, common, 32 * (size_t)ns); return ZKP_TB_OK; }
+  if (flag_noncanonical(N, m, responses, nullptr)) return ZKP_TB_VERIFICATION_FAILURE;   // proofs.rs:27-32 through serde
   std::vector<uint8_t> failed(N, 0);
   build_verifiers(st, N, ts, inst, common, n_threads, failed.data());  // :75-77, :92-94, :105-107, :125-128
   for (uint8_t f : failed) if (f) return ZKP_TB_VERIFICATION_FAILURE;
@@ -778,6 +802,7 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, 
   }
   std::vector<uint8_t> minus_c(32 * (size_t)N);
   if (N) {
+    if (flag_noncanonical(N, m, responses, nullptr)) return ZKP_TB_VERIFICATION_FAILURE;   // proofs.rs:27-32 through serde
     std::vector<uint8_t> failed(N, 0);
     build_verifiers(st, N, ts, inst, common, n_threads, failed.data());  // :75-77, :92-94, :105-107, :125-128
     for (uint8_t f : failed) if (f) return ZKP_TB_VERIFICATION_FAILURE;
@@ -819,6 +844,38 @@ int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t
                      const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
                      int n_threads) {
   return zkp_batch_verify_coeffs(ctx, st, N, n_transcripts, ts, inst, common, commitments, responses, weights16, n_threads, nullptr);
+}
+
+int zkp_batch_verify_many(zkp_ctx* ctx, const zkp_statement* stp, uint32_t K, uint32_t N_each, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
+                          const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16, int n_threads,
+                          int* verdicts) {
+  if (!ctx || !stp || !verdicts || K == 0 || N_each == 0 || (uint64_t)K * N_each > 0x7fffffffull) return ZKP_TB_BAD_STATEMENT;
+  const uint32_t N = K * N_each;
+  if (n_transcripts != N) return ZKP_TB_BATCH_SIZE_MISMATCH;           // batch_verifier.rs:72-74
+  if (!ts) return ZKP_TB_BAD_STATEMENT;
+  const zkp_statement& st = *stp;
+  const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), ni = st.ni;
+  std::vector<uint8_t> own_w;
+  if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
+  if (use_fused(ts, N)) {
+    FusedView fv(st);
+    const int rc = zkp_fused_batch_verify_many(ctx, &fv.fs, K, N_each, ts, inst, common, commitments, responses, weights16, verdicts, nullptr);
+    if (rc) return rc;
+    for (uint32_t b = 0; b < K; ++b) verdicts[b] = verdicts[b] ? ZKP_TB_VERIFICATION_FAILURE : ZKP_TB_OK;
+    return ZKP_TB_OK;
+  }
+  // one by one: batch b's columns of the instance rows and of the weights, gathered into arrays of its own
+  std::vector<uint8_t> inst_b(32 * (size_t)ni * N_each), w_b(16 * (size_t)nc * N_each);
+  for (uint32_t b = 0; b < K; ++b) {
+    const size_t j0 = (size_t)b * N_each;
+    for (uint32_t r = 0; r < ni; ++r) std::memcpy(inst_b.data() + 32 * (size_t)r * N_each, inst + 32 * ((size_t)r * N + j0), 32 * (size_t)N_each);
+    for (uint32_t k = 0; k < nc; ++k) std::memcpy(w_b.data() + 16 * (size_t)k * N_each, weights16 + 16 * ((size_t)k * N + j0), 16 * (size_t)N_each);
+    const int rc = zkp_batch_verify(ctx, stp, N_each, N_each, ts + TB * j0, inst_b.data(), common, commitments + 32 * j0 * nc, responses + 32 * j0 * m,
+                                    w_b.data(), n_threads);
+    if (rc < 0 || rc == ZKP_TB_BATCH_SIZE_MISMATCH) return rc;
+    verdicts[b] = rc;
+  }
+  return ZKP_TB_OK;
 }
 
 int zkp_batch_verify_locate(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,

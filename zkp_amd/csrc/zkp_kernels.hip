@@ -457,25 +457,51 @@ struct pip_cfg {
   }
 };
 
+// K independent MSMs of n terms each in one run ("segmented" Pippenger: the batch index is one more window coordinate of
+// every kernel below -- window id = b * W1 + w).  K = 1: one MSM over scalars[n] / points[n] (zkp_msm_optional).  K > 1: the
+// operand list of zkp_fused_batch_verify_many -- K batch verifications of N_each proofs whose proofs lie next to each other,
+//   scalars = static coefficients [K][ns] || Matrix rows [rows][K * N_each]      points = static [ns] || rows [rows][K * N_each]
+// term l of MSM b:  l < ns: static point l with coefficient (b, l);  else  row r = (l - ns) / N_each, proof j = b N_each + (l - ns) % N_each.
+struct pip_seg {
+  uint32_t K = 1, ns = 0, N_each = 0;
+};
+__device__ __forceinline__ void pip_seg_src(const pip_seg& seg, uint32_t b, uint32_t l, size_t& si, size_t& pi) {
+  si = pi = l;
+  if (seg.K > 1) {
+    if (l < seg.ns) {
+      si = (size_t)b * seg.ns + l;
+    } else {
+      const uint32_t q = l - seg.ns, r = q / seg.N_each, j = q - r * seg.N_each;
+      const size_t col = ((size_t)r * seg.K + b) * seg.N_each + j;
+      si = (size_t)seg.K * seg.ns + col;
+      pi = (size_t)seg.ns + col;
+    }
+  }
+}
+
 template <int C>
 __global__ void __launch_bounds__(256, 2)
-k_pip_prepare(uint32_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
+k_pip_prepare(uint32_t n, const pip_seg seg, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
               dev_niels* __restrict__ niels, uint32_t* __restrict__ digits, uint32_t* __restrict__ invalid) {
   using cfg = pip_cfg<C>;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (i >= n) return;
+  size_t si, pi;
+  pip_seg_src(seg, b, i, si, pi);
+  niels += (size_t)b * n;
+  digits += (size_t)b * cfg::W1 * n;
   {
     uint32_t w[8];
-    load_vec<2>(w, points + 32 * (size_t)i);
+    load_vec<2>(w, points + 32 * pi);
     ge_p3 p;
     const uint32_t ok = ristretto_decode(p, w);
     ge_niels q;
     ge_affine_to_niels(q, p);
     store_niels(niels + i, q, ok);
-    if (!ok) atomicOr(invalid, 1u);
+    if (!ok) atomicOr(invalid + b, 1u);
   }
   uint32_t s[8], e[10];
-  load_vec<2>(s, scalars + 32 * (size_t)i);
+  load_vec<2>(s, scalars + 32 * si);
   const uint32_t flip = sc_fold_sign(s);      // s * P = (l - s) * (-P): the point's sign moves into the digits
   {
     uint64_t c = 0;
@@ -640,7 +666,7 @@ k_pip_vmap(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t* __restr
 }
 
 __global__ void __launch_bounds__(256, 2)
-k_pip_bucket_part(uint32_t n, uint32_t bins, uint32_t L, uint32_t vmax, const uint32_t* __restrict__ start,
+k_pip_bucket_part(uint32_t n, uint32_t W1, uint32_t bins, uint32_t L, uint32_t vmax, const uint32_t* __restrict__ start,
                   const uint32_t* __restrict__ hist, const uint32_t* __restrict__ vstart, const uint32_t* __restrict__ vmap,
                   const uint32_t* __restrict__ sorted, const dev_niels* __restrict__ niels,
                   dev_ext* __restrict__ parts) {
@@ -653,6 +679,7 @@ k_pip_bucket_part(uint32_t n, uint32_t bins, uint32_t L, uint32_t vmax, const ui
   const uint32_t first = (v - vs[b]) * pl;
   const uint32_t cnt = min(pl, hist[g] - first);
   const uint32_t* lst = sorted + (size_t)w * n + start[g] + first;
+  niels += (size_t)(w / W1) * n;                      // window id = batch * W1 + window: the sorted lists hold indices within the batch
   ge_p3 acc;
   ge_identity(acc);
   // ping-pong software pipeline: the gather of the next entry is in flight while the current one is added, and the
@@ -751,15 +778,17 @@ k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t ou
   pip_reduce_quad(g, q, n_out, in_stride, out_stride, level, m, shift, A_in, R_in, A_out, R_out);
 }
 
-// The last tree level (one output per window: W1 quads of this one block), then
-// result = sum_w 2^(C w) T_w  (Horner, one quad: 256 inherently sequential doublings);  encode.
+// The last tree level (one output per window: W1 quads of this block), then
+// result = sum_w 2^(C w) T_w  (Horner, one quad: 256 inherently sequential doublings);  encode.  One block per MSM of the run.
 __global__ void __launch_bounds__(256)
 k_pip_combine(int W1, int C, uint32_t in_stride, int level, int m, int shift, const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
-              dev_ext* __restrict__ T, const uint32_t* __restrict__ invalid, uint8_t* __restrict__ out_point, uint32_t* __restrict__ status,
-              uint32_t shared_flags /*1: *invalid also carries bit 1 = "a transcript rejected a proof" -> status[1]*/) {
+              dev_ext* __restrict__ T_all, const uint32_t* __restrict__ invalid, uint8_t* __restrict__ out_point, uint32_t* __restrict__ status,
+              uint32_t shared_flags /*1: invalid[b] also carries bit 1 = "a transcript rejected a proof" -> status[2 b + 1]*/) {
+  const uint32_t b = blockIdx.x;
+  dev_ext* T = T_all + (size_t)b * W1;             // this MSM's window sums
   {
     const uint32_t g = threadIdx.x >> 2;
-    if (g < (uint32_t)W1) pip_reduce_quad(g, (int)(threadIdx.x & 3u), 1u, in_stride, 1u, level, m, shift, A_in, R_in, T, nullptr);
+    if (g < (uint32_t)W1) pip_reduce_quad(b * (uint32_t)W1 + g, (int)(threadIdx.x & 3u), 1u, in_stride, 1u, level, m, shift, A_in, R_in, T_all, nullptr);
   }
   __syncthreads();                                 // (T is written and read by this block only)
   if (threadIdx.x >= 4) return;                    // one quad of lanes (quad.h)
@@ -778,15 +807,15 @@ k_pip_combine(int W1, int C, uint32_t in_stride, int level, int m, int shift, co
   uint32_t o[8];
   ristretto_encode(o, full);
   if (q != 0) return;
-  const uint32_t flags = *invalid;
+  const uint32_t flags = invalid[b];
   const uint32_t bad = flags & 1u;
   if (bad) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = 0;
   }
-  store_vec<2>(out_point, o);
-  status[0] = bad;
-  if (shared_flags) status[1] = (flags >> 1) & 1u;
+  store_vec<2>(out_point + 32 * (size_t)b, o);
+  if (shared_flags) { status[2 * b] = bad; status[2 * b + 1] = (flags >> 1) & 1u; }
+  else status[b] = bad;
 }
 
 // self-test hook for the 4-lane cooperative arithmetic: for pair i (P, Q): out[i] = enc(2P), enc(P+Q), enc(P+Q) via the
@@ -847,19 +876,24 @@ __device__ __forceinline__ void coeff_of_point(sc& acc, uint32_t p, uint32_t j, 
   }
 }
 
-// The whole coefficient build in one launch, grid (ceil(N / 256), ni + nc + ns):
+// The whole coefficient build in one launch, grid (K * ceil(N_each / 256), ni + nc + ns) for K batches of N_each proofs that lie
+// next to each other (N = K * N_each proofs; K = 1: one batch):
 //   blockIdx.y <  ni + nc : instance rows and commitment rows of the coefficient matrix, lane (row, proof)
-//   blockIdx.y >= ni + nc : static coefficients -- block-level partial sums over the proofs (k_coeff_static_final adds them up)
+//   blockIdx.y >= ni + nc : static coefficients -- block-level partial sums over the proofs OF ONE BATCH (a block never straddles
+//                           two batches; k_coeff_static_final adds them up per batch: batch_verifier.rs:187, :198 sum over the batch)
+// scalars = static coefficients [K][ns] || Matrix rows [ni + nc][N]
 __global__ void __launch_bounds__(256)
-k_coeff_build(uint32_t N, uint32_t m, uint32_t ns, uint32_t ni, uint32_t nc, const uint32_t* __restrict__ inc_off,
+k_coeff_build(uint32_t N, uint32_t N_each, uint32_t nblk_each, uint32_t K, uint32_t m, uint32_t ns, uint32_t ni, uint32_t nc, const uint32_t* __restrict__ inc_off,
               const uint32_t* __restrict__ inc_k, const uint32_t* __restrict__ inc_sc, const uint8_t* __restrict__ minus_c,
               const uint8_t* __restrict__ responses, const uint8_t* __restrict__ weights16, uint8_t* __restrict__ scalars,
               uint32_t* __restrict__ partial /*[ns][gridDim.x][8]*/) {
   __shared__ uint32_t red[256][8];
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = blockIdx.x / nblk_each, jl = (blockIdx.x - b * nblk_each) * blockDim.x + threadIdx.x;
+  const bool live = jl < N_each;
+  const uint32_t j = b * N_each + jl;
   const uint32_t row = blockIdx.y;
   if (row < ni + nc) {
-    if (j >= N) return;
+    if (!live) return;
     sc acc;
     if (row < ni) {
       coeff_of_point(acc, ns + row, j, N, m, inc_off, inc_k, inc_sc, minus_c, responses, weights16);
@@ -869,22 +903,22 @@ k_coeff_build(uint32_t N, uint32_t m, uint32_t ns, uint32_t ni, uint32_t nc, con
       load_vec<1>(r.v, weights16 + 16 * ((size_t)(row - ni) * N + j));
       sc_neg(acc, r);                                                // batch_verifier.rs:183
     }
-    store_vec<2>(scalars + 32 * ((size_t)ns + (size_t)row * N + j), acc.v);
+    store_vec<2>(scalars + 32 * ((size_t)K * ns + (size_t)row * N + j), acc.v);
     return;
   }
   const uint32_t s = row - ni - nc;
   sc acc;
   sc_zero(acc);
-  if (j < N) coeff_of_point(acc, s, j, N, m, inc_off, inc_k, inc_sc, minus_c, responses, weights16);
+  if (live) coeff_of_point(acc, s, j, N, m, inc_off, inc_k, inc_sc, minus_c, responses, weights16);
 #pragma unroll
   for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc.v[i];
   __syncthreads();
   for (uint32_t d = 128; d >= 1; d >>= 1) {
     if (threadIdx.x < d) {
-      sc a, b;
+      sc a, bb;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { a.v[i] = red[threadIdx.x][i]; b.v[i] = red[threadIdx.x + d][i]; }
-      sc_add(a, a, b);
+      for (int i = 0; i < 8; ++i) { a.v[i] = red[threadIdx.x][i]; bb.v[i] = red[threadIdx.x + d][i]; }
+      sc_add(a, a, bb);
 #pragma unroll
       for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = a.v[i];
     }
@@ -892,18 +926,19 @@ k_coeff_build(uint32_t N, uint32_t m, uint32_t ns, uint32_t ni, uint32_t nc, con
   }
   if (threadIdx.x < 8) partial[((size_t)s * gridDim.x + blockIdx.x) * 8 + threadIdx.x] = red[0][threadIdx.x];
 }
+// grid (ns, K): static coefficient s of batch b = sum of its nblk_each block partials
 __global__ void __launch_bounds__(64)
-k_coeff_static_final(uint32_t nblocks, const uint32_t* __restrict__ partial, uint8_t* __restrict__ scalars) {
+k_coeff_static_final(uint32_t nblk_each, uint32_t ns, const uint32_t* __restrict__ partial, uint8_t* __restrict__ scalars) {
   if (threadIdx.x != 0) return;
-  const uint32_t s = blockIdx.x;
+  const uint32_t s = blockIdx.x, b = blockIdx.y, nblocks = nblk_each * gridDim.y;
   sc acc, t;
   sc_zero(acc);
-  for (uint32_t b = 0; b < nblocks; ++b) {
+  for (uint32_t q = 0; q < nblk_each; ++q) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t.v[i] = partial[((size_t)s * nblocks + b) * 8 + i];
+    for (int i = 0; i < 8; ++i) t.v[i] = partial[((size_t)s * nblocks + (size_t)b * nblk_each + q) * 8 + i];
     sc_add(acc, acc, t);
   }
-  store_vec<2>(scalars + 32 * (size_t)s, acc.v);
+  store_vec<2>(scalars + 32 * ((size_t)b * ns + s), acc.v);
 }
 
 // =============================================================================================
@@ -1280,64 +1315,71 @@ size_t pip_vmax(uint64_t n) { return (size_t)(n / pip_part_len(n)) + pip_cfg<C>:
 template <int C>
 uint32_t pip_tiles(uint64_t n) { return (uint32_t)((n + sort_cfg<C>::TILE - 1) / sort_cfg<C>::TILE); }
 
+// K = number of independent MSMs of n terms each that share the run (pip_seg)
 template <int C>
-size_t pip_ws(uint64_t n) {
+size_t pip_ws(uint64_t n, uint32_t K = 1) {
   using cfg = pip_cfg<C>;
+  const size_t WK = (size_t)cfg::W1 * K;         // (batch, window) pairs
   carve cv;
-  cv.take(n * sizeof(dev_niels));
-  cv.take((size_t)cfg::W1 * n * 4);            // digits
-  cv.take((size_t)cfg::W1 * n * 4);            // sorted
-  cv.take((size_t)cfg::W1 * cfg::B1 * 4 * 3);  // hist, start, cursor
-  cv.take((size_t)cfg::W1 * (cfg::B1 + 1) * 4);               // vstart
-  cv.take((size_t)cfg::W1 * pip_tiles<C>(n) * cfg::B1 * 4);   // tile histograms / tile base offsets
-  cv.take((size_t)cfg::W1 * pip_vmax<C>(n) * sizeof(dev_ext)); // bucket parts
-  cv.take((size_t)cfg::W1 * pip_vmax<C>(n) * 4);               // vmap
-  cv.take(256);                                // invalid flag
-  cv.take((size_t)cfg::W1 * cfg::B1 * sizeof(dev_ext));       // buckets
-  cv.take((size_t)cfg::W1 * (cfg::B + 8) * sizeof(dev_ext) * 2);  // reduction levels (A and R)
+  cv.take((size_t)K * n * sizeof(dev_niels));
+  cv.take(WK * n * 4);                           // digits
+  cv.take(WK * n * 4);                           // sorted
+  cv.take(WK * cfg::B1 * 4 * 3);                 // hist, start, cursor
+  cv.take(WK * (cfg::B1 + 1) * 4);               // vstart
+  cv.take(WK * pip_tiles<C>(n) * cfg::B1 * 4);   // tile histograms / tile base offsets
+  cv.take(WK * pip_vmax<C>(n) * sizeof(dev_ext)); // bucket parts
+  cv.take(WK * pip_vmax<C>(n) * 4);               // vmap
+  cv.take((size_t)K * 4 + 256);                  // invalid flags
+  cv.take(WK * cfg::B1 * sizeof(dev_ext));       // buckets
+  cv.take(WK * (cfg::B + 8) * sizeof(dev_ext) * 2);  // reduction levels (A and R)
   return cv.off;
 }
 
+// d_out [K][32]; d_status [K] words, or [K][2] with shared_flags (the caller's K zeroed flag words: bit 0 ours, bit 1 the caller's)
 template <int C>
 int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_points, uint8_t* d_out,
-            uint32_t* d_status, size_t ws_reserved, uint32_t* shared_flags) {
+            uint32_t* d_status, size_t ws_reserved, uint32_t* shared_flags, const pip_seg seg = pip_seg()) {
   using cfg = pip_cfg<C>;
+  const uint32_t K = seg.K;
+  const size_t WK = (size_t)cfg::W1 * K;
+  if (WK > 65535) return fail(ZKP_ERR_ARG, "too many batches in one call");
   carve cv;
   cv.off = ws_reserved;
   char* base = static_cast<char*>(c->ws);
-  dev_niels* niels = reinterpret_cast<dev_niels*>(base + cv.take((size_t)n * sizeof(dev_niels)));
-  uint32_t* digits = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * n * 4));
-  uint32_t* sorted = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * n * 4));
-  const size_t nb = (size_t)cfg::W1 * cfg::B1;
+  dev_niels* niels = reinterpret_cast<dev_niels*>(base + cv.take((size_t)K * n * sizeof(dev_niels)));
+  uint32_t* digits = reinterpret_cast<uint32_t*>(base + cv.take(WK * n * 4));
+  uint32_t* sorted = reinterpret_cast<uint32_t*>(base + cv.take(WK * n * 4));
+  const size_t nb = WK * cfg::B1;
+  if (nb * 4 > 0xffffffffull) return fail(ZKP_ERR_ARG, "too many batches in one call");
   uint32_t* hist = reinterpret_cast<uint32_t*>(base + cv.take(nb * 4 * 3));
   uint32_t* start = hist + nb;
   uint32_t* cursor = start + nb;
-  uint32_t* vstart = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * (cfg::B1 + 1) * 4));
+  uint32_t* vstart = reinterpret_cast<uint32_t*>(base + cv.take(WK * (cfg::B1 + 1) * 4));
   const uint32_t tiles = pip_tiles<C>(n);
-  uint32_t* tilehist = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * tiles * cfg::B1 * 4));
+  uint32_t* tilehist = reinterpret_cast<uint32_t*>(base + cv.take(WK * tiles * cfg::B1 * 4));
   const uint32_t L = pip_part_len(n);
   const size_t vmax = pip_vmax<C>(n);
-  dev_ext* parts = reinterpret_cast<dev_ext*>(base + cv.take((size_t)cfg::W1 * vmax * sizeof(dev_ext)));
-  uint32_t* vmap = reinterpret_cast<uint32_t*>(base + cv.take((size_t)cfg::W1 * vmax * 4));
-  uint32_t* invalid = reinterpret_cast<uint32_t*>(base + cv.take(256));
-  if (shared_flags) invalid = shared_flags;          // the caller's flag word, already zero (bit 0: ours; bit 1: the caller's, for status[1])
+  dev_ext* parts = reinterpret_cast<dev_ext*>(base + cv.take(WK * vmax * sizeof(dev_ext)));
+  uint32_t* vmap = reinterpret_cast<uint32_t*>(base + cv.take(WK * vmax * 4));
+  uint32_t* invalid = reinterpret_cast<uint32_t*>(base + cv.take((size_t)K * 4 + 256));
+  if (shared_flags) invalid = shared_flags;          // the caller's flag words, already zero (bit 0: ours; bit 1: the caller's, for status[2 b + 1])
   dev_ext* buckets = reinterpret_cast<dev_ext*>(base + cv.take(nb * sizeof(dev_ext)));
-  const size_t lvl_cap = (size_t)cfg::W1 * (cfg::B + 8);
+  const size_t lvl_cap = WK * (cfg::B + 8);
   dev_ext* lvlA = reinterpret_cast<dev_ext*>(base + cv.take(lvl_cap * sizeof(dev_ext) * 2));
   dev_ext* lvlR = lvlA + lvl_cap;
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
 
-  if (!shared_flags) HIP_TRY(hipMemsetAsync(invalid, 0, 4, c->stream));
-  hipLaunchKernelGGL(k_pip_prepare<C>, grid1(n, 256), dim3(256), 0, c->stream, n, d_scalars, d_points, niels, digits, invalid);
+  if (!shared_flags) HIP_TRY(hipMemsetAsync(invalid, 0, (size_t)K * 4, c->stream));
+  hipLaunchKernelGGL(k_pip_prepare<C>, dim3((n + 255) / 256, K), dim3(256), 0, c->stream, n, seg, d_scalars, d_points, niels, digits, invalid);
   prof_mark(c, ZKP_K_DECODE);
-  hipLaunchKernelGGL(k_pip_tile_hist<C>, dim3(tiles, cfg::W1), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist);
+  hipLaunchKernelGGL(k_pip_tile_hist<C>, dim3(tiles, (unsigned)WK), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist);
   hipLaunchKernelGGL(k_pip_tile_total, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, tiles, (uint32_t)nb, tilehist, hist);
-  hipLaunchKernelGGL(k_pip_scan, dim3(cfg::W1), dim3(256), 0, c->stream, cfg::B1, L, hist, start, cursor, vstart);
+  hipLaunchKernelGGL(k_pip_scan, dim3((unsigned)WK), dim3(256), 0, c->stream, cfg::B1, L, hist, start, cursor, vstart);
   hipLaunchKernelGGL(k_pip_tile_base, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, tiles, (uint32_t)nb, start, tilehist);
-  hipLaunchKernelGGL(k_pip_tile_scatter<C>, dim3(tiles, cfg::W1), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist, sorted);
+  hipLaunchKernelGGL(k_pip_tile_scatter<C>, dim3(tiles, (unsigned)WK), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist, sorted);
   prof_mark(c, ZKP_K_SORT);
   hipLaunchKernelGGL(k_pip_vmap, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, (uint32_t)nb, (uint32_t)vmax, vstart, vmap);
-  hipLaunchKernelGGL(k_pip_bucket_part, dim3((unsigned)((vmax + 255) / 256), cfg::W1), dim3(256), 0, c->stream, n, cfg::B1, L, (uint32_t)vmax,
+  hipLaunchKernelGGL(k_pip_bucket_part, dim3((unsigned)((vmax + 255) / 256), (unsigned)WK), dim3(256), 0, c->stream, n, (uint32_t)cfg::W1, cfg::B1, L, (uint32_t)vmax,
                      start, hist, vstart, vmap, sorted, niels, parts);
   hipLaunchKernelGGL(k_pip_bucket_merge, grid1(nb * 4, 256), dim3(256), 0, c->stream, cfg::B1, (uint32_t)nb, (uint32_t)vmax, vstart, parts, buckets);
   prof_mark(c, ZKP_K_BUCKET);
@@ -1356,9 +1398,9 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
     const uint32_t m = 1u << mbits, n_out = n_in >> mbits;
     dev_ext* Aout = lvlA + lvl_off;
     dev_ext* Rout = lvlR + lvl_off;
-    const uint32_t total = cfg::W1 * n_out;
-    if (n_out == 1) {                                                 // the last level shares the launch of the Horner tail
-      hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(256), 0, c->stream, cfg::W1, C, in_stride, level, (int)m, shift, Ain, Rin, Aout, invalid, d_out, d_status, shared_flags ? 1u : 0u);
+    const uint32_t total = (uint32_t)WK * n_out;
+    if (n_out == 1) {                                                 // the last level shares the launch of the Horner tails (one block per MSM)
+      hipLaunchKernelGGL(k_pip_combine, dim3(K), dim3(256), 0, c->stream, cfg::W1, C, in_stride, level, (int)m, shift, Ain, Rin, Aout, invalid, d_out, d_status, shared_flags ? 1u : 0u);
       break;
     }
     hipLaunchKernelGGL(k_pip_reduce_lvl, grid1((size_t)total * 4, 256), dim3(256), 0, c->stream, n_out, total, in_stride, n_out, level, (int)m, shift,

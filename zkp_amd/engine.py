@@ -25,7 +25,7 @@ EXPORTS = (
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
     "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest", "zkp_batch_check", "zkp_fused_prove", "zkp_fused_verify_compact", "zkp_fused_batch_verify",
     "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_batch_verify_dev",
-    "zkp_fused_verify_batchable_coeffs", "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_graph_launch", "zkp_graph_destroy",
+    "zkp_fused_verify_batchable_coeffs", "zkp_fused_batch_verify_many", "zkp_fused_batch_verify_many_dev", "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_graph_launch", "zkp_graph_destroy",
 )
 
 
@@ -196,6 +196,34 @@ class Engine:
         _check(self._lib.zkp_fused_batch_verify_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ctypes.c_uint32(strobe_pos),
                                                     *[ctypes.c_void_p(x) for x in (d_ts, d_points, d_coms, d_resp, d_w, d_out, d_status)]),
                "zkp_fused_batch_verify_dev")
+
+    def fused_batch_verify_many_dev(self, fst: "FusedStatement", n_batches, n_each, strobe_pos, d_ts, d_points, d_coms, d_resp, d_w, d_out, d_status) -> None:
+        """K batch verifications of n_each proofs in one pass; d_out [K][32], d_status [K][2] int32 (zkp_fused_batch_verify_many_dev)."""
+        _check(self._lib.zkp_fused_batch_verify_many_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n_batches), ctypes.c_uint32(n_each), ctypes.c_uint32(strobe_pos),
+                                                         *[ctypes.c_void_p(x) for x in (d_ts, d_points, d_coms, d_resp, d_w, d_out, d_status)]),
+               "zkp_fused_batch_verify_many_dev")
+
+    def fused_batch_verify_many(self, fst: "FusedStatement", n_batches: int, transcripts, inst, common, commitments, responses, weights16, want_coeffs: bool = False):
+        """zkp_fused_batch_verify_many on host arrays: the len(transcripts) = n_batches * N_each proofs lie next to each other, batch b =
+        proofs [b N_each, (b + 1) N_each) -> verdicts[n_batches] (0 = the batch verifies) [, the coefficient vector the device built];
+        the transcripts [N][208] are advanced in place."""
+        n = len(transcripts)
+        if n_batches <= 0 or n % n_batches:
+            raise ValueError("the number of proofs must be a multiple of n_batches")
+        n_each = n // n_batches
+        k = n_batches * fst.n_static + (fst.n_instance + len(fst._lhs)) * n
+        verdicts = (ctypes.c_int * n_batches)(*([1] * n_batches))
+        co = np.zeros((k, 32), np.uint8) if want_coeffs else None
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (transcripts, inst, common, commitments, responses, weights16)]
+        if arrs[1].shape != (fst.n_instance, n, 32) or arrs[2].shape != (fst.n_static, 32) or arrs[3].shape != (n, len(fst._lhs), 32) or \
+                arrs[4].shape[:1] != (n,) or arrs[5].shape != (len(fst._lhs), n, 16) or arrs[0].shape != (n, 208):
+            raise ValueError("array shapes do not match the statement / batch sizes")
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _check(self._lib.zkp_fused_batch_verify_many(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n_batches), ctypes.c_uint32(n_each), ptr(arrs[0]), ptr(arrs[1]),
+                                                     ptr(arrs[2]), ptr(arrs[3]), ptr(arrs[4]), ptr(arrs[5]), verdicts, _ptr(co)), "zkp_fused_batch_verify_many")
+        transcripts[...] = arrs[0]
+        v = np.array(list(verdicts), np.int32)
+        return (v, co) if want_coeffs else v
 
     def fused_verify_batchable_coeffs(self, fst: "FusedStatement", transcripts, inst, common, commitments, responses, weights16):
         """zkp_fused_verify_batchable_coeffs on host arrays -> (results[N], coefficient vectors [N][np + nc][32]); the

@@ -39,7 +39,7 @@ EXPORTS = (
     "zkp_verify_compact_batch", "zkp_verify_batchable_each", "zkp_batch_verify", "zkp_batch_verify_coeffs", "zkp_batch_verify_build",
     "zkp_prove_phase_a", "zkp_prove_phase_b", "zkp_toolbox_set_fused_min_batch", "zkp_toolbox_get_fused_min_batch", "zkp_chacha20_block",
     "zkp_proof_compact_size", "zkp_proof_batchable_size", "zkp_proof_compact_encode", "zkp_proof_compact_decode",
-    "zkp_proof_batchable_encode", "zkp_proof_batchable_decode", "zkp_batch_verify_locate",
+    "zkp_proof_batchable_encode", "zkp_proof_batchable_decode", "zkp_batch_verify_locate", "zkp_batch_verify_many",
 )
 
 
@@ -136,11 +136,15 @@ class Transcript:
         return Transcript(_state=self.state)
 
     def append_message(self, label: bytes, message: bytes) -> None:
-        lib().zkp_transcript_append_message(_p(self.state), label, message, ctypes.c_size_t(len(message)))
+        rc = lib().zkp_transcript_append_message(_p(self.state), label, message, ctypes.c_size_t(len(message)))
+        if rc != 0:
+            raise ValueError("zkp_transcript_append_message: code %d (messages and labels are limited to 2^32 - 1 bytes, as in merlin)" % rc)
 
     def challenge_bytes(self, label: bytes, n: int) -> bytes:
         out = ctypes.create_string_buffer(n)
-        lib().zkp_transcript_challenge_bytes(_p(self.state), label, out, ctypes.c_size_t(n))
+        rc = lib().zkp_transcript_challenge_bytes(_p(self.state), label, out, ctypes.c_size_t(n))
+        if rc != 0:
+            raise ValueError("zkp_transcript_challenge_bytes: code %d" % rc)
         return out.raw
 
 
@@ -338,9 +342,26 @@ def batch_verify(eng, st, transcripts, inst, common, commitments, responses, wei
     _raise(rc, "zkp_batch_verify")
 
 
-def batch_verify_locate(eng, st, transcripts, inst, common, commitments, responses, weights16=None, threads: int = 0) -> np.ndarray:
-    """zkp_batch_verify_locate: the batch check and, if it fails, which proofs fail -> results[N] (0 = verifies).  Never raises
-    VerificationFailure: an all-zero result means the batch verified."""
+def batch_verify_many(eng, st, n_batches: int, transcripts, inst, common, commitments, responses, weights16=None, threads: int = 0) -> np.ndarray:
+    """zkp_batch_verify_many: n_batches independent BatchVerifier::verify_batchable runs over consecutive ranges of the
+    len(commitments) proofs -> verdicts[n_batches] (0 = Ok, 1 = VerificationFailure)."""
+    n = len(commitments)
+    if n_batches <= 0 or n % n_batches:
+        raise ValueError("the number of proofs must be a positive multiple of n_batches")
+    _check_batch_shapes(st, n, inst, common, commitments, responses, weights16)
+    verdicts = (ctypes.c_int * n_batches)(*([1] * n_batches))
+    rc = lib().zkp_batch_verify_many(eng._h, st._h, ctypes.c_uint32(n_batches), ctypes.c_uint32(n // n_batches), ctypes.c_uint32(len(transcripts)),
+                                     _p(transcripts), _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                     _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
+                                     _p(None if weights16 is None else np.ascontiguousarray(weights16)), threads, verdicts)
+    _raise(rc, "zkp_batch_verify_many")
+    return np.array(list(verdicts), np.int32)
+
+
+def batch_verify_locate(eng, st, transcripts, inst, common, commitments, responses, weights16=None, threads: int = 0):
+    """zkp_batch_verify_locate: the batch check and, if it fails, which proofs fail -> (ok, results[N]): ok = the batch
+    verified (results then all 0); otherwise results[j] = 1 for the proofs that fail on their own.  A failed batch whose
+    per-proof pass finds nothing (the C contract allows it) is still ok = False: never read success from results alone."""
     n = len(commitments)
     _check_batch_shapes(st, n, inst, common, commitments, responses, weights16)
     res = np.ones(n, np.uint8)
@@ -350,7 +371,7 @@ def batch_verify_locate(eng, st, transcripts, inst, common, commitments, respons
                                        _p(None if weights16 is None else np.ascontiguousarray(weights16)), threads, _p(res))
     if rc not in (0, 1):
         _raise(rc, "zkp_batch_verify_locate")
-    return res
+    return rc == 0, res
 
 
 def batch_verify_coeffs(eng, st, transcripts, inst, common, commitments, responses, weights16, threads: int = 0):

@@ -415,11 +415,9 @@ def run_workload(cx, args, cfg, n, steps, warmup, K, n_streams, primary):
         barrier()
         if not args.no_graphs:
             for k in range(n_streams):
-                engines[k].capture_begin()
-                try:
+                with engines[k].capture() as cap:              # a failing call aborts the capture instead of leaving the stream capturing
                     enqueue(k, which)
-                finally:
-                    graphs[k] = engines[k].capture_end()       # always ends the capture: a failed call must not leave the stream capturing
+                graphs[k] = cap.graph
 
         def call(i):
             # consecutive calls go to different engine contexts = different HIP streams, so the narrow phases of one call

@@ -87,11 +87,16 @@ const char* zkp_version(void);
  *   ZKP_OPT_TRANSCRIPT_LANES: lanes per proof in the Merlin transcript kernel of the fused flows.  2 = a lane pair per proof
  *     (each lane holds one 32-bit half of every STROBE word: half the latency), 1 = one lane per proof (23 % fewer
  *     instructions per Keccak-f), UINT64_MAX = default: 1 in asynchronous _dev calls of 8192 proofs or more, 2 otherwise. 
- *   (Measurement only, not part of the interface: option 9 = n empty kernels added to every zkp_fused_prove_dev call -- what a launch
- *    costs a pipelined caller; option 10 = 0 sends the fused flows through the generic six-kernel term classifier instead of
- *    k_stmt_classify.  profiles/r02_ab_experiments.txt, blocks o and p.) */
+ *   ZKP_OPT_CT_MASKED_SCANS: 1 = the safe mode of the constant-time schedule.  By default a ZKP_CT call reads fixed-base rows (and, in
+ *     wide calls, comb rows) from LDS at an index derived from the secret digit, from banks that no other lane of the ds_read_b128
+ *     service group touches -- constant time under the LDS service-group / bank model of the hardware guide, checked with PMC
+ *     counters and per-wavefront cycle counts (profiles/r03_constant_time_counters.txt).  With this option every table look-up of a
+ *     ZKP_CT call is what curve25519-dalek does on a CPU: all entries of the row are read at fixed addresses and the wanted one is
+ *     kept with v_cndmask (fixed-base rows: 32 entries, comb / ladder rows: 8), and the grouped comb walk is off.  Same bytes out;
+ *     about 1.6 x the instructions of the term kernel.  Default 0.
+ *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
-       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8 };
+       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~35 short kernels (75 in round 1); enqueueing them one by one costs the host ~0.1 ms per
@@ -102,10 +107,17 @@ int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
  * the recording with ONE host call.  Replays read and write the same device addresses, so the buffers must stay alive
  * and are reused by every replay.  Preconditions: the same calls ran once before on this context with the same shapes
  * (statement plans compiled, workspace sized, fixed points registered) -- otherwise ZKP_ERR_ARG -- and profiling is off.
- * A graph belongs to the context (its workspace) it was captured on. */
+ * Lifetime rules.  A graph belongs to the context it was captured on: the recorded kernels hold raw addresses inside that
+ * context's workspace and statement plans.  Each graph is stamped with the context's workspace / plan generation;
+ * zkp_graph_launch returns ZKP_ERR_ARG ("stale graph") -- it never runs the recording -- when, after the capture, a larger
+ * call made the workspace grow (it is reallocated), the plan cache was flushed (more than 64 distinct (flow, statement, N)
+ * plans on one context), the context was destroyed, or when the graph is offered to another context.  Capture again then.
+ * If a call between _begin and _end fails, the capture is poisoned: call zkp_ctx_capture_abort (ends and discards it; the
+ * context is usable again) -- zkp_ctx_capture_end on a poisoned capture returns an error and also leaves capture mode. */
 typedef struct zkp_graph zkp_graph;
 int zkp_ctx_capture_begin(zkp_ctx* ctx);
 int zkp_ctx_capture_end(zkp_ctx* ctx, zkp_graph** out);
+int zkp_ctx_capture_abort(zkp_ctx* ctx);                /* no capture in progress: no-op */
 int zkp_graph_launch(zkp_graph* graph, zkp_ctx* ctx);   /* asynchronous, on the context's current stream */
 void zkp_graph_destroy(zkp_graph* graph);
 
@@ -277,11 +289,6 @@ int zkp_decode_check(zkp_ctx* ctx, uint64_t n, const uint8_t* points /*[n][32]*/
  *     32-byte little-endian field element (need not be reduced below p, bit 255 ignored). */
 int zkp_encode_many(zkp_ctx* ctx, uint64_t n, const uint8_t* xyzt /*[n][128]*/, uint8_t* out /*[n][32]*/);
 
-/* Test hook (not part of the drop-in surface): exercises the 4-lane cooperative point arithmetic used by the
- * latency-bound kernels.  pairs = [n][2][32] encodings (P, Q); out = [n][4][32] = enc(2P), enc(P+Q), enc(P+Q) through
- * Q's niels form, enc(P-Q) through the negated niels form. */
-int zkp_debug_quad_selftest(zkp_ctx* ctx, uint32_t n, const uint8_t* pairs /*[n][64]*/, uint8_t* out /*[n][128]*/);
-
 /* Timing of the last *_dev / host call on this context, measured with HIP events on the stream the
  * kernels were launched on.  kernel_ms[] is indexed by ZKP_K_*; returns the number of entries. */
 enum {
@@ -299,6 +306,24 @@ enum {
 int zkp_ctx_last_timing(zkp_ctx* ctx, float* kernel_ms /*[ZKP_K_COUNT]*/, float* total_ms);
 /* Enable (1) / disable (0) per-kernel event timing (off by default: events add launch gaps). */
 int zkp_ctx_set_profiling(zkp_ctx* ctx, int enabled);
+
+#ifdef ZKP_BUILD_TEST_HOOKS
+/* ---- test-hook builds only (zkp_amd/libzkp_mi355x_testhooks.so, compiled with -DZKP_BUILD_TEST_HOOKS; the shipped library
+ *      has none of this: no extra options, no k_noop / k_debug_quad kernels, no scratch in its code object) ----------------
+ * zkp_debug_quad_selftest: exercises the 4-lane cooperative point arithmetic used by the latency-bound kernels.  pairs =
+ *   [n][2][32] encodings (P, Q); out = [n][4][32] = enc(2P), enc(P+Q), enc(P+Q) through Q's niels form, enc(P-Q) through the
+ *   negated niels form.
+ * zkp_ctx_set_option extras (measurement, profiles/r02_ab_experiments.txt blocks o and p):
+ *   ZKP_TESTOPT_DUMMY_LAUNCHES = n empty kernels added to every zkp_fused_prove_dev call (what a launch costs a pipelined caller);
+ *   ZKP_TESTOPT_GENERIC_CLASSIFIER = 1 sends the fused flows through the generic six-kernel term classifier instead of
+ *   k_stmt_classify;
+ *   ZKP_TESTOPT_WAVE_CYCLES = 1 switches on a per-wavefront cycle recorder in the term kernel (s_memtime at entry and exit);
+ * zkp_debug_wave_cycles copies out (and clears) up to cap records, [block][wavefront 0..3] = block class << 56 | cycles (class 1 =
+ *   ladder, 2 = comb scan, 3 = grouped comb walk, 4 = fixed-base; 0 = no record): the timing side of the constant-time evidence. */
+int zkp_debug_quad_selftest(zkp_ctx* ctx, uint32_t n, const uint8_t* pairs /*[n][64]*/, uint8_t* out /*[n][128]*/);
+int zkp_debug_wave_cycles(zkp_ctx* ctx, uint64_t* out, uint32_t cap);     /* returns the number of records copied */
+enum { ZKP_TESTOPT_DUMMY_LAUNCHES = 1001, ZKP_TESTOPT_GENERIC_CLASSIFIER = 1002, ZKP_TESTOPT_WAVE_CYCLES = 1003 };
+#endif
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,7 @@ extern "C" {
     pub fn zkp_ctx_set_option(ctx: *mut zkp_ctx, option: c_int, value: u64) -> c_int;
     pub fn zkp_ctx_capture_begin(ctx: *mut zkp_ctx) -> c_int;
     pub fn zkp_ctx_capture_end(ctx: *mut zkp_ctx, out: *mut *mut zkp_graph) -> c_int;
+    pub fn zkp_ctx_capture_abort(ctx: *mut zkp_ctx) -> c_int;
     pub fn zkp_graph_launch(graph: *mut zkp_graph, ctx: *mut zkp_ctx) -> c_int;
     pub fn zkp_graph_destroy(graph: *mut zkp_graph);
     pub fn zkp_ctx_prepare_fixed_points(ctx: *mut zkp_ctx, n: u32, encodings: *const u8) -> c_int;
@@ -129,7 +130,6 @@ extern "C" {
     // ---- (3), (4) stand-alone codec: verifier.rs:87-92, mod.rs:180 -------------------------------------------------------
     pub fn zkp_decode_check(ctx: *mut zkp_ctx, n: u64, points: *const u8, status: *mut u8, xyzt: *mut u8) -> c_int;
     pub fn zkp_encode_many(ctx: *mut zkp_ctx, n: u64, xyzt: *const u8, out: *mut u8) -> c_int;
-    pub fn zkp_debug_quad_selftest(ctx: *mut zkp_ctx, n: u32, pairs: *const u8, out: *mut u8) -> c_int;
     pub fn zkp_ctx_last_timing(ctx: *mut zkp_ctx, kernel_ms: *mut f32, total_ms: *mut f32) -> c_int;
     pub fn zkp_ctx_set_profiling(ctx: *mut zkp_ctx, enabled: c_int) -> c_int;
 

@@ -247,11 +247,9 @@ def test_many_dev_entry_equals_host_entry_and_graph_replay(eng):
             d_coms[11 * n_each, 2] = 0
             run()
             eng.synchronize()
-            eng.capture_begin()
-            try:
+            with eng.capture() as cap:
                 run()
-            finally:
-                g = eng.capture_end()
+            g = cap.graph
             d_out.fill_(7); d_bst.fill_(7)
             g.launch()
             eng.synchronize()

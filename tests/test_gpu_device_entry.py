@@ -219,7 +219,7 @@ def test_hip_graph_replay_equals_direct_calls(eng):
     e.close()
 
 
-@pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1), (0, "masked"), (1, "masked")])
 def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_tables, grouped):
     """ZKP_OPT_CT_SINGLE_USE_TABLES: a constant-time call serves a point that only one term multiplies either through a comb
     table (default when the call has shared points) or through the masked radix-16 ladder; both must give the oracle's bytes.
@@ -231,7 +231,13 @@ def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_ta
     rng = np.random.default_rng(12)
     e = Engine(0)
     e.set_option(3, single_use_tables)
-    e.set_option(6, grouped)
+    if grouped == "masked":
+        # ZKP_OPT_CT_MASKED_SCANS: the safe mode -- every table look-up of the constant-time call is a masked scan over the whole
+        # row (fixed-base rows too), and the grouped walk stays off even when asked for
+        e.set_option(9, 1)
+        e.set_option(6, 1)
+    else:
+        e.set_option(6, grouped)
     n = 80
     off, pidx, n_pts = bench.cmz_shape(n)
     ks = rng.integers(0, 256, size=(n_pts, 32), dtype=np.uint8)
@@ -301,8 +307,32 @@ def test_grouped_comb_walk_with_mixed_group_sizes(single_use_tables):
     e = Engine(0)
     e.prepare_fixed_points(pts[[3, 12]])                                 # two of the points are fixed-base points as well
     e.set_option(3, single_use_tables)
-    for grouped in (1, 0):
+    for grouped, masked in ((1, 0), (0, 0), (1, 1)):
         e.set_option(6, grouped)
+        e.set_option(9, masked)                                          # ZKP_OPT_CT_MASKED_SCANS
         got, st = e.msm_many(off, sc, pidx, pts, 1)
-        assert (st == wst).all() and (got[wst == 0] == want[wst == 0]).all(), grouped
+        assert (st == wst).all() and (got[wst == 0] == want[wst == 0]).all(), (grouped, masked)
     e.close()
+
+
+def test_masked_scan_safe_mode_gives_the_same_proofs(eng):
+    """ZKP_OPT_CT_MASKED_SCANS through the fused prover at the size where the wide-call variants (grouped walk, ladder) switch on
+    by themselves: byte-identical proofs, and the batch of them verifies."""
+    from zkp_amd.engine import Engine
+    n = 13000                                                            # 403,000 terms: a wide call also for the synchronous entry points
+    mod, secrets, inst, common = _cmz_batch(64, 33)
+    reps = (n + 63) // 64
+    secrets = np.ascontiguousarray(np.tile(secrets, (reps, 1, 1))[:n])
+    inst = np.ascontiguousarray(np.tile(inst, (1, reps, 1))[:, :n])
+    entropy = np.random.default_rng(34).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    out = {}
+    for masked in (0, 1):
+        e = Engine(0)
+        e.set_option(9, masked)
+        ts = np.stack([T.Transcript(b"safe-mode").state] * n)
+        out[masked] = T.prove_batch(e, mod.statement, ts, secrets, inst, common, entropy)
+        e.close()
+    for a, b in zip(out[0], out[1]):
+        assert (a == b).all()
+    ts = np.stack([T.Transcript(b"safe-mode").state] * n)
+    T.batch_verify(eng, mod.statement, ts, inst, common, out[1][2], out[1][1])

@@ -218,9 +218,19 @@ def test_msm_many_fixed_base_tables(base_points, flags):
     hot.close()
 
 
-def test_quad_cooperative_point_ops(eng, base_points):
+def test_quad_cooperative_point_ops(base_points):
     """4-lane cooperative doubling / addition / mixed addition (quad.h) against the oracle, incl. identity operands,
-    P = Q (the unified formulas must double) and P = -Q (sum = identity)."""
+    P = Q (the unified formulas must double) and P = -Q (sum = identity).  The self-test kernel lives in the test-hook
+    build of the library only (-DZKP_BUILD_TEST_HOOKS); the shipped library does not carry it."""
+    from zkp_amd.engine import Engine, ZkpError
+    with pytest.raises((ZkpError, AttributeError)):
+        plain = Engine(0)
+        try:
+            plain.debug_quad_selftest(np.zeros((1, 64), np.uint8))
+        finally:
+            plain.close()
+    eng = Engine(0, test_hooks=True)
+    assert "+test-hooks" in eng.version
     rng = random.Random(31337)
     _, encs = base_points
     ident = bytes(32)
@@ -229,6 +239,7 @@ def test_quad_cooperative_point_ops(eng, base_points):
     pairs += [(encs[rng.randrange(64)], encs[rng.randrange(64)]) for _ in range(300)]
     arr = np.frombuffer(b"".join(p + q for p, q in pairs), np.uint8).reshape(-1, 64)
     out = eng.debug_quad_selftest(arr)
+    eng.close()
     for i, (pe, qe) in enumerate(pairs):
         P, Q = M.ristretto_decode(pe), M.ristretto_decode(qe)
         exp = [M.pt_double(P), M.pt_add(P, Q), M.pt_add(P, Q), M.pt_add(P, M.pt_neg(Q))]

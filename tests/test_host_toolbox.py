@@ -32,9 +32,14 @@ def arr(rows, width=32):
     return np.frombuffer(b"".join(rows), np.uint8).reshape(-1, width) if rows else np.zeros((0, width), np.uint8)
 
 
-def _declared(header):
+def _declared(header, test_hooks=False):
+    """function names a header declares; the `#ifdef ZKP_BUILD_TEST_HOOKS` section only when asked for"""
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    hooks = re.findall(r"#ifdef ZKP_BUILD_TEST_HOOKS(.*?)#endif", src, flags=re.S)
+    src = re.sub(r"#ifdef ZKP_BUILD_TEST_HOOKS.*?#endif", "", src, flags=re.S)
+    if test_hooks:
+        src = "".join(hooks)
     return sorted(set(re.findall(r"\b(zkp_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -43,11 +48,52 @@ def test_c_abi_exports_every_declared_symbol():
     for name in _declared("zkp_mi355x.h"):
         assert hasattr(hip, name), name
     assert set(engine.EXPORTS) == set(_declared("zkp_mi355x.h"))
+    # measurement / self-test hooks exist in the test-hook build only: the shipped library does not export them
+    assert set(engine.TEST_HOOK_EXPORTS) == set(_declared("zkp_mi355x.h", test_hooks=True)) and engine.TEST_HOOK_EXPORTS
+    hooks = ctypes.CDLL(engine.TESTHOOKS_LIB_PATH)
+    for name in engine.TEST_HOOK_EXPORTS:
+        assert hasattr(hooks, name) and not hasattr(hip, name), name
+    for name in engine.EXPORTS:
+        assert hasattr(hooks, name), name
     tb = ctypes.CDLL(T.LIB_PATH)
     declared = [n for n in _declared("zkp_toolbox.h") if n not in _declared("zkp_mi355x.h")]
     for name in declared:
         assert hasattr(tb, name), name
     assert set(T.EXPORTS) == set(declared)
+
+
+def test_shipped_code_object_has_no_scratch_no_spills_and_no_hook_kernels(tmp_path):
+    """The gfx950 code object inside libzkp_mi355x.so: no kernel uses scratch (private segment) or spills, and the self-test /
+    measurement kernels (k_debug_quad: 396 B of scratch, k_noop) are not in it -- they live in the test-hook build."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        pytest.skip("ROCm llvm tools not installed")
+    notes = {}
+    for tag, path in (("shipped", engine.LIB_PATH), ("hooks", engine.TESTHOOKS_LIB_PATH)):
+        fat, co = str(tmp_path / (tag + ".fat")), str(tmp_path / (tag + ".co"))
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", path, fat])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat,
+                               "--output=" + co, "--unbundle"])
+        txt = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", co], text=True)
+        kernels, cur = {}, None
+        for line in txt.splitlines():
+            m = re.match(r"\s+\.(name|private_segment_fixed_size|sgpr_spill_count|vgpr_spill_count):\s+(\S+)", line)
+            if not m:
+                continue
+            if m.group(1) == "name":
+                cur = kernels.setdefault(m.group(2), {})
+            elif cur is not None:
+                cur[m.group(1)] = int(m.group(2))
+        notes[tag] = kernels
+    shipped, hooks = notes["shipped"], notes["hooks"]
+    assert len(shipped) > 40
+    bad = {k: v for k, v in shipped.items() if v.get("private_segment_fixed_size") or v.get("vgpr_spill_count") or v.get("sgpr_spill_count")}
+    assert not bad, bad
+    assert not any("k_debug_quad" in k or "k_noop" in k for k in shipped)
+    assert any("k_debug_quad" in k for k in hooks) and any("k_noop" in k for k in hooks)
+    shutil.rmtree(str(tmp_path), ignore_errors=True)
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -9,6 +9,7 @@ no load/store was taken or skipped because of a scalar.
     rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL \\
               --output-format csv -d OUT -o lds -- python tools/ct_check.py
     python tools/ct_check.py --summarise OUT/ct_counter_collection.csv OUT/lds_counter_collection.csv
+    python tools/ct_check.py --cycles          # (no profiler) per-wavefront cycle counts of the term kernel, test-hook build
 
 The second pass is the evidence for the fixed-base look-up (hot_tables.h): a lane reads the table entry its secret digit names
 straight from LDS, from a copy of the row that no other lane of its ds_read_b128 service group uses; SQ_LDS_BANK_CONFLICT (extra
@@ -19,6 +20,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 PATTERNS = ["zero", "one", "l-1", "all-ones-252", "random-a", "random-b", "random-b again"]   # the last one repeats the sixth input
+# (ZKP_OPT_CT_SINGLE_USE_TABLES, ZKP_OPT_GROUPED_COMB, ZKP_OPT_CT_MASKED_SCANS): tables + masked comb scans; ladder for single-use points;
+# the grouped comb walk through LDS; the safe mode (every look-up a masked scan, fixed-base rows included)
+SCHEDULES = ((1, 0, 0), (0, 0, 0), (0, 1, 0), (0, 0, 1))
 _last_random = [None]
 
 
@@ -56,9 +60,10 @@ def run():
     eng.prepare_fixed_points(pts[:11])
     # a table for every cold point with masked scans; the constant-time radix-16 ladder for single-use points; the same with the
     # grouped comb walk through LDS (ZKP_OPT_GROUPED_COMB, the default of large calls)
-    for single_use_tables, grouped in ((1, 0), (0, 0), (0, 1)):
+    for single_use_tables, grouped, masked in SCHEDULES:
         eng.set_option(3, single_use_tables)    # ZKP_OPT_CT_SINGLE_USE_TABLES
         eng.set_option(6, grouped)
+        eng.set_option(9, masked)               # ZKP_OPT_CT_MASKED_SCANS: the safe mode (fixed-base rows scanned with masks too)
         for kind in PATTERNS:                   # one msm_many(ZKP_CT) call per pattern, in this order
             out, st = eng.msm_many(off, scalars(kind, 31 * n, rng), pidx, pts, ZKP_CT)
             assert not st.any()
@@ -76,15 +81,15 @@ def summarise(paths):
     P = len(PATTERNS)
     # (k_terms_split<true, 16, true>: one group of launches with masked scans, then one with the grouped walk through LDS; the comb-table /
     #  decode kernels run once per call: the launches of the last two groups of calls are compared, group by group)
-    for prefix, n_last in (("k_terms_split<true, 16, false>", P), ("k_terms_split<true, 16, true>", 2 * P), ("k_reduce_encode<unsigned char>", 2 * P),
-                           ("zkp::k_comb_tables<16>", 2 * P), ("zkp::k_comb_slots", 2 * P), ("k_decode_affine", 2 * P)):
+    for prefix, n_last in (("k_terms_split<true, 16, false, false>", P), ("k_terms_split<true, 16, true, false>", 2 * P), ("k_terms_split<true, 16, true, true>", P),
+                           ("k_reduce_encode<unsigned char>", 3 * P), ("zkp::k_comb_tables<16>", 3 * P), ("zkp::k_comb_slots", 3 * P), ("k_decode_affine", 3 * P)):
         for k in sorted(per):
             if not k.startswith(prefix):
                 continue
             for c, v in sorted(per[k].items()):
                 tail = v[-n_last:]
                 # the table kernel builds P and Q tables in the first half and only P tables in the second: compare within halves
-                halves = [tail] if n_last == P else [tail[:P], tail[P:]]
+                halves = [tail[i:i + P] for i in range(0, len(tail), P)]
                 same = all(len(set(h)) == 1 for h in halves)
                 word = "IDENTICAL" if same else "DIFFERENT"
                 # SQ_LDS_IDX_ACTIVE counts LDS-pipeline cycles; with rows arriving by LDS-DMA (global_load_lds) next to the lanes'
@@ -96,8 +101,65 @@ def summarise(paths):
     print("# verdict:", "every instruction and bank-conflict counter identical across scalar patterns" if ok else "counters differ")
 
 
+def cycles():
+    """Timing side of the evidence: the test-hook build records s_memtime at entry and exit of every wavefront of
+    the term kernel.  For each schedule and scalar pattern: the median over the wavefronts of a block class of the cycles a
+    wavefront took, over REPS lone launches.  Constant time = the medians of the patterns differ by no more than the same-input
+    repeat ("random-b" vs "random-b again") differs from itself."""
+    import bench
+    from zkp_amd.engine import Engine, ZKP_CT, ZKP_TESTOPT_WAVE_CYCLES
+    REPS = 5
+    names = {1: "ladder", 2: "comb scan", 3: "grouped walk", 4: "fixed-base"}
+    eng = Engine(0, test_hooks=True)
+    n = 4096
+    rng = np.random.default_rng(5)
+    off, pidx, n_pts = bench.cmz_shape(n)
+    base = np.frombuffer(bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"), np.uint8).reshape(1, 32)
+    ks = rng.integers(0, 256, size=(n_pts, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x0f
+    pts, st = eng.msm_many(np.arange(n_pts + 1, dtype=np.uint32), ks, np.zeros(n_pts, np.uint32), base, ZKP_CT)
+    eng.prepare_fixed_points(pts[:11])
+    eng.set_option(ZKP_TESTOPT_WAVE_CYCLES, 1)
+    print("# per-wavefront cycles (s_memtime) of k_terms_split, CMZ prover job of %d proofs, median over the wavefronts of a block class and %d lone launches" % (n, REPS))
+    print("# columns: " + " | ".join(PATTERNS))
+    verdict = True
+    for single_use_tables, grouped, masked in SCHEDULES:
+        eng.set_option(3, single_use_tables)
+        eng.set_option(6, grouped)
+        eng.set_option(9, masked)
+        med = {}
+        for kind in PATTERNS:
+            sc = scalars(kind, 31 * n, rng)
+            eng.msm_many(off, sc, pidx, pts, ZKP_CT)            # warm (tables of this schedule, caches)
+            eng.debug_wave_cycles()
+            acc = {}
+            for _ in range(REPS):
+                out, st = eng.msm_many(off, sc, pidx, pts, ZKP_CT)
+                assert not st.any()
+                cls, cyc = eng.debug_wave_cycles()
+                for c in np.unique(cls):
+                    acc.setdefault(int(c), []).append(np.median(cyc[cls == c]))
+            for c, v in acc.items():
+                med.setdefault(c, []).append(float(np.median(v)))
+        print("schedule: single-use tables = %d, grouped walk = %d, masked scans = %d" % (single_use_tables, grouped, masked))
+        for c in sorted(med):
+            v = np.array(med[c])
+            noise = abs(v[-1] - v[-2])                         # the same input twice
+            spread = float(v.max() - v.min())
+            rel = spread / v.mean()
+            ok = spread <= max(3.0 * noise, 0.005 * v.mean())
+            verdict &= ok
+            print("  %-13s %s   spread %.0f cycles = %.3f %% of the mean; same-input repeat %.0f cycles  -> %s"
+                  % (names.get(c, str(c)), " ".join("%.0f" % x for x in v), spread, 100 * rel, noise, "WITHIN NOISE" if ok else "EXCEEDS NOISE"))
+    print("# verdict:", "median wavefront times of every block class are independent of the scalar pattern (within 3 x the same-input repeat or 0.5 %)"
+          if verdict else "some block class shows a pattern-dependent time: see above")
+    eng.close()
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
         summarise(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "--cycles":
+        cycles()
     else:
         run()

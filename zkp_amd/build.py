@@ -11,6 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HIP_LIB = os.path.join(HERE, "libzkp_mi355x.so")
+HIP_TESTHOOKS_LIB = os.path.join(HERE, "libzkp_mi355x_testhooks.so")   # the same sources with -DZKP_BUILD_TEST_HOOKS (tests / A-B tools only)
 HOST_LIB = os.path.join(HERE, "libzkp_toolbox.so")
 
 
@@ -29,15 +30,29 @@ def _deps(*dirs, exts=(".h", ".hip", ".cpp", ".c")):
     return out
 
 
+def _hip_cmd(out: str, test_hooks: bool):
+    return ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"] + (["-DZKP_BUILD_TEST_HOOKS"] if test_hooks else []) + [
+        os.path.join(CSRC, "zkp_kernels.hip"), "-o", out]
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950: kernels + C ABI -> zkp_amd/libzkp_mi355x.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950: kernels + C ABI -> zkp_amd/libzkp_mi355x.so (cross-compiles without a GPU), and the
+    test-hook build of the same sources -> libzkp_mi355x_testhooks.so (the shipped library carries no measurement hooks).
+    The two compilations run side by side."""
+    force = force or bool(os.environ.get("ZKP_FORCE_BUILD"))
     deps = _deps(CSRC, os.path.join(HERE, "..", "include"))
-    if force or _stale(HIP_LIB, deps):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-               os.path.join(CSRC, "zkp_kernels.hip"), "-o", HIP_LIB]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+    procs = []
+    for out, hooks in ((HIP_LIB, False), (HIP_TESTHOOKS_LIB, True)):
+        if force or _stale(out, deps):
+            cmd = _hip_cmd(out, hooks)
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((cmd, subprocess.Popen(cmd)))
+        elif verbose:
+            print("up to date (mtime): %s  [ZKP_FORCE_BUILD=1 rebuilds]" % out, file=sys.stderr)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     return HIP_LIB
 
 
@@ -50,6 +65,7 @@ def build_host(force: bool = False, verbose: bool = False):
     if not srcs:
         return None
     deps = _deps(host_dir, os.path.join(HERE, "..", "include"))
+    force = force or bool(os.environ.get("ZKP_FORCE_BUILD"))
     if force or _stale(HOST_LIB, deps):
         cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall", "-I", os.path.join(HERE, "..", "include")] + srcs + [
             "-o", HOST_LIB, "-L", HERE, "-lzkp_mi355x", "-Wl,-rpath,$ORIGIN"]
@@ -60,6 +76,10 @@ def build_host(force: bool = False, verbose: bool = False):
 
 
 def build_all(force: bool = False, verbose: bool = False):
+    """Rebuilds what is stale by mtime; force = True or ZKP_FORCE_BUILD=1 in the environment rebuilds everything from source."""
+    mode = "forced rebuild from source" if (force or os.environ.get("ZKP_FORCE_BUILD")) else "incremental (mtime)"
+    if verbose:
+        print("zkp_amd.build: %s" % mode, file=sys.stderr)
     return build_hip(force, verbose), build_host(force, verbose)
 
 

@@ -610,7 +610,9 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
 
 // throughput = the caller keeps calls in flight (_dev entry points): one lane per proof when the call is wide; otherwise a lane
 // pair per proof
+#ifdef ZKP_BUILD_TEST_HOOKS
 __global__ void k_noop(uint32_t* p) { if (p) *p = 0; }
+#endif
 bool transcript_single_lane(const zkp_ctx* c, uint32_t N, bool throughput) {
   return c->tr_lanes < 0 ? (throughput && N >= zkp_ctx::kWideCallProofs) : c->tr_lanes == 1;
 }
@@ -710,7 +712,9 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
   tk.stmt.toff = pl.d_tarr; tk.stmt.tpt = pl.d_tarr + nc + 1 + T; tk.stmt.N = N; tk.stmt.T = T; tk.stmt.nc = nc; tk.stmt.ns = pl.s.ns; tk.stmt.np = pl.s.np;
   tk.stmt.off = w.u32(o.off); tk.stmt.pidx = w.u32(o.pidx); tk.stmt.on = c->stmt_classify;
+#ifdef ZKP_BUILD_TEST_HOOKS
   for (int q = 0; q < c->debug_dummy_launches; ++q) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, c->stream, (uint32_t*)nullptr);   // (launch-count sensitivity probe)
+#endif
   offer_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput, overlap);
   {   // side stream: operand indices, decode, classification, comb tables (nothing here depends on the blindings)
     hipStream_t main;
@@ -954,6 +958,7 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
 }  // namespace
 
 void free_fused_plans(zkp_ctx* c) {
+  if (!c->fused_plans.empty()) ++c->plans_generation;      // graphs captured over these plans' device blocks are stale from here on
   for (auto& kv : c->fused_plans) {
     fused_plan* pl = static_cast<fused_plan*>(kv.second);
     if (pl->d_block) hipFree(pl->d_block);

@@ -392,6 +392,10 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
 // __syncthreads() would also wait for the next row's prefetch (vmcnt) and expose its latency once per window.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// SCAN = the safe mode of ZKP_OPT_CT_MASKED_SCANS: the lane reads EVERY entry of the row (from its own copy, at addresses that do not
+// depend on the digit) and keeps the one it wants with v_cndmask -- curve25519-dalek's masked scan; 224 LDS reads + 864 selects per
+// addition instead of 7 reads, for callers who do not want the secret-index look-up to rest on the LDS service-group / bank model.
+template <bool SCAN = false>
 __device__ __forceinline__ void fixed_base_block(ge_p3& acc, uint32_t e[9], bool live, const uint4* __restrict__ rows, uint4* rep) {
   const uint32_t tid = threadIdx.x, copy = tid & (HOT_COPIES - 1);
   const bool loader = tid < (uint32_t)HOT_ROW_CHUNKS;
@@ -409,12 +413,32 @@ __device__ __forceinline__ void fixed_base_block(ge_p3& acc, uint32_t e[9], bool
     if (live) {
       uint32_t mag, neg;
       hot_next_digit(e, mag, neg);
-      const uint4* ent = rep + (size_t)mag * (sizeof(dev_niels) / 16) * HOT_COPIES + copy;
       uint32_t wd[28];
+      if constexpr (SCAN) {
+        const uint4* ent = rep + copy;                               // entry 0 (the identity) first, then every other entry masked in
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const uint4 x = ent[i * HOT_COPIES];
-        wd[4 * i + 0] = x.x; wd[4 * i + 1] = x.y; wd[4 * i + 2] = x.z; wd[4 * i + 3] = x.w;
+        for (int i = 0; i < 7; ++i) {
+          const uint4 x = ent[i * HOT_COPIES];
+          wd[4 * i + 0] = x.x; wd[4 * i + 1] = x.y; wd[4 * i + 2] = x.z; wd[4 * i + 3] = x.w;
+        }
+#pragma unroll 1
+        for (uint32_t k = 1; k <= (uint32_t)HOT_HALF; ++k) {
+          const uint4* ek = rep + (size_t)k * (sizeof(dev_niels) / 16) * HOT_COPIES + copy;
+          const bool hit = k == mag;
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+            const uint4 x = ek[i * HOT_COPIES];
+            wd[4 * i + 0] = hit ? x.x : wd[4 * i + 0]; wd[4 * i + 1] = hit ? x.y : wd[4 * i + 1];
+            wd[4 * i + 2] = hit ? x.z : wd[4 * i + 2]; wd[4 * i + 3] = hit ? x.w : wd[4 * i + 3];
+          }
+        }
+      } else {
+        const uint4* ent = rep + (size_t)mag * (sizeof(dev_niels) / 16) * HOT_COPIES + copy;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const uint4 x = ent[i * HOT_COPIES];
+          wd[4 * i + 0] = x.x; wd[4 * i + 1] = x.y; wd[4 * i + 2] = x.z; wd[4 * i + 3] = x.w;
+        }
       }
       ge_niels q;
       fe_set(q.ypx, wd); fe_set(q.ymx, wd + 9); fe_set(q.xy2d, wd + 18);

@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 #include "../../include/zkp_mi355x.h"
@@ -137,7 +139,20 @@ k_terms_r4(uint32_t n_terms, const uint8_t* __restrict__ scalars, const uint32_t
 // (Measured and dropped: the same kernel capped at 168 VGPRs for a third wavefront per SIMD needs 39 spills and is no
 // faster, 4.51 vs 4.51 M proofs/s pipelined; three separate kernels -- comb 154, fixed-base 161 VGPRs without spills, 3 per
 // SIMD -- lose more to serialisation on the stream than the occupancy returns, 4.38 M/s.)
-template <bool CT, int TEETH, bool LADDER>
+#ifdef ZKP_BUILD_TEST_HOOKS
+// per-wavefront cycle recorder of the term kernel (tools/ct_check.py): [block][wavefront] = class << 56 | s_memtime cycles
+__device__ uint64_t* g_wave_cycles = nullptr;
+__device__ uint32_t g_wave_cycles_cap = 0;
+#define ZKP_WAVE_T0 const uint64_t wave_t0_ = __builtin_readcyclecounter();
+#define ZKP_WAVE_T1(cls) do { const uint64_t dt_ = __builtin_readcyclecounter() - wave_t0_; const uint32_t wi_ = blockIdx.x * 4 + (threadIdx.x >> 6); \
+  if (g_wave_cycles && (threadIdx.x & 63u) == 0 && wi_ < g_wave_cycles_cap) g_wave_cycles[wi_] = ((uint64_t)(cls) << 56) | (dt_ & 0x00ffffffffffffffull); } while (0)
+#else
+#define ZKP_WAVE_T0
+#define ZKP_WAVE_T1(cls)
+#endif
+
+// SCAN (constant-time calls only): the fixed-base blocks pick their table entries with masked scans (ZKP_OPT_CT_MASKED_SCANS)
+template <bool CT, int TEETH, bool LADDER, bool SCAN = false>
 __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
@@ -154,6 +169,7 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
   const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
   const uint32_t group_blocks = (n_group + blockDim.x - 1) / blockDim.x;
+  ZKP_WAVE_T0
   if (LADDER && blockIdx.x < ladder_blocks) {
     if constexpr (LADDER) {
       const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,6 +179,7 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
         term_ladder16<CT>(t, scalars, pts + pi, ladder_rw + (size_t)i * LADDER_ENTRIES, partial, ecol);
       }
     }
+    ZKP_WAVE_T1(1);
   } else if (blockIdx.x < ladder_blocks + comb_blocks) {
     const uint32_t i = (blockIdx.x - ladder_blocks) * blockDim.x + threadIdx.x;
     if (i < n_comb) {
@@ -173,9 +190,11 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
         if (slot != 0xffffffffu) term_comb<CT, TEETH>(t, scalars, comb + (size_t)slot * comb_cfg<TEETH>::ENTRIES, partial, ecol);
       }
     }
+    ZKP_WAVE_T1(2);
   } else if (blockIdx.x < ladder_blocks + comb_blocks + group_blocks) {
     if constexpr (CT && TEETH == 16)                              // terms of points with many uses, listed point by point: rows through LDS
       comb_group_block((blockIdx.x - ladder_blocks - comb_blocks) * 256u, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
+    ZKP_WAVE_T1(3);
   } else {
     const uint32_t hb = blockIdx.x - ladder_blocks - comb_blocks - group_blocks;
     if (hb >= blk_start[HOT_SLOTS]) return;                       // (uniform in the block)
@@ -192,8 +211,9 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
       load_vec<2>(s, scalars + 32 * (size_t)t);
       hot_recode(e, s);
     }
-    fixed_base_block(acc, e, live, src, hot_lds);
+    fixed_base_block<SCAN>(acc, e, live, src, hot_lds);
     if (live) store_ext(partial + t, acc);
+    ZKP_WAVE_T1(4);
   }
 }
 
@@ -328,6 +348,7 @@ __device__ __forceinline__ void encode_invert_block(enc_tree& tree, int tid, uin
   if (tid == 0) {
     fe r, inv;
     tree_get(r, tree, 1);
+    fe_pin_vgpr(r);            // one lane, one LDS address: left alone, hipcc moves the whole inversion to the scalar ALU (2.3 x slower, 71 SGPR spills)
     fe_invert(inv, r);
     tree_put(tree, 1, inv);
   }
@@ -818,6 +839,7 @@ k_pip_combine(int W1, int C, uint32_t in_stride, int level, int m, int shift, co
   else status[b] = bad;
 }
 
+#ifdef ZKP_BUILD_TEST_HOOKS
 // self-test hook for the 4-lane cooperative arithmetic: for pair i (P, Q): out[i] = enc(2P), enc(P+Q), enc(P+Q) via the
 // niels form of Q, enc(P-Q) via the negated niels form
 __global__ void __launch_bounds__(256, 2)
@@ -851,6 +873,7 @@ k_debug_quad(uint32_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ 
     if (q == 0) store_vec<2>(out + 128 * (size_t)i + 32 * op, o);
   }
 }
+#endif  // ZKP_BUILD_TEST_HOOKS
 
 // =============================================================================================
 // batch-verification coefficient build (batch_verifier.rs:173-206) with scalar arithmetic mod l on the device
@@ -977,6 +1000,10 @@ k_encode_many(uint32_t n, const uint8_t* __restrict__ xyzt, uint8_t* __restrict_
 // host side: context, workspace, C ABI
 // =============================================================================================
 static thread_local std::string g_last_error = "";
+struct zkp_ctx;
+// contexts that are alive (a graph may outlive its context: launching it then is an error, not a use after free)
+static std::mutex g_ctx_mu;
+static std::set<zkp_ctx*> g_live_ctx;
 
 static int fail(int code, const std::string& msg) {
   g_last_error = msg;
@@ -1014,11 +1041,16 @@ struct zkp_ctx {
   // k_tables_transcript); consumed by msm_terms_path if it builds tables with one lane per point, else run by the flow itself
   struct { bool offered = false, active = false; const tr_op* ops = nullptr; uint32_t n_ops = 0; const uint64_t* tables = nullptr; uint32_t N = 0; tr_bufs bufs{};
            uint8_t* ts = nullptr; uint32_t* saved = nullptr; uint32_t* failed = nullptr; uint32_t tail = 0; } pending_tr;
-  int debug_dummy_launches = 0;      // option 9 (measurement only): empty kernels added to every prove call
-  bool stmt_classify = true;         // option 10 (A/B): the fused flows' one-launch term classifier
+  int debug_dummy_launches = 0;      // ZKP_TESTOPT_DUMMY_LAUNCHES (test-hook builds only): empty kernels added to every prove call
+  bool stmt_classify = true;         // the fused flows' one-launch term classifier (ZKP_TESTOPT_GENERIC_CLASSIFIER of test-hook builds turns it off)
   bool fuse_tables_transcript = false;   // ZKP_OPT_FUSE_TABLES_TRANSCRIPT
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
+  bool ct_masked_scans = false;      // ZKP_OPT_CT_MASKED_SCANS: constant-time calls pick every table entry with masked scans (no secret-indexed LDS read)
+#ifdef ZKP_BUILD_TEST_HOOKS
+  uint64_t* wave_cycles = nullptr;   // ZKP_TESTOPT_WAVE_CYCLES: per-wavefront cycle recorder of the term kernel
+  static constexpr uint32_t kWaveCyclesCap = 1u << 20;
+#endif
   static constexpr size_t kGroupedCombTerms = 400000;
   bool dev_overlap = false;          // ZKP_OPT_DEV_OVERLAP: the _dev flows fork their scalar-independent half onto the side stream too
   int tr_lanes = -1;                 // ZKP_OPT_TRANSCRIPT_LANES: -1 = by entry point, 1 = one lane per proof, 2 = a lane pair per proof
@@ -1031,6 +1063,10 @@ struct zkp_ctx {
   }
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  // Captured graphs hold raw pointers into the workspace and into the fused plans' device blocks: each is stamped with these
+  // generation numbers, and zkp_graph_launch refuses a graph whose stamps are stale (the workspace was reallocated by a larger
+  // call, the plan cache was flushed) instead of running recorded kernels on freed memory.
+  uint64_t ws_generation = 0, plans_generation = 0;
   bool profiling = false;
   hipEvent_t ev[kMaxEvents] = {};
   int ev_kind[kMaxEvents] = {};
@@ -1070,6 +1106,7 @@ int ensure_ws(zkp_ctx* c, size_t bytes) {
     HIP_TRY(hipFree(c->ws));
     c->ws = nullptr;
     c->ws_bytes = 0;
+    ++c->ws_generation;                          // graphs captured over the old workspace are stale from here on
   }
   const size_t want = bytes + bytes / 8;
   HIP_TRY(hipMalloc(&c->ws, want));
@@ -1166,15 +1203,15 @@ inline bool terms_batched_encode(const zkp_ctx* c, uint32_t n_terms, uint32_t n_
   return n_terms >= 1024 && (uint64_t)n_msm >= ((throughput && !c->batch_encode_user) ? kThroughputEncodeMin : c->batch_encode_min);
 }
 
-template <bool CT, int TEETH>
+template <bool CT, int TEETH, bool SCAN = false>
 void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
                         const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
                         const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part) {
   if (ladder)
-    hipLaunchKernelGGL((k_terms_split<CT, TEETH, true>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
+    hipLaunchKernelGGL((k_terms_split<CT, TEETH, true, SCAN>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
                        c->hot_tables, pts, ladder_rw, max_ladder, part);
   else
-    hipLaunchKernelGGL((k_terms_split<CT, TEETH, false>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
+    hipLaunchKernelGGL((k_terms_split<CT, TEETH, false, SCAN>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
                        c->hot_tables, pts, ladder_rw, max_ladder, part);
 }
 
@@ -1210,7 +1247,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     // (the LDS walk has fewer instructions but less independent work per lane than the masked scans: it wins once the call
     //  keeps every SIMD busy -- single kernel, 4096 CMZ proofs 590 vs 370 us, 8192: 860 vs 690, 16384: 1300 vs 1390; pipelined
     //  step: 4096 proofs -1 %, 8192 +1.6 %, 16384 +7 %, 524,288 +4.7 %)
-    const bool group_on = c->grouped_comb < 0 ? n_terms >= (k.throughput ? zkp_ctx::kWideCallTerms : zkp_ctx::kGroupedCombTerms) : c->grouped_comb != 0;
+    const bool group_on = c->ct_masked_scans ? false : c->grouped_comb < 0 ? n_terms >= (k.throughput ? zkp_ctx::kWideCallTerms : zkp_ctx::kGroupedCombTerms) : c->grouped_comb != 0;
     const uint32_t group_min = (flags == ZKP_CT && k.teeth == 16 && group_on && k.max_tables) ? GROUP_MIN_USES : 0xffffffffu;
     uint32_t* gstart = reinterpret_cast<uint32_t*>(base + o.gstart);
     uint32_t* gfill = reinterpret_cast<uint32_t*>(base + o.gfill);
@@ -1268,7 +1305,10 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
       }
     }
     if (phase & PH_SCALARS) {
-      if (flags == ZKP_CT) {
+      if (flags == ZKP_CT && c->ct_masked_scans) {
+        if (k.teeth == 16) launch_terms_split<true, 16, true>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        else launch_terms_split<true, 4, true>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+      } else if (flags == ZKP_CT) {
         if (k.teeth == 16) launch_terms_split<true, 16>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
         else launch_terms_split<true, 4>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
       } else {
@@ -1467,7 +1507,11 @@ terms_cfg host_terms_cfg(const zkp_ctx* c, uint32_t n_terms, const uint32_t* pid
 extern "C" {
 
 const char* zkp_last_error(void) { return g_last_error.c_str(); }
-const char* zkp_version(void) { return "zkp-mi355x 0.1 gfx950 (9x29-bit limbs, v_mad_u64_u32)"; }
+#ifdef ZKP_BUILD_TEST_HOOKS
+const char* zkp_version(void) { return "zkp-mi355x 0.3 gfx950 (9x29-bit limbs, v_mad_u64_u32) +test-hooks"; }
+#else
+const char* zkp_version(void) { return "zkp-mi355x 0.3 gfx950 (9x29-bit limbs, v_mad_u64_u32)"; }
+#endif
 
 int zkp_ctx_create(zkp_ctx** out, int device_id) {
   if (!out) return fail(ZKP_ERR_ARG, "zkp_ctx_create: out is NULL");
@@ -1486,19 +1530,25 @@ int zkp_ctx_create(zkp_ctx** out, int device_id) {
   c->stream = c->own_stream;
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(ZKP_ERR_HIP, "hipEventCreate failed"); }
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_live_ctx.insert(c); }
   *out = c;
   return ZKP_OK;
 }
 
 void zkp_ctx_destroy(zkp_ctx* c) {
   if (!c) return;
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_live_ctx.erase(c); }
   hipSetDevice(c->device);
+  if (c->capturing) { hipGraph_t g = nullptr; hipStreamEndCapture(c->stream, &g); if (g) hipGraphDestroy(g); c->capturing = false; }
   hipStreamSynchronize(c->stream);
   if (c->ws) hipFree(c->ws);
   if (c->hot_tables) hipFree(c->hot_tables);
   if (c->hot_reg_words) hipFree(c->hot_reg_words);
   if (c->hot_reg_slot) hipFree(c->hot_reg_slot);
   if (c->hot_scratch) hipFree(c->hot_scratch);
+#ifdef ZKP_BUILD_TEST_HOOKS
+  if (c->wave_cycles) { uint64_t* z = nullptr; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_cycles), &z, sizeof(z)); hipFree(c->wave_cycles); }
+#endif
   free_fused_plans(c);
   if (c->side_stream) hipStreamDestroy(c->side_stream);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -1519,11 +1569,29 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
     case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_single_use_tables = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_DEV_OVERLAP: c->dev_overlap = value != 0; return ZKP_OK;
-    case 10: c->stmt_classify = value != 0; return ZKP_OK;
-    case 9: c->debug_dummy_launches = (int)std::min<uint64_t>(value, 1000); return ZKP_OK;
+#ifdef ZKP_BUILD_TEST_HOOKS
+    case ZKP_TESTOPT_GENERIC_CLASSIFIER: c->stmt_classify = value == 0; return ZKP_OK;
+    case ZKP_TESTOPT_DUMMY_LAUNCHES: c->debug_dummy_launches = (int)std::min<uint64_t>(value, 1000); return ZKP_OK;
+    case ZKP_TESTOPT_WAVE_CYCLES: {
+      HIP_TRY(hipSetDevice(c->device));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      uint64_t* p = nullptr;
+      uint32_t cap = 0;
+      if (value) {
+        if (!c->wave_cycles) HIP_TRY(hipMalloc(&c->wave_cycles, sizeof(uint64_t) * zkp_ctx::kWaveCyclesCap));
+        HIP_TRY(hipMemset(c->wave_cycles, 0, sizeof(uint64_t) * zkp_ctx::kWaveCyclesCap));
+        p = c->wave_cycles;
+        cap = zkp_ctx::kWaveCyclesCap;
+      }
+      HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_cycles), &p, sizeof(p)));
+      HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_cycles_cap), &cap, sizeof(cap)));
+      return ZKP_OK;
+    }
+#endif
     case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value != 0; return ZKP_OK;
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
+    case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;
     case ZKP_OPT_TRANSCRIPT_LANES:
       if (value != ~0ull && value != 1 && value != 2) return fail(ZKP_ERR_ARG, "ZKP_OPT_TRANSCRIPT_LANES: 1, 2 or UINT64_MAX");
       c->tr_lanes = value == ~0ull ? -1 : (int)value;
@@ -1549,7 +1617,10 @@ struct zkp_graph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   int device = 0;
+  zkp_ctx* ctx = nullptr;                        // the context whose workspace / plans the recorded kernels point into
+  uint64_t ws_generation = 0, plans_generation = 0;
 };
+
 int zkp_ctx_capture_begin(zkp_ctx* c) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   if (c->capturing) return fail(ZKP_ERR_ARG, "capture already in progress");
@@ -1573,12 +1644,33 @@ int zkp_ctx_capture_end(zkp_ctx* c, zkp_graph** out) {
   zg->graph = g;
   zg->exec = e;
   zg->device = c->device;
+  zg->ctx = c;
+  zg->ws_generation = c->ws_generation;
+  zg->plans_generation = c->plans_generation;
   *out = zg;
+  return ZKP_OK;
+}
+int zkp_ctx_capture_abort(zkp_ctx* c) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (!c->capturing) return ZKP_OK;
+  c->capturing = false;
+  c->pending_tr.offered = c->pending_tr.active = false;
+  hipGraph_t g = nullptr;
+  const hipError_t rc = hipStreamEndCapture(c->stream, &g);       // (an invalidated capture reports an error here: the stream leaves capture mode either way)
+  if (g) hipGraphDestroy(g);
+  (void)hipGetLastError();
+  (void)rc;
   return ZKP_OK;
 }
 int zkp_graph_launch(zkp_graph* g, zkp_ctx* c) {
   if (!g || !c) return fail(ZKP_ERR_ARG, "NULL pointer");
-  if (g->device != c->device) return fail(ZKP_ERR_ARG, "graph and context are on different devices");
+  if (g->ctx != c) return fail(ZKP_ERR_ARG, "a graph can only be launched on the context it was captured on (it records that context's workspace addresses)");
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); if (!g_live_ctx.count(c)) return fail(ZKP_ERR_ARG, "the graph's context has been destroyed"); }
+  if (g->ws_generation != c->ws_generation)
+    return fail(ZKP_ERR_ARG, "stale graph: the context's workspace was reallocated by a larger call after the capture -- capture again");
+  if (g->plans_generation != c->plans_generation)
+    return fail(ZKP_ERR_ARG, "stale graph: the context's statement plans were flushed after the capture -- capture again");
+  if (c->capturing) return fail(ZKP_ERR_ARG, "a capture is in progress on this context");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipGraphLaunch(g->exec, c->stream));
   return ZKP_OK;
@@ -1879,6 +1971,7 @@ int zkp_decode_check(zkp_ctx* c, uint64_t n, const uint8_t* points, uint8_t* sta
   return ZKP_OK;
 }
 
+#ifdef ZKP_BUILD_TEST_HOOKS
 int zkp_debug_quad_selftest(zkp_ctx* c, uint32_t n, const uint8_t* pairs, uint8_t* out) {
   if (!c || !pairs || !out) return fail(ZKP_ERR_ARG, "NULL pointer");
   if (n == 0) return ZKP_OK;
@@ -1896,6 +1989,20 @@ int zkp_debug_quad_selftest(zkp_ctx* c, uint32_t n, const uint8_t* pairs, uint8_
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ZKP_OK;
 }
+#endif  // ZKP_BUILD_TEST_HOOKS
+
+#ifdef ZKP_BUILD_TEST_HOOKS
+int zkp_debug_wave_cycles(zkp_ctx* c, uint64_t* out, uint32_t cap) {
+  if (!c || !out) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (!c->wave_cycles) return fail(ZKP_ERR_ARG, "ZKP_TESTOPT_WAVE_CYCLES is off");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const uint32_t n = std::min(cap, zkp_ctx::kWaveCyclesCap);
+  HIP_TRY(hipMemcpy(out, c->wave_cycles, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(c->wave_cycles, 0, sizeof(uint64_t) * zkp_ctx::kWaveCyclesCap));
+  return (int)n;
+}
+#endif
 
 int zkp_encode_many(zkp_ctx* c, uint64_t n, const uint8_t* xyzt, uint8_t* out) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");

@@ -13,6 +13,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkp_mi355x.so")
+TESTHOOKS_LIB_PATH = os.path.join(_HERE, "libzkp_mi355x_testhooks.so")     # -DZKP_BUILD_TEST_HOOKS build (tests / A-B tools)
+ZKP_TESTOPT_DUMMY_LAUNCHES, ZKP_TESTOPT_GENERIC_CLASSIFIER, ZKP_TESTOPT_WAVE_CYCLES = 1001, 1002, 1003
+ZKP_OPT_CT_MASKED_SCANS = 9
 
 ZKP_VARTIME = 0
 ZKP_CT = 1
@@ -23,10 +26,11 @@ EXPORTS = (
     "zkp_ctx_create", "zkp_ctx_destroy", "zkp_ctx_set_stream", "zkp_ctx_synchronize", "zkp_last_error",
     "zkp_version", "zkp_ctx_set_option", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
-    "zkp_ctx_prepare_fixed_points", "zkp_debug_quad_selftest", "zkp_batch_check", "zkp_fused_prove", "zkp_fused_verify_compact", "zkp_fused_batch_verify",
+    "zkp_ctx_prepare_fixed_points", "zkp_batch_check", "zkp_fused_prove", "zkp_fused_verify_compact", "zkp_fused_batch_verify",
     "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_batch_verify_dev",
-    "zkp_fused_verify_batchable_coeffs", "zkp_fused_batch_verify_many", "zkp_fused_batch_verify_many_dev", "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_graph_launch", "zkp_graph_destroy",
+    "zkp_fused_verify_batchable_coeffs", "zkp_fused_batch_verify_many", "zkp_fused_batch_verify_many_dev", "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_ctx_capture_abort", "zkp_graph_launch", "zkp_graph_destroy",
 )
+TEST_HOOK_EXPORTS = ("zkp_debug_quad_selftest", "zkp_debug_wave_cycles")      # only in libzkp_mi355x_testhooks.so
 
 
 class ZkpError(RuntimeError):
@@ -34,17 +38,22 @@ class ZkpError(RuntimeError):
 
 
 _lib = None
+_hooks_lib = None
 
 
-def load_library() -> ctypes.CDLL:
-    """dlopen the HIP library; raises (never falls back) when it has not been built."""
-    global _lib
-    if _lib is not None:
+def load_library(test_hooks: bool = False) -> ctypes.CDLL:
+    """dlopen the HIP library; raises (never falls back) when it has not been built.  test_hooks = the -DZKP_BUILD_TEST_HOOKS
+    build of the same sources (a second, independent copy of the library: its contexts must not be handed to libzkp_toolbox.so)."""
+    global _lib, _hooks_lib
+    if test_hooks and _hooks_lib is not None:
+        return _hooks_lib
+    if not test_hooks and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ZkpError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = TESTHOOKS_LIB_PATH if test_hooks else LIB_PATH
+    if not os.path.exists(path):
+        raise ZkpError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     vp, u8p, u32p, i32 = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int
     lib.zkp_ctx_create.argtypes = [ctypes.POINTER(vp), i32]
     lib.zkp_ctx_destroy.argtypes = [vp]
@@ -67,8 +76,13 @@ def load_library() -> ctypes.CDLL:
     lib.zkp_graph_destroy.argtypes = [vp]
     lib.zkp_graph_destroy.restype = None
     lib.zkp_ctx_prepare_fixed_points.argtypes = [vp, ctypes.c_uint32, u8p]
-    lib.zkp_debug_quad_selftest.argtypes = [vp, ctypes.c_uint32, u8p, u8p]
-    _lib = lib
+    lib.zkp_ctx_capture_abort.argtypes = [vp]
+    if test_hooks:
+        lib.zkp_debug_quad_selftest.argtypes = [vp, ctypes.c_uint32, u8p, u8p]
+        lib.zkp_debug_wave_cycles.argtypes = [vp, ctypes.c_void_p, ctypes.c_uint32]
+        _hooks_lib = lib
+    else:
+        _lib = lib
     return lib
 
 
@@ -91,8 +105,9 @@ def _ptr(a: Optional[np.ndarray]):
 class Engine:
     """One context on one GPU (HIP device ordinal `device`)."""
 
-    def __init__(self, device: int = 0):
-        self._lib = load_library()
+    def __init__(self, device: int = 0, test_hooks: bool = False):
+        self._lib = load_library(test_hooks)
+        self.test_hooks = test_hooks
         h = ctypes.c_void_p()
         _check(self._lib.zkp_ctx_create(ctypes.byref(h), device), "zkp_ctx_create")
         self._h = h
@@ -159,8 +174,22 @@ class Engine:
     def debug_quad_selftest(self, pairs) -> np.ndarray:
         pairs = _u8(pairs, 64)
         out = np.zeros((len(pairs), 4, 32), np.uint8)
+        if not self.test_hooks:
+            raise ZkpError("zkp_debug_quad_selftest exists in the test-hook build only: Engine(device, test_hooks=True)")
         _check(self._lib.zkp_debug_quad_selftest(self._h, len(pairs), _ptr(pairs), _ptr(out)), "zkp_debug_quad_selftest")
         return out
+
+    def debug_wave_cycles(self, cap: int = 1 << 20):
+        """(test-hook build, after set_option(ZKP_TESTOPT_WAVE_CYCLES, 1)) -> (class[n], cycles[n]) of the term kernel's wavefronts since the last read"""
+        if not self.test_hooks:
+            raise ZkpError("zkp_debug_wave_cycles exists in the test-hook build only: Engine(device, test_hooks=True)")
+        buf = np.zeros(cap, np.uint64)
+        n = self._lib.zkp_debug_wave_cycles(self._h, _ptr(buf), ctypes.c_uint32(cap))
+        if n < 0:
+            _check(n, "zkp_debug_wave_cycles")
+        buf = buf[:n]
+        buf = buf[buf != 0]
+        return (buf >> np.uint64(56)).astype(np.int64), (buf & np.uint64((1 << 56) - 1)).astype(np.int64)
 
     def prepare_fixed_points(self, encodings) -> None:
         """Hint: these points (the statement's common / static points) will be referenced by many terms."""
@@ -252,6 +281,15 @@ class Engine:
         _check(self._lib.zkp_ctx_capture_end(self._h, ctypes.byref(g)), "zkp_ctx_capture_end")
         return Graph(self, g)
 
+    def capture_abort(self) -> None:
+        """End and discard a capture (after a failed call inside it); the context is usable again."""
+        _check(self._lib.zkp_ctx_capture_abort(self._h), "zkp_ctx_capture_abort")
+
+    def capture(self):
+        """Context manager around capture_begin / capture_end: `with eng.capture() as cap: ...calls...` then `cap.graph`.  An
+        exception inside the block aborts the capture (zkp_ctx_capture_abort) instead of leaving the stream in capture mode."""
+        return _Capture(self)
+
     def set_profiling(self, enabled: bool) -> None:
         _check(self._lib.zkp_ctx_set_profiling(self._h, int(enabled)), "zkp_ctx_set_profiling")
 
@@ -264,8 +302,25 @@ class Engine:
         return {k: float(arr[i]) for i, k in enumerate(K_NAMES)}, float(tot.value)
 
 
+class _Capture:
+    def __init__(self, eng: "Engine"):
+        self._eng, self.graph = eng, None
+
+    def __enter__(self):
+        self._eng.capture_begin()
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is not None:
+            self._eng.capture_abort()
+            return False
+        self.graph = self._eng.capture_end()
+        return False
+
+
 class Graph:
-    """zkp_graph: a recorded chain of *_dev calls, replayed with one host call."""
+    """zkp_graph: a recorded chain of *_dev calls, replayed with one host call.  launch() raises ZkpError ("stale graph") when
+    the context's workspace or plans changed after the capture (see zkp_mi355x.h, HIP graphs: lifetime rules)."""
 
     def __init__(self, eng: "Engine", handle):
         self._eng, self._h = eng, handle

@@ -94,9 +94,13 @@ const char* zkp_version(void);
  *     ZKP_CT call is what curve25519-dalek does on a CPU: all entries of the row are read at fixed addresses and the wanted one is
  *     kept with v_cndmask (fixed-base rows: 32 entries, comb / ladder rows: 8), and the grouped comb walk is off.  Same bytes out;
  *     about 1.6 x the instructions of the term kernel.  Default 0.
+ *   ZKP_OPT_EACH_STRAUS: how zkp_fused_verify_batchable computes a proof's MSM over its points and commitments (verifier.rs:162-166).
+ *     UINT64_MAX = default: one Straus walk per proof -- 256 shared doublings and one table addition per operand and window, with 8
+ *     lanes per proof at 4,096 proofs down to 1 from 65,536 proofs on; 1 .. 8 = that many lanes per proof; 0 = the round-2 schedule
+ *     (every single-use point on a ladder of its own: 256 doublings per operand).
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
-       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9 };
+       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~35 short kernels (75 in round 1); enqueueing them one by one costs the host ~0.1 ms per

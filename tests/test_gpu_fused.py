@@ -573,3 +573,47 @@ def test_debug_transcript_env_lists_the_compiled_program():
     assert "<- entropy[j * 32 + 0]" in err and "EMIT state.word[" in err and "-> wide(blindings)" in err and "-> wide(challenge)" in err
     assert "SAVE(clone <- state)" in err and "RESTORE(state <- clone)" in err and "KECCAK-F" in err
     assert "6 Keccak-f permutations per proof" in err or "Keccak-f permutations per proof" in err
+
+
+@pytest.mark.parametrize("n", [3, 300])
+def test_verify_batchable_straus_lane_counts_agree(n):
+    """ZKP_OPT_EACH_STRAUS: verify_batchable's per-proof MSM (verifier.rs:162-166) as one Straus walk per proof with 1 .. 8 lanes
+    per proof, and the round-2 schedule (a ladder per operand, option 0): the same verdicts for valid proofs, tampered responses,
+    wrong / identity / undecodable points and commitments, a non-canonical response; equal to the oracle's."""
+    from zkp_amd.engine import Engine
+    mod, secrets, inst, common = _cmz_batch(n, 91)
+    st = mod.statement
+    label = b"straus"
+    rng = np.random.default_rng(92)
+    e0 = Engine(0)
+    ts = _fresh(label, n)
+    chal, resp, coms = T.prove_batch(e0, st, ts, secrets, inst, common, rng.integers(0, 256, size=(n, 32), dtype=np.uint8))
+    e0.close()
+    w = rng.integers(0, 256, size=(n, st.nc, 16), dtype=np.uint8)
+    resp, coms, inst = resp.copy(), coms.copy(), inst.copy()
+    bad = set()
+    if n >= 300:
+        resp[5, 2, 0] ^= 1; bad.add(5)
+        coms[17, 3] = coms[18, 3]; bad.add(17)
+        coms[40, 0] = 0; bad.add(40)
+        coms[41, 10] = np.frombuffer(bytes([1] + [0] * 31), np.uint8); bad.add(41)
+        inst[12, 77] = np.frombuffer(bytes([1] + [0] * 31), np.uint8); bad.add(77)
+        inst[0, 78] = inst[0, 79]; bad.add(78)
+        resp[100, 20] = np.frombuffer((int.from_bytes(resp[100, 20].tobytes(), "little") + M.L).to_bytes(32, "little"), np.uint8); bad.add(100)
+    else:
+        resp[1, 0, 0] ^= 1; bad.add(1)
+    want = np.array([1 if j in bad else 0 for j in range(n)], np.uint8)
+    cst = C.Statement.from_model(M.cmz_statement(10))
+    for j in sorted(bad) + [0]:
+        assert C.verify_batchable(cst, label, np.concatenate([inst[:, j], common]), coms[j], resp[j], w[j]) == want[j]
+    T.set_fused_min_batch(0)
+    try:
+        for opt in (2**64 - 1, 0, 1, 2, 3, 4, 8):
+            e = Engine(0)
+            e.set_option(10, opt)
+            ts = _fresh(label, n)
+            got = T.verify_batchable_each(e, st, ts, inst, common, coms, resp, w)
+            e.close()
+            assert (got == want).all(), (opt, np.nonzero(got != want)[0][:8])
+    finally:
+        T.set_fused_min_batch(32)

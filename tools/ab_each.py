@@ -10,8 +10,12 @@ def main():
     import bench
     from zkp_amd.engine import Engine
     from zkp_amd import toolbox as T
-    ns = [int(a) for a in sys.argv[1:]] or [4096, 65536]
+    opts = [a for a in sys.argv[1:] if "=" in a]                       # ID=VALUE: zkp_ctx_set_option (e.g. 10=0: the round-2 ladders)
+    ns = [int(a) for a in sys.argv[1:] if "=" not in a] or [4096, 65536]
     eng = Engine(0)
+    for kv in opts:
+        eng.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
+    print("# options:", opts or "defaults")
     mod = T.cmz_module(10)
     st = mod.statement
     rng = np.random.default_rng(3)

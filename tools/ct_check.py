@@ -108,7 +108,7 @@ def cycles():
     repeat ("random-b" vs "random-b again") differs from itself."""
     import bench
     from zkp_amd.engine import Engine, ZKP_CT, ZKP_TESTOPT_WAVE_CYCLES
-    REPS = 5
+    REPS = 9
     names = {1: "ladder", 2: "comb scan", 3: "grouped walk", 4: "fixed-base"}
     eng = Engine(0, test_hooks=True)
     n = 4096
@@ -127,7 +127,7 @@ def cycles():
         eng.set_option(3, single_use_tables)
         eng.set_option(6, grouped)
         eng.set_option(9, masked)
-        med = {}
+        med, noise = {}, {}
         for kind in PATTERNS:
             sc = scalars(kind, 31 * n, rng)
             eng.msm_many(off, sc, pidx, pts, ZKP_CT)            # warm (tables of this schedule, caches)
@@ -141,17 +141,17 @@ def cycles():
                     acc.setdefault(int(c), []).append(np.median(cyc[cls == c]))
             for c, v in acc.items():
                 med.setdefault(c, []).append(float(np.median(v)))
+                noise[c] = max(noise.get(c, 0.0), float(max(v) - min(v)))     # launch-to-launch spread of the SAME input
         print("schedule: single-use tables = %d, grouped walk = %d, masked scans = %d" % (single_use_tables, grouped, masked))
         for c in sorted(med):
             v = np.array(med[c])
-            noise = abs(v[-1] - v[-2])                         # the same input twice
             spread = float(v.max() - v.min())
             rel = spread / v.mean()
-            ok = spread <= max(3.0 * noise, 0.005 * v.mean())
+            ok = spread <= max(1.5 * noise[c], 0.005 * v.mean())
             verdict &= ok
-            print("  %-13s %s   spread %.0f cycles = %.3f %% of the mean; same-input repeat %.0f cycles  -> %s"
-                  % (names.get(c, str(c)), " ".join("%.0f" % x for x in v), spread, 100 * rel, noise, "WITHIN NOISE" if ok else "EXCEEDS NOISE"))
-    print("# verdict:", "median wavefront times of every block class are independent of the scalar pattern (within 3 x the same-input repeat or 0.5 %)"
+            print("  %-13s %s   spread of the pattern medians %.0f cycles = %.3f %% of the mean; launch-to-launch spread of one input: up to %.0f cycles  -> %s"
+                  % (names.get(c, str(c)), " ".join("%.0f" % x for x in v), spread, 100 * rel, noise[c], "WITHIN NOISE" if ok else "EXCEEDS NOISE"))
+    print("# verdict:", "median wavefront times of every block class are independent of the scalar pattern (within 1.5 x the launch-to-launch spread of one input, or 0.5 %)"
           if verdict else "some block class shows a pattern-dependent time: see above")
     eng.close()
 

@@ -237,6 +237,120 @@ k_each_finish(uint32_t N, uint32_t m, const uint8_t* __restrict__ out, const uin
   results[j] = d ? 1 : 0;
 }
 
+// ---- verify_batchable: one Straus MSM per proof (verifier.rs:162-166) ---------------------------------------------------------
+// A proof's MSM has K = np + nc operands, almost all of them points nobody else multiplies (CMZ: 13 instance points + 11
+// commitments, 24 of 36).  Lane-per-term ladders pay 256 doublings PER OPERAND (K x 321 point operations); Straus shares them:
+//     acc = 16 acc ; acc += d_i * P_i  for every operand,   64 windows            256 doublings + K x ~60 additions per MSM
+// over per-point tables {1 P .. 8 P} (signed radix-16 digits of the sign-folded coefficient: the -r weights of the commitment
+// operands are 128-bit after folding, their upper 32 windows add nothing).  Variable time (public data): zero digits are skipped.
+// L lanes share a proof (operand i goes to lane i mod L, each lane runs its own 256 doublings and the partial sums are added at the
+// end): a lone lane per proof is a 2,300-operation dependent chain and 4,096 proofs are 64 wavefronts on 1,024 SIMDs, so small
+// batches trade some of the shared doublings for parallelism (L = 8 at 4,096 proofs ... 1 from 65,536 on).
+// k_straus_tables: lane per point of the call: tab[p][k] = (k + 1) P_p in cached form
+__global__ void __launch_bounds__(256, 2)
+k_straus_tables(uint32_t n_points, const dev_affine* __restrict__ pts, dev_ext* __restrict__ tab) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_points) return;
+  ge_p3 P, m2, m3, m4, m;
+  ge_cached c1, c;
+  load_affine(P, pts + p);                                           // (an undecodable point: garbage multiples, the proof is flagged by k_straus_finish)
+  dev_ext* t = tab + (size_t)p * 8;
+  ge_to_cached(c1, P);
+  store_comb_entry(t + 0, c1);
+  ge_double<true>(m2, P);
+  ge_to_cached(c, m2); store_comb_entry(t + 1, c);
+  ge_add_cached(m3, m2, c1);
+  ge_to_cached(c, m3); store_comb_entry(t + 2, c);
+  ge_double<true>(m4, m2);
+  ge_to_cached(c, m4); store_comb_entry(t + 3, c);
+  ge_add_cached(m, m4, c1);
+  ge_to_cached(c, m); store_comb_entry(t + 4, c);
+  ge_double<true>(m, m3);
+  ge_to_cached(c, m); store_comb_entry(t + 5, c);
+  ge_add_cached(m, m, c1);
+  ge_to_cached(c, m); store_comb_entry(t + 6, c);
+  ge_double<true>(m, m4);
+  ge_to_cached(c, m); store_comb_entry(t + 7, c);
+}
+// lane (proof j, part l of L): operands i = l, l + L, ... < K of proof j.  digits = scratch [N K][9] words (recoded coefficient +
+// sign), written and read by the owning lane only.  spart[j L + l] = the part's sum.
+__global__ void __launch_bounds__(256, 2)
+k_straus_each(uint32_t N, uint32_t K, uint32_t L, const uint8_t* __restrict__ scalars /*[N K][32]*/, const uint32_t* __restrict__ pidx /*[N K]*/,
+              const dev_ext* __restrict__ tab, uint32_t* __restrict__ digits, dev_ext* __restrict__ spart) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * L) return;
+  const uint32_t j = g / L, l = g - j * L;
+  const size_t base = (size_t)j * K;
+  for (uint32_t i = l; i < K; i += L) {                              // recode this lane's coefficients: signed radix-16, sign folded
+    uint32_t sw[8], e[8], top;
+    load_vec<2>(sw, scalars + 32 * (base + i));
+    const uint32_t flip = sc_fold_sign(sw);                         // s P = (l - s)(-P); canonical s: the folded value is < 2^252
+    sc_add_pattern(e, top, sw, 0x88888888u);
+    uint32_t* d = digits + 9 * (base + i);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) d[w] = e[w];
+    d[8] = flip | (top << 1);
+  }
+  ge_p3 acc;
+  ge_identity(acc);
+  bool started = false;                                              // (doubling the identity is skipped: short coefficients start late)
+  for (uint32_t i = l; i < K; i += L) {                              // carry out of bit 255 (non-canonical inputs only): one more P at the top
+    if (digits[9 * (base + i) + 8] & 2u) {
+      ge_cached c;
+      load_comb_entry(c, tab + (size_t)pidx[base + i] * 8);
+      ge_cached_cneg(c, digits[9 * (base + i) + 8] & 1u);
+      ge_add_cached(acc, acc, c);
+      started = true;
+    }
+  }
+#pragma unroll 1
+  for (int w = 7; w >= 0; --w) {
+#pragma unroll 1
+    for (int k = 7; k >= 0; --k) {
+      if (started) ge_double4(acc);
+#pragma unroll 1
+      for (uint32_t i = l; i < K; i += L) {
+        const uint32_t* d = digits + 9 * (base + i);
+        const uint32_t nib = (d[w] >> (4 * k)) & 15u;
+        const uint32_t neg = (uint32_t)(nib < 8u);
+        const uint32_t mag = neg ? 8u - nib : nib - 8u;
+        if (mag) {
+          ge_cached c;
+          load_comb_entry(c, tab + (size_t)pidx[base + i] * 8 + (mag - 1));
+          ge_cached_cneg(c, neg ^ (d[8] & 1u));
+          ge_add_cached(acc, acc, c);
+          started = true;
+        }
+      }
+    }
+  }
+  store_ext(spart + g, acc);
+}
+// lane per proof: sum of its L parts, decode status of its K operands, canonical encoding of the sum (verifier.rs:162-168)
+__global__ void __launch_bounds__(256, 2)
+k_straus_finish(uint32_t N, uint32_t K, uint32_t L, const uint32_t* __restrict__ pidx, const dev_affine* __restrict__ pts, const dev_ext* __restrict__ spart,
+                uint8_t* __restrict__ out, uint8_t* __restrict__ status8) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  ge_p3 acc;
+  load_ext(acc, spart + (size_t)j * L);
+  for (uint32_t l = 1; l < L; ++l) {
+    ge_p3 q;
+    load_ext(q, spart + (size_t)j * L + l);
+    ge_add_p3(acc, acc, q);
+  }
+  uint32_t bad = 0;
+  for (uint32_t i = 0; i < K; ++i) bad |= pts[pidx[(size_t)j * K + i]].valid ^ 1u;
+  uint32_t w[8];
+  ristretto_encode(w, acc);
+  if (bad) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = 0;
+  }
+  store_vec<2>(out + 32 * (size_t)j, w);
+  status8[j] = (uint8_t)bad;
+}
+
 // Batch verification, after the transcripts, in one launch: any rejected proof of batch b -> any[b * any_stride] |= any_bit; -c mod l
 // from the 64 challenge bytes; commitment rows of the operand list (rows[k][j] = commitments[j][k], batch_verifier.rs:208-212).
 // A response that is not a canonical scalar rejects its batch too: the reference can only receive responses through serde,
@@ -926,6 +1040,28 @@ terms_cfg each_terms_cfg(const fused_plan& pl) {
   k.teeth = pl.N >= 6 ? 16 : 4;
   return k;
 }
+// The Straus path of verify_batchable (k_straus_each) and its workspace behind each_inter
+struct straus_inter { size_t pts, tab, digits, spart, end; };
+constexpr uint32_t kStrausMaxLanes = 8;
+inline bool each_uses_straus(const zkp_ctx* c, const fused_plan& pl) {
+  return c->each_straus && (uint64_t)pl.s.np + pl.s.nc >= 4;         // (tiny statements: nothing to share)
+}
+inline uint32_t straus_lanes(const zkp_ctx* c, uint32_t N) {
+  if (c->each_straus_lanes) return std::min<uint32_t>(c->each_straus_lanes, kStrausMaxLanes);
+  return N >= 65536 ? 1u : (N >= 32768 ? 2u : (N >= 16384 ? 4u : 8u));
+}
+straus_inter straus_carve(const fused_plan& pl, size_t start) {
+  const size_t N = pl.N, K = (size_t)pl.s.np + pl.s.nc, n_points = (size_t)pl.s.ns + (size_t)pl.s.ni * N + N * pl.s.nc;
+  carve cv;
+  cv.off = start;
+  straus_inter o;
+  o.pts = cv.take(n_points * sizeof(dev_affine));
+  o.tab = cv.take(n_points * 8 * sizeof(dev_ext));
+  o.digits = cv.take(N * K * 9 * 4);
+  o.spart = cv.take(N * kStrausMaxLanes * sizeof(dev_ext));
+  o.end = cv.off;
+  return o;
+}
 int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_resp,
               const uint8_t* d_w, uint8_t* d_results) {
   const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni, K = pl.s.np + nc;
@@ -946,9 +1082,28 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
                      d_inc_k + pl.s.inc_k.size(), w.u8(o.mc), d_resp, d_w, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx));
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
-  const int rc = msm_terms_path(c, N, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * K, ZKP_VARTIME, w.u8(o.out), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true,
-                                PH_ALL, each_terms_cfg(pl));
-  if (rc) return rc;
+  if (each_uses_straus(c, pl)) {
+    // one Straus MSM per proof, L lanes each (see k_straus_each)
+    const straus_inter so = straus_carve(pl, o.end);
+    if (so.end > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
+    dev_affine* pts = reinterpret_cast<dev_affine*>(w.base + so.pts);
+    dev_ext* tab = reinterpret_cast<dev_ext*>(w.base + so.tab);
+    dev_ext* spart = reinterpret_cast<dev_ext*>(w.base + so.spart);
+    const uint32_t L = straus_lanes(c, N);
+    hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_tbl, pts, (const uint32_t*)nullptr);
+    prof_mark(c, ZKP_K_DECODE);
+    hipLaunchKernelGGL(k_straus_tables, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, pts, tab);
+    prof_mark(c, ZKP_K_TABLES);
+    hipLaunchKernelGGL(k_straus_each, grid1((size_t)N * L, 256), dim3(256), 0, c->stream, N, K, L, w.u8(o.sc), w.u32(o.pidx), tab, w.u32(so.digits), spart);
+    prof_mark(c, ZKP_K_TERMS);
+    hipLaunchKernelGGL(k_straus_finish, grid1(N, 256), dim3(256), 0, c->stream, N, K, L, w.u32(o.pidx), pts, spart, w.u8(o.out), w.u8(o.st8));
+    prof_mark(c, ZKP_K_REDUCE);
+    HIP_TRY(hipGetLastError());
+  } else {
+    const int rc = msm_terms_path(c, N, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * K, ZKP_VARTIME, w.u8(o.out), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true,
+                                  PH_ALL, each_terms_cfg(pl));
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_each_finish, grid1(N, 256), dim3(256), 0, c->stream, N, pl.s.m, w.u8(o.out), w.u8(o.st8), w.u32(o.failed), d_resp, d_results);
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
@@ -1362,7 +1517,7 @@ int zkp_fused_verify_batchable_coeffs(zkp_ctx* c, const zkp_fused_statement* st,
   const size_t o_w = cv.take((size_t)N * nc * 16 + 16);
   const size_t o_res = cv.take((size_t)N + 4);
   const each_inter o = each_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N, each_terms_cfg(*pl)));
+  rc = ensure_ws(c, each_uses_straus(c, *pl) ? straus_carve(*pl, o.end).end : o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N, each_terms_cfg(*pl)));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));

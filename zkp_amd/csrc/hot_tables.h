@@ -424,12 +424,15 @@ __device__ __forceinline__ void fixed_base_block(ge_p3& acc, uint32_t e[9], bool
 #pragma unroll 1
         for (uint32_t k = 1; k <= (uint32_t)HOT_HALF; ++k) {
           const uint4* ek = rep + (size_t)k * (sizeof(dev_niels) / 16) * HOT_COPIES + copy;
-          const bool hit = k == mag;
+          const uint32_t m = 0u - (uint32_t)(k == mag);                // all-ones for the wanted entry
 #pragma unroll
           for (int i = 0; i < 7; ++i) {
-            const uint4 x = ek[i * HOT_COPIES];
-            wd[4 * i + 0] = hit ? x.x : wd[4 * i + 0]; wd[4 * i + 1] = hit ? x.y : wd[4 * i + 1];
-            wd[4 * i + 2] = hit ? x.z : wd[4 * i + 2]; wd[4 * i + 3] = hit ? x.w : wd[4 * i + 3];
+            uint4 x = ek[i * HOT_COPIES];
+            // the read happens for EVERY entry: without this the compiler sinks it under "some lane wants entry k" (a branch on the
+            // secret digits -- caught by tools/ct_check.py: 9 x the LDS instructions for random scalars)
+            asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
+            wd[4 * i + 0] = (wd[4 * i + 0] & ~m) | (x.x & m); wd[4 * i + 1] = (wd[4 * i + 1] & ~m) | (x.y & m);
+            wd[4 * i + 2] = (wd[4 * i + 2] & ~m) | (x.z & m); wd[4 * i + 3] = (wd[4 * i + 3] & ~m) | (x.w & m);
           }
         }
       } else {

@@ -1046,6 +1046,8 @@ struct zkp_ctx {
   bool fuse_tables_transcript = false;   // ZKP_OPT_FUSE_TABLES_TRANSCRIPT
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
+  bool each_straus = true;           // ZKP_OPT_EACH_STRAUS: verify_batchable's per-proof MSMs as one Straus walk per proof (0: one ladder per operand)
+  uint32_t each_straus_lanes = 0;    //   ... with this many lanes per proof (0 = by batch size)
   bool ct_masked_scans = false;      // ZKP_OPT_CT_MASKED_SCANS: constant-time calls pick every table entry with masked scans (no secret-indexed LDS read)
 #ifdef ZKP_BUILD_TEST_HOOKS
   uint64_t* wave_cycles = nullptr;   // ZKP_TESTOPT_WAVE_CYCLES: per-wavefront cycle recorder of the term kernel
@@ -1592,6 +1594,11 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;
+    case ZKP_OPT_EACH_STRAUS:
+      if (value != ~0ull && value > 8) return fail(ZKP_ERR_ARG, "ZKP_OPT_EACH_STRAUS: 0 (off), 1 .. 8 lanes per proof, or UINT64_MAX (default)");
+      c->each_straus = value != 0;
+      c->each_straus_lanes = (value == ~0ull || value == 0) ? 0u : (uint32_t)value;
+      return ZKP_OK;
     case ZKP_OPT_TRANSCRIPT_LANES:
       if (value != ~0ull && value != 1 && value != 2) return fail(ZKP_ERR_ARG, "ZKP_OPT_TRANSCRIPT_LANES: 1, 2 or UINT64_MAX");
       c->tr_lanes = value == ~0ull ? -1 : (int)value;

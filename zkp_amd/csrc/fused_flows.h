@@ -246,79 +246,149 @@ k_each_finish(uint32_t N, uint32_t m, const uint8_t* __restrict__ out, const uin
 // L lanes share a proof (operand i goes to lane i mod L, each lane runs its own 256 doublings and the partial sums are added at the
 // end): a lone lane per proof is a 2,300-operation dependent chain and 4,096 proofs are 64 wavefronts on 1,024 SIMDs, so small
 // batches trade some of the shared doublings for parallelism (L = 8 at 4,096 proofs ... 1 from 65,536 on).
-// k_straus_tables: lane per point of the call: tab[p][k] = (k + 1) P_p in cached form
+// Tables: the walk is bound by its gathers (1,440 per CMZ proof; 1.6 GB of tables at 65,536 proofs, far beyond every cache), not by
+// arithmetic, so an entry is ONE 128-byte cache line: the cached form (Y + X, Y - X, 2 Z, 2 d T) with every coordinate carried down to
+// 256 bits and packed into 32 bytes (the 144-byte limb form straddles two or three lines: 8.96 -> 6.7 ms for the walk of 65,536 proofs).
+// Affine entries (112 B, one multiplication less per addition) were measured too: their shared inversion per 256 points costs the table
+// kernel 2.5 instead of 0.7 ms, more than the walk gains.
+struct alignas(128) straus_entry { uint32_t w[32]; };     // YpX | YmX | Z2 | T2d, 8 words each
+// value of a (limbs up to ~2^31) as 256 bits: three carry passes (the first two fold bits >= 255 back with 19), then 29-bit limbs -> words
+__device__ __forceinline__ void fe_pack256(uint32_t w[8], const fe& a) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t[i] = a.v[i];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { t[i + 1] += t[i] >> 29; t[i] &= FE_M29; }
+    const uint32_t c = t[8] >> 23;
+    t[8] &= FE_M23;
+    t[0] += 19u * c;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { t[i + 1] += t[i] >> 29; t[i] &= FE_M29; }       // t[0] + 19: at most one more unit travels up; t[8] <= 2^23
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w[j] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+    w[wi] |= t[i] << sh;
+    if (sh > 3 && wi < 7) w[wi + 1] |= t[i] >> (32 - sh);
+  }
+}
+__device__ __forceinline__ void fe_unpack256(fe& r, const uint32_t w[8]) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+    uint32_t x = w[wi] >> sh;
+    if (sh > 3 && wi < 7) x |= w[wi + 1] << (32 - sh);
+    r.v[i] = i == 8 ? x : (x & FE_M29);                    // the top limb keeps bit 255 (24 bits)
+  }
+  FE_TRACK(fe_set_ub_tight(r));
+}
+__device__ __forceinline__ void store_straus_entry(straus_entry* dst, const ge_cached& c) {
+  uint32_t w[32];
+  fe_pack256(w, c.YpX); fe_pack256(w + 8, c.YmX); fe_pack256(w + 16, c.Z2); fe_pack256(w + 24, c.T2d);
+  store_vec<8>(dst, w);
+}
+__device__ __forceinline__ void load_straus_entry(ge_cached& c, const straus_entry* src) {
+  uint32_t w[32];
+  load_vec<8>(w, src);
+  fe_unpack256(c.YpX, w); fe_unpack256(c.YmX, w + 8); fe_unpack256(c.Z2, w + 16); fe_unpack256(c.T2d, w + 24);
+}
+// k_straus_tables: lane per point of the call: tab[p][k] = (k + 1) P_p
 __global__ void __launch_bounds__(256, 2)
-k_straus_tables(uint32_t n_points, const dev_affine* __restrict__ pts, dev_ext* __restrict__ tab) {
+k_straus_tables(uint32_t n_points, const dev_affine* __restrict__ pts, straus_entry* __restrict__ tab) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_points) return;
   ge_p3 P, m2, m3, m4, m;
   ge_cached c1, c;
   load_affine(P, pts + p);                                           // (an undecodable point: garbage multiples, the proof is flagged by k_straus_finish)
-  dev_ext* t = tab + (size_t)p * 8;
+  straus_entry* t = tab + (size_t)p * 8;
   ge_to_cached(c1, P);
-  store_comb_entry(t + 0, c1);
+  store_straus_entry(t + 0, c1);
   ge_double<true>(m2, P);
-  ge_to_cached(c, m2); store_comb_entry(t + 1, c);
+  ge_to_cached(c, m2); store_straus_entry(t + 1, c);
   ge_add_cached(m3, m2, c1);
-  ge_to_cached(c, m3); store_comb_entry(t + 2, c);
+  ge_to_cached(c, m3); store_straus_entry(t + 2, c);
   ge_double<true>(m4, m2);
-  ge_to_cached(c, m4); store_comb_entry(t + 3, c);
+  ge_to_cached(c, m4); store_straus_entry(t + 3, c);
   ge_add_cached(m, m4, c1);
-  ge_to_cached(c, m); store_comb_entry(t + 4, c);
+  ge_to_cached(c, m); store_straus_entry(t + 4, c);
   ge_double<true>(m, m3);
-  ge_to_cached(c, m); store_comb_entry(t + 5, c);
+  ge_to_cached(c, m); store_straus_entry(t + 5, c);
   ge_add_cached(m, m, c1);
-  ge_to_cached(c, m); store_comb_entry(t + 6, c);
+  ge_to_cached(c, m); store_straus_entry(t + 6, c);
   ge_double<true>(m, m4);
-  ge_to_cached(c, m); store_comb_entry(t + 7, c);
+  ge_to_cached(c, m); store_straus_entry(t + 7, c);
 }
-// lane (proof j, part l of L): operands i = l, l + L, ... < K of proof j.  digits = scratch [N K][9] words (recoded coefficient +
-// sign), written and read by the owning lane only.  spart[j L + l] = the part's sum.
+// lane (proof j, part l of L): operands i = l, l + L, ... < K of proof j (operand i: point id i for i < np, commitment i - np after that;
+// table index as in k_each_coeffs).  digits = scratch [N K][9] words (recoded coefficient + sign), written and read by the owning lane
+// only.  spart[j L + l] = the part's sum.  Dynamic LDS: ceil(K / L) words per lane (the digit words of the current 32-bit slice).
+// The entry of the NEXT operand is requested before the current addition starts, the first entry of the next window before the four
+// doublings: the gathers (a dependent HBM round trip each) overlap the arithmetic instead of serialising with it.
 __global__ void __launch_bounds__(256, 2)
-k_straus_each(uint32_t N, uint32_t K, uint32_t L, const uint8_t* __restrict__ scalars /*[N K][32]*/, const uint32_t* __restrict__ pidx /*[N K]*/,
-              const dev_ext* __restrict__ tab, uint32_t* __restrict__ digits, dev_ext* __restrict__ spart) {
+k_straus_each(uint32_t N, uint32_t K, uint32_t L, uint32_t ns, uint32_t ni, uint32_t nc, const uint8_t* __restrict__ scalars /*[N K][32]*/,
+              const straus_entry* __restrict__ tab, uint32_t* __restrict__ digits, dev_ext* __restrict__ spart) {
+  extern __shared__ uint32_t straus_lds[];
+  uint32_t* col = straus_lds + threadIdx.x;                            // word of operand ordinal o at col[256 o]
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N * L) return;
-  const uint32_t j = g / L, l = g - j * L;
+  const uint32_t j = g / L, l = g - j * L, np = ns + ni;
   const size_t base = (size_t)j * K;
-  for (uint32_t i = l; i < K; i += L) {                              // recode this lane's coefficients: signed radix-16, sign folded
+  auto table_of = [&](uint32_t i) -> const straus_entry* {
+    const size_t p = i < ns ? i : (i < np ? (size_t)ns + (size_t)(i - ns) * N + j : (size_t)ns + (size_t)ni * N + (size_t)j * nc + (i - np));
+    return tab + p * 8;
+  };
+  ge_p3 acc;
+  ge_identity(acc);
+  bool started = false;                                                // (doubling the identity is skipped: short coefficients start late)
+  uint64_t flipmask = 0;                                               // bit o: operand ordinal o was sign-folded (at most 60 operands per lane)
+  uint32_t oo = 0;
+  for (uint32_t i = l; i < K; i += L, ++oo) {                          // recode this lane's coefficients: signed radix-16, sign folded
     uint32_t sw[8], e[8], top;
     load_vec<2>(sw, scalars + 32 * (base + i));
-    const uint32_t flip = sc_fold_sign(sw);                         // s P = (l - s)(-P); canonical s: the folded value is < 2^252
+    const uint32_t flip = sc_fold_sign(sw);                           // s P = (l - s)(-P); canonical s: the folded value is < 2^252
     sc_add_pattern(e, top, sw, 0x88888888u);
     uint32_t* d = digits + 9 * (base + i);
 #pragma unroll
     for (int w = 0; w < 8; ++w) d[w] = e[w];
-    d[8] = flip | (top << 1);
-  }
-  ge_p3 acc;
-  ge_identity(acc);
-  bool started = false;                                              // (doubling the identity is skipped: short coefficients start late)
-  for (uint32_t i = l; i < K; i += L) {                              // carry out of bit 255 (non-canonical inputs only): one more P at the top
-    if (digits[9 * (base + i) + 8] & 2u) {
-      ge_cached c;
-      load_comb_entry(c, tab + (size_t)pidx[base + i] * 8);
-      ge_cached_cneg(c, digits[9 * (base + i) + 8] & 1u);
-      ge_add_cached(acc, acc, c);
+    d[8] = flip;
+    flipmask |= (uint64_t)flip << oo;
+    if (top) {                                                         // carry out of bit 255 (non-canonical inputs only): one more P at the top
+      ge_cached q;
+      load_straus_entry(q, table_of(i));
+      ge_cached_cneg(q, flip);
+      ge_add_cached(acc, acc, q);
       started = true;
     }
   }
+  ge_cached qn;                                                        // the prefetched entry of the upcoming operand
+  uint32_t magn = 0, negn = 0;
+  auto fetch = [&](uint32_t i, uint32_t o, int k) {
+    const uint32_t nib = (col[256 * o] >> (4 * k)) & 15u;
+    const uint32_t neg = (uint32_t)(nib < 8u);
+    magn = neg ? 8u - nib : nib - 8u;
+    negn = neg ^ (uint32_t)((flipmask >> o) & 1u);
+    if (magn) load_straus_entry(qn, table_of(i) + (magn - 1));
+  };
 #pragma unroll 1
   for (int w = 7; w >= 0; --w) {
+    uint32_t o = 0;
+    for (uint32_t i = l; i < K; i += L, ++o) col[256 * o] = digits[9 * (base + i) + w];
 #pragma unroll 1
     for (int k = 7; k >= 0; --k) {
+      fetch(l, 0, k);
       if (started) ge_double4(acc);
+      o = 0;
 #pragma unroll 1
-      for (uint32_t i = l; i < K; i += L) {
-        const uint32_t* d = digits + 9 * (base + i);
-        const uint32_t nib = (d[w] >> (4 * k)) & 15u;
-        const uint32_t neg = (uint32_t)(nib < 8u);
-        const uint32_t mag = neg ? 8u - nib : nib - 8u;
+      for (uint32_t i = l; i < K; i += L, ++o) {
+        ge_cached q = qn;
+        const uint32_t mag = magn, neg = negn;
+        if (i + L < K) fetch(i + L, o + 1, k);
         if (mag) {
-          ge_cached c;
-          load_comb_entry(c, tab + (size_t)pidx[base + i] * 8 + (mag - 1));
-          ge_cached_cneg(c, neg ^ (d[8] & 1u));
-          ge_add_cached(acc, acc, c);
+          ge_cached_cneg(q, neg);
+          ge_add_cached(acc, acc, q);
           started = true;
         }
       }
@@ -1042,13 +1112,16 @@ terms_cfg each_terms_cfg(const fused_plan& pl) {
 }
 // The Straus path of verify_batchable (k_straus_each) and its workspace behind each_inter
 struct straus_inter { size_t pts, tab, digits, spart, end; };
-constexpr uint32_t kStrausMaxLanes = 8;
-inline bool each_uses_straus(const zkp_ctx* c, const fused_plan& pl) {
-  return c->each_straus && (uint64_t)pl.s.np + pl.s.nc >= 4;         // (tiny statements: nothing to share)
+constexpr uint32_t kStrausMaxLanes = 8, kStrausMaxOpsPerLane = 60;      // (60 KB of dynamic LDS per block at most)
+inline uint32_t straus_lanes(const zkp_ctx* c, const fused_plan& pl) {
+  const uint32_t K = pl.s.np + pl.s.nc, N = pl.N;
+  uint32_t L = c->each_straus_lanes ? std::min<uint32_t>(c->each_straus_lanes, kStrausMaxLanes) : (N >= 65536 ? 1u : (N >= 32768 ? 2u : (N >= 16384 ? 4u : 8u)));
+  while (L < kStrausMaxLanes && (K + L - 1) / L > kStrausMaxOpsPerLane) L *= 2;
+  return std::min(L, kStrausMaxLanes);
 }
-inline uint32_t straus_lanes(const zkp_ctx* c, uint32_t N) {
-  if (c->each_straus_lanes) return std::min<uint32_t>(c->each_straus_lanes, kStrausMaxLanes);
-  return N >= 65536 ? 1u : (N >= 32768 ? 2u : (N >= 16384 ? 4u : 8u));
+inline bool each_uses_straus(const zkp_ctx* c, const fused_plan& pl) {
+  const uint64_t K = (uint64_t)pl.s.np + pl.s.nc;
+  return c->each_straus && K >= 4 && (K + kStrausMaxLanes - 1) / kStrausMaxLanes <= kStrausMaxOpsPerLane;       // (tiny statements: nothing to share)
 }
 straus_inter straus_carve(const fused_plan& pl, size_t start) {
   const size_t N = pl.N, K = (size_t)pl.s.np + pl.s.nc, n_points = (size_t)pl.s.ns + (size_t)pl.s.ni * N + N * pl.s.nc;
@@ -1056,7 +1129,7 @@ straus_inter straus_carve(const fused_plan& pl, size_t start) {
   cv.off = start;
   straus_inter o;
   o.pts = cv.take(n_points * sizeof(dev_affine));
-  o.tab = cv.take(n_points * 8 * sizeof(dev_ext));
+  o.tab = cv.take(n_points * 8 * sizeof(straus_entry) + 128);
   o.digits = cv.take(N * K * 9 * 4);
   o.spart = cv.take(N * kStrausMaxLanes * sizeof(dev_ext));
   o.end = cv.off;
@@ -1087,14 +1160,15 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
     const straus_inter so = straus_carve(pl, o.end);
     if (so.end > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
     dev_affine* pts = reinterpret_cast<dev_affine*>(w.base + so.pts);
-    dev_ext* tab = reinterpret_cast<dev_ext*>(w.base + so.tab);
+    straus_entry* tab = reinterpret_cast<straus_entry*>(w.base + so.tab);
     dev_ext* spart = reinterpret_cast<dev_ext*>(w.base + so.spart);
-    const uint32_t L = straus_lanes(c, N);
+    const uint32_t L = straus_lanes(c, pl);
     hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_tbl, pts, (const uint32_t*)nullptr);
     prof_mark(c, ZKP_K_DECODE);
     hipLaunchKernelGGL(k_straus_tables, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, pts, tab);
     prof_mark(c, ZKP_K_TABLES);
-    hipLaunchKernelGGL(k_straus_each, grid1((size_t)N * L, 256), dim3(256), 0, c->stream, N, K, L, w.u8(o.sc), w.u32(o.pidx), tab, w.u32(so.digits), spart);
+    hipLaunchKernelGGL(k_straus_each, grid1((size_t)N * L, 256), dim3(256), (size_t)((K + L - 1) / L) * 1024, c->stream, N, K, L, ns, ni, nc, w.u8(o.sc), tab,
+                       w.u32(so.digits), spart);
     prof_mark(c, ZKP_K_TERMS);
     hipLaunchKernelGGL(k_straus_finish, grid1(N, 256), dim3(256), 0, c->stream, N, K, L, w.u32(o.pidx), pts, spart, w.u8(o.out), w.u8(o.st8));
     prof_mark(c, ZKP_K_REDUCE);

@@ -23,6 +23,8 @@ pub enum Error {
     BatchSizeMismatch,
     /// negative return code of the C ABI with `zkp_last_error()`; no output may be trusted
     Backend(c_int, String),
+    /// a slice handed to a safe wrapper does not have the length the statement / batch size implies (checked before any FFI call)
+    Shape(&'static str),
 }
 fn check(rc: c_int) -> Result<(), Error> {
     match rc {
@@ -86,7 +88,14 @@ pub mod multiscalar {
     /// `table[pidx[..]]`.  `None` = a referenced point failed to decompress.
     pub fn multiscalar_mul_many(eng: &Engine, off: &[u32], scalars: &[Scalar], pidx: &[u32], table: &[CompressedRistretto],
                                 constant_time: bool) -> Result<Vec<Option<CompressedRistretto>>, Error> {
+        if off.is_empty() || off[0] != 0 || off.windows(2).any(|w| w[1] < w[0]) {
+            return Err(Error::Shape("off must be non-empty, start at 0 and be non-decreasing"));
+        }
         let n = off.len() - 1;
+        let n_terms = off[n] as usize;
+        if scalars.len() != n_terms || pidx.len() != n_terms || pidx.iter().any(|&i| i as usize >= table.len()) {
+            return Err(Error::Shape("scalars / pidx must have off[n] entries and index into table"));
+        }
         let (s, p) = (flat_scalars(scalars.iter()), flat_points(table.iter()));
         let mut out = vec![0u8; 32 * n];
         let mut status = vec![0u8; n];
@@ -109,13 +118,17 @@ impl Transcript {
         unsafe { sys::zkp_transcript_init(t.as_mut_ptr(), label.as_ptr(), label.len()) };
         Transcript(t)
     }
+    /// Panics (like merlin's `encode_usize_as_u32` assert) when the message is longer than u32::MAX bytes: the C side returns
+    /// ZKP_TB_TOO_LONG and leaves the transcript untouched.
     pub fn append_message(&mut self, label: &'static [u8], message: &[u8]) {
         let l = CString::new(label).expect("labels are NUL-free");
-        unsafe { sys::zkp_transcript_append_message(self.0.as_mut_ptr(), l.as_ptr(), message.as_ptr(), message.len()) }
+        let rc = unsafe { sys::zkp_transcript_append_message(self.0.as_mut_ptr(), l.as_ptr(), message.as_ptr(), message.len()) };
+        assert_eq!(rc, 0, "zkp_transcript_append_message: code {} (message longer than u32::MAX bytes?)", rc);
     }
     pub fn challenge_bytes(&mut self, label: &'static [u8], dest: &mut [u8]) {
         let l = CString::new(label).expect("labels are NUL-free");
-        unsafe { sys::zkp_transcript_challenge_bytes(self.0.as_mut_ptr(), l.as_ptr(), dest.as_mut_ptr(), dest.len()) }
+        let rc = unsafe { sys::zkp_transcript_challenge_bytes(self.0.as_mut_ptr(), l.as_ptr(), dest.as_mut_ptr(), dest.len()) };
+        assert_eq!(rc, 0, "zkp_transcript_challenge_bytes: code {}", rc);
     }
 }
 
@@ -130,7 +143,9 @@ pub struct Statement(*mut sys::zkp_statement);
 impl Statement {
     pub fn new(proof_label: &'static [u8]) -> Statement {
         let l = CString::new(proof_label).unwrap();
-        Statement(unsafe { sys::zkp_statement_new(l.as_ptr()) })
+        let h = unsafe { sys::zkp_statement_new(l.as_ptr()) };
+        assert!(!h.is_null(), "zkp_statement_new returned NULL");
+        Statement(h)
     }
     pub fn allocate_scalar(&mut self, label: &'static [u8]) -> ScalarVar {
         let l = CString::new(label).unwrap();
@@ -149,6 +164,22 @@ impl Statement {
     }
     fn m(&self) -> usize { unsafe { sys::zkp_statement_num_secrets(self.0) as usize } }
     fn nc(&self) -> usize { unsafe { sys::zkp_statement_num_constraints(self.0) as usize } }
+    fn ni(&self) -> usize { unsafe { sys::zkp_statement_num_instance(self.0) as usize } }
+    fn ns(&self) -> usize { unsafe { sys::zkp_statement_num_common(self.0) as usize } }
+    /// The C side reads [ni][N][32], [ns][32], [N][m][32], [N][nc][32] straight from the slices: any other length would be an
+    /// out-of-bounds read from a safe function, so every length is checked against the statement's shape before the FFI call.
+    fn check_shapes(&self, n: usize, inst: usize, common: usize, per_proof: &[(&str, usize, usize)]) -> Result<(), Error> {
+        if inst != self.ni() * n || common != self.ns() {
+            return Err(Error::Shape("instance / common points do not match the statement and batch size"));
+        }
+        for (what, len, per) in per_proof {
+            if *len != n * per {
+                let _ = what;
+                return Err(Error::Shape("a per-proof array does not match the statement and batch size"));
+            }
+        }
+        Ok(())
+    }
 }
 impl Drop for Statement {
     fn drop(&mut self) {
@@ -168,6 +199,7 @@ pub struct Proofs {
 pub fn prove_batch(eng: &Engine, st: &Statement, transcripts: &mut [Transcript], secrets: &[Scalar], inst_points: &[CompressedRistretto],
                    common_points: &[CompressedRistretto]) -> Result<Proofs, Error> {
     let n = transcripts.len();
+    st.check_shapes(n, inst_points.len(), common_points.len(), &[("secrets", secrets.len(), st.m())])?;
     let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
     let sec: Vec<u8> = secrets.iter().flat_map(|s| s.as_bytes().iter().copied()).collect();
     let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
@@ -187,6 +219,7 @@ pub fn prove_batch(eng: &Engine, st: &Statement, transcripts: &mut [Transcript],
 pub fn verify_compact_batch(eng: &Engine, st: &Statement, transcripts: &mut [Transcript], inst_points: &[CompressedRistretto],
                             common_points: &[CompressedRistretto], challenges: &[u8], responses: &[u8]) -> Result<Vec<Result<(), Error>>, Error> {
     let n = transcripts.len();
+    st.check_shapes(n, inst_points.len(), common_points.len(), &[("challenges", challenges.len(), 32), ("responses", responses.len(), 32 * st.m())])?;
     let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
     let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
     let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
@@ -206,6 +239,8 @@ pub fn verify_compact_batch(eng: &Engine, st: &Statement, transcripts: &mut [Tra
 pub fn batch_verify(eng: &Engine, st: &Statement, transcripts: &mut [Transcript], inst_points: &[CompressedRistretto],
                     common_points: &[CompressedRistretto], commitments: &[u8], responses: &[u8]) -> Result<(), Error> {
     let n = (commitments.len() / 32).checked_div(st.nc()).unwrap_or(transcripts.len());
+    // (a transcript count different from n is the reference's BatchSizeMismatch, reported by the C side: batch_verifier.rs:72-74)
+    st.check_shapes(n, inst_points.len(), common_points.len(), &[("commitments", commitments.len(), 32 * st.nc()), ("responses", responses.len(), 32 * st.m())])?;
     let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
     let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
     let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();

@@ -59,7 +59,7 @@ VALU_PEAK = 34.5e12           # 4-cycle-class VALU lane-instructions / s (v_mad_
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
 LABEL = b"Benchmark"
 BASE = bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76")
-PMC_PATTERN = os.path.join("profiles", "r03_pmc_counters_cfg%s.json")      # one counter file per workload (tools/collect_profiles.sh)
+PMC_PATTERN = os.path.join("profiles", "r03_pmc_counters_cfg%s_k%d.json")   # one counter file per workload and batches-per-call (tools/collect_profiles.sh)
 # what the HIP-event timing kinds of zkp_ctx_last_timing are, per flow: (kernel names as rocprofv3 prints them, launches per call).
 # roofline.kernel is chosen among the GROUPS below by kernel name, summed across flows (k_transcript_run* = 3 launches per step).
 KERNELS = {
@@ -216,30 +216,24 @@ def pick_streams(steps):
     return min(range(12, 26), key=lambda s: ((-steps) % s, -s))
 
 
-CALL_SHAPES = {}       # filled from measurements: steps -> (batches per call, streams); see pick_call_shape
+MAX_BATCHES_PER_CALL = 50      # 204,800 CMZ proofs per call (workspace ~ 8 GB per stream)
 
 
 def pick_call_shape(steps, want_k=0, want_streams=0):
     """(K, S) for --config 2: K batches per call chain, S call chains in flight.  K must divide --steps (exactly --steps batches
-    are timed).  Wide calls fill the chip on their own, so few streams are needed; two to four of them overlap one call's
-    remaining narrow kernels (the K Horner quads, the inversion of the batched encoder) with the others' wide ones.
-    Defaults: the largest divisor of steps that is <= 16 and leaves at least 4 calls (<= 40 steps: at least 2 calls)."""
+    are timed).  Wide calls fill the chip on their own, so few streams are needed: four of them overlap one call's remaining
+    narrow kernels (the K Horner quads, the inversion of the batched encoder, table and transcript chains of the smaller calls)
+    with the others' wide ones.  Default: the largest divisor of steps that is <= 50 and leaves at least 4 calls, 4 streams --
+    measured (profiles/r03_ab_experiments.txt): 20 steps: 1 x 20 calls 3.9, 2 x 10 4.6, 4 x 5 5.6, 5 x 4 6.15, 10 x 2 5.9, 20 x 1
+    5.6 M proofs/s; 1000 steps: 5 x 4 streams 6.1, 10 x 4 6.5, 20 x 4 6.8, 25 x 8 6.8, 50 x 4 6.85, 50 x 2 6.7."""
     if want_k > 0:
         if steps % want_k:
             raise SystemExit("--batches-per-call must divide --steps (exactly --steps batches are timed)")
         k = want_k
-    elif steps in CALL_SHAPES:
-        k = CALL_SHAPES[steps][0]
     else:
-        min_calls = 2 if steps <= 40 else 4
-        k = max([d for d in range(1, 17) if steps % d == 0 and steps // d >= min_calls] or [1])
+        k = max([d for d in range(1, MAX_BATCHES_PER_CALL + 1) if steps % d == 0 and steps // d >= min(4, steps)] or [1])
     calls = steps // k
-    if want_streams > 0:
-        s = want_streams
-    elif steps in CALL_SHAPES and not want_k:
-        s = CALL_SHAPES[steps][1]
-    else:
-        s = pick_streams(steps) if k == 1 else min(4, calls)
+    s = want_streams if want_streams > 0 else (pick_streams(steps) if k == 1 and steps > 4 else 4)
     return k, max(1, min(s, calls))
 
 
@@ -583,7 +577,7 @@ def main():
     ap.add_argument("--no-multi-configs", action="store_true", help="--gpus > 1: skip the strong-scaling sub-records of BASELINE configs[3] / configs[4]")
     ap.add_argument("--multi-total4", type=int, default=1 << 22, help="--gpus > 1: total proofs of the configs[3] sub-record (2^22 CMZ proofs over the GPUs)")
     ap.add_argument("--multi-total5", type=int, default=1 << 18, help="--gpus > 1: total proofs of the configs[4] sub-record (2^18 W64 proofs over the GPUs)")
-    ap.add_argument("--pmc-json", default=None, help="rocprofv3 --pmc summary (tools/pmc_summary.py); default profiles/r03_pmc_counters_cfg<config>.json; "
+    ap.add_argument("--pmc-json", default=None, help="rocprofv3 --pmc summary (tools/pmc_summary.py); default profiles/r03_pmc_counters_cfg<config>_k<batches per call>.json; "
                                                      "used only if its source hash and workload shape match")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
                     help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
@@ -702,7 +696,7 @@ def main():
     # ---- PMC-derived fields: only from a counter file collected from exactly these sources and this call shape ---------------------------
     sha = source_sha256()
     pmc_source, step_valu = None, None
-    pmc_rel = args.pmc_json or (PMC_PATTERN % args.config)
+    pmc_rel = args.pmc_json or (PMC_PATTERN % (args.config, K))
     pmc_path = pmc_rel if os.path.isabs(pmc_rel) else os.path.join(ROOT, pmc_rel)
     if os.path.exists(pmc_path):
         try:

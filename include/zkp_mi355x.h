@@ -82,11 +82,13 @@ const char* zkp_version(void);
  *     (0: a quarter of the latency); UINT64_MAX = default: 1 in the asynchronous _dev entry points, 0 in the synchronous ones.
  *   ZKP_OPT_FUSE_TABLES_TRANSCRIPT: 1 = zkp_fused_prove_dev / _verify_compact_dev run their first transcript program in the same
  *     launch as the comb-table construction (both are long dependent chains on few wavefronts, independent of each other): a
- *     lone call of 4096 CMZ proofs takes 1.47 instead of 1.99 ms, while pipelined callers lose 7 % (the transcript
- *     wavefronts then carry the table builder's 212 registers instead of their own 118).  Default 0.
+ *     lone call of 4096 CMZ proofs takes 1.47 instead of 1.99 ms, while callers that pipeline 25 such calls lose 7 % (the
+ *     transcript wavefronts then carry the table builder's 212 registers instead of their own 118).  0 = never; UINT64_MAX =
+ *     default: in calls of 8,192 .. 65,535 proofs (a few batches per call, a few calls in flight: +5 % at 4 calls of 20,480
+ *     proofs; from 65,536 proofs on separate launches are 1.5 - 3 % faster).
  *   ZKP_OPT_TRANSCRIPT_LANES: lanes per proof in the Merlin transcript kernel of the fused flows.  2 = a lane pair per proof
  *     (each lane holds one 32-bit half of every STROBE word: half the latency), 1 = one lane per proof (23 % fewer
- *     instructions per Keccak-f), UINT64_MAX = default: 1 in asynchronous _dev calls of 8192 proofs or more, 2 otherwise. 
+ *     instructions per Keccak-f), UINT64_MAX = default: 1 in asynchronous _dev calls of 65,536 proofs or more, 2 otherwise.
  *   ZKP_OPT_CT_MASKED_SCANS: 1 = the safe mode of the constant-time schedule.  By default a ZKP_CT call reads fixed-base rows (and, in
  *     wide calls, comb rows) from LDS at an index derived from the secret digit, from banks that no other lane of the ds_read_b128
  *     service group touches -- constant time under the LDS service-group / bank model of the hardware guide, checked with PMC

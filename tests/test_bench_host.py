@@ -57,7 +57,8 @@ def test_call_shape_picker():
     """--config 2 packs K batches into one call chain: K divides --steps (exactly --steps batches are timed)"""
     for steps in (1, 4, 7, 20, 40, 100, 1000):
         k, s = bench.pick_call_shape(steps)
-        assert steps % k == 0 and 1 <= s <= steps // k and k <= 16
+        assert steps % k == 0 and 1 <= s <= steps // k and k <= bench.MAX_BATCHES_PER_CALL
+    assert bench.pick_call_shape(20) == (5, 4) and bench.pick_call_shape(1000) == (50, 4) and bench.pick_call_shape(4) == (1, 4)
     assert bench.pick_call_shape(20, want_k=5, want_streams=3) == (5, 3)
     assert bench.pick_call_shape(20, want_k=1) == (1, 20)
     with pytest.raises(SystemExit):

@@ -90,7 +90,7 @@ def test_bench_eight_rank_control_flow_on_one_gpu():
     env.pop("GPU_MAX_HW_QUEUES", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
-           "--batch", "256", "--streams", "2", "--no-flow-lines", "--multi-total4", "2048", "--multi-total5", "1024"]
+           "--batch", "256", "--batches-per-call", "2", "--streams", "2", "--no-flow-lines", "--multi-total4", "2048", "--multi-total5", "1024"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

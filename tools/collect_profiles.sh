@@ -26,6 +26,8 @@ print("%-46s %6s %12s %12s %12s %8s" % ("kernel", "calls", "avg_us", "min_us", "
 for r in rows:
     print("%-46s %6s %12.1f %12.1f %12.1f %8s" % (r["Name"].split("(")[0].replace("void ", "")[:46], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
 PY
-python tools/pmc_summary.py $O/${TAG}_pmc_counters_cfg${CFG}.json $O/${S}_kt.log $O/${S}_prof/fetch_counter_collection.csv $O/${S}_prof/write_counter_collection.csv $O/${S}_prof/sq_counter_collection.csv $O/${S}_prof/sq2_counter_collection.csv > $O/${TAG}_pmc_counters_cfg${CFG}.txt
+KPC=$(python -c "import json,sys; print(json.loads([l for l in open('$O/${S}_kt.log').read().splitlines() if l.startswith('{')][-1])['config']['batches_per_call'])")
+python tools/pmc_summary.py $O/${TAG}_pmc_counters_cfg${CFG}_k${KPC}.json $O/${S}_kt.log $O/${S}_prof/fetch_counter_collection.csv $O/${S}_prof/write_counter_collection.csv $O/${S}_prof/sq_counter_collection.csv $O/${S}_prof/sq2_counter_collection.csv > $O/${TAG}_pmc_counters_cfg${CFG}_k${KPC}.txt
+mv $O/${S}_kernel_stats.txt $O/${TAG}_kernel_stats_cfg${CFG}_k${KPC}.txt
 rm -rf $O/${S}_prof
-head -14 $O/${S}_kernel_stats.txt; grep -E "k_terms|_step_totals|k_pip_prep|k_pip_bucket_part" $O/${TAG}_pmc_counters_cfg${CFG}.txt | cut -c1-300
+head -14 $O/${TAG}_kernel_stats_cfg${CFG}_k${KPC}.txt; grep -E "k_terms|_step_totals|k_pip_prep|k_pip_bucket_part" $O/${TAG}_pmc_counters_cfg${CFG}_k${KPC}.txt | cut -c1-300

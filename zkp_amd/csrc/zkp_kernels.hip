@@ -1043,7 +1043,7 @@ struct zkp_ctx {
            uint8_t* ts = nullptr; uint32_t* saved = nullptr; uint32_t* failed = nullptr; uint32_t tail = 0; } pending_tr;
   int debug_dummy_launches = 0;      // ZKP_TESTOPT_DUMMY_LAUNCHES (test-hook builds only): empty kernels added to every prove call
   bool stmt_classify = true;         // the fused flows' one-launch term classifier (ZKP_TESTOPT_GENERIC_CLASSIFIER of test-hook builds turns it off)
-  bool fuse_tables_transcript = false;   // ZKP_OPT_FUSE_TABLES_TRANSCRIPT
+  int fuse_tables_transcript = -1;       // ZKP_OPT_FUSE_TABLES_TRANSCRIPT: -1 = asynchronous _dev calls of kWideCallProofs .. kVeryWideCallProofs proofs, 0 = never, 1 = always
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
   bool each_straus = true;           // ZKP_OPT_EACH_STRAUS: verify_batchable's per-proof MSMs as one Straus walk per proof (0: one ladder per operand)
@@ -1060,6 +1060,12 @@ struct zkp_ctx {
   // proof) lengthen a call's narrow kernels; they pay once a single call fills the chip.  Measured on CMZ batches
   // (profiles/r02_ab_experiments.txt): 4096 proofs (127 k terms) -1 % / 0 %, 16384 proofs (508 k terms) +7 % / +2.5 %.
   static constexpr size_t kWideCallTerms = 250000, kWideCallProofs = 8192;
+  // Round 3: callers hand over several batches per call and keep only a few calls in flight.  Between 8,192 and 65,536 proofs a call's
+  // transcript and table kernels are still a few hundred wavefronts of long dependent chains: there the lane-pair transcript (half the
+  // latency) running inside the comb tables' launch wins (20 steps of 4,096 proofs as 4 calls of 5 batches: 5.7 -> 6.15 M proofs/s;
+  // 1000 steps, 10 batches per call: +1 %); from 65,536 proofs on every kernel fills the chip and the instruction-saving forms win
+  // (one transcript lane per proof, separate launches: fusing costs 1.5 - 3 % at 20 - 50 batches per call).  profiles/r03_ab_experiments.txt
+  static constexpr size_t kVeryWideCallProofs = 65536;
   uint32_t ct_comb_min(bool throughput, size_t n_terms) const {
     return ct_single_use_tables < 0 ? (throughput && n_terms >= kWideCallTerms ? 2u : 1u) : (ct_single_use_tables ? 1u : 2u);
   }
@@ -1590,7 +1596,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
       return ZKP_OK;
     }
 #endif
-    case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value != 0; return ZKP_OK;
+    case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;

@@ -663,9 +663,12 @@ def main():
     call_n = n * K
     if args.config in ("2", "4share") and call_n * 31 >= 250000:      # a call that fills the chip on its own: ladder for Q, grouped comb walk
         names[("prove", "terms")] = ("k_terms_split<true, 16, true>", 1)
-    if call_n >= 8192:                                                 # ... and one transcript lane per proof
+    if call_n >= 65536:                                                # ... and one transcript lane per proof
         names[("prove", "transcript")] = ("k_transcript_run1", 2)
         names[("batch_verify", "transcript")] = ("k_transcript_run1", 1)
+    elif call_n >= 8192 and args.config != "5share":                   # mid-size calls: transcript program A rides in the comb tables' launch
+        names[("prove", "tables")] = ("k_tables_transcript<16> (comb tables + transcript program A)", 1)
+        names[("prove", "transcript")] = ("k_transcript_run", 1)
     if args.config == "5share":                 # every point of the wide statement is a common generator: fixed-base blocks only, no ladder blocks
         names[("prove", "terms")] = ("k_terms_split<true, T, false> (fixed-base blocks only)", 1)
     groups = {}
@@ -706,6 +709,7 @@ def main():
                 pmc_source = "%s: rocprofv3 --pmc passes of `python bench.py --config %s --steps %s` at kernel-source sha256 %s (tools/collect_profiles.sh)" % (
                     pmc_rel, args.config, shape.get("steps"), sha[:12])
                 pmc_prefix = {"k_terms_split": "k_terms_split<true", "k_comb_tables_lane": "zkp::k_comb_tables_lane<16", "k_transcript_run1": "zkp::k_transcript_run1",
+                              "k_tables_transcript": "zkp::k_tables_transcript<16",
                               "k_transcript_run": "zkp::k_transcript_run", "k_pip_prepare": "k_pip_prepare<", "k_pip_vmap": "k_pip_bucket_part",
                               "k_encode_prepare": "k_encode_prepare"}
                 key = next((v for k_, v in sorted(pmc_prefix.items(), key=lambda kv: -len(kv[0])) if dom["kernels"].startswith(k_)), None)

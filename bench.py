@@ -693,6 +693,9 @@ def main():
                                       % (dom["kernels"], dom["launches_per_call"], "" if dom["launches_per_call"] == 1 else "es", K, "" if K == 1 else "es", 100 * dom["share"]),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": achieved * 1e9 * dom["avg_launch_ms"] * 1e-3, "launch_ms": dom["avg_launch_ms"],
+            "launch_ms_note": "HIP events on the engine's stream around the launch, one call chain in flight (the kernel alone on the chip): rocprofv3's average for the same "
+                              "shape with ONE stream agrees (profiles/r03_kernel_stats_cfg2_k5_one_stream.txt); in the timed loop four chains share the chip and "
+                              "a launch takes correspondingly longer (profiles/r03_kernel_stats_cfg2_k<K>.txt: average over lone and overlapped launches)",
             "note": "integer-VALU bound by construction (SURVEY.md 8(d)): algorithmic bytes = 64 B per (scalar, point) term + 32 B per output, "
                     "so the HBM fraction of ANY kernel of this path is ~1e-3; the binding roofline is step_valu / *_valu_issue_frac (PMC)",
             "by_kernel": by_kernel}

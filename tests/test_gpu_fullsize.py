@@ -311,3 +311,48 @@ def test_config5_share_complete_flows_w64_32768(eng):
     ts = np.repeat(t0[None], n, axis=0)
     with pytest.raises(T.VerificationFailure):
         T.batch_verify(eng, st, ts, inst, gens, coms, resp)
+
+
+def test_config2_bench_shape_many_batches_per_call(eng):
+    """The shape bench.py times since round 3: K = 8 batches of 4096 CMZ proofs (BASELINE configs[1]) proven by ONE wide call and
+    verified by ONE zkp_fused_batch_verify_many call.  Every batch verifies; the coefficient vector of a batch equals that of a
+    call of its own; tampering with proofs of two batches fails exactly those two; sampled proofs equal the oracle's."""
+    from zkp_amd.engine import FusedStatement
+    from zkp_amd import toolbox as T
+    import bench
+    K, n_each = 8, 4096
+    n = K * n_each
+    rng = np.random.default_rng(2026)
+    st3 = bench.cmz_statement()
+    secrets, inst, common = bench.make_instance(eng, st3, n, rng)
+    mod = T.cmz_module(10)
+    st = mod.statement
+    fst = FusedStatement(b"CMZ cred show n=10", *st3)
+    label = b"Benchmark"
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    eng.prepare_fixed_points(common)
+    ts = np.stack([T.Transcript(label).state] * n)
+    chal, resp, coms = T.prove_batch(eng, st, ts, secrets, inst, common, entropy)
+    cst = C.Statement.from_model(M.cmz_statement(10))
+    for j in (0, n_each - 1, n_each, 5 * n_each + 17, n - 1):
+        ec, er, ek, _ = C.prove(cst, label, secrets[j], np.concatenate([inst[:, j], common]), entropy[j].tobytes())
+        assert chal[j].tobytes() == ec.tobytes() and (resp[j] == er).all() and (coms[j] == ek).all(), j
+    w = rng.integers(0, 256, size=(st.nc, n, 16), dtype=np.uint8)
+    ts = np.stack([T.Transcript(label).state] * n)
+    v, co = eng.fused_batch_verify_many(fst, K, ts, inst, common, coms, resp, w, want_coeffs=True)
+    assert not v.any()
+    b = 3
+    sl = slice(b * n_each, (b + 1) * n_each)
+    ts1 = np.stack([T.Transcript(label).state] * n_each)
+    ok, co1 = T.batch_verify_coeffs(eng, st, ts1, np.ascontiguousarray(inst[:, sl]), common, coms[sl], resp[sl], np.ascontiguousarray(w[:, sl]))
+    assert ok
+    rows = st.ni + st.nc
+    assert (co[b * st.ns:(b + 1) * st.ns] == co1[:st.ns]).all()
+    assert (co[K * st.ns:].reshape(rows, n, 32)[:, sl] == co1[st.ns:].reshape(rows, n_each, 32)).all()
+    assert C.batch_verify(cst, label, n_each, np.ascontiguousarray(inst[:, sl]), common, coms[sl], resp[sl], np.ascontiguousarray(w[:, sl])) == 0
+    bad = resp.copy()
+    bad[1 * n_each + 5, 0, 0] ^= 1
+    bad[6 * n_each + 4000, 20, 31] ^= 8
+    ts = np.stack([T.Transcript(label).state] * n)
+    v = T.batch_verify_many(eng, st, K, ts, inst, common, coms, bad, w)
+    assert v.tolist() == [0, 1, 0, 0, 0, 0, 1, 0]

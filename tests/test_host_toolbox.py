@@ -219,6 +219,57 @@ def test_batch_verify_build_matches_oracle_macro_order():
         T.batch_verify_build(mod.statement, ts, inst, common, bad, resps, w16)
     with pytest.raises(T.BatchSizeMismatch):
         T.batch_verify_build(mod.statement, ts[:-1], inst, common, coms, resps, w16)
+    # a response that is not a canonical scalar (s + l: same residue, bytes serde would refuse, proofs.rs:27-32): the batch fails on
+    # the host before any arithmetic, and in the oracle; l - 1 and 0 are canonical
+    big = resps.copy()
+    big[4, 0] = np.frombuffer((int.from_bytes(resps[4, 0].tobytes(), "little") + M.L).to_bytes(32, "little"), np.uint8)
+    ts = np.stack([T.Transcript(label).state for _ in range(n)])
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify_build(mod.statement, ts, inst, common, coms, big, w16)
+    assert C.batch_verify(cst, label, n, inst, common, coms, big, w16) == 1
+    edge = resps.copy()
+    edge[0, 0] = np.frombuffer((M.L - 1).to_bytes(32, "little"), np.uint8)
+    edge[1, 0] = 0
+    ts = np.stack([T.Transcript(label).state for _ in range(n)])
+    T.batch_verify_build(mod.statement, ts, inst, common, coms, edge, w16)       # builds (the MSM would then fail: wrong responses)
+    exactly_l = resps.copy()
+    exactly_l[2, 0] = np.frombuffer(M.L.to_bytes(32, "little"), np.uint8)
+    ts = np.stack([T.Transcript(label).state for _ in range(n)])
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify_build(mod.statement, ts, inst, common, coms, exactly_l, w16)
+
+
+def test_transcript_lengths_beyond_u32_are_an_error_not_a_truncated_prefix():
+    """merlin frames lengths as u32 and asserts that they fit (tests/sig_and_vrf_example.rs:224-241 is the ignored > 4 GiB case): the C
+    ABI returns ZKP_TB_TOO_LONG before it reads a byte and leaves the transcript untouched."""
+    lib = T.lib()
+    lib.zkp_transcript_append_message.restype = ctypes.c_int
+    lib.zkp_transcript_challenge_bytes.restype = ctypes.c_int
+    t = T.Transcript(b"len")
+    before = t.state.copy()
+    small = ctypes.create_string_buffer(16)
+    for n in (1 << 32, (1 << 32) + 5, 1 << 40):
+        assert lib.zkp_transcript_append_message(t.state.ctypes.data_as(ctypes.c_void_p), b"msg", small, ctypes.c_size_t(n)) == -14
+        assert lib.zkp_transcript_challenge_bytes(t.state.ctypes.data_as(ctypes.c_void_p), b"out", small, ctypes.c_size_t(n)) == -14
+        assert (t.state == before).all()
+    assert lib.zkp_transcript_append_message(t.state.ctypes.data_as(ctypes.c_void_p), b"msg", small, ctypes.c_size_t(16)) == 0
+    assert not (t.state == before).all()
+
+
+def test_oracle_verifiers_apply_the_canonical_scalar_rule():
+    """what serde does in front of the reference's verifiers (proofs.rs:14-32): a challenge / response >= l never verifies"""
+    rng = random.Random(10)
+    mst = M.dleq_statement()
+    cst = C.Statement.from_model(mst)
+    secs, encs = _instances(mst, rng, 1, "dleq")
+    pts = arr([encs[0][p] for p in cst.points])
+    chal, resp, coms, _ = C.prove(cst, b"canon", arr([sc(secs[0]["x"])]), pts, bytes(32))
+    w = np.arange(32, dtype=np.uint8).reshape(2, 16)
+    assert C.verify_compact(cst, b"canon", pts, chal, resp) == 0 and C.verify_batchable(cst, b"canon", pts, coms, resp, w) == 0
+    plus_l = lambda a: np.frombuffer((int.from_bytes(a.tobytes(), "little") + M.L).to_bytes(32, "little"), np.uint8)
+    assert C.verify_compact(cst, b"canon", pts, plus_l(chal), resp) == 1
+    assert C.verify_compact(cst, b"canon", pts, chal, plus_l(resp[0]).reshape(1, 32)) == 1
+    assert C.verify_batchable(cst, b"canon", pts, coms, plus_l(resp[0]).reshape(1, 32), w) == 1
 
 
 def test_batch_verify_build_constraint_api_order():

@@ -18,6 +18,8 @@
  * prover.rs:82).  This library is pinned by tests/test_oracle_c.py against the RFC 9496 vectors,
  * Merlin's known-answer test, the big-integer model oracle/model.py (itself cross-checked against
  * libsodium 1.0.18) and the committed fixtures in tests/golden/.
+ * What would pin it against the crate is staged: tests/golden/interop/ + rust/interop/ (the real crate verifies this side's proofs and emits
+ * its own for tests/test_oracle_interop.py / tests/test_gpu_interop.py); until somebody runs it with cargo the status above stands.
  */
 #ifndef ZKP_ORACLE_H
 #define ZKP_ORACLE_H

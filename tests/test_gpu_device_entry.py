@@ -1,6 +1,8 @@
 """The device-pointer (_dev) entry points of include/zkp_mi355x.h -- asynchronous, operands resident in HBM, what
 bench.py measures -- against the host-pointer entry points and the oracle on the same inputs, byte for byte.
 torch is used for nothing but device buffers."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -215,8 +217,48 @@ def test_hip_graph_replay_equals_direct_calls(eng):
     chal_h, resp_h, coms_h = T.prove_batch(eng, mod.statement, ts_h, secrets, inst, common, entropy2)
     assert (got[0] == chal_h).all() and (got[1] == resp_h).all() and (got[2] == coms_h).all()
     assert not (got[0] == want[0].cpu().numpy()).all()
-    g.close()
+    # ---- lifetime rules (zkp_mi355x.h, HIP graphs) -------------------------------------------------------------------------------
+    # a failing call inside a capture: the context manager aborts the capture and the context stays usable
+    import bench
+    from zkp_amd.engine import FusedStatement
+    other = FusedStatement(b"another statement", *bench.dleq_macro_statement())
+    with pytest.raises(ZkpError):
+        with e.capture():
+            with torch.cuda.stream(stream):
+                e.fused_prove_dev(other, n, pos, ts.data_ptr(), d_sec.data_ptr(), d_tbl.data_ptr(), d_ent.data_ptr(), chal.data_ptr(), resp.data_ptr(),
+                                  coms.data_ptr(), st.data_ptr())            # no plan for this statement yet: refused inside a capture
+    e.capture_abort()                                                         # (no capture in progress any more: a no-op)
+    chain()
+    e.synchronize(); torch.cuda.synchronize()
+    assert int(bst.abs().sum().item()) == 0 and not bool(out.any().item())
+    g.launch()                                                                # the old graph is still valid: nothing it points into has moved
+    e.synchronize()
+    # a graph belongs to its context
+    e2 = Engine(0)
+    assert e._lib.zkp_graph_launch(g._h, e2._h) == -2 and b"context it was captured on" in e._lib.zkp_last_error()     # ZKP_ERR_ARG
+    e2.close()
+    # a larger call on the same context makes the workspace grow (it is reallocated): the graph is stale and refuses to replay
+    n_big = 4 * n
+    mod2, secrets2, inst2, common2 = _cmz_batch(n_big, 9)
+    ts_big = np.stack([t0] * n_big)
+    T.set_fused_min_batch(0)
+    try:
+        T.prove_batch(e, mod2.statement, ts_big, secrets2, inst2, common2, rng.integers(0, 256, size=(n_big, 32), dtype=np.uint8))
+    finally:
+        T.set_fused_min_batch(32)
+    with pytest.raises(ZkpError, match="stale graph"):
+        g.launch()
+    with e.capture() as cap:                                                  # capture again: fine
+        chain()
+    cap.graph.launch()
+    e.synchronize(); torch.cuda.synchronize()
+    assert int(bst.abs().sum().item()) == 0 and not bool(out.any().item())
+    # a graph must not outlive its context
+    stale, lib, h_old = cap.graph, e._lib, e._h.value
     e.close()
+    assert lib.zkp_graph_launch(stale._h, ctypes.c_void_p(h_old)) == -2 and b"destroyed" in lib.zkp_last_error()
+    g.close()
+    stale.close()
 
 
 @pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1), (0, "masked"), (1, "masked")])

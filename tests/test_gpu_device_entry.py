@@ -357,6 +357,51 @@ def test_grouped_comb_walk_with_mixed_group_sizes(single_use_tables):
     e.close()
 
 
+@pytest.mark.parametrize("opts", [{}, {8: 0}, {4: 1}])
+def test_mid_size_dev_call_variants_give_the_same_proofs(eng, opts):
+    """Asynchronous _dev calls of 8,192 .. 65,535 proofs run the lane-pair transcript inside the comb tables' launch by default
+    (k_tables_transcript; round-3 wide-call rule).  Default, ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 0 and one transcript lane per proof
+    must all give the bytes of the synchronous host-pointer flow, and the proofs batch-verify in two batches of one pass."""
+    torch = _torch()
+    from zkp_amd.engine import Engine
+    n = 8256                                                             # 129 x 64 proofs
+    mod, secrets, inst, common = _cmz_batch(64, 35)
+    reps = n // 64
+    secrets = np.ascontiguousarray(np.tile(secrets, (reps, 1, 1)))
+    inst = np.ascontiguousarray(np.tile(inst, (1, reps, 1)))
+    entropy = np.random.default_rng(36).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    t0 = T.Transcript(b"mid-size").state
+    pos = int(t0[200]) | int(t0[201]) << 8 | int(t0[202]) << 16
+    ts = np.stack([t0] * n)
+    chal, resp, coms = T.prove_batch(eng, mod.statement, ts, secrets, inst, common, entropy)      # synchronous reference
+    e = Engine(0)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    e.prepare_fixed_points(common)
+    fst = _cmz_fused_statement()
+    z = lambda *s: torch.zeros(s, dtype=torch.uint8, device="cuda:0")
+    d_ts, d_sec, d_tbl, d_ent = _dev(np.stack([t0] * n)), _dev(secrets), _dev(np.concatenate([common, inst.reshape(-1, 32)])), _dev(entropy)
+    d_chal, d_resp, d_coms, d_st = z(n, 32), z(n, 21, 32), z(n, 11, 32), z(11 * n)
+    torch.cuda.synchronize()
+    e.fused_prove_dev(fst, n, pos, d_ts.data_ptr(), d_sec.data_ptr(), d_tbl.data_ptr(), d_ent.data_ptr(), d_chal.data_ptr(), d_resp.data_ptr(),
+                      d_coms.data_ptr(), d_st.data_ptr())
+    e.synchronize()
+    assert not d_st.cpu().numpy().any()
+    assert (d_chal.cpu().numpy() == chal).all() and (d_resp.cpu().numpy() == resp).all() and (d_coms.cpu().numpy() == coms).all()
+    assert (d_ts.cpu().numpy()[:, :203] == ts[:, :203]).all()
+    w = np.random.default_rng(37).integers(0, 256, size=(11, n, 16), dtype=np.uint8)
+    d_ts2, d_w = _dev(np.stack([t0] * n)), _dev(w)
+    d_pts = z(12 + 24 * n, 32)
+    d_pts[: 12 + 13 * n] = d_tbl
+    d_out, d_bst = torch.ones((2, 32), dtype=torch.uint8, device="cuda:0"), torch.ones((2, 2), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    e.fused_batch_verify_many_dev(fst, 2, n // 2, pos, d_ts2.data_ptr(), d_pts.data_ptr(), d_coms.data_ptr(), d_resp.data_ptr(), d_w.data_ptr(),
+                                  d_out.data_ptr(), d_bst.data_ptr())
+    e.synchronize()
+    assert not d_out.cpu().numpy().any() and not d_bst.cpu().numpy().any()
+    e.close()
+
+
 def test_masked_scan_safe_mode_gives_the_same_proofs(eng):
     """ZKP_OPT_CT_MASKED_SCANS through the fused prover at the size where the wide-call variants (grouped walk, ladder) switch on
     by themselves: byte-identical proofs, and the batch of them verifies."""

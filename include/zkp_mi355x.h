@@ -6,9 +6,12 @@
  * `-sys` binding a maintainer would add is shown in INTEGRATION.md.
  *
  * Conventions
- *   scalar  : 32 bytes, little-endian integer.  Any 256-bit value is accepted and is used as an
- *             integer multiplier (so non-canonical scalars give the same group element dalek's
- *             `Scalar` would after reduction mod l).
+ *   scalar  : 32 bytes, little-endian integer.  The MSM entry points (1), (2), (2b) accept any 256-bit value and use
+ *             it as an integer multiplier (so non-canonical scalars give the same group element dalek's
+ *             `Scalar` would after reduction mod l).  The fused VERIFY flows (2c) take proofs, and there the
+ *             reference's rule applies: a response >= l (which serde would refuse to deserialise into a
+ *             `Scalar`, proofs.rs:14-32) is a verification failure for that proof / batch, and a compact proof's
+ *             challenge is compared byte for byte with the recomputed canonical one (verifier.rs:115).
  *   point   : 32 bytes, ristretto255 encoding (RFC 9496).  Decoding rejects exactly what
  *             `CompressedRistretto::decompress` rejects (non-canonical, negative s, non-square,
  *             negative t, y == 0).

@@ -63,6 +63,12 @@ def main():
         transcripts = np.stack([T.Transcript(b"DLEQTest").state] * n)
         each = T.verify_batchable_each(eng, st, transcripts, inst, G, coms, resp)
         print("batch with one corrupted proof rejected; per-proof check points at proof", int(np.nonzero(each)[0][0]))
+    # many batches in one pass (zkp_batch_verify_many): the same proofs as 4 consecutive batches, each with a verdict of its own -- what a
+    # service that would otherwise call BatchVerifier::verify_batchable four times hands to the GPU in one call
+    if n % 4 == 0:
+        transcripts = np.stack([T.Transcript(b"DLEQTest").state] * n)
+        verdicts = T.batch_verify_many(eng, st, 4, transcripts, inst, G, coms, resp)
+        print("4 batches of %d proofs in one pass: verdicts %s (0 = ok; the corrupted proof %d sits in batch %d)" % (n // 4, verdicts.tolist(), n // 2, (n // 2) // (n // 4)))
     eng.close()
 
 

@@ -103,9 +103,13 @@ const char* zkp_version(void);
  *     UINT64_MAX = default: one Straus walk per proof -- 256 shared doublings and one table addition per operand and window, with 8
  *     lanes per proof at 4,096 proofs down to 1 from 65,536 proofs on; 1 .. 8 = that many lanes per proof; 0 = the round-2 schedule
  *     (every single-use point on a ladder of its own: 256 doublings per operand).
+ *   ZKP_OPT_LADDER_INTERLEAVE: 1 = the term kernel's ladder blocks (single-use points: CMZ's Q) are spread over the first half of its grid
+ *     instead of all starting first (fewer per-lane ladder tables in flight together: -20 % HBM fetch in that kernel); 0 = all first;
+     UINT64_MAX = default: spread when the launch has 256 or more ladder blocks (65,536 single-use points), where it also is ~1 % faster --
+     in a lone smaller launch the later start of the last ladder block lengthens the kernel (profiles/r03_ab_experiments.txt, block l).
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
-       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10 };
+       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~35 short kernels (75 in round 1); enqueueing them one by one costs the host ~0.1 ms per

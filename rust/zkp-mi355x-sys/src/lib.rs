@@ -36,6 +36,9 @@ pub const ZKP_OPT_DEV_OVERLAP: c_int = 5;
 pub const ZKP_OPT_GROUPED_COMB: c_int = 6;
 pub const ZKP_OPT_TABLES_LANE: c_int = 7;
 pub const ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c_int = 8;
+pub const ZKP_OPT_CT_MASKED_SCANS: c_int = 9;
+pub const ZKP_OPT_EACH_STRAUS: c_int = 10;
+pub const ZKP_OPT_LADDER_INTERLEAVE: c_int = 11;
 
 pub const ZKP_TB_OK: c_int = 0;
 pub const ZKP_TB_VERIFICATION_FAILURE: c_int = 1; // ProofError::VerificationFailure (errors.rs:6)

@@ -261,7 +261,7 @@ def test_hip_graph_replay_equals_direct_calls(eng):
     stale.close()
 
 
-@pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1), (0, "masked"), (1, "masked")])
+@pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1), (0, "masked"), (1, "masked"), (0, "interleave")])
 def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_tables, grouped):
     """ZKP_OPT_CT_SINGLE_USE_TABLES: a constant-time call serves a point that only one term multiplies either through a comb
     table (default when the call has shared points) or through the masked radix-16 ladder; both must give the oracle's bytes.
@@ -277,6 +277,11 @@ def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_ta
         # ZKP_OPT_CT_MASKED_SCANS: the safe mode -- every table look-up of the constant-time call is a masked scan over the whole
         # row (fixed-base rows too), and the grouped walk stays off even when asked for
         e.set_option(9, 1)
+        e.set_option(6, 1)
+    elif grouped == "interleave":
+        # ZKP_OPT_LADDER_INTERLEAVE: the ladder blocks spread over the front of the term kernel's grid (the default of launches with
+        # 65,536 single-use points or more), forced here on grids of a few blocks: strides 0 (too few blocks), 2 and more
+        e.set_option(11, 1)
         e.set_option(6, 1)
     else:
         e.set_option(6, grouped)
@@ -357,11 +362,12 @@ def test_grouped_comb_walk_with_mixed_group_sizes(single_use_tables):
     e.close()
 
 
-@pytest.mark.parametrize("opts", [{}, {8: 0}, {4: 1}])
+@pytest.mark.parametrize("opts", [{}, {8: 0}, {4: 1}, {11: 1}])
 def test_mid_size_dev_call_variants_give_the_same_proofs(eng, opts):
     """Asynchronous _dev calls of 8,192 .. 65,535 proofs run the lane-pair transcript inside the comb tables' launch by default
     (k_tables_transcript; round-3 wide-call rule).  Default, ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 0 and one transcript lane per proof
-    must all give the bytes of the synchronous host-pointer flow, and the proofs batch-verify in two batches of one pass."""
+    must all give the bytes of the synchronous host-pointer flow, and the proofs batch-verify in two batches of one pass.
+    {11: 1} = ZKP_OPT_LADDER_INTERLEAVE forced on (33 ladder blocks spread over the first half of the term kernel's grid)."""
     torch = _torch()
     from zkp_amd.engine import Engine
     n = 8256                                                             # 129 x 64 proofs

@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
               const uint32_t* __restrict__ blk_start, const uint32_t* __restrict__ list, const dev_niels* __restrict__ tables,
-              const dev_affine* __restrict__ pts, dev_ext* __restrict__ ladder_rw, uint32_t max_ladder, dev_ext* __restrict__ partial) {
+              const dev_affine* __restrict__ pts, dev_ext* __restrict__ ladder_rw, uint32_t max_ladder, dev_ext* __restrict__ partial,
+              uint32_t ladder_stride) {
   // A block of fixed-base terms serves ONE table; its rows pass through LDS one window at a time, in 16 copies, so that every
   // lane reads the entry its digit names from banks of its own (hot_tables.h): no masked scan, no bank conflict, the same
   // LDS cycles for every scalar.
@@ -169,10 +170,20 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
   const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
   const uint32_t group_blocks = (n_group + blockDim.x - 1) / blockDim.x;
+  // Logical block number (ladder blocks, comb blocks, grouped blocks, fixed-base blocks -- longest first).  ladder_stride > 1 spreads the
+  // ladder blocks over the front of the grid (ladder block i sits at position i * stride) instead of starting them all at once: a ladder
+  // lane scans its own 1.1 KB table 65 times, and only as many of those tables as are in flight together have to fit the L2s
+  // (one block in `stride` instead of every block of the first wave of the launch).  The mapping depends on the launch shape only.
+  uint32_t vb = blockIdx.x;
+  if (LADDER && ladder_stride > 1) {
+    const uint32_t q = blockIdx.x / ladder_stride, r = blockIdx.x - q * ladder_stride;
+    if (r == 0 && q < ladder_blocks) vb = q;
+    else vb = ladder_blocks + blockIdx.x - min((blockIdx.x + ladder_stride - 1) / ladder_stride, ladder_blocks);
+  }
   ZKP_WAVE_T0
-  if (LADDER && blockIdx.x < ladder_blocks) {
+  if (LADDER && vb < ladder_blocks) {
     if constexpr (LADDER) {
-      const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+      const uint32_t i = vb * blockDim.x + threadIdx.x;
       if (i < n_ladder && i < max_ladder) {                       // (max_ladder bounds n_ladder by construction)
         const uint32_t t = list[n_hot + n_comb + i];
         const uint32_t pi = pidx[t];                              // < n_points (out-of-range indices are classed with the comb terms)
@@ -180,8 +191,8 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
       }
     }
     ZKP_WAVE_T1(1);
-  } else if (blockIdx.x < ladder_blocks + comb_blocks) {
-    const uint32_t i = (blockIdx.x - ladder_blocks) * blockDim.x + threadIdx.x;
+  } else if (vb < ladder_blocks + comb_blocks) {
+    const uint32_t i = (vb - ladder_blocks) * blockDim.x + threadIdx.x;
     if (i < n_comb) {
       const uint32_t t = list[n_hot + i];
       const uint32_t pi = pidx[t];
@@ -191,12 +202,12 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
       }
     }
     ZKP_WAVE_T1(2);
-  } else if (blockIdx.x < ladder_blocks + comb_blocks + group_blocks) {
+  } else if (vb < ladder_blocks + comb_blocks + group_blocks) {
     if constexpr (CT && TEETH == 16)                              // terms of points with many uses, listed point by point: rows through LDS
-      comb_group_block((blockIdx.x - ladder_blocks - comb_blocks) * 256u, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
+      comb_group_block((vb - ladder_blocks - comb_blocks) * 256u, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
     ZKP_WAVE_T1(3);
   } else {
-    const uint32_t hb = blockIdx.x - ladder_blocks - comb_blocks - group_blocks;
+    const uint32_t hb = vb - ladder_blocks - comb_blocks - group_blocks;
     if (hb >= blk_start[HOT_SLOTS]) return;                       // (uniform in the block)
     uint32_t c = 0;
     while (blk_start[c + 1] <= hb) ++c;                           // class = table slot of this block
@@ -1046,6 +1057,9 @@ struct zkp_ctx {
   int fuse_tables_transcript = -1;       // ZKP_OPT_FUSE_TABLES_TRANSCRIPT: -1 = asynchronous _dev calls of kWideCallProofs .. kVeryWideCallProofs proofs, 0 = never, 1 = always
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
+  int ladder_interleave = -1;        // ZKP_OPT_LADDER_INTERLEAVE: the term kernel's ladder blocks spread over the front of its grid instead of all first
+                                     // (-1 = by size: from kInterleaveLadderBlocks ladder blocks up, where the later start of the last one no longer shows)
+  static constexpr uint32_t kInterleaveLadderBlocks = 256;
   bool each_straus = true;           // ZKP_OPT_EACH_STRAUS: verify_batchable's per-proof MSMs as one Straus walk per proof (0: one ladder per operand)
   uint32_t each_straus_lanes = 0;    //   ... with this many lanes per proof (0 = by batch size)
   bool ct_masked_scans = false;      // ZKP_OPT_CT_MASKED_SCANS: constant-time calls pick every table entry with masked scans (no secret-indexed LDS read)
@@ -1215,12 +1229,19 @@ template <bool CT, int TEETH, bool SCAN = false>
 void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
                         const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
                         const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part) {
+  // ladder blocks spread over the first half of the grid (ZKP_OPT_LADDER_INTERLEAVE), or all at the front
+  uint32_t stride = 0;
+  const uint32_t lb = (max_ladder + 255) / 256;
+  if (ladder && lb && (c->ladder_interleave < 0 ? lb >= zkp_ctx::kInterleaveLadderBlocks : c->ladder_interleave != 0)) {
+    stride = (grid.x / 2) / lb;
+    if (stride < 2) stride = 0;
+  }
   if (ladder)
     hipLaunchKernelGGL((k_terms_split<CT, TEETH, true, SCAN>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
-                       c->hot_tables, pts, ladder_rw, max_ladder, part);
+                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
   else
     hipLaunchKernelGGL((k_terms_split<CT, TEETH, false, SCAN>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
-                       c->hot_tables, pts, ladder_rw, max_ladder, part);
+                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
 }
 
 // phase: everything (default), or only the part that does not look at the scalars (decode, classification, comb tables:
@@ -1600,6 +1621,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;
+    case ZKP_OPT_LADDER_INTERLEAVE: c->ladder_interleave = value == ~0ull ? -1 : value != 0; return ZKP_OK;
     case ZKP_OPT_EACH_STRAUS:
       if (value != ~0ull && value > 8) return fail(ZKP_ERR_ARG, "ZKP_OPT_EACH_STRAUS: 0 (off), 1 .. 8 lanes per proof, or UINT64_MAX (default)");
       c->each_straus = value != 0;

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkp_mi355x.so")
 TESTHOOKS_LIB_PATH = os.path.join(_HERE, "libzkp_mi355x_testhooks.so")     # -DZKP_BUILD_TEST_HOOKS build (tests / A-B tools)
 ZKP_TESTOPT_DUMMY_LAUNCHES, ZKP_TESTOPT_GENERIC_CLASSIFIER, ZKP_TESTOPT_WAVE_CYCLES = 1001, 1002, 1003
-ZKP_OPT_CT_MASKED_SCANS = 9
+ZKP_OPT_CT_MASKED_SCANS, ZKP_OPT_EACH_STRAUS, ZKP_OPT_LADDER_INTERLEAVE = 9, 10, 11
 
 ZKP_VARTIME = 0
 ZKP_CT = 1

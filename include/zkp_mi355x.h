@@ -100,13 +100,15 @@ const char* zkp_version(void);
  *     kept with v_cndmask (fixed-base rows: 32 entries, comb / ladder rows: 8), and the grouped comb walk is off.  Same bytes out;
  *     about 1.6 x the instructions of the term kernel.  Default 0.
  *   ZKP_OPT_EACH_STRAUS: how zkp_fused_verify_batchable computes a proof's MSM over its points and commitments (verifier.rs:162-166).
- *     UINT64_MAX = default: one Straus walk per proof -- 256 shared doublings and one table addition per operand and window, with 8
- *     lanes per proof at 4,096 proofs down to 1 from 65,536 proofs on; 1 .. 8 = that many lanes per proof; 0 = the round-2 schedule
+ *     UINT64_MAX = default: one Straus walk per proof -- 256 shared doublings and one table addition per operand and window; below
+ *     65,536 proofs split over 32 lanes per proof by windows (each lane: two windows of every operand; one quad of lanes per proof then
+ *     joins the partial sums), from 65,536 proofs on one lane per proof.  0x200 + P (P = 1, 2, 4 .. 64) = P window parts per proof;
+ *     1 .. 8 = split by operands over that many lanes per proof (every lane runs the 256 doublings); 0 = the round-2 schedule
  *     (every single-use point on a ladder of its own: 256 doublings per operand).
  *   ZKP_OPT_LADDER_INTERLEAVE: 1 = the term kernel's ladder blocks (single-use points: CMZ's Q) are spread over the first half of its grid
  *     instead of all starting first (fewer per-lane ladder tables in flight together: -20 % HBM fetch in that kernel); 0 = all first;
-     UINT64_MAX = default: spread when the launch has 256 or more ladder blocks (65,536 single-use points), where it also is ~1 % faster --
-     in a lone smaller launch the later start of the last ladder block lengthens the kernel (profiles/r03_ab_experiments.txt, block l).
+ *     UINT64_MAX = default: spread when the launch has 256 or more ladder blocks (65,536 single-use points), where it also is ~1 % faster --
+ *     in a lone smaller launch the later start of the last ladder block lengthens the kernel (profiles/r03_ab_experiments.txt, block l).
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
        ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11 };

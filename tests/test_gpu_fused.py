@@ -578,7 +578,7 @@ def test_debug_transcript_env_lists_the_compiled_program():
 @pytest.mark.parametrize("n", [3, 300])
 def test_verify_batchable_straus_lane_counts_agree(n):
     """ZKP_OPT_EACH_STRAUS: verify_batchable's per-proof MSM (verifier.rs:162-166) as one Straus walk per proof with 1 .. 8 lanes
-    per proof, and the round-2 schedule (a ladder per operand, option 0): the same verdicts for valid proofs, tampered responses,
+    per proof (operand split) or split into 1 .. 64 window parts per proof (the default below 65,536 proofs), and the round-2 schedule (a ladder per operand, option 0): the same verdicts for valid proofs, tampered responses,
     wrong / identity / undecodable points and commitments, a non-canonical response; equal to the oracle's."""
     from zkp_amd.engine import Engine
     mod, secrets, inst, common = _cmz_batch(n, 91)
@@ -608,7 +608,7 @@ def test_verify_batchable_straus_lane_counts_agree(n):
         assert C.verify_batchable(cst, label, np.concatenate([inst[:, j], common]), coms[j], resp[j], w[j]) == want[j]
     T.set_fused_min_batch(0)
     try:
-        for opt in (2**64 - 1, 0, 1, 2, 3, 4, 8):
+        for opt in (2**64 - 1, 0, 1, 2, 3, 4, 8, 0x201, 0x204, 0x210, 0x240):       # 0x200 + P: the walk split into P window parts per proof (default: 32)
             e = Engine(0)
             e.set_option(10, opt)
             ts = _fresh(label, n)

@@ -243,9 +243,11 @@ k_each_finish(uint32_t N, uint32_t m, const uint8_t* __restrict__ out, const uin
 //     acc = 16 acc ; acc += d_i * P_i  for every operand,   64 windows            256 doublings + K x ~60 additions per MSM
 // over per-point tables {1 P .. 8 P} (signed radix-16 digits of the sign-folded coefficient: the -r weights of the commitment
 // operands are 128-bit after folding, their upper 32 windows add nothing).  Variable time (public data): zero digits are skipped.
-// L lanes share a proof (operand i goes to lane i mod L, each lane runs its own 256 doublings and the partial sums are added at the
-// end): a lone lane per proof is a 2,300-operation dependent chain and 4,096 proofs are 64 wavefronts on 1,024 SIMDs, so small
-// batches trade some of the shared doublings for parallelism (L = 8 at 4,096 proofs ... 1 from 65,536 on).
+// A lone lane per proof is a 2,300-operation dependent chain and 4,096 proofs are 64 wavefronts on 1,024 SIMDs, so below 65,536 proofs
+// a proof is split over lanes -- by WINDOWS (k_straus_each_win: 32 lanes of two windows each, all operands, 4 doublings per lane; a quad
+// per proof then joins the 32 partial sums with the 252 doublings once), which keeps the doublings shared.  The earlier split by
+// OPERANDS (k_straus_each: operand i on lane i mod L, every lane running its own 256 doublings; L = 1 is the lone lane) serves the
+// large batches and statements of more than 64 operands.
 // Tables: the walk is bound by its gathers (1,440 per CMZ proof; 1.6 GB of tables at 65,536 proofs, far beyond every cache), not by
 // arithmetic, so an entry is ONE 128-byte cache line: the cached form (Y + X, Y - X, 2 Z, 2 d T) with every coordinate carried down to
 // 256 bits and packed into 32 bytes (the 144-byte limb form straddles two or three lines: 8.96 -> 6.7 ms for the walk of 65,536 proofs).
@@ -396,7 +398,104 @@ k_straus_each(uint32_t N, uint32_t K, uint32_t L, uint32_t ns, uint32_t ni, uint
   }
   store_ext(spart + g, acc);
 }
-// lane per proof: sum of its L parts, decode status of its K operands, canonical encoding of the sum (verifier.rs:162-168)
+// The walk split by WINDOWS instead of by operands: part p of P adds, for ALL K operands of the proof, the digits of the 64 / P radix-16
+// windows [p 64/P, (p+1) 64/P) -- 4 (64/P - 1) doublings instead of 252 per part, so splitting a proof over many lanes no longer
+// multiplies the doublings -- and one quad per proof then joins the parts by Horner, sum_p 16^(p 64/P) S_p: the 252 doublings that no
+// schedule can avoid, once per proof, on four lanes (k_straus_combine_quad).  digits[N K][9]: the recoded coefficient (8 words of
+// signed radix-16 nibbles), word 8 = sign fold | carry out of bit 255 << 1 (k_straus_recode).  LDS: K words per lane.
+__global__ void __launch_bounds__(256)
+k_straus_recode(uint32_t NK, const uint8_t* __restrict__ scalars, uint32_t* __restrict__ digits) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= NK) return;
+  uint32_t sw[8], e[8], top;
+  load_vec<2>(sw, scalars + 32 * (size_t)g);
+  const uint32_t flip = sc_fold_sign(sw);
+  sc_add_pattern(e, top, sw, 0x88888888u);
+  uint32_t* d = digits + 9 * (size_t)g;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) d[w] = e[w];
+  d[8] = flip | (top << 1);
+}
+__global__ void __launch_bounds__(256, 2)
+k_straus_each_win(uint32_t N, uint32_t K, uint32_t P, uint32_t ns, uint32_t ni, uint32_t nc, const straus_entry* __restrict__ tab,
+                  const uint32_t* __restrict__ digits, dev_ext* __restrict__ spart) {
+  extern __shared__ uint32_t straus_lds[];
+  uint32_t* col = straus_lds + threadIdx.x;                            // the current digit word of operand i at col[256 i]
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * P) return;
+  const uint32_t j = g / P, p = g - j * P, np = ns + ni, Wp = 64u / P;
+  const uint32_t* dj = digits + 9 * (size_t)j * K;
+  auto table_of = [&](uint32_t i) -> const straus_entry* {
+    const size_t t = i < ns ? i : (i < np ? (size_t)ns + (size_t)(i - ns) * N + j : (size_t)ns + (size_t)ni * N + (size_t)j * nc + (i - np));
+    return tab + t * 8;
+  };
+  ge_p3 acc;
+  ge_identity(acc);
+  bool started = false;
+  uint64_t flipmask = 0;                                               // (K <= 64: straus_win_parts)
+  for (uint32_t i = 0; i < K; ++i) {
+    const uint32_t f = dj[9 * i + 8];
+    flipmask |= (uint64_t)(f & 1u) << i;
+    if ((f >> 1) && p == P - 1) {                                      // carry out of bit 255 (non-canonical inputs only): one more P above the top window
+      ge_cached q;
+      load_straus_entry(q, table_of(i));
+      ge_cached_cneg(q, f & 1u);
+      ge_add_cached(acc, acc, q);
+      started = true;
+    }
+  }
+  ge_cached qn;
+  uint32_t magn = 0, negn = 0;
+  auto fetch = [&](uint32_t i, int k) {
+    const uint32_t nib = (col[256 * i] >> (4 * k)) & 15u;
+    const uint32_t neg = (uint32_t)(nib < 8u);
+    magn = neg ? 8u - nib : nib - 8u;
+    negn = neg ^ (uint32_t)((flipmask >> i) & 1u);
+    if (magn) load_straus_entry(qn, table_of(i) + (magn - 1));
+  };
+  const int w_hi = (int)(Wp * (p + 1)) - 1, w_lo = (int)(Wp * p);
+#pragma unroll 1
+  for (int w = w_hi; w >= w_lo; --w) {
+    const int k = w & 7;
+    if (k == 7 || w == w_hi)
+      for (uint32_t i = 0; i < K; ++i) col[256 * i] = dj[9 * i + (w >> 3)];
+    fetch(0, k);
+    if (started) ge_double4(acc);
+#pragma unroll 1
+    for (uint32_t i = 0; i < K; ++i) {
+      ge_cached q = qn;
+      const uint32_t mag = magn, neg = negn;
+      if (i + 1 < K) fetch(i + 1, k);
+      if (mag) {
+        ge_cached_cneg(q, neg);
+        ge_add_cached(acc, acc, q);
+        started = true;
+      }
+    }
+  }
+  store_ext(spart + g, acc);
+}
+// quad per proof: out[j] = sum_p 16^(p Wp) spart[j P + p]
+__global__ void __launch_bounds__(256)
+k_straus_combine_quad(uint32_t N, uint32_t P, const dev_ext* __restrict__ spart, dev_ext* __restrict__ out) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, j = gt >> 2;
+  const int q = (int)(gt & 3u);
+  if (j >= N) return;
+  const dev_ext* s = spart + (size_t)j * P;
+  const uint32_t dbl = 4u * (64u / P);
+  qpt acc;
+  q_load_ext(acc, s + (P - 1), q);
+#pragma unroll 1
+  for (int p = (int)P - 2; p >= 0; --p) {
+#pragma unroll 1
+    for (uint32_t d = 0; d < dbl; ++d) q_double(acc, acc, q);
+    qpt t;
+    q_load_ext(t, s + p, q);
+    q_add(acc, acc, t, q);
+  }
+  q_store_ext(out + j, acc, q);
+}
+// lane per proof: sum of its L parts, decode status of its K operands, is the sum the identity (verifier.rs:162-168)
 __global__ void __launch_bounds__(256, 2)
 k_straus_finish(uint32_t N, uint32_t K, uint32_t L, const uint32_t* __restrict__ pidx, const dev_affine* __restrict__ pts, const dev_ext* __restrict__ spart,
                 uint8_t* __restrict__ out, uint8_t* __restrict__ status8) {
@@ -411,12 +510,12 @@ k_straus_finish(uint32_t N, uint32_t K, uint32_t L, const uint32_t* __restrict__
   }
   uint32_t bad = 0;
   for (uint32_t i = 0; i < K; ++i) bad |= pts[pidx[(size_t)j * K + i]].valid ^ 1u;
+  // the verdict needs is_identity() only (verifier.rs:166-168): a point is in the identity's coset iff X = 0 or Y = 0, which is when its
+  // canonical encoding is 32 zero bytes -- no inversion.  out = those zero bytes, or a non-zero marker (k_each_finish tests for zero).
   uint32_t w[8];
-  ristretto_encode(w, acc);
-  if (bad) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = 0;
-  }
+  for (int k = 0; k < 8; ++k) w[k] = 0;
+  if (!bad) w[0] = (fe_iszero(acc.X) | fe_iszero(acc.Y)) ^ 1u;
   store_vec<2>(out + 32 * (size_t)j, w);
   status8[j] = (uint8_t)bad;
 }
@@ -1114,6 +1213,16 @@ terms_cfg each_terms_cfg(const fused_plan& pl) {
 // The Straus path of verify_batchable (k_straus_each) and its workspace behind each_inter
 struct straus_inter { size_t pts, tab, digits, spart, end; };
 constexpr uint32_t kStrausMaxLanes = 8, kStrausMaxOpsPerLane = 60;      // (60 KB of dynamic LDS per block at most)
+// Window parts per proof (k_straus_each_win), 0 = the walk split by operands.  Measured (profiles/r03_ab_verify_batchable_each.txt): 32 parts
+// of two windows are the fastest split from 256 to 32,768 proofs (16 and 64 within 3 %); from 65,536 proofs on one lane per proof fills
+// the chip by itself and the joining pass only adds work.
+constexpr uint32_t kStrausWinParts = 32, kStrausWinMaxProofs = 65536;
+inline uint32_t straus_win_parts(const zkp_ctx* c, const fused_plan& pl) {
+  const uint32_t K = pl.s.np + pl.s.nc, N = pl.N;
+  if (K > 64 || c->each_straus_lanes) return 0;                          // (K: one bit per operand in the lane's sign mask, K KB of LDS per block)
+  if (c->each_straus_wins) return c->each_straus_wins;
+  return N < kStrausWinMaxProofs ? kStrausWinParts : 0;
+}
 inline uint32_t straus_lanes(const zkp_ctx* c, const fused_plan& pl) {
   const uint32_t K = pl.s.np + pl.s.nc, N = pl.N;
   uint32_t L = c->each_straus_lanes ? std::min<uint32_t>(c->each_straus_lanes, kStrausMaxLanes) : (N >= 65536 ? 1u : (N >= 32768 ? 2u : (N >= 16384 ? 4u : 8u)));
@@ -1124,7 +1233,7 @@ inline bool each_uses_straus(const zkp_ctx* c, const fused_plan& pl) {
   const uint64_t K = (uint64_t)pl.s.np + pl.s.nc;
   return c->each_straus && K >= 4 && (K + kStrausMaxLanes - 1) / kStrausMaxLanes <= kStrausMaxOpsPerLane;       // (tiny statements: nothing to share)
 }
-straus_inter straus_carve(const fused_plan& pl, size_t start) {
+straus_inter straus_carve(const zkp_ctx* c, const fused_plan& pl, size_t start) {
   const size_t N = pl.N, K = (size_t)pl.s.np + pl.s.nc, n_points = (size_t)pl.s.ns + (size_t)pl.s.ni * N + N * pl.s.nc;
   carve cv;
   cv.off = start;
@@ -1132,7 +1241,7 @@ straus_inter straus_carve(const fused_plan& pl, size_t start) {
   o.pts = cv.take(n_points * sizeof(dev_affine));
   o.tab = cv.take(n_points * 8 * sizeof(straus_entry) + 128);
   o.digits = cv.take(N * K * 9 * 4);
-  o.spart = cv.take(N * kStrausMaxLanes * sizeof(dev_ext));
+  o.spart = cv.take(N * (std::max(kStrausMaxLanes, straus_win_parts(c, pl)) + 1) * sizeof(dev_ext));
   o.end = cv.off;
   return o;
 }
@@ -1147,6 +1256,25 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
   hb.dst[DST_CHAL] = w.u8(o.wchal);
   HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
   prof_begin(c);
+  // one Straus MSM per proof (see k_straus_each): its points decode and its tables are built on the side stream, next to the transcripts
+  // (this entry point is synchronous, one call in flight per context: latency matters -- see side_begin)
+  const bool straus = each_uses_straus(c, pl);
+  straus_inter so{};
+  dev_affine* pts = nullptr;
+  straus_entry* tab = nullptr;
+  if (straus) {
+    so = straus_carve(c, pl, o.end);
+    if (so.end > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
+    pts = reinterpret_cast<dev_affine*>(w.base + so.pts);
+    tab = reinterpret_cast<straus_entry*>(w.base + so.tab);
+    hipStream_t main;
+    int rc = side_begin(c, &main, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_tbl, pts, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_straus_tables, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, pts, tab);
+    rc = side_end(c, main, true);
+    if (rc) return rc;
+  }
   run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), false);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.mc));
@@ -1156,20 +1284,19 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
                      d_inc_k + pl.s.inc_k.size(), w.u8(o.mc), d_resp, d_w, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx));
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
-  if (each_uses_straus(c, pl)) {
-    // one Straus MSM per proof, L lanes each (see k_straus_each)
-    const straus_inter so = straus_carve(pl, o.end);
-    if (so.end > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
-    dev_affine* pts = reinterpret_cast<dev_affine*>(w.base + so.pts);
-    straus_entry* tab = reinterpret_cast<straus_entry*>(w.base + so.tab);
+  if (straus) {
     dev_ext* spart = reinterpret_cast<dev_ext*>(w.base + so.spart);
-    const uint32_t L = straus_lanes(c, pl);
-    hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_tbl, pts, (const uint32_t*)nullptr);
-    prof_mark(c, ZKP_K_DECODE);
-    hipLaunchKernelGGL(k_straus_tables, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, pts, tab);
-    prof_mark(c, ZKP_K_TABLES);
-    hipLaunchKernelGGL(k_straus_each, grid1((size_t)N * L, 256), dim3(256), (size_t)((K + L - 1) / L) * 1024, c->stream, N, K, L, ns, ni, nc, w.u8(o.sc), tab,
-                       w.u32(so.digits), spart);
+    const uint32_t Wn = straus_win_parts(c, pl), L = Wn ? 1 : straus_lanes(c, pl);
+    if (Wn) hipLaunchKernelGGL(k_straus_recode, grid1((size_t)N * K, 256), dim3(256), 0, c->stream, N * K, w.u8(o.sc), w.u32(so.digits));
+    const int rcj = side_join(c, true);
+    if (rcj) return rcj;
+    prof_mark(c, ZKP_K_TABLES);                                        // (what the main stream waited for the side stream, if anything)
+    if (Wn) {
+      hipLaunchKernelGGL(k_straus_each_win, grid1((size_t)N * Wn, 256), dim3(256), (size_t)K * 1024, c->stream, N, K, Wn, ns, ni, nc, tab, w.u32(so.digits), spart + N);
+      hipLaunchKernelGGL(k_straus_combine_quad, grid1((size_t)N * 4, 256), dim3(256), 0, c->stream, N, Wn, spart + N, spart);
+    } else
+      hipLaunchKernelGGL(k_straus_each, grid1((size_t)N * L, 256), dim3(256), (size_t)((K + L - 1) / L) * 1024, c->stream, N, K, L, ns, ni, nc, w.u8(o.sc), tab,
+                         w.u32(so.digits), spart);
     prof_mark(c, ZKP_K_TERMS);
     hipLaunchKernelGGL(k_straus_finish, grid1(N, 256), dim3(256), 0, c->stream, N, K, L, w.u32(o.pidx), pts, spart, w.u8(o.out), w.u8(o.st8));
     prof_mark(c, ZKP_K_REDUCE);
@@ -1592,7 +1719,7 @@ int zkp_fused_verify_batchable_coeffs(zkp_ctx* c, const zkp_fused_statement* st,
   const size_t o_w = cv.take((size_t)N * nc * 16 + 16);
   const size_t o_res = cv.take((size_t)N + 4);
   const each_inter o = each_carve(*pl, cv.off);
-  rc = ensure_ws(c, each_uses_straus(c, *pl) ? straus_carve(*pl, o.end).end : o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N, each_terms_cfg(*pl)));
+  rc = ensure_ws(c, each_uses_straus(c, *pl) ? straus_carve(c, *pl, o.end).end : o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N, each_terms_cfg(*pl)));
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
   HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));

@@ -1062,6 +1062,7 @@ struct zkp_ctx {
   static constexpr uint32_t kInterleaveLadderBlocks = 256;
   bool each_straus = true;           // ZKP_OPT_EACH_STRAUS: verify_batchable's per-proof MSMs as one Straus walk per proof (0: one ladder per operand)
   uint32_t each_straus_lanes = 0;    //   ... with this many lanes per proof (0 = by batch size)
+  uint32_t each_straus_wins = 0;     //   ... or with this many window parts per proof (0 = by batch size)
   bool ct_masked_scans = false;      // ZKP_OPT_CT_MASKED_SCANS: constant-time calls pick every table entry with masked scans (no secret-indexed LDS read)
 #ifdef ZKP_BUILD_TEST_HOOKS
   uint64_t* wave_cycles = nullptr;   // ZKP_TESTOPT_WAVE_CYCLES: per-wavefront cycle recorder of the term kernel
@@ -1623,10 +1624,15 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;
     case ZKP_OPT_LADDER_INTERLEAVE: c->ladder_interleave = value == ~0ull ? -1 : value != 0; return ZKP_OK;
     case ZKP_OPT_EACH_STRAUS:
-      if (value != ~0ull && value > 8) return fail(ZKP_ERR_ARG, "ZKP_OPT_EACH_STRAUS: 0 (off), 1 .. 8 lanes per proof, or UINT64_MAX (default)");
+    {
+      const bool wins = value > 0x200 && value <= 0x200 + 64 && ((value - 0x200) & (value - 0x201)) == 0;
+      if (value != ~0ull && value > 8 && !wins)
+        return fail(ZKP_ERR_ARG, "ZKP_OPT_EACH_STRAUS: 0 (off), 1 .. 8 lanes per proof, 0x200 + (1, 2, 4 .. 64) window parts per proof, or UINT64_MAX (default)");
       c->each_straus = value != 0;
-      c->each_straus_lanes = (value == ~0ull || value == 0) ? 0u : (uint32_t)value;
+      c->each_straus_lanes = (value == ~0ull || value == 0 || value > 8) ? 0u : (uint32_t)value;
+      c->each_straus_wins = wins ? (uint32_t)(value - 0x200) : 0u;
       return ZKP_OK;
+    }
     case ZKP_OPT_TRANSCRIPT_LANES:
       if (value != ~0ull && value != 1 && value != 2) return fail(ZKP_ERR_ARG, "ZKP_OPT_TRANSCRIPT_LANES: 1, 2 or UINT64_MAX");
       c->tr_lanes = value == ~0ull ? -1 : (int)value;

@@ -144,6 +144,30 @@ def test_msm_optional_sizes(eng, base_points, n):
     assert got == M.ristretto_encode(M.pt_mul(dlog, M.BASEPOINT))
 
 
+@pytest.mark.parametrize("n,kind", [(5000, "ones"), (5000, "weights"), (70000, "ones"), (70000, "weights"), (300000, "weights"), (70000, "two-values")])
+def test_msm_optional_skewed_digits(eng, base_points, n, kind):
+    """Pippenger with HUGE buckets.  A batch verification multiplies its commitments by -r, r a 128-bit weight
+    (batch_verifier.rs:179-183): sign-folded, half of them carry a signed digit +1 into the window above bit 127, all in one
+    bucket.  "weights": 60 % of the scalars are l - r; "ones": every scalar is 1 (one bucket holds the whole MSM: thousands of
+    parts for the block-wide merge of k_pip_bucket_merge and the wavefront-wide writes of k_pip_vmap); "two-values": two scalars
+    whose digits fill two buckets per window with 33 .. 63 parts or more."""
+    rng = random.Random(4000 + n)
+    logs, encs = base_points
+    idx = [rng.randrange(64) for _ in range(n)]
+    if kind == "ones":
+        scalars = [1] * n
+    elif kind == "weights":
+        scalars = [(M.L - rng.randrange(1 << 128)) if rng.random() < 0.6 else rng.randrange(M.L) for _ in range(n)]
+    else:
+        a, b = rng.randrange(M.L), rng.randrange(M.L)
+        scalars = [a if rng.random() < 0.97 else b for _ in range(n)]
+    pts = enc_arr([encs[j] for j in idx])
+    sca = np.stack([sc(s) for s in scalars])
+    got = eng.msm_optional(sca, pts)
+    dlog = sum(s * logs[j] for s, j in zip(scalars, idx)) % M.L
+    assert got == M.ristretto_encode(M.pt_mul(dlog, M.BASEPOINT))
+
+
 @pytest.mark.parametrize("n", [5, 250, 6000])
 def test_msm_optional_none_on_bad_point(eng, base_points, n):
     rng = random.Random(77 + n)

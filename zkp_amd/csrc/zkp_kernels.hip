@@ -563,11 +563,13 @@ k_pip_prepare(uint32_t n, const pip_seg seg, const uint8_t* __restrict__ scalars
   }
 }
 
-// Entries per part of a bucket with cnt entries: at least L, and about sqrt(cnt) for big buckets so that the
-// part sums (k_pip_bucket_part) and their merge (k_pip_bucket_merge) have equal sequential depth.
+// Entries per part of a bucket with cnt entries: L .. 2 L (about sqrt(cnt) in between).  A bucket may be HUGE: the 128-bit
+// weights of a batch verification (batch_verifier.rs:179) leave a signed-digit carry in the window above their top one, so half of
+// all commitment operands of the call meet in bucket 1 of that window (2.9 M entries at 524,288 CMZ proofs).  Its parts stay
+// short -- a part is one lane's sequential chain -- and k_pip_bucket_merge sums the parts of such a bucket with a whole block.
 __device__ __forceinline__ uint32_t part_len(uint32_t cnt, uint32_t L) {
   const uint32_t r = (uint32_t)ceilf(sqrtf((float)cnt));
-  return r > L ? r : L;
+  return r > 2 * L ? 2 * L : (r > L ? r : L);
 }
 __device__ __forceinline__ uint32_t part_count(uint32_t cnt, uint32_t L) {
   const uint32_t pl = part_len(cnt, L);
@@ -691,10 +693,22 @@ k_pip_tile_scatter(uint32_t n, const uint32_t* __restrict__ digits, const uint32
 __global__ void __launch_bounds__(256)
 k_pip_vmap(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t* __restrict__ vstart, uint32_t* __restrict__ vmap) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= total) return;
-  const uint32_t w = g / bins, b = g - w * bins;
-  const uint32_t* vs = vstart + (size_t)w * (bins + 1);
-  for (uint32_t v = vs[b]; v < vs[b + 1]; ++v) vmap[(size_t)w * vmax + v] = b;
+  uint32_t w = 0, b = 0, v0 = 0, v1 = 0;
+  if (g < total) {
+    w = g / bins; b = g - w * bins;
+    const uint32_t* vs = vstart + (size_t)w * (bins + 1);
+    v0 = vs[b]; v1 = vs[b + 1];
+  }
+  // a huge bucket (part_len) has thousands of parts: its entries are written by the whole wavefront
+  uint64_t bigmask = __ballot(v1 - v0 > 64u);
+  while (bigmask) {
+    const int src = __ffsll((unsigned long long)bigmask) - 1;
+    bigmask &= bigmask - 1;
+    const uint32_t bw = (uint32_t)__shfl((int)w, src), bb = (uint32_t)__shfl((int)b, src), b0 = (uint32_t)__shfl((int)v0, src), b1 = (uint32_t)__shfl((int)v1, src);
+    for (uint32_t v = b0 + (threadIdx.x & 63u); v < b1; v += 64) vmap[(size_t)bw * vmax + v] = bb;
+  }
+  if (v1 - v0 <= 64u)
+    for (uint32_t v = v0; v < v1; ++v) vmap[(size_t)w * vmax + v] = b;
 }
 
 __global__ void __launch_bounds__(256, 2)
@@ -733,31 +747,79 @@ k_pip_bucket_part(uint32_t n, uint32_t W1, uint32_t bins, uint32_t L, uint32_t v
   store_ext(parts + (size_t)w * vmax + v, acc);
 }
 
-// one QUAD of lanes per bucket (quad.h): the top window's buckets have ~sqrt(cnt) parts each, a latency-bound chain
+// one QUAD of lanes per bucket (quad.h) sums the bucket's parts in sequence (a latency-bound chain: the top window's buckets have a
+// dozen parts each).  Buckets with more than kMergeSeqParts parts -- see part_len -- are then summed by the whole block, one after
+// the other: quad i adds up parts i, i + 64, ..., and a tree over the 64 quads (through LDS) finishes.
+constexpr uint32_t kMergeSeqParts = 32;
 __global__ void __launch_bounds__(256, 2)
 k_pip_bucket_merge(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t* __restrict__ vstart,
                    const dev_ext* __restrict__ parts, dev_ext* __restrict__ buckets) {
+  __shared__ uint32_t big[64];
+  __shared__ uint32_t n_big;
+  __shared__ uint32_t red[64][4][9];
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t g = gt >> 2;
+  const uint32_t g = gt >> 2, qi = threadIdx.x >> 2;
   const int q = (int)(gt & 3u);
-  if (g >= total) return;
-  const uint32_t w = g / bins, b = g - w * bins;
-  const uint32_t* vs = vstart + (size_t)w * (bins + 1);
-  const uint32_t v0 = vs[b], v1 = vs[b + 1];
-  const dev_ext* p = parts + (size_t)w * vmax;
-  qpt acc;
-  if (v1 == v0) {
-    q_identity(acc, q);
-  } else {
-    q_load_ext(acc, p + v0, q);
+  if (threadIdx.x == 0) n_big = 0;
+  __syncthreads();
+  if (g < total) {
+    const uint32_t w = g / bins, b = g - w * bins;
+    const uint32_t* vs = vstart + (size_t)w * (bins + 1);
+    const uint32_t v0 = vs[b], v1 = vs[b + 1];
+    const dev_ext* p = parts + (size_t)w * vmax;
+    if (v1 - v0 > kMergeSeqParts) {
+      if (q == 0) big[atomicAdd(&n_big, 1u)] = g;
+    } else {
+      qpt acc;
+      if (v1 == v0) {
+        q_identity(acc, q);
+      } else {
+        q_load_ext(acc, p + v0, q);
 #pragma unroll 1
-    for (uint32_t v = v0 + 1; v < v1; ++v) {
+        for (uint32_t v = v0 + 1; v < v1; ++v) {
+          qpt t;
+          q_load_ext(t, p + v, q);
+          q_add(acc, acc, t, q);
+        }
+      }
+      q_store_ext(buckets + g, acc, q);
+    }
+  }
+  __syncthreads();
+  const uint32_t nb = n_big;                                           // (the same for every lane of the block)
+#pragma unroll 1
+  for (uint32_t i = 0; i < nb; ++i) {
+    const uint32_t gb = big[i], w = gb / bins, b = gb - w * bins;
+    const uint32_t* vs = vstart + (size_t)w * (bins + 1);
+    const uint32_t v0 = vs[b], v1 = vs[b + 1];
+    const dev_ext* p = parts + (size_t)w * vmax;
+    qpt acc;
+    q_identity(acc, q);                                                // (33 .. 63 parts leave some quads empty)
+    if (v0 + qi < v1) q_load_ext(acc, p + v0 + qi, q);
+#pragma unroll 1
+    for (uint32_t v = v0 + qi + 64; v < v1; v += 64) {
       qpt t;
       q_load_ext(t, p + v, q);
       q_add(acc, acc, t, q);
     }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[qi][q][k] = acc.c.v[k];
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+      if (qi < d) {
+        qpt t;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t.c.v[k] = red[qi + d][q][k];
+        q_add(acc, acc, t, q);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) red[qi][q][k] = acc.c.v[k];
+      }
+      __syncthreads();
+    }
+    if (qi == 0) q_store_ext(buckets + gb, acc, q);
+    __syncthreads();
   }
-  q_store_ext(buckets + g, acc, q);
 }
 
 // One level of the tree evaluation of T = sum_g g * S_g  (g = 0 .. B-1, B a power of two).
@@ -960,19 +1022,33 @@ k_coeff_build(uint32_t N, uint32_t N_each, uint32_t nblk_each, uint32_t K, uint3
   }
   if (threadIdx.x < 8) partial[((size_t)s * gridDim.x + blockIdx.x) * 8 + threadIdx.x] = red[0][threadIdx.x];
 }
-// grid (ns, K): static coefficient s of batch b = sum of its nblk_each block partials
+// grid (ns, K), 64 lanes: static coefficient s of batch b = sum of its nblk_each block partials (2,048 of them at 524,288 proofs:
+// a lone lane adding them one after the other took 0.6 ms)
 __global__ void __launch_bounds__(64)
 k_coeff_static_final(uint32_t nblk_each, uint32_t ns, const uint32_t* __restrict__ partial, uint8_t* __restrict__ scalars) {
-  if (threadIdx.x != 0) return;
+  __shared__ uint32_t red[64][8];
   const uint32_t s = blockIdx.x, b = blockIdx.y, nblocks = nblk_each * gridDim.y;
   sc acc, t;
   sc_zero(acc);
-  for (uint32_t q = 0; q < nblk_each; ++q) {
+  for (uint32_t q = threadIdx.x; q < nblk_each; q += 64) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) t.v[i] = partial[((size_t)s * nblocks + (size_t)b * nblk_each + q) * 8 + i];
     sc_add(acc, acc, t);
   }
-  store_vec<2>(scalars + 32 * ((size_t)b * ns + s), acc.v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc.v[i];
+  __syncthreads();
+  for (uint32_t d = 32; d >= 1; d >>= 1) {
+    if (threadIdx.x < d) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t.v[i] = red[threadIdx.x + d][i];
+      sc_add(acc, acc, t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc.v[i];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_vec<2>(scalars + 32 * ((size_t)b * ns + s), acc.v);
 }
 
 // =============================================================================================

@@ -260,8 +260,11 @@ def test_w64_statement_fused_equals_host_route(eng):
         res = T.verify_compact_batch(eng, st, ts2, inst, G, chal, resp)
         ts3 = _fresh(b"wide", n)
         ok, coeffs = T.batch_verify_coeffs(eng, st, ts3, inst, G, coms, resp, w)
-        out[route] = (chal, resp, coms, ts[:, :203], res, ts2[:, :203], coeffs, ts3[:, :203])
-        assert ok and not res.any()
+        # verify_batchable per proof: 66 operands per MSM -- more than the window-split Straus walk takes (64), so the operand split runs
+        bad = resp.copy(); bad[7, 63, 0] ^= 1
+        each = T.verify_batchable_each(eng, st, _fresh(b"wide", n), inst, G, coms, bad, np.ascontiguousarray(w.transpose(1, 0, 2)))
+        out[route] = (chal, resp, coms, ts[:, :203], res, ts2[:, :203], coeffs, ts3[:, :203], each)
+        assert ok and not res.any() and each[7] == 1 and each.sum() == 1
     T.set_fused_min_batch(32)
     for a, b in zip(out["host"], out["fused"]):
         assert (a == b).all()

@@ -283,6 +283,12 @@ int zkp_fused_batch_verify_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint
                                uint8_t* d_transcripts, uint8_t* d_points, const uint8_t* d_commitments,
                                const uint8_t* d_responses, const uint8_t* d_weights16, uint8_t* d_out_point,
                                uint32_t* d_status);
+/*     zkp_fused_verify_batchable_dev (verifier.rs:123-173 for N proofs, one verdict per proof): d_table = common points, instance rows and
+ *     then the proofs' commitments, [n_static + n_instance * N][32] || [N][n_constraints][32]; d_weights16 [N][n_constraints][16] (the
+ *     factors verifier.rs:153 draws per proof); d_results [N] bytes, 0 = verified. */
+int zkp_fused_verify_batchable_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos,
+                                   uint8_t* d_transcripts, const uint8_t* d_table, const uint8_t* d_responses,
+                                   const uint8_t* d_weights16, uint8_t* d_results);
 
 /* zkp_fused_batch_verify_many on device buffers: d_points [n_static + (n_instance + n_constraints) * N][32] (N = n_batches *
  * N_each; static points and instance rows filled in, commitment rows written by the call), d_out_points [n_batches][32],

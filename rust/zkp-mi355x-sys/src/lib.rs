@@ -124,6 +124,9 @@ extern "C" {
     pub fn zkp_fused_verify_compact_dev(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, strobe_pos: u32,
                                         d_transcripts: *mut u8, d_table: *const u8, d_challenges: *const u8, d_responses: *const u8,
                                         d_results: *mut u8) -> c_int;
+    pub fn zkp_fused_verify_batchable_dev(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, strobe_pos: u32,
+                                          d_transcripts: *mut u8, d_table: *const u8, d_responses: *const u8,
+                                          d_weights16: *const u8, d_results: *mut u8) -> c_int;
     pub fn zkp_fused_batch_verify_dev(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, strobe_pos: u32,
                                       d_transcripts: *mut u8, d_points: *mut u8, d_commitments: *const u8, d_responses: *const u8,
                                       d_weights16: *const u8, d_out_point: *mut u8, d_status: *mut u32) -> c_int;

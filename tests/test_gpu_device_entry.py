@@ -68,7 +68,7 @@ def test_msm_many_dev_equals_host_entry_and_oracle(eng, flags):
 
 @pytest.mark.parametrize("n,wide", [(40, False), (1500, False), (40, True), (1500, True), (40, "fuse"), (1500, "fuse")])
 def test_fused_dev_flows_equal_host_pointer_flows(eng, n, wide):
-    """zkp_fused_prove_dev / _verify_compact_dev / _batch_verify_dev against zkp_fused_prove / ... (through the toolbox).
+    """zkp_fused_prove_dev / _verify_compact_dev / _batch_verify_dev / _verify_batchable_dev against zkp_fused_prove / ... (through the toolbox).
     wide: with the variants the _dev entry points pick for calls that fill the chip on their own (one transcript lane per
     proof, constant-time ladder for single-use points), forced here at a small batch size; "fuse": with
     ZKP_OPT_FUSE_TABLES_TRANSCRIPT."""
@@ -154,6 +154,18 @@ def _fused_dev_flows(eng, n):
                                d_out.data_ptr(), d_bst.data_ptr())
     eng.synchronize()
     assert d_bst.cpu().numpy()[1] == 1
+    # verify_batchable per proof on device buffers (table = common || instance rows || commitments [n][11]; weights [n][11][16]):
+    # the verdicts of the host-pointer flow, for valid proofs, a corrupted response, an identity commitment
+    w_each = np.ascontiguousarray(w.transpose(1, 0, 2))
+    for d_r, d_c, bad_at in ((d_resp, d_coms, None), (d_bad, d_coms, n // 3), (d_resp, d_zc, n // 2)):
+        want = T.verify_batchable_each(eng, st, ts0.copy(), inst, common, d_c.cpu().numpy(), d_r.cpu().numpy(), w_each)
+        d_tbl_each = torch.cat([d_tbl, d_c.reshape(-1, 32)])
+        d_ts4, d_we, d_res4 = _dev(ts0), _dev(w_each), z(n) + 7
+        torch.cuda.synchronize()
+        eng.fused_verify_batchable_dev(fst, n, pos, d_ts4.data_ptr(), d_tbl_each.data_ptr(), d_r.data_ptr(), d_we.data_ptr(), d_res4.data_ptr())
+        eng.synchronize()
+        got = d_res4.cpu().numpy()
+        assert (got == want).all() and (got.sum() == 0 if bad_at is None else (got[bad_at] == 1 and got.sum() == 1))
 
 
 def test_hip_graph_replay_equals_direct_calls(eng):

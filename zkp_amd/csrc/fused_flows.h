@@ -1246,7 +1246,7 @@ straus_inter straus_carve(const zkp_ctx* c, const fused_plan& pl, size_t start) 
   return o;
 }
 int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_resp,
-              const uint8_t* d_w, uint8_t* d_results) {
+              const uint8_t* d_w, uint8_t* d_results, bool overlap) {
   const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni, K = pl.s.np + nc;
   const uint32_t n_points = ns + ni * N + N * nc;
   const ws_view w{static_cast<char*>(c->ws)};
@@ -1257,7 +1257,8 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
   HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
   prof_begin(c);
   // one Straus MSM per proof (see k_straus_each): its points decode and its tables are built on the side stream, next to the transcripts
-  // (this entry point is synchronous, one call in flight per context: latency matters -- see side_begin)
+  // (overlap: the synchronous entry point, one call in flight per context, latency matters -- see side_begin; the _dev entry point
+  // follows ZKP_OPT_DEV_OVERLAP like the other flows)
   const bool straus = each_uses_straus(c, pl);
   straus_inter so{};
   dev_affine* pts = nullptr;
@@ -1268,11 +1269,11 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
     pts = reinterpret_cast<dev_affine*>(w.base + so.pts);
     tab = reinterpret_cast<straus_entry*>(w.base + so.tab);
     hipStream_t main;
-    int rc = side_begin(c, &main, true);
+    int rc = side_begin(c, &main, overlap);
     if (rc) return rc;
     hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_tbl, pts, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_straus_tables, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, pts, tab);
-    rc = side_end(c, main, true);
+    rc = side_end(c, main, overlap);
     if (rc) return rc;
   }
   run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), false);
@@ -1288,7 +1289,7 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
     dev_ext* spart = reinterpret_cast<dev_ext*>(w.base + so.spart);
     const uint32_t Wn = straus_win_parts(c, pl), L = Wn ? 1 : straus_lanes(c, pl);
     if (Wn) hipLaunchKernelGGL(k_straus_recode, grid1((size_t)N * K, 256), dim3(256), 0, c->stream, N * K, w.u8(o.sc), w.u32(so.digits));
-    const int rcj = side_join(c, true);
+    const int rcj = side_join(c, overlap);
     if (rcj) return rcj;
     prof_mark(c, ZKP_K_TABLES);                                        // (what the main stream waited for the side stream, if anything)
     if (Wn) {
@@ -1688,6 +1689,26 @@ int zkp_fused_batch_verify_many(zkp_ctx* c, const zkp_fused_statement* st, uint3
 }
 
 // ---- verify_batchable, one verdict per proof -----------------------------------------------------------------------------
+int zkp_fused_verify_batchable_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos, uint8_t* d_transcripts,
+                                   const uint8_t* d_table, const uint8_t* d_responses, const uint8_t* d_weights16, uint8_t* d_results) {
+  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
+  if (N == 0) return ZKP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  fused_plan* pl = nullptr;
+  int rc = get_plan(c, FLOW_BATCH, st, N, strobe_pos, &pl);
+  if (rc) return rc;
+  const fused_shape& s = pl->s;
+  if (!d_transcripts || !d_results || (s.m && !d_responses) || (s.nc && !d_weights16) || ((s.np || s.nc) && !d_table)) return fail(ZKP_ERR_ARG, "NULL device pointer");
+  if (!aligned16(d_transcripts) || !aligned16(d_table) || !aligned16(d_responses) || !aligned16(d_weights16))
+    return fail(ZKP_ERR_ARG, "device buffers must be 16-byte aligned");
+  const size_t n_points = (size_t)s.ns + (size_t)s.ni * N + (size_t)N * s.nc, K = (size_t)s.np + s.nc;
+  if (n_points > 0x7fffffffull || (size_t)N * K > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
+  const each_inter o = each_carve(*pl, 0);
+  rc = ensure_ws(c, each_uses_straus(c, *pl) ? straus_carve(c, *pl, o.end).end : o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N, each_terms_cfg(*pl)));
+  if (rc) return rc;
+  return each_core(c, *pl, o, d_transcripts, d_table, d_responses, d_weights16, d_results, /*overlap=*/c->dev_overlap);
+}
+
 int zkp_fused_verify_batchable(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
                                const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
                                uint8_t* results) {
@@ -1730,7 +1751,7 @@ int zkp_fused_verify_batchable_coeffs(zkp_ctx* c, const zkp_fused_statement* st,
     HIP_TRY(hipMemcpyAsync(w.base + o_w, weights16, (size_t)N * nc * 16, hipMemcpyHostToDevice, c->stream));
   }
   if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  rc = each_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_resp), w.u8(o_w), w.u8(o_res));
+  rc = each_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_resp), w.u8(o_w), w.u8(o_res), /*overlap=*/true);
   if (rc) return rc;
   if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, w.base + o.sc, (size_t)N * K * 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(results, w.base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));

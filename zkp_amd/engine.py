@@ -27,7 +27,7 @@ EXPORTS = (
     "zkp_version", "zkp_ctx_set_option", "zkp_msm_many", "zkp_msm_many_dev", "zkp_msm_optional", "zkp_msm_optional_dev",
     "zkp_decode_check", "zkp_encode_many", "zkp_ctx_last_timing", "zkp_ctx_set_profiling",
     "zkp_ctx_prepare_fixed_points", "zkp_batch_check", "zkp_fused_prove", "zkp_fused_verify_compact", "zkp_fused_batch_verify",
-    "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_batch_verify_dev",
+    "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_verify_batchable_dev", "zkp_fused_batch_verify_dev",
     "zkp_fused_verify_batchable_coeffs", "zkp_fused_batch_verify_many", "zkp_fused_batch_verify_many_dev", "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_ctx_capture_abort", "zkp_graph_launch", "zkp_graph_destroy",
 )
 TEST_HOOK_EXPORTS = ("zkp_debug_quad_selftest", "zkp_debug_wave_cycles")      # only in libzkp_mi355x_testhooks.so
@@ -215,6 +215,12 @@ class Engine:
         _check(self._lib.zkp_fused_prove_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ctypes.c_uint32(strobe_pos),
                                              *[ctypes.c_void_p(x) for x in (d_ts, d_secrets, d_table, d_entropy, d_chal, d_resp, d_coms, d_status)]),
                "zkp_fused_prove_dev")
+
+    def fused_verify_batchable_dev(self, fst: "FusedStatement", n, strobe_pos, d_ts, d_table, d_resp, d_w, d_results) -> None:
+        """d_table = common || instance rows || commitments [n][nc]; d_w [n][nc][16]; d_results [n] bytes (0 = verified)"""
+        _check(self._lib.zkp_fused_verify_batchable_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ctypes.c_uint32(strobe_pos),
+                                                        *[ctypes.c_void_p(x) for x in (d_ts, d_table, d_resp, d_w, d_results)]),
+               "zkp_fused_verify_batchable_dev")
 
     def fused_verify_compact_dev(self, fst: "FusedStatement", n, strobe_pos, d_ts, d_table, d_chal, d_resp, d_results) -> None:
         _check(self._lib.zkp_fused_verify_compact_dev(self._h, ctypes.byref(fst.c), ctypes.c_uint32(n), ctypes.c_uint32(strobe_pos),

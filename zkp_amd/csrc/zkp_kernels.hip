@@ -563,13 +563,14 @@ k_pip_prepare(uint32_t n, const pip_seg seg, const uint8_t* __restrict__ scalars
   }
 }
 
-// Entries per part of a bucket with cnt entries: L .. 2 L (about sqrt(cnt) in between).  A bucket may be HUGE: the 128-bit
-// weights of a batch verification (batch_verifier.rs:179) leave a signed-digit carry in the window above their top one, so half of
-// all commitment operands of the call meet in bucket 1 of that window (2.9 M entries at 524,288 CMZ proofs).  Its parts stay
-// short -- a part is one lane's sequential chain -- and k_pip_bucket_merge sums the parts of such a bucket with a whole block.
+// Entries per part of a bucket with cnt entries: about sqrt(cnt) -- a part is one lane's sequential chain, the merge of a bucket's
+// parts one quad's -- but never more than 4 L.  A bucket may be HUGE: the 128-bit weights of a batch verification
+// (batch_verifier.rs:179) leave a signed-digit carry in the window above their top one, so half of all commitment operands of the
+// call meet in bucket 1 of that window (2.9 M entries at 524,288 CMZ proofs; sqrt would be a 1,700-addition chain per lane and
+// another in the merge).  Such a bucket gets many parts of 4 L entries and k_pip_bucket_merge sums them with a whole block.
 __device__ __forceinline__ uint32_t part_len(uint32_t cnt, uint32_t L) {
   const uint32_t r = (uint32_t)ceilf(sqrtf((float)cnt));
-  return r > 2 * L ? 2 * L : (r > L ? r : L);
+  return r > 4 * L ? 4 * L : (r > L ? r : L);
 }
 __device__ __forceinline__ uint32_t part_count(uint32_t cnt, uint32_t L) {
   const uint32_t pl = part_len(cnt, L);
@@ -648,8 +649,15 @@ k_pip_tile_total(uint32_t bins, uint32_t tiles, uint32_t total, const uint32_t* 
   if (g >= total) return;
   const uint32_t w = g / bins, b = g - w * bins;
   const uint32_t* p = tilehist + (size_t)w * tiles * bins + b;
-  uint32_t sum = 0;
-  for (uint32_t t = 0; t < tiles; ++t) sum += p[(size_t)t * bins];
+  uint32_t sum = 0, t = 0;
+  for (; t + 8 <= tiles; t += 8) {                   // eight loads in flight (a column of up to ~1,000 tiles, one lane)
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(t + k) * bins];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += v[k];
+  }
+  for (; t < tiles; ++t) sum += p[(size_t)t * bins];
   hist[g] = sum;
 }
 // tilehist[w][t][b] <- first slot of (tile t, bucket b) in the window's sorted list
@@ -659,8 +667,15 @@ k_pip_tile_base(uint32_t bins, uint32_t tiles, uint32_t total, const uint32_t* _
   if (g >= total) return;
   const uint32_t w = g / bins, b = g - w * bins;
   uint32_t* p = tilehist + (size_t)w * tiles * bins + b;
-  uint32_t run = start[g];
-  for (uint32_t t = 0; t < tiles; ++t) {
+  uint32_t run = start[g], t = 0;
+  for (; t + 8 <= tiles; t += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(t + k) * bins];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { p[(size_t)(t + k) * bins] = run; run += v[k]; }
+  }
+  for (; t < tiles; ++t) {
     const uint32_t c = p[(size_t)t * bins];
     p[(size_t)t * bins] = run;
     run += c;
@@ -747,10 +762,11 @@ k_pip_bucket_part(uint32_t n, uint32_t W1, uint32_t bins, uint32_t L, uint32_t v
   store_ext(parts + (size_t)w * vmax + v, acc);
 }
 
-// one QUAD of lanes per bucket (quad.h) sums the bucket's parts in sequence (a latency-bound chain: the top window's buckets have a
-// dozen parts each).  Buckets with more than kMergeSeqParts parts -- see part_len -- are then summed by the whole block, one after
-// the other: quad i adds up parts i, i + 64, ..., and a tree over the 64 quads (through LDS) finishes.
-constexpr uint32_t kMergeSeqParts = 32;
+// one QUAD of lanes per bucket (quad.h) sums the bucket's parts in sequence (a latency-bound chain: the buckets of a short top
+// window have sqrt(cnt) parts each -- a batch of 32,768 CMZ proofs has 64 such buckets of 75 parts side by side).  The few buckets
+// with more than kMergeSeqParts parts -- the huge ones, see part_len -- are then summed by the whole block, one after the other:
+// quad i adds up parts i, i + 64, ..., and a tree over the 64 quads (through LDS) finishes.
+constexpr uint32_t kMergeSeqParts = 128;
 __global__ void __launch_bounds__(256, 2)
 k_pip_bucket_merge(uint32_t bins, uint32_t total, uint32_t vmax, const uint32_t* __restrict__ vstart,
                    const dev_ext* __restrict__ parts, dev_ext* __restrict__ buckets) {

@@ -254,6 +254,77 @@ pub fn batch_verify(eng: &Engine, st: &Statement, transcripts: &mut [Transcript]
     check(rc)
 }
 
+/// N x { build_verifier ; Verifier::verify_batchable } (verifier.rs:123-173): one `Result` per proof -- what a caller runs after
+/// `batch_verify` failed and it has to know WHICH proofs are bad.  The per-proof u128 factors of verifier.rs:153 are drawn inside
+/// the library.
+pub fn verify_batchable_each(eng: &Engine, st: &Statement, transcripts: &mut [Transcript], inst_points: &[CompressedRistretto],
+                             common_points: &[CompressedRistretto], commitments: &[u8], responses: &[u8]) -> Result<Vec<Result<(), Error>>, Error> {
+    let n = transcripts.len();
+    st.check_shapes(n, inst_points.len(), common_points.len(), &[("commitments", commitments.len(), 32 * st.nc()), ("responses", responses.len(), 32 * st.m())])?;
+    let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
+    let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let mut results = vec![1u8; n];
+    check(unsafe {
+        sys::zkp_verify_batchable_each(eng.0, st.0, n as u32, ts.as_mut_ptr(), inst.as_ptr(), com.as_ptr(), commitments.as_ptr(),
+                                       responses.as_ptr(), ptr::null(), 0, results.as_mut_ptr())
+    })?;
+    for (t, chunk) in transcripts.iter_mut().zip(ts.chunks(sys::ZKP_TRANSCRIPT_BYTES)) {
+        t.0.copy_from_slice(chunk);
+    }
+    Ok(results.into_iter().map(|r| if r == 0 { Ok(()) } else { Err(Error::VerificationFailure) }).collect())
+}
+
+/// K independent `BatchVerifier::verify_batchable` runs (batch_verifier.rs:137-235 each) over K * n_each proofs that lie next to
+/// each other, in one pass over the GPU: one verdict per batch, each with its own weights and static-coefficient sums.
+/// `inst_points` is [ni][K * n_each], everything else per proof in batch order.
+pub fn batch_verify_many(eng: &Engine, st: &Statement, n_batches: usize, transcripts: &mut [Transcript], inst_points: &[CompressedRistretto],
+                         common_points: &[CompressedRistretto], commitments: &[u8], responses: &[u8]) -> Result<Vec<Result<(), Error>>, Error> {
+    let n = transcripts.len();
+    if n_batches == 0 || n % n_batches != 0 {
+        return Err(Error::Shape("the transcripts do not split into n_batches equal batches"));
+    }
+    st.check_shapes(n, inst_points.len(), common_points.len(), &[("commitments", commitments.len(), 32 * st.nc()), ("responses", responses.len(), 32 * st.m())])?;
+    let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
+    let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let mut verdicts = vec![1 as std::os::raw::c_int; n_batches];
+    let rc = unsafe {
+        sys::zkp_batch_verify_many(eng.0, st.0, n_batches as u32, (n / n_batches) as u32, n as u32, ts.as_mut_ptr(), inst.as_ptr(), com.as_ptr(),
+                                   commitments.as_ptr(), responses.as_ptr(), ptr::null(), 0, verdicts.as_mut_ptr())
+    };
+    for (t, chunk) in transcripts.iter_mut().zip(ts.chunks(sys::ZKP_TRANSCRIPT_BYTES)) {
+        t.0.copy_from_slice(chunk);
+    }
+    check(rc)?; // 0 = every verdict was computed; BatchSizeMismatch / negative = none was
+    Ok(verdicts.into_iter().map(|v| if v == 0 { Ok(()) } else { Err(Error::VerificationFailure) }).collect())
+}
+
+/// `batch_verify`, and -- only when the batch check fails -- the per-proof verdicts of `verify_batchable_each` in the same call
+/// (batch_verifier.rs:233 can only say that SOME proof is wrong).  `Ok(Ok(()))`: the batch verified; `Ok(Err(bad))`: it did not, and
+/// `bad[j]` says whether proof j failed on its own (all `false` is possible: fail closed on the batch verdict, never on `bad`).
+pub fn batch_verify_locate(eng: &Engine, st: &Statement, transcripts: &mut [Transcript], inst_points: &[CompressedRistretto],
+                           common_points: &[CompressedRistretto], commitments: &[u8], responses: &[u8]) -> Result<Result<(), Vec<bool>>, Error> {
+    let n = transcripts.len();
+    st.check_shapes(n, inst_points.len(), common_points.len(), &[("commitments", commitments.len(), 32 * st.nc()), ("responses", responses.len(), 32 * st.m())])?;
+    let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
+    let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+    let mut results = vec![0u8; n];
+    let rc = unsafe {
+        sys::zkp_batch_verify_locate(eng.0, st.0, n as u32, n as u32, ts.as_mut_ptr(), inst.as_ptr(), com.as_ptr(), commitments.as_ptr(),
+                                     responses.as_ptr(), ptr::null(), 0, results.as_mut_ptr())
+    };
+    for (t, chunk) in transcripts.iter_mut().zip(ts.chunks(sys::ZKP_TRANSCRIPT_BYTES)) {
+        t.0.copy_from_slice(chunk);
+    }
+    match rc {
+        0 => Ok(Ok(())),
+        sys::ZKP_TB_VERIFICATION_FAILURE => Ok(Err(results.into_iter().map(|r| r != 0).collect())),
+        _ => check(rc).map(|_| Ok(())),
+    }
+}
+
 /// `bincode::serialize(&CompactProof)` / `deserialize` (tests/zkp.rs:53-54) through the C codec.
 pub fn compact_proof_to_bytes(challenge: &Scalar, responses: &[Scalar]) -> Vec<u8> {
     let r: Vec<u8> = responses.iter().flat_map(|s| s.as_bytes().iter().copied()).collect();

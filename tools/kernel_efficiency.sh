@@ -27,6 +27,8 @@ for f in ("valu", "occ"):
 tot = sum(sum(v) for v in dur.values())
 print("# $B")
 print("# one stream; issue %% = SQ_INSTS_VALU x 64 lanes / duration / 34.5e12; occupancy = MeanOccupancyPerCU (wavefronts per CU, 32 = full)")
+print("# note: the trace covers the whole process, so the kernels of the bench's UNTIMED setup are listed too (instance construction through zkp_msm_many")
+print("#       without registered fixed bases, fixed-base table building): k_use_count, k_class_*, k_comb_tables<16>, k_hot_*, k_terms_split<false,...>, k_terms_r4")
 print("%-50s %6s %10s %7s %12s %8s %8s %9s" % ("kernel", "calls", "avg_us", "time%", "valu_instr", "issue%", "occ/CU", "waves"))
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     avg = sum(v) / len(v)

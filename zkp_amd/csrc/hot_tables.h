@@ -178,10 +178,29 @@ k_hot_match(uint32_t n_points, const uint8_t* __restrict__ points, uint32_t nreg
 __global__ void __launch_bounds__(256)
 k_use_count(uint32_t n_terms, const uint32_t* __restrict__ pidx, uint32_t n_points, const int32_t* __restrict__ hotmap,
             uint32_t* __restrict__ uses) {
+  // The block counts its 256 terms per distinct point in LDS first (open addressing, 512 slots) and sends ONE atomic per distinct point:
+  // a common point that was not registered as a fixed base is named by millions of terms, and atomics on one address serialise
+  // beyond the L2s at ~20 ns each (5.9 ms for 2.6 M terms, measured).
+  __shared__ uint32_t key[512];
+  __shared__ uint32_t cnt[512];
+  for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) { key[i] = 0xffffffffu; cnt[i] = 0; }
+  __syncthreads();
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_terms) return;
-  const uint32_t pi = pidx[t];
-  if (pi < n_points && hotmap[pi] < 0) atomicAdd(&uses[pi], 1u);
+  if (t < n_terms) {
+    const uint32_t pi = pidx[t];
+    if (pi < n_points && hotmap[pi] < 0) {
+      uint32_t slot = (pi * 2654435761u) >> 23;                     // 9 bits
+      for (;;) {
+        const uint32_t seen = atomicCAS(&key[slot], 0xffffffffu, pi);
+        if (seen == 0xffffffffu || seen == pi) break;
+        slot = (slot + 1) & 511u;                                   // (at most 256 keys in 512 slots: always terminates)
+      }
+      atomicAdd(&cnt[slot], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x)
+    if (cnt[i]) atomicAdd(&uses[key[i]], cnt[i]);
 }
 // group_min: from this many cold uses on, the terms of a point are listed together (CLASS_GROUP) and walk its table through
 // LDS (comb_group_block); 0xffffffff = no such class in this call.

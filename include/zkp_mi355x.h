@@ -85,10 +85,11 @@ const char* zkp_version(void);
  *     (0: a quarter of the latency); UINT64_MAX = default: 1 in the asynchronous _dev entry points, 0 in the synchronous ones.
  *   ZKP_OPT_FUSE_TABLES_TRANSCRIPT: 1 = zkp_fused_prove_dev / _verify_compact_dev run their first transcript program in the same
  *     launch as the comb-table construction (both are long dependent chains on few wavefronts, independent of each other): a
- *     lone call of 4096 CMZ proofs takes 1.47 instead of 1.99 ms, while callers that pipeline 25 such calls lose 7 % (the
- *     transcript wavefronts then carry the table builder's 212 registers instead of their own 118).  0 = never; UINT64_MAX =
- *     default: in calls of 8,192 .. 65,535 proofs (a few batches per call, a few calls in flight: +5 % at 4 calls of 20,480
- *     proofs; from 65,536 proofs on separate launches are 1.5 - 3 % faster).
+ *     lone call of 4096 CMZ proofs takes 1.37 instead of 1.92 ms (one such call after the other, prove + batch verify: 1.36 -> 1.68 M
+ *     proofs/s; four call chains in flight: 3.27 -> 3.70 M), while callers that keep 25 such calls in flight lose 9 % (the transcript
+ *     wavefronts then carry the table builder's 212 registers instead of their own 118) -- they are better served by one wide call
+ *     (zkp_fused_prove_dev over K * 4096 proofs + zkp_fused_batch_verify_many_dev: 6.1 - 6.9 M proofs/s).  0 = never; UINT64_MAX =
+ *     default: in calls of fewer than 65,536 proofs (from there on separate launches are 1.5 - 3 % faster).
  *   ZKP_OPT_TRANSCRIPT_LANES: lanes per proof in the Merlin transcript kernel of the fused flows.  2 = a lane pair per proof
  *     (each lane holds one 32-bit half of every STROBE word: half the latency), 1 = one lane per proof (23 % fewer
  *     instructions per Keccak-f), UINT64_MAX = default: 1 in asynchronous _dev calls of 65,536 proofs or more, 2 otherwise.

@@ -82,7 +82,7 @@ def test_fused_dev_flows_equal_host_pointer_flows(eng, n, wide):
     finally:
         eng.set_option(4, 2**64 - 1)
         eng.set_option(3, 2**64 - 1)
-        eng.set_option(8, 0)
+        eng.set_option(8, 2**64 - 1)
 
 
 def _fused_dev_flows(eng, n):

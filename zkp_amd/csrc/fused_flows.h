@@ -916,7 +916,7 @@ void run_program(zkp_ctx* c, const prog_dev& p_in, uint32_t N, const tr_bufs& bu
 // one: k_tables_transcript); run_program_pending() afterwards runs it on its own if nobody took it.
 void offer_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput, bool overlap) {
   auto& t = c->pending_tr;
-  const bool fuse = c->fuse_tables_transcript < 0 ? (N >= zkp_ctx::kWideCallProofs && N < zkp_ctx::kVeryWideCallProofs) : c->fuse_tables_transcript != 0;
+  const bool fuse = c->fuse_tables_transcript < 0 ? N < zkp_ctx::kVeryWideCallProofs : c->fuse_tables_transcript != 0;
   t.offered = t.active = fuse && p.n != 0 && throughput && !overlap && !transcript_single_lane(c, N, throughput);
   t.ops = p.ops; t.n_ops = p.n; t.tables = p.tables; t.N = N; t.bufs = bufs; t.ts = d_ts; t.saved = reinterpret_cast<uint32_t*>(d_saved); t.failed = d_failed; t.tail = p.tail;
 }

@@ -1146,7 +1146,7 @@ struct zkp_ctx {
            uint8_t* ts = nullptr; uint32_t* saved = nullptr; uint32_t* failed = nullptr; uint32_t tail = 0; } pending_tr;
   int debug_dummy_launches = 0;      // ZKP_TESTOPT_DUMMY_LAUNCHES (test-hook builds only): empty kernels added to every prove call
   bool stmt_classify = true;         // the fused flows' one-launch term classifier (ZKP_TESTOPT_GENERIC_CLASSIFIER of test-hook builds turns it off)
-  int fuse_tables_transcript = -1;       // ZKP_OPT_FUSE_TABLES_TRANSCRIPT: -1 = asynchronous _dev calls of kWideCallProofs .. kVeryWideCallProofs proofs, 0 = never, 1 = always
+  int fuse_tables_transcript = -1;       // ZKP_OPT_FUSE_TABLES_TRANSCRIPT: -1 = asynchronous _dev calls below kVeryWideCallProofs proofs, 0 = never, 1 = always
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
   int ladder_interleave = -1;        // ZKP_OPT_LADDER_INTERLEAVE: the term kernel's ladder blocks spread over the front of its grid instead of all first

@@ -73,7 +73,7 @@ const char* zkp_version(void);
  *     the point's own eight multiples (26 % fewer instructions for that term, but a 321-operation dependent chain inside the
  *     term kernel), UINT64_MAX = default: the ladder in asynchronous _dev calls of 250,000 terms or more (a call that fills the
  *     chip on its own), tables otherwise.
- *   ZKP_OPT_DEV_OVERLAP: 1 = zkp_fused_prove_dev / _verify_compact_dev run the half of their work that does not depend on the
+ *   ZKP_OPT_DEV_OVERLAP: 1 = zkp_fused_prove_dev / _verify_compact_dev / _verify_batchable_dev run the half of their work that does not depend on the
  *     transcripts (decoding, classification, comb tables) on a second stream of the context, as the synchronous entry points
  *     always do: a shorter call, more cross-stream dependencies.  Default 0.
  *   ZKP_OPT_GROUPED_COMB: 1 = constant-time calls list the terms of every point with 8 or more uses next to each other and
@@ -100,7 +100,7 @@ const char* zkp_version(void);
  *     ZKP_CT call is what curve25519-dalek does on a CPU: all entries of the row are read at fixed addresses and the wanted one is
  *     kept with v_cndmask (fixed-base rows: 32 entries, comb / ladder rows: 8), and the grouped comb walk is off.  Same bytes out;
  *     about 1.6 x the instructions of the term kernel.  Default 0.
- *   ZKP_OPT_EACH_STRAUS: how zkp_fused_verify_batchable computes a proof's MSM over its points and commitments (verifier.rs:162-166).
+ *   ZKP_OPT_EACH_STRAUS: how zkp_fused_verify_batchable[_dev] computes a proof's MSM over its points and commitments (verifier.rs:162-166).
  *     UINT64_MAX = default: one Straus walk per proof -- 256 shared doublings and one table addition per operand and window; below
  *     65,536 proofs split over 32 lanes per proof by windows (each lane: two windows of every operand; one quad of lanes per proof then
  *     joins the partial sums), from 65,536 proofs on one lane per proof.  0x200 + P (P = 1, 2, 4 .. 64) = P window parts per proof;

@@ -1227,7 +1227,9 @@ inline uint32_t straus_lanes(const zkp_ctx* c, const fused_plan& pl) {
   const uint32_t K = pl.s.np + pl.s.nc, N = pl.N;
   uint32_t L = c->each_straus_lanes ? std::min<uint32_t>(c->each_straus_lanes, kStrausMaxLanes) : (N >= 65536 ? 1u : (N >= 32768 ? 2u : (N >= 16384 ? 4u : 8u)));
   while (L < kStrausMaxLanes && (K + L - 1) / L > kStrausMaxOpsPerLane) L *= 2;
-  return std::min(L, kStrausMaxLanes);
+  // never more lanes than operands: a lane without an operand would still fetch "its" first table entry every window (an LDS column
+  // nobody wrote, a gather past the proof's commitments)
+  return std::max(1u, std::min(std::min(L, kStrausMaxLanes), K));
 }
 inline bool each_uses_straus(const zkp_ctx* c, const fused_plan& pl) {
   const uint64_t K = (uint64_t)pl.s.np + pl.s.nc;
@@ -1534,6 +1536,8 @@ int zkp_fused_batch_verify_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32
   if (!d_out_point || !d_status || (N && (!d_transcripts || (s.nc && (!d_commitments || !d_weights16)) || (s.m && !d_responses))) ||
       ((s.ns || (N && (s.ni || s.nc))) && !d_points))
     return fail(ZKP_ERR_ARG, "NULL device pointer");
+  if (!aligned16(d_transcripts) || !aligned16(d_points) || !aligned16(d_commitments) || !aligned16(d_responses) || !aligned16(d_weights16) || !aligned16(d_out_point))
+    return fail(ZKP_ERR_ARG, "device buffers must be 16-byte aligned");
   const size_t total = (size_t)s.ns + ((size_t)s.ni + s.nc) * N;
   if (total > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const batch_inter o = batch_carve(*pl, 0);
@@ -1601,7 +1605,12 @@ static int check_many(uint32_t K, uint32_t N_each, const fused_shape& s, uint64_
   if (K == 0 || N_each == 0) return fail(ZKP_ERR_ARG, "n_batches and N_each must be positive");
   if ((uint64_t)K * N_each > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const uint64_t n_each = (uint64_t)s.ns + ((uint64_t)s.ni + s.nc) * N_each;
-  if (n_each * K > 0x7fffffffull || (uint64_t)K * 65 > 65535) return fail(ZKP_ERR_ARG, "batch too large");
+  // the segmented Pippenger launches grids with one y-coordinate per (batch, window): K * W1(c) of them for the window size c that
+  // n_each selects (pip_cfg<c>::W1 = ceil(256 / c) + 1), and a grid's y dimension ends at 65,535
+  const uint64_t W1 = [&]() -> uint64_t {
+    switch (pick_c(n_each)) { case 7: return pip_cfg<7>::W1; case 10: return pip_cfg<10>::W1; case 11: return pip_cfg<11>::W1; default: return pip_cfg<16>::W1; }
+  }();
+  if (n_each * K > 0x7fffffffull || (uint64_t)K * W1 > 65535) return fail(ZKP_ERR_ARG, "batch too large (n_batches x windows exceeds the grid)");
   *n_each_out = n_each;
   return ZKP_OK;
 }
@@ -1610,6 +1619,9 @@ int zkp_fused_batch_verify_many_dev(zkp_ctx* c, const zkp_fused_statement* st, u
                                     const uint8_t* d_weights16, uint8_t* d_out_points, uint32_t* d_status) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
+  // the K-batch kernels read these with 16-byte vector loads (k_batch_after_transcript, k_coeff_build, k_pip_prepare)
+  if (!aligned16(d_transcripts) || !aligned16(d_points) || !aligned16(d_commitments) || !aligned16(d_responses) || !aligned16(d_weights16) || !aligned16(d_out_points))
+    return fail(ZKP_ERR_ARG, "device buffers must be 16-byte aligned");
   if (K == 1) return zkp_fused_batch_verify_dev(c, st, N_each, strobe_pos, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_points, d_status);
   fused_shape s0;
   int rc = check_fused_statement(st, s0);

@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -1107,6 +1108,9 @@ struct zkp_ctx;
 // contexts that are alive (a graph may outlive its context: launching it then is an error, not a use after free)
 static std::mutex g_ctx_mu;
 static std::set<zkp_ctx*> g_live_ctx;
+// every context gets a process-unique id: a graph remembers the id, not just the address, so a context that happens to be
+// allocated where a destroyed one lived (both generations still 0) cannot replay the dead context's recording
+static std::atomic<uint64_t> g_ctx_next_id{1};
 
 static int fail(int code, const std::string& msg) {
   g_last_error = msg;
@@ -1122,6 +1126,7 @@ static int fail(int code, const std::string& msg) {
 
 constexpr int kMaxEvents = 32;     // timing marks per call (a fused flow records more than one per kind)
 struct zkp_ctx {
+  uint64_t uid = 0;                        // process-unique (g_ctx_next_id)
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -1647,6 +1652,7 @@ int zkp_ctx_create(zkp_ctx** out, int device_id) {
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
     return fail(ZKP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   zkp_ctx* c = new zkp_ctx();
+  c->uid = g_ctx_next_id.fetch_add(1);
   c->device = device_id;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(ZKP_ERR_HIP, "hipStreamCreate failed"); }
   c->stream = c->own_stream;
@@ -1751,6 +1757,7 @@ struct zkp_graph {
   hipGraphExec_t exec = nullptr;
   int device = 0;
   zkp_ctx* ctx = nullptr;                        // the context whose workspace / plans the recorded kernels point into
+  uint64_t ctx_uid = 0;
   uint64_t ws_generation = 0, plans_generation = 0;
 };
 
@@ -1778,6 +1785,7 @@ int zkp_ctx_capture_end(zkp_ctx* c, zkp_graph** out) {
   zg->exec = e;
   zg->device = c->device;
   zg->ctx = c;
+  zg->ctx_uid = c->uid;
   zg->ws_generation = c->ws_generation;
   zg->plans_generation = c->plans_generation;
   *out = zg;
@@ -1799,6 +1807,7 @@ int zkp_graph_launch(zkp_graph* g, zkp_ctx* c) {
   if (!g || !c) return fail(ZKP_ERR_ARG, "NULL pointer");
   if (g->ctx != c) return fail(ZKP_ERR_ARG, "a graph can only be launched on the context it was captured on (it records that context's workspace addresses)");
   { std::lock_guard<std::mutex> lk(g_ctx_mu); if (!g_live_ctx.count(c)) return fail(ZKP_ERR_ARG, "the graph's context has been destroyed"); }
+  if (g->ctx_uid != c->uid) return fail(ZKP_ERR_ARG, "the graph's context has been destroyed (another context now lives at its address)");
   if (g->ws_generation != c->ws_generation)
     return fail(ZKP_ERR_ARG, "stale graph: the context's workspace was reallocated by a larger call after the capture -- capture again");
   if (g->plans_generation != c->plans_generation)

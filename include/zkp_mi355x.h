@@ -110,9 +110,12 @@ const char* zkp_version(void);
  *     instead of all starting first (fewer per-lane ladder tables in flight together: -20 % HBM fetch in that kernel); 0 = all first;
  *     UINT64_MAX = default: spread when the launch has 256 or more ladder blocks (65,536 single-use points), where it also is ~1 % faster --
  *     in a lone smaller launch the later start of the last ladder block lengthens the kernel (profiles/r03_ab_experiments.txt, block l).
+ *   ZKP_OPT_WS_LIMIT_BYTES: the largest device workspace this context may allocate (it grows with the largest call it has served: ~75 KB per CMZ
+ *     proof of a prove call).  A call that would need more returns ZKP_ERR_OOM instead of allocating -- the way to keep several contexts of a
+ *     zkp_pipe (zkp_toolbox.h) inside one GPU's memory.  0 / UINT64_MAX = no cap (default).
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
-       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11 };
+       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~35 short kernels (75 in round 1); enqueueing them one by one costs the host ~0.1 ms per
@@ -298,6 +301,60 @@ int zkp_fused_verify_batchable_dev(zkp_ctx* ctx, const zkp_fused_statement* st, 
 int zkp_fused_batch_verify_many_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t n_batches, uint32_t N_each, uint32_t strobe_pos,
                                     uint8_t* d_transcripts, uint8_t* d_points, const uint8_t* d_commitments, const uint8_t* d_responses,
                                     const uint8_t* d_weights16, uint8_t* d_out_points, uint32_t* d_status);
+
+/* (2d) The fused flows on HOST buffers as asynchronous jobs (round 4).  One job per context at a time:
+ *       zkp_fused_*_submit   queues host -> device copies, the flow and device -> host copies on the context's stream and returns;
+ *       zkp_ctx_job_wait     blocks until that job is done and writes what needs the host (verdicts, invalid_point).
+ *     The synchronous host-pointer calls of (2c) are exactly submit + wait.  A caller that wants throughput keeps SEVERAL contexts busy --
+ *     on one GPU or on several (zkp_pipe of zkp_toolbox.h does that): the copies of one job overlap the kernels of the others.
+ *     Host buffers: every input and output buffer named by a submit must stay valid and untouched until zkp_ctx_job_wait returns.  Pinned
+ *     memory (zkp_host_alloc / zkp_host_register) makes the copies truly asynchronous; with ordinary memory HIP stages each copy and the
+ *     submit call blocks for its duration (same results).
+ *     flags: ZKP_JOB_SHARED_TRANSCRIPT -- `transcripts` is ONE 208-byte blob that every proof starts from (the reference's callers write
+ *       `Transcript::new(label)` per proof: tests/zkp.rs:44, benches/zkp.rs:60) instead of [N][208].
+ *     transcripts_out: NULL, or [N][208] receiving the advanced transcripts (what the reference leaves in its `&mut Transcript`s).
+ *     inst_stride: proofs per row of the caller's `inst` array, >= N: row r of this job's instance points starts at inst + 32 * r * inst_stride.
+ *       A job over the proof range [j0, j0 + N) of a larger batch passes inst + 32 * j0 and the batch size (weights_stride likewise for
+ *       the [n_constraints][.][16] weights of the batch verifier) -- no gathering of columns on the host.
+ *     entropy / weights16 == NULL: drawn ON THE DEVICE from the ChaCha20 stream (RFC 8439 block function, 64-bit counter from 0, 64-bit nonce)
+ *       keyed with rng_seed[40] = key[32] || nonce[8], which the caller takes from the operating system per job -- what `thread_rng()` is
+ *       to the reference (prover.rs:82, verifier.rs:153, batch_verifier.rs:179: rand 0.7's ThreadRng is a ChaCha stream keyed from the OS);
+ *       entropy[j] = stream bytes [32 j, 32 j + 32), weights16 = the first 16 * n_constraints * N stream bytes in the array's own order.
+ *     Errors: a submit that fails leaves no job pending and has waited for whatever it had queued (the caller's buffers are free again);
+ *       zkp_ctx_job_wait < 0 means the device failed underneath the job: verdicts are set to 1 (rejected), *invalid_point to 1, and no
+ *       output buffer may be used.  Any other call on a context with a pending job returns ZKP_ERR_ARG. */
+#define ZKP_JOB_SHARED_TRANSCRIPT 1u
+int zkp_fused_prove_submit(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts,
+                           const uint8_t* secrets, const uint8_t* inst, uint32_t inst_stride, const uint8_t* common,
+                           const uint8_t* entropy, const uint8_t* rng_seed /*[40], used when entropy == NULL*/, uint8_t* transcripts_out,
+                           uint8_t* challenges, uint8_t* responses, uint8_t* commitments, int* invalid_point);
+int zkp_fused_verify_compact_submit(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts,
+                                    const uint8_t* inst, uint32_t inst_stride, const uint8_t* common, const uint8_t* challenges,
+                                    const uint8_t* responses, uint8_t* transcripts_out, uint8_t* results /*[N]*/);
+int zkp_fused_batch_verify_many_submit(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t n_batches, uint32_t N_each, uint32_t flags,
+                                       const uint8_t* transcripts, const uint8_t* inst, uint32_t inst_stride, const uint8_t* common,
+                                       const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
+                                       uint32_t weights_stride, const uint8_t* rng_seed, uint8_t* transcripts_out, int* verdicts /*[n_batches]*/);
+int zkp_fused_verify_batchable_submit(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts,
+                                      const uint8_t* inst, uint32_t inst_stride, const uint8_t* common, const uint8_t* commitments,
+                                      const uint8_t* responses, const uint8_t* weights16 /*[N][n_constraints][16]*/, const uint8_t* rng_seed,
+                                      uint8_t* transcripts_out, uint8_t* results /*[N]*/);
+int zkp_ctx_job_wait(zkp_ctx* ctx);      /* no job pending: ZKP_OK at once */
+int zkp_ctx_job_poll(zkp_ctx* ctx);      /* 1 = zkp_ctx_job_wait would not block, 0 = still running */
+int zkp_ctx_job_pending(zkp_ctx* ctx);   /* 1 = a job was submitted and not yet waited for */
+
+/* Pinned host memory for the jobs above (hipHostMalloc / hipHostRegister, visible to every GPU of the process).  zkp_host_is_pinned: 1 if p
+ * points into such memory.  Registering costs ~12 us per MiB (profiles/r04_pcie_copy_rates.txt): register long-lived buffers once. */
+int zkp_host_alloc(void** out, size_t bytes);
+void zkp_host_free(void* p);
+int zkp_host_register(void* p, size_t bytes);
+int zkp_host_unregister(void* p);
+int zkp_host_is_pinned(const void* p);
+
+/* The device-side generator behind `entropy == NULL` / `weights16 == NULL`, exposed for the known-answer test: bytes (a multiple of 64)
+ * of the ChaCha20 stream, block b = zkp_chacha20_block(key, first_block + b, nonce) of zkp_toolbox.h, into d_out (device, 16-byte aligned);
+ * asynchronous on the context's stream. */
+int zkp_chacha20_fill_dev(zkp_ctx* ctx, const uint8_t key[32], uint64_t nonce, uint64_t first_block, uint8_t* d_out, size_t bytes);
 
 /* (3) Stand-alone decode / validity check, batched.  Replaces the
  *     `.map(|pt| pt.decompress()).collect::<Option<Vec<_>>>()` of verifier.rs:87-92.

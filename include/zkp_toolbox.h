@@ -135,6 +135,86 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, u
                             const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
                             const uint8_t* responses, const uint8_t* weights16, int n_threads, uint8_t* coeffs);
 
+/* ---- pipelines and device groups (round 4) ---------------------------------------------------------------------------
+ * A zkp_pipe owns `contexts_per_device` engine contexts on each of the listed GPUs (HIP ordinals; an ordinal may be listed more than once)
+ * and offers the calls above in two forms:
+ *
+ * (a) ASYNCHRONOUS JOBS -- zkp_*_submit puts one call on the next free context and returns a zkp_job; zkp_job_wait returns what the
+ *     synchronous call would have returned and fills the outputs.  With >= 3 jobs in flight the host <-> device copies of one job overlap
+ *     the kernels of the others: this is the throughput a caller with host buffers gets (bench.py: e2e_host_buffers.pipelined).
+ *       - every buffer named by a submit stays valid and untouched until zkp_job_wait returns (which also frees the job);
+ *       - buffers in pinned memory (zkp_host_alloc / zkp_host_register of zkp_mi355x.h) go to the DMA engines as they are; others are
+ *         staged through pinned rings the pipe owns (one host memcpy each way);
+ *       - flags = ZKP_JOB_SHARED_TRANSCRIPT: `transcripts` is ONE blob every proof starts from (`Transcript::new(label)` per proof, as the
+ *         reference's callers write); transcripts_out = NULL or [N][208] for the advanced states;
+ *       - inst_stride / weights_stride = proofs per row of the caller's [.][stride][32|16] arrays (>= N): a proof range of a larger batch
+ *         is passed by pointer offset, nothing is gathered by the caller;
+ *       - entropy == NULL / weights16 == NULL: 40 bytes of getrandom() per job key a ChaCha20 stream that is expanded ON THE DEVICE
+ *         (the reference's thread_rng(), prover.rs:82 / verifier.rs:153 / batch_verifier.rs:179); getrandom failing = ZKP_TB_NO_ENTROPY;
+ *       - all contexts busy = ZKP_TB_PIPE_FULL (wait for the oldest job); jobs complete independently: a failing job -- a rejected batch,
+ *         ZKP_ERR_OOM on one context, a device fault -- leaves the verdicts of the others intact, and its own outputs fail closed
+ *         (results / verdicts set to "rejected", negative return code from zkp_job_wait);
+ *       - batches below the fused threshold or with ragged transcripts run the synchronous call inside submit (same results).
+ *     A pipe and its jobs belong to one host thread at a time.
+ *
+ * (b) SYNCHRONOUS CALLS OVER ALL CONTEXTS -- zkp_pipe_prove_batch, _verify_compact_batch, _verify_batchable_each, _batch_verify[_many],
+ *     _batch_verify_locate: same arguments and results as the single-context calls, the N proofs sharded as contiguous ranges
+ *     [g N / G, (g + 1) N / G) over the G = min(contexts, N) contexts, one host thread per GPU, common points replicated.  Proving and
+ *     per-proof verification give the bytes / verdicts of the single-context call.  zkp_pipe_batch_verify gives ONE verdict: each range
+ *     is a batch check of its own (own weights, own static-coefficient sums: batch_verifier.rs:173-206 per range) and the batch verifies
+ *     iff every range does -- the AND is taken on the host, no collective, no other process.  zkp_pipe_batch_verify_many
+ *     hands whole batches to the contexts.  This is how one process uses the 8 GPUs of a node.
+ */
+#define ZKP_TB_PIPE_FULL 3              /* every context of the pipe has a job in flight */
+typedef struct zkp_pipe zkp_pipe;
+typedef struct zkp_job zkp_job;
+int zkp_pipe_create(zkp_pipe** out, const int* device_ids, int n_devices, int contexts_per_device);
+void zkp_pipe_destroy(zkp_pipe* pipe);                    /* waits for jobs in flight */
+int zkp_pipe_num_contexts(const zkp_pipe* pipe);
+int zkp_pipe_num_devices(const zkp_pipe* pipe);
+zkp_ctx* zkp_pipe_context(zkp_pipe* pipe, int i);        /* context i (tuning options, ZKP_OPT_WS_LIMIT_BYTES); do not destroy it */
+int zkp_pipe_context_device(const zkp_pipe* pipe, int i);
+int zkp_pipe_jobs_in_flight(const zkp_pipe* pipe);
+const char* zkp_pipe_last_error(const zkp_pipe* pipe);    /* text of the last failure of a pipe call (never NULL) */
+
+int zkp_prove_batch_submit(zkp_pipe* pipe, const zkp_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts,
+                           const uint8_t* secrets, const uint8_t* inst_points, uint32_t inst_stride, const uint8_t* common_points,
+                           const uint8_t* entropy, uint8_t* transcripts_out, uint8_t* challenges, uint8_t* responses,
+                           uint8_t* commitments, zkp_job** job);
+int zkp_verify_compact_batch_submit(zkp_pipe* pipe, const zkp_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts,
+                                    const uint8_t* inst_points, uint32_t inst_stride, const uint8_t* common_points,
+                                    const uint8_t* challenges, const uint8_t* responses, uint8_t* transcripts_out, uint8_t* results,
+                                    zkp_job** job);
+int zkp_verify_batchable_each_submit(zkp_pipe* pipe, const zkp_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts,
+                                     const uint8_t* inst_points, uint32_t inst_stride, const uint8_t* common_points,
+                                     const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16 /*[N][nc][16]*/,
+                                     uint8_t* transcripts_out, uint8_t* results, zkp_job** job);
+int zkp_batch_verify_many_submit(zkp_pipe* pipe, const zkp_statement* st, uint32_t n_batches, uint32_t N_each, uint32_t flags,
+                                 const uint8_t* transcripts, const uint8_t* inst_points, uint32_t inst_stride,
+                                 const uint8_t* common_points, const uint8_t* commitments, const uint8_t* responses,
+                                 const uint8_t* weights16 /*[nc][weights_stride][16]*/, uint32_t weights_stride, uint8_t* transcripts_out,
+                                 int* verdicts /*[n_batches]: ZKP_TB_OK | ZKP_TB_VERIFICATION_FAILURE after zkp_job_wait*/, zkp_job** job);
+int zkp_job_done(const zkp_job* job);    /* 1 = zkp_job_wait would not block */
+int zkp_job_wait(zkp_job* job);          /* the synchronous call's return code; frees the job */
+
+int zkp_pipe_prove_batch(zkp_pipe* pipe, const zkp_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
+                         const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* entropy, uint8_t* challenges,
+                         uint8_t* responses, uint8_t* commitments);
+int zkp_pipe_verify_compact_batch(zkp_pipe* pipe, const zkp_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst_points,
+                                  const uint8_t* common_points, const uint8_t* challenges, const uint8_t* responses, uint8_t* results);
+int zkp_pipe_verify_batchable_each(zkp_pipe* pipe, const zkp_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst_points,
+                                   const uint8_t* common_points, const uint8_t* commitments, const uint8_t* responses,
+                                   const uint8_t* weights16, uint8_t* results);
+int zkp_pipe_batch_verify(zkp_pipe* pipe, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* transcripts,
+                          const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments, const uint8_t* responses,
+                          const uint8_t* weights16);
+int zkp_pipe_batch_verify_many(zkp_pipe* pipe, const zkp_statement* st, uint32_t n_batches, uint32_t N_each, uint32_t n_transcripts,
+                               uint8_t* transcripts, const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
+                               const uint8_t* responses, const uint8_t* weights16, int* verdicts);
+int zkp_pipe_batch_verify_locate(zkp_pipe* pipe, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* transcripts,
+                                 const uint8_t* inst_points, const uint8_t* common_points, const uint8_t* commitments,
+                                 const uint8_t* responses, const uint8_t* weights16, uint8_t* results);
+
 /* Batches of at least this many proofs whose transcripts stand at one STROBE position run entirely on the device
  * (zkp_mi355x.h section 2c: transcripts, scalars and MSMs); smaller or ragged batches hash their transcripts on the
  * host threads and use the GPU for the group arithmetic only.  Both routes produce the same bytes.  Default 32 (the measured crossover for the CMZ statement);

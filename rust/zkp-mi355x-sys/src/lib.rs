@@ -20,6 +20,14 @@ pub struct zkp_graph {
 pub struct zkp_statement {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct zkp_pipe {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct zkp_job {
+    _private: [u8; 0],
+}
 
 pub const ZKP_OK: c_int = 0;
 pub const ZKP_ERR_HIP: c_int = -1;
@@ -39,10 +47,13 @@ pub const ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c_int = 8;
 pub const ZKP_OPT_CT_MASKED_SCANS: c_int = 9;
 pub const ZKP_OPT_EACH_STRAUS: c_int = 10;
 pub const ZKP_OPT_LADDER_INTERLEAVE: c_int = 11;
+pub const ZKP_OPT_WS_LIMIT_BYTES: c_int = 12;
+pub const ZKP_JOB_SHARED_TRANSCRIPT: u32 = 1;
 
 pub const ZKP_TB_OK: c_int = 0;
 pub const ZKP_TB_VERIFICATION_FAILURE: c_int = 1; // ProofError::VerificationFailure (errors.rs:6)
 pub const ZKP_TB_BATCH_SIZE_MISMATCH: c_int = 2; //  ProofError::BatchSizeMismatch   (errors.rs:9)
+pub const ZKP_TB_PIPE_FULL: c_int = 3; //             every context of a zkp_pipe has a job in flight
 pub const ZKP_TB_BAD_STATEMENT: c_int = -10;
 pub const ZKP_TB_INVALID_POINT: c_int = -11;
 pub const ZKP_TB_NO_ENTROPY: c_int = -12;
@@ -133,6 +144,31 @@ extern "C" {
     pub fn zkp_fused_batch_verify_many_dev(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n_batches: u32, n_each: u32, strobe_pos: u32,
                                            d_transcripts: *mut u8, d_points: *mut u8, d_commitments: *const u8, d_responses: *const u8,
                                            d_weights16: *const u8, d_out_points: *mut u8, d_status: *mut u32) -> c_int;
+    // ---- (2d) the fused flows on host buffers as asynchronous jobs (one per context), pinned memory, device ChaCha20 ------
+    pub fn zkp_fused_prove_submit(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, flags: u32, transcripts: *const u8, secrets: *const u8,
+                                  inst: *const u8, inst_stride: u32, common: *const u8, entropy: *const u8, rng_seed: *const u8,
+                                  transcripts_out: *mut u8, challenges: *mut u8, responses: *mut u8, commitments: *mut u8,
+                                  invalid_point: *mut c_int) -> c_int;
+    pub fn zkp_fused_verify_compact_submit(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, flags: u32, transcripts: *const u8,
+                                           inst: *const u8, inst_stride: u32, common: *const u8, challenges: *const u8, responses: *const u8,
+                                           transcripts_out: *mut u8, results: *mut u8) -> c_int;
+    pub fn zkp_fused_batch_verify_many_submit(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n_batches: u32, n_each: u32, flags: u32,
+                                              transcripts: *const u8, inst: *const u8, inst_stride: u32, common: *const u8,
+                                              commitments: *const u8, responses: *const u8, weights16: *const u8, weights_stride: u32,
+                                              rng_seed: *const u8, transcripts_out: *mut u8, verdicts: *mut c_int) -> c_int;
+    pub fn zkp_fused_verify_batchable_submit(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, flags: u32, transcripts: *const u8,
+                                             inst: *const u8, inst_stride: u32, common: *const u8, commitments: *const u8,
+                                             responses: *const u8, weights16: *const u8, rng_seed: *const u8, transcripts_out: *mut u8,
+                                             results: *mut u8) -> c_int;
+    pub fn zkp_ctx_job_wait(ctx: *mut zkp_ctx) -> c_int;
+    pub fn zkp_ctx_job_poll(ctx: *mut zkp_ctx) -> c_int;
+    pub fn zkp_ctx_job_pending(ctx: *mut zkp_ctx) -> c_int;
+    pub fn zkp_host_alloc(out: *mut *mut c_void, bytes: usize) -> c_int;
+    pub fn zkp_host_free(p: *mut c_void);
+    pub fn zkp_host_register(p: *mut c_void, bytes: usize) -> c_int;
+    pub fn zkp_host_unregister(p: *mut c_void) -> c_int;
+    pub fn zkp_host_is_pinned(p: *const c_void) -> c_int;
+    pub fn zkp_chacha20_fill_dev(ctx: *mut zkp_ctx, key: *const u8, nonce: u64, first_block: u64, d_out: *mut u8, bytes: usize) -> c_int;
     // ---- (3), (4) stand-alone codec: verifier.rs:87-92, mod.rs:180 -------------------------------------------------------
     pub fn zkp_decode_check(ctx: *mut zkp_ctx, n: u64, points: *const u8, status: *mut u8, xyzt: *mut u8) -> c_int;
     pub fn zkp_encode_many(ctx: *mut zkp_ctx, n: u64, xyzt: *const u8, out: *mut u8) -> c_int;
@@ -179,6 +215,49 @@ extern "C" {
     pub fn zkp_batch_verify_locate(ctx: *mut zkp_ctx, st: *const zkp_statement, n: u32, n_transcripts: u32, transcripts: *mut u8,
                                    inst_points: *const u8, common_points: *const u8, commitments: *const u8, responses: *const u8,
                                    weights16: *const u8, n_threads: c_int, results: *mut u8) -> c_int;
+    // ---- pipelines and device groups: contexts over one or several GPUs, asynchronous jobs, sharded synchronous calls ------
+    pub fn zkp_pipe_create(out: *mut *mut zkp_pipe, device_ids: *const c_int, n_devices: c_int, contexts_per_device: c_int) -> c_int;
+    pub fn zkp_pipe_destroy(pipe: *mut zkp_pipe);
+    pub fn zkp_pipe_num_contexts(pipe: *const zkp_pipe) -> c_int;
+    pub fn zkp_pipe_num_devices(pipe: *const zkp_pipe) -> c_int;
+    pub fn zkp_pipe_context(pipe: *mut zkp_pipe, i: c_int) -> *mut zkp_ctx;
+    pub fn zkp_pipe_context_device(pipe: *const zkp_pipe, i: c_int) -> c_int;
+    pub fn zkp_pipe_jobs_in_flight(pipe: *const zkp_pipe) -> c_int;
+    pub fn zkp_pipe_last_error(pipe: *const zkp_pipe) -> *const c_char;
+    pub fn zkp_prove_batch_submit(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, flags: u32, transcripts: *const u8, secrets: *const u8,
+                                  inst_points: *const u8, inst_stride: u32, common_points: *const u8, entropy: *const u8,
+                                  transcripts_out: *mut u8, challenges: *mut u8, responses: *mut u8, commitments: *mut u8,
+                                  job: *mut *mut zkp_job) -> c_int;
+    pub fn zkp_verify_compact_batch_submit(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, flags: u32, transcripts: *const u8,
+                                           inst_points: *const u8, inst_stride: u32, common_points: *const u8, challenges: *const u8,
+                                           responses: *const u8, transcripts_out: *mut u8, results: *mut u8, job: *mut *mut zkp_job) -> c_int;
+    pub fn zkp_verify_batchable_each_submit(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, flags: u32, transcripts: *const u8,
+                                            inst_points: *const u8, inst_stride: u32, common_points: *const u8, commitments: *const u8,
+                                            responses: *const u8, weights16: *const u8, transcripts_out: *mut u8, results: *mut u8,
+                                            job: *mut *mut zkp_job) -> c_int;
+    pub fn zkp_batch_verify_many_submit(pipe: *mut zkp_pipe, st: *const zkp_statement, n_batches: u32, n_each: u32, flags: u32,
+                                        transcripts: *const u8, inst_points: *const u8, inst_stride: u32, common_points: *const u8,
+                                        commitments: *const u8, responses: *const u8, weights16: *const u8, weights_stride: u32,
+                                        transcripts_out: *mut u8, verdicts: *mut c_int, job: *mut *mut zkp_job) -> c_int;
+    pub fn zkp_job_done(job: *const zkp_job) -> c_int;
+    pub fn zkp_job_wait(job: *mut zkp_job) -> c_int;
+    pub fn zkp_pipe_prove_batch(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, transcripts: *mut u8, secrets: *const u8,
+                                inst_points: *const u8, common_points: *const u8, entropy: *const u8, challenges: *mut u8,
+                                responses: *mut u8, commitments: *mut u8) -> c_int;
+    pub fn zkp_pipe_verify_compact_batch(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, transcripts: *mut u8, inst_points: *const u8,
+                                         common_points: *const u8, challenges: *const u8, responses: *const u8, results: *mut u8) -> c_int;
+    pub fn zkp_pipe_verify_batchable_each(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, transcripts: *mut u8, inst_points: *const u8,
+                                          common_points: *const u8, commitments: *const u8, responses: *const u8, weights16: *const u8,
+                                          results: *mut u8) -> c_int;
+    pub fn zkp_pipe_batch_verify(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, n_transcripts: u32, transcripts: *mut u8,
+                                 inst_points: *const u8, common_points: *const u8, commitments: *const u8, responses: *const u8,
+                                 weights16: *const u8) -> c_int;
+    pub fn zkp_pipe_batch_verify_many(pipe: *mut zkp_pipe, st: *const zkp_statement, n_batches: u32, n_each: u32, n_transcripts: u32,
+                                      transcripts: *mut u8, inst_points: *const u8, common_points: *const u8, commitments: *const u8,
+                                      responses: *const u8, weights16: *const u8, verdicts: *mut c_int) -> c_int;
+    pub fn zkp_pipe_batch_verify_locate(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, n_transcripts: u32, transcripts: *mut u8,
+                                        inst_points: *const u8, common_points: *const u8, commitments: *const u8, responses: *const u8,
+                                        weights16: *const u8, results: *mut u8) -> c_int;
     pub fn zkp_toolbox_set_fused_min_batch(n: u32);
     pub fn zkp_toolbox_get_fused_min_batch() -> u32;
     pub fn zkp_chacha20_block(key: *const u8, counter: u64, nonce: u64, out: *mut u8);

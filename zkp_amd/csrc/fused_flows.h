@@ -1394,6 +1394,8 @@ int zkp_batch_check(zkp_ctx* c, const zkp_batch_statement* st, uint32_t N, const
   return ZKP_OK;
 }
 
+// (the host-pointer twins of the entry points below -- zkp_fused_prove, _verify_compact, _batch_verify[_many], _verify_batchable -- are
+//  host_jobs.h: the same flows as asynchronous jobs, followed by zkp_ctx_job_wait)
 // ---- prove ---------------------------------------------------------------------------------------------------------
 int zkp_fused_prove_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos, uint8_t* d_transcripts,
                         const uint8_t* d_secrets, const uint8_t* d_table, const uint8_t* d_entropy, uint8_t* d_challenges,
@@ -1414,58 +1416,6 @@ int zkp_fused_prove_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, u
   return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status, /*overlap=*/c->dev_overlap, /*throughput=*/true);
 }
 
-int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
-                    const uint8_t* inst, const uint8_t* common, const uint8_t* entropy, uint8_t* challenges,
-                    uint8_t* responses, uint8_t* commitments, int* invalid_point) {
-  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
-  if (N == 0) { if (invalid_point) *invalid_point = 0; return ZKP_OK; }
-  if (!transcripts) return fail(ZKP_ERR_ARG, "NULL pointer");
-  uint32_t pos = 0;
-  int rc = common_tail(transcripts, N, &pos);
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(c->device));
-  fused_plan* pl = nullptr;
-  rc = get_plan(c, FLOW_PROVE, st, N, pos, &pl);
-  if (rc) return rc;
-  const fused_shape& s = pl->s;
-  if (!entropy || !challenges || !invalid_point || (s.m && (!secrets || !responses)) || (s.nc && !commitments) || (s.ni && !inst) || (s.ns && !common))
-    return fail(ZKP_ERR_ARG, "NULL pointer");
-  if ((uint64_t)N * s.T > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
-  const uint32_t m = s.m, nc = s.nc, n_points = s.ns + s.ni * N;
-  carve cv;
-  const size_t o_ts = cv.take((size_t)N * 208);
-  const size_t o_sec = cv.take((size_t)N * m * 32 + 32);
-  const size_t o_tbl = cv.take((size_t)n_points * 32 + 32);
-  const size_t o_ent = cv.take((size_t)N * 32);
-  const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
-  const size_t o_st = cv.take((size_t)N * nc + 4);
-  const size_t o_chal = cv.take((size_t)N * 32);
-  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
-  const prove_inter o = prove_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min(false, (size_t)N * s.T))));
-  if (rc) return rc;
-  const ws_view w{static_cast<char*>(c->ws)};
-  HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
-  if (m) HIP_TRY(hipMemcpyAsync(w.base + o_sec, secrets, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  if (s.ns) HIP_TRY(hipMemcpyAsync(w.base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
-  if (s.ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(w.base + o_ent, entropy, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
-  rc = prove_core(c, *pl, o, w.u8(o_ts), w.u8(o_sec), w.u8(o_tbl), w.u8(o_ent), w.u8(o_chal), w.u8(o_resp), w.u8(o_coms), w.u8(o_st), /*overlap=*/true, /*throughput=*/false);
-  if (rc) return rc;
-  std::vector<uint8_t> status((size_t)N * nc);
-  HIP_TRY(hipMemcpyAsync(challenges, w.base + o_chal, (size_t)N * 32, hipMemcpyDeviceToHost, c->stream));
-  if (m) HIP_TRY(hipMemcpyAsync(responses, w.base + o_resp, (size_t)N * m * 32, hipMemcpyDeviceToHost, c->stream));
-  if (nc) {
-    HIP_TRY(hipMemcpyAsync(commitments, w.base + o_coms, (size_t)N * nc * 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(status.data(), w.base + o_st, (size_t)N * nc, hipMemcpyDeviceToHost, c->stream));
-  }
-  HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  *invalid_point = 0;
-  for (uint8_t b : status) if (b) *invalid_point = 1;
-  return ZKP_OK;
-}
-
 // ---- verify_compact --------------------------------------------------------------------------------------------------
 int zkp_fused_verify_compact_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos, uint8_t* d_transcripts,
                                  const uint8_t* d_table, const uint8_t* d_challenges, const uint8_t* d_responses, uint8_t* d_results) {
@@ -1482,45 +1432,6 @@ int zkp_fused_verify_compact_dev(zkp_ctx* c, const zkp_fused_statement* st, uint
   rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1, N * s.nc, cfg_from_terms(pl->tpt.data(), pl->T1, s.ns, s.np, N, 2)));
   if (rc) return rc;
   return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results, /*overlap=*/c->dev_overlap, /*throughput=*/true);
-}
-
-int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
-                             const uint8_t* common, const uint8_t* challenges, const uint8_t* responses, uint8_t* results) {
-  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
-  if (N == 0) return ZKP_OK;
-  if (!transcripts) return fail(ZKP_ERR_ARG, "NULL pointer");
-  uint32_t pos = 0;
-  int rc = common_tail(transcripts, N, &pos);
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(c->device));
-  fused_plan* pl = nullptr;
-  rc = get_plan(c, FLOW_VERIFY, st, N, pos, &pl);
-  if (rc) return rc;
-  const fused_shape& s = pl->s;
-  if (!challenges || !results || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
-  const uint32_t m = s.m, n_points = s.ns + s.ni * N;
-  if ((uint64_t)N * pl->T1 > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
-  carve cv;
-  const size_t o_ts = cv.take((size_t)N * 208);
-  const size_t o_tbl = cv.take((size_t)n_points * 32 + 32);
-  const size_t o_claim = cv.take((size_t)N * 32);
-  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
-  const size_t o_res = cv.take((size_t)N);
-  const verify_inter o = verify_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * pl->T1, N * s.nc, cfg_from_terms(pl->tpt.data(), pl->T1, s.ns, s.np, N, 2)));
-  if (rc) return rc;
-  const ws_view w{static_cast<char*>(c->ws)};
-  HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
-  if (s.ns) HIP_TRY(hipMemcpyAsync(w.base + o_tbl, common, (size_t)s.ns * 32, hipMemcpyHostToDevice, c->stream));
-  if (s.ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)s.ns, inst, (size_t)s.ni * N * 32, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(w.base + o_claim, challenges, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
-  if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  rc = verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res), /*overlap=*/true, /*throughput=*/false);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(results, w.base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return ZKP_OK;
 }
 
 // ---- batch verification ----------------------------------------------------------------------------------------------
@@ -1544,60 +1455,6 @@ int zkp_fused_batch_verify_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32
   rc = ensure_ws(c, o.end + optional_ws(total));
   if (rc) return rc;
   return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_point, d_status, /*throughput=*/true);
-}
-
-int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
-                           const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
-                           int* verdict, uint8_t* debug_scalars) {
-  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
-  if (!verdict || (N && !transcripts)) return fail(ZKP_ERR_ARG, "NULL pointer");
-  uint32_t pos = 0;
-  int rc = N ? common_tail(transcripts, N, &pos) : ZKP_OK;
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(c->device));
-  fused_plan* pl = nullptr;
-  rc = get_plan(c, FLOW_BATCH, st, N, pos, &pl);
-  if (rc) return rc;
-  const fused_shape& s = pl->s;
-  if (N && ((s.nc && (!commitments || !weights16)) || (s.m && !responses) || (s.ni && !inst))) return fail(ZKP_ERR_ARG, "NULL pointer");
-  if (s.ns && !common) return fail(ZKP_ERR_ARG, "NULL pointer");
-  const uint32_t m = s.m, nc = s.nc, ns = s.ns, ni = s.ni;
-  const size_t total = (size_t)ns + ((size_t)ni + nc) * N;
-  if (total > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
-  carve cv;
-  const size_t o_pts = cv.take(total * 32 + 32);
-  const size_t o_out = cv.take(32);
-  const size_t o_st = cv.take(16);
-  const size_t o_ts = cv.take((size_t)N * 208);
-  const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
-  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
-  const size_t o_w = cv.take((size_t)nc * N * 16 + 16);
-  const batch_inter o = batch_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + optional_ws(total));
-  if (rc) return rc;
-  const ws_view w{static_cast<char*>(c->ws)};
-  if (ns) HIP_TRY(hipMemcpyAsync(w.base + o_pts, common, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
-  if (N) {
-    if (ni) HIP_TRY(hipMemcpyAsync(w.base + o_pts + 32 * (size_t)ns, inst, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
-    if (nc) {
-      HIP_TRY(hipMemcpyAsync(w.base + o_coms, commitments, (size_t)N * nc * 32, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hipMemcpyAsync(w.base + o_w, weights16, (size_t)nc * N * 16, hipMemcpyHostToDevice, c->stream));
-    }
-    if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  }
-  rc = batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st), /*throughput=*/false);
-  if (rc) return rc;
-  uint8_t out[32];
-  uint32_t stv[2] = {1, 1};
-  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, w.base + o.sc, total * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(out, w.base + o_out, 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(stv, w.base + o_st, 8, hipMemcpyDeviceToHost, c->stream));
-  if (N) HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  static const uint8_t zero[32] = {0};
-  *verdict = (stv[0] == 0 && stv[1] == 0 && memcmp(out, zero, 32) == 0) ? 0 : 1;   // batch_verifier.rs:230-234
-  return ZKP_OK;
 }
 
 // ---- K batch verifications in one pass ------------------------------------------------------------------------------
@@ -1641,65 +1498,6 @@ int zkp_fused_batch_verify_many_dev(zkp_ctx* c, const zkp_fused_statement* st, u
   return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_points, d_status, /*throughput=*/true, K);
 }
 
-int zkp_fused_batch_verify_many(zkp_ctx* c, const zkp_fused_statement* st, uint32_t K, uint32_t N_each, uint8_t* transcripts, const uint8_t* inst,
-                                const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
-                                int* verdicts, uint8_t* debug_scalars) {
-  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
-  if (!verdicts || !transcripts) return fail(ZKP_ERR_ARG, "NULL pointer");
-  if (K == 1) return zkp_fused_batch_verify(c, st, N_each, transcripts, inst, common, commitments, responses, weights16, verdicts, debug_scalars);
-  fused_shape s0;
-  int rc = check_fused_statement(st, s0);
-  if (rc) return rc;
-  uint64_t n_each = 0;
-  rc = check_many(K, N_each, s0, &n_each);
-  if (rc) return rc;
-  const uint32_t N = K * N_each;
-  uint32_t pos = 0;
-  rc = common_tail(transcripts, N, &pos);
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(c->device));
-  fused_plan* pl = nullptr;
-  rc = get_plan(c, FLOW_BATCH, st, N, pos, &pl);
-  if (rc) return rc;
-  const fused_shape& s = pl->s;
-  if ((s.nc && (!commitments || !weights16)) || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
-  const uint32_t m = s.m, nc = s.nc, ns = s.ns, ni = s.ni;
-  const size_t n_pts = (size_t)ns + ((size_t)ni + nc) * N, n_sc = (size_t)K * ns + ((size_t)ni + nc) * N;
-  carve cv;
-  const size_t o_pts = cv.take(n_pts * 32 + 32);
-  const size_t o_out = cv.take((size_t)K * 32);
-  const size_t o_st = cv.take((size_t)K * 8);
-  const size_t o_ts = cv.take((size_t)N * 208);
-  const size_t o_coms = cv.take((size_t)N * nc * 32 + 32);
-  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
-  const size_t o_w = cv.take((size_t)nc * N * 16 + 16);
-  const batch_inter o = batch_carve(*pl, cv.off, K);
-  rc = ensure_ws(c, o.end + optional_many_ws(n_each, K));
-  if (rc) return rc;
-  const ws_view w{static_cast<char*>(c->ws)};
-  if (ns) HIP_TRY(hipMemcpyAsync(w.base + o_pts, common, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
-  if (ni) HIP_TRY(hipMemcpyAsync(w.base + o_pts + 32 * (size_t)ns, inst, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
-  if (nc) {
-    HIP_TRY(hipMemcpyAsync(w.base + o_coms, commitments, (size_t)N * nc * 32, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(w.base + o_w, weights16, (size_t)nc * N * 16, hipMemcpyHostToDevice, c->stream));
-  }
-  if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  rc = batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st), /*throughput=*/false, K);
-  if (rc) return rc;
-  std::vector<uint8_t> out((size_t)K * 32);
-  std::vector<uint32_t> stv((size_t)K * 2, 1u);
-  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, w.base + o.sc, n_sc * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(out.data(), w.base + o_out, out.size(), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(stv.data(), w.base + o_st, stv.size() * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  static const uint8_t zero[32] = {0};
-  for (uint32_t b = 0; b < K; ++b)                    // batch_verifier.rs:230-234, once per batch
-    verdicts[b] = (stv[2 * b] == 0 && stv[2 * b + 1] == 0 && memcmp(out.data() + 32 * (size_t)b, zero, 32) == 0) ? 0 : 1;
-  return ZKP_OK;
-}
-
 // ---- verify_batchable, one verdict per proof -----------------------------------------------------------------------------
 int zkp_fused_verify_batchable_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos, uint8_t* d_transcripts,
                                    const uint8_t* d_table, const uint8_t* d_responses, const uint8_t* d_weights16, uint8_t* d_results) {
@@ -1719,57 +1517,6 @@ int zkp_fused_verify_batchable_dev(zkp_ctx* c, const zkp_fused_statement* st, ui
   rc = ensure_ws(c, each_uses_straus(c, *pl) ? straus_carve(c, *pl, o.end).end : o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N, each_terms_cfg(*pl)));
   if (rc) return rc;
   return each_core(c, *pl, o, d_transcripts, d_table, d_responses, d_weights16, d_results, /*overlap=*/c->dev_overlap);
-}
-
-int zkp_fused_verify_batchable(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
-                               const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
-                               uint8_t* results) {
-  return zkp_fused_verify_batchable_coeffs(c, st, N, transcripts, inst, common, commitments, responses, weights16, results, nullptr);
-}
-
-int zkp_fused_verify_batchable_coeffs(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst,
-                                      const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
-                                      uint8_t* results, uint8_t* debug_scalars) {
-  if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
-  if (N == 0) return ZKP_OK;
-  if (!transcripts || !results) return fail(ZKP_ERR_ARG, "NULL pointer");
-  uint32_t pos = 0;
-  int rc = common_tail(transcripts, N, &pos);
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(c->device));
-  fused_plan* pl = nullptr;
-  rc = get_plan(c, FLOW_BATCH, st, N, pos, &pl);          // same transcript program as the batch verifier (:134-142 = :152-167)
-  if (rc) return rc;
-  const fused_shape& s = pl->s;
-  if ((s.nc && (!commitments || !weights16)) || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
-  const uint32_t m = s.m, nc = s.nc, ns = s.ns, ni = s.ni;
-  const size_t n_points = (size_t)ns + (size_t)ni * N + (size_t)N * nc, K = (size_t)s.np + nc;
-  if (n_points > 0x7fffffffull || (size_t)N * K > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
-  carve cv;
-  const size_t o_ts = cv.take((size_t)N * 208);
-  const size_t o_tbl = cv.take(n_points * 32 + 32);
-  const size_t o_resp = cv.take((size_t)N * m * 32 + 32);
-  const size_t o_w = cv.take((size_t)N * nc * 16 + 16);
-  const size_t o_res = cv.take((size_t)N + 4);
-  const each_inter o = each_carve(*pl, cv.off);
-  rc = ensure_ws(c, each_uses_straus(c, *pl) ? straus_carve(c, *pl, o.end).end : o.end + terms_path_ws((uint32_t)n_points, (uint32_t)(N * K), N, each_terms_cfg(*pl)));
-  if (rc) return rc;
-  const ws_view w{static_cast<char*>(c->ws)};
-  HIP_TRY(hipMemcpyAsync(w.base + o_ts, transcripts, (size_t)N * 208, hipMemcpyHostToDevice, c->stream));
-  if (ns) HIP_TRY(hipMemcpyAsync(w.base + o_tbl, common, (size_t)ns * 32, hipMemcpyHostToDevice, c->stream));
-  if (ni) HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * (size_t)ns, inst, (size_t)ni * N * 32, hipMemcpyHostToDevice, c->stream));
-  if (nc) {
-    HIP_TRY(hipMemcpyAsync(w.base + o_tbl + 32 * ((size_t)ns + (size_t)ni * N), commitments, (size_t)N * nc * 32, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(w.base + o_w, weights16, (size_t)N * nc * 16, hipMemcpyHostToDevice, c->stream));
-  }
-  if (m) HIP_TRY(hipMemcpyAsync(w.base + o_resp, responses, (size_t)N * m * 32, hipMemcpyHostToDevice, c->stream));
-  rc = each_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_resp), w.u8(o_w), w.u8(o_res), /*overlap=*/true);
-  if (rc) return rc;
-  if (debug_scalars) HIP_TRY(hipMemcpyAsync(debug_scalars, w.base + o.sc, (size_t)N * K * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(results, w.base + o_res, (size_t)N, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(transcripts, w.base + o_ts, (size_t)N * 208, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return ZKP_OK;
 }
 
 }  // extern "C"

@@ -1204,6 +1204,18 @@ struct zkp_ctx {
   uint32_t hot_nreg = 0;
   // fused flows (fused_flows.h): compiled transcript programs and operand templates per (flow, statement, N, position)
   std::map<std::string, void*> fused_plans;
+  // asynchronous host-buffer jobs (host_jobs.h): at most one in flight per context
+  struct job_t {
+    char kind = 0;                     // 0 = none pending; 'P' prove, 'V' verify_compact, 'E' verify_batchable (each), 'B' batch verification(s)
+    hipEvent_t done = nullptr;         // recorded behind the job's last copy
+    uint8_t* pin = nullptr;            // pinned scratch for the few words zkp_ctx_job_wait turns into verdicts (MSM outputs, status words)
+    size_t pin_bytes = 0;
+    uint32_t K = 0;
+    int* verdicts = nullptr;           // 'B': [K], the caller's
+    int* invalid_point = nullptr;      // 'P': the caller's
+  } job;
+  size_t ws_limit = 0;                 // ZKP_OPT_WS_LIMIT_BYTES: a call that would need a larger workspace fails with ZKP_ERR_OOM (0 = no cap)
+  bool hot_registry_uploaded = false;  // the device copy of the fixed-base registry matches hot_key[]
 };
 void free_fused_plans(zkp_ctx* c);
 
@@ -1219,7 +1231,11 @@ struct carve {
 };
 
 int ensure_ws(zkp_ctx* c, size_t bytes) {
+  // every flow passes here before it touches the workspace: a submitted host-buffer job still owns it
+  if (c->job.kind) return fail(ZKP_ERR_ARG, "a submitted job is pending on this context: zkp_ctx_job_wait first");
   if (bytes <= c->ws_bytes) return ZKP_OK;
+  if (c->ws_limit && bytes + bytes / 8 > c->ws_limit)
+    return fail(ZKP_ERR_OOM, "the call needs a workspace of " + std::to_string(bytes + bytes / 8) + " bytes, ZKP_OPT_WS_LIMIT_BYTES allows " + std::to_string(c->ws_limit));
   if (c->capturing) return fail(ZKP_ERR_ARG, "graph capture: the workspace would grow -- run the same calls once before capturing them");
   if (c->ws) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1669,6 +1685,8 @@ void zkp_ctx_destroy(zkp_ctx* c) {
   hipSetDevice(c->device);
   if (c->capturing) { hipGraph_t g = nullptr; hipStreamEndCapture(c->stream, &g); if (g) hipGraphDestroy(g); c->capturing = false; }
   hipStreamSynchronize(c->stream);
+  if (c->job.done) hipEventDestroy(c->job.done);
+  if (c->job.pin) hipHostFree(c->job.pin);
   if (c->ws) hipFree(c->ws);
   if (c->hot_tables) hipFree(c->hot_tables);
   if (c->hot_reg_words) hipFree(c->hot_reg_words);
@@ -1721,6 +1739,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;
     case ZKP_OPT_LADDER_INTERLEAVE: c->ladder_interleave = value == ~0ull ? -1 : value != 0; return ZKP_OK;
+    case ZKP_OPT_WS_LIMIT_BYTES: c->ws_limit = value == ~0ull ? 0 : (size_t)value; return ZKP_OK;
     case ZKP_OPT_EACH_STRAUS:
     {
       const bool wins = value > 0x200 && value <= 0x200 + 64 && ((value - 0x200) & (value - 0x201)) == 0;
@@ -1865,6 +1884,9 @@ int zkp_ctx_prepare_fixed_points(zkp_ctx* c, uint32_t n, const uint8_t* encoding
     if (!found && std::find(fresh.begin(), fresh.end(), key) == fresh.end()) fresh.push_back(key);
   }
   if (fresh.size() > (size_t)HOT_SLOTS) fresh.resize(HOT_SLOTS);
+  if (fresh.empty() && c->hot_registry_uploaded) return ZKP_OK;      // every point has its table already: nothing to launch, nothing to wait for
+  if (c->job.kind) return fail(ZKP_ERR_ARG, "a submitted job is pending on this context: zkp_ctx_job_wait first");
+  c->hot_registry_uploaded = false;
   if (!fresh.empty()) {
     const uint32_t nh = (uint32_t)fresh.size();
     char* sc = c->hot_scratch;
@@ -1931,6 +1953,7 @@ int zkp_ctx_prepare_fixed_points(zkp_ctx* c, uint32_t n, const uint8_t* encoding
     HIP_TRY(hipMemcpyAsync(c->hot_reg_slot, slots.data(), 4 * (size_t)c->hot_nreg, hipMemcpyHostToDevice, c->stream));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->hot_registry_uploaded = true;
   return ZKP_OK;
 }
 
@@ -2171,3 +2194,4 @@ int zkp_encode_many(zkp_ctx* c, uint64_t n, const uint8_t* xyzt, uint8_t* out) {
 }  // extern "C"
 
 #include "fused_flows.h"
+#include "host_jobs.h"

@@ -40,7 +40,14 @@ EXPORTS = (
     "zkp_prove_phase_a", "zkp_prove_phase_b", "zkp_toolbox_set_fused_min_batch", "zkp_toolbox_get_fused_min_batch", "zkp_chacha20_block",
     "zkp_proof_compact_size", "zkp_proof_batchable_size", "zkp_proof_compact_encode", "zkp_proof_compact_decode",
     "zkp_proof_batchable_encode", "zkp_proof_batchable_decode", "zkp_batch_verify_locate", "zkp_batch_verify_many",
+    "zkp_pipe_create", "zkp_pipe_destroy", "zkp_pipe_num_contexts", "zkp_pipe_num_devices", "zkp_pipe_context", "zkp_pipe_context_device",
+    "zkp_pipe_jobs_in_flight", "zkp_pipe_last_error", "zkp_prove_batch_submit", "zkp_verify_compact_batch_submit",
+    "zkp_verify_batchable_each_submit", "zkp_batch_verify_many_submit", "zkp_job_done", "zkp_job_wait", "zkp_pipe_prove_batch",
+    "zkp_pipe_verify_compact_batch", "zkp_pipe_verify_batchable_each", "zkp_pipe_batch_verify", "zkp_pipe_batch_verify_many",
+    "zkp_pipe_batch_verify_locate",
 )
+ZKP_JOB_SHARED_TRANSCRIPT = 1
+ZKP_TB_PIPE_FULL = 3
 
 
 class ProofError(Exception):
@@ -84,6 +91,30 @@ def lib() -> ctypes.CDLL:
         _lib.zkp_proof_compact_decode.argtypes = [ctypes.c_char_p, sz, vp, vp, u32, ctypes.POINTER(u32), ctypes.POINTER(sz)]
         _lib.zkp_proof_batchable_encode.argtypes = [vp, u32, vp, u32, ctypes.c_char_p, sz]
         _lib.zkp_proof_batchable_decode.argtypes = [ctypes.c_char_p, sz, vp, u32, ctypes.POINTER(u32), vp, u32, ctypes.POINTER(u32), ctypes.POINTER(sz)]
+        i32 = ctypes.c_int
+        _lib.zkp_pipe_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i32), i32, i32]
+        _lib.zkp_pipe_destroy.argtypes = [vp]
+        _lib.zkp_pipe_destroy.restype = None
+        for f in ("num_contexts", "num_devices", "jobs_in_flight"):
+            getattr(_lib, "zkp_pipe_" + f).argtypes = [vp]
+        _lib.zkp_pipe_context.argtypes = [vp, i32]
+        _lib.zkp_pipe_context.restype = vp
+        _lib.zkp_pipe_context_device.argtypes = [vp, i32]
+        _lib.zkp_pipe_last_error.argtypes = [vp]
+        _lib.zkp_pipe_last_error.restype = ctypes.c_char_p
+        pj = ctypes.POINTER(vp)
+        _lib.zkp_prove_batch_submit.argtypes = [vp, vp, u32, u32, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, pj]
+        _lib.zkp_verify_compact_batch_submit.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, vp, vp, vp, pj]
+        _lib.zkp_verify_batchable_each_submit.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp, pj]
+        _lib.zkp_batch_verify_many_submit.argtypes = [vp, vp, u32, u32, u32, vp, vp, u32, vp, vp, vp, vp, u32, vp, vp, pj]
+        _lib.zkp_job_done.argtypes = [vp]
+        _lib.zkp_job_wait.argtypes = [vp]
+        _lib.zkp_pipe_prove_batch.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+        _lib.zkp_pipe_verify_compact_batch.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp]
+        _lib.zkp_pipe_verify_batchable_each.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
+        _lib.zkp_pipe_batch_verify.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp, vp, vp]
+        _lib.zkp_pipe_batch_verify_many.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
+        _lib.zkp_pipe_batch_verify_locate.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp]
     return _lib
 
 
@@ -402,6 +433,254 @@ def batch_verify_build(st, transcripts, inst, common, commitments, responses, we
                                       _p(np.ascontiguousarray(weights16)), threads, _p(ms), _p(mp))
     _raise(rc, "zkp_batch_verify_build")
     return ms, mp
+
+
+
+# ---- pipelines and device groups (include/zkp_toolbox.h, round 4) ------------------------------------------------------
+def pinned_empty(shape, dtype=np.uint8) -> np.ndarray:
+    """A numpy array in pinned host memory (zkp_host_alloc): jobs copy from / to it without staging.  The memory is freed when
+    the array (and every view of it) is gone."""
+    hip = load_library()
+    hip.zkp_host_alloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.zkp_host_free.argtypes = [ctypes.c_void_p]
+    hip.zkp_host_free.restype = None
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = ctypes.c_void_p()
+    rc = hip.zkp_host_alloc(ctypes.byref(ptr), ctypes.c_size_t(max(nbytes, 1)))
+    if rc != 0:
+        _raise(rc, "zkp_host_alloc")
+
+    class _Owner:
+        def __init__(self, p):
+            self.p = p
+
+        def __del__(self):
+            try:
+                hip.zkp_host_free(self.p)
+            except Exception:
+                pass
+    buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(ptr.value)
+    buf._owner = _Owner(ptr)                                     # keeps the allocation alive as long as the ctypes buffer is
+    return np.frombuffer(buf, dtype=np.uint8, count=nbytes).view(dtype).reshape(shape)
+
+
+def pinned_copy(a) -> np.ndarray:
+    a = np.ascontiguousarray(a)
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
+class Job:
+    """A submitted call of a Pipe.  wait() returns what the synchronous call returns; the arrays handed to submit (kept alive
+    here) hold the outputs afterwards."""
+
+    def __init__(self, handle, keep, outputs, kind):
+        self._h, self._keep, self.outputs, self.kind = handle, keep, outputs, kind
+
+    def done(self) -> bool:
+        return self._h is None or bool(lib().zkp_job_done(self._h))
+
+    def wait(self, raise_on_failure: bool = True):
+        if self._h is None:
+            raise RuntimeError("job already waited for")
+        rc = lib().zkp_job_wait(self._h)
+        self._h = None
+        self.rc = rc
+        if rc < 0 or (raise_on_failure and rc != 0):
+            _raise(rc, "zkp_job_wait")
+        return self.outputs
+
+
+class Pipe:
+    """zkp_pipe: `contexts_per_device` engine contexts on each listed GPU; asynchronous jobs (submit_* -> Job) and synchronous
+    calls sharded over all contexts (prove_batch, batch_verify, ...)."""
+
+    def __init__(self, devices=(0,), contexts_per_device: int = 3):
+        devs = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = lib().zkp_pipe_create(ctypes.byref(h), devs, len(devices), contexts_per_device)
+        if rc != 0:
+            _raise(rc, "zkp_pipe_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().zkp_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    @property
+    def num_contexts(self) -> int:
+        return int(lib().zkp_pipe_num_contexts(self._h))
+
+    @property
+    def jobs_in_flight(self) -> int:
+        return int(lib().zkp_pipe_jobs_in_flight(self._h))
+
+    def last_error(self) -> str:
+        return lib().zkp_pipe_last_error(self._h).decode()
+
+    def set_option(self, option: int, value: int, context: Optional[int] = None) -> None:
+        """zkp_ctx_set_option on one context of the pipe, or on all of them"""
+        hip = load_library()
+        hip.zkp_ctx_set_option.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64]
+        for i in ([context] if context is not None else range(self.num_contexts)):
+            rc = hip.zkp_ctx_set_option(lib().zkp_pipe_context(self._h, i), option, ctypes.c_uint64(value))
+            if rc != 0:
+                _raise(rc, "zkp_ctx_set_option")
+
+    # -- asynchronous jobs ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _ts(transcripts, n):
+        """-> (array, flags): one 208-byte blob (shared) or [n][208]"""
+        t = np.ascontiguousarray(transcripts, dtype=np.uint8)
+        if t.shape == (TRANSCRIPT_BYTES,):
+            return t, ZKP_JOB_SHARED_TRANSCRIPT
+        if t.shape != (n, TRANSCRIPT_BYTES):
+            raise ValueError("transcripts must be one blob [208] or [%d][208]" % n)
+        return t, 0
+
+    def _submit(self, rc, h, what):
+        if rc == ZKP_TB_PIPE_FULL:
+            raise BlockingIOError("every context of the pipe has a job in flight")
+        if rc != 0:
+            _raise(rc, what)
+        return h
+
+    def submit_prove(self, st: Statement, n: int, transcripts, secrets, inst, common, entropy=None, want_transcripts=False, out=None,
+                     inst_stride: Optional[int] = None) -> Job:
+        """zkp_prove_batch_submit.  transcripts: one blob [208] (every proof starts from it) or [n][208].  out = optional dict of
+        preallocated (e.g. pinned) arrays chal / resp / coms / ts.  -> Job whose outputs are (chal, resp, coms[, ts])."""
+        ts, flags = self._ts(transcripts, n)
+        out = out or {}
+        chal = out.get("chal") if out.get("chal") is not None else np.zeros((n, 32), np.uint8)
+        resp = out.get("resp") if out.get("resp") is not None else np.zeros((n, st.m, 32), np.uint8)
+        coms = out.get("coms") if out.get("coms") is not None else np.zeros((n, st.nc, 32), np.uint8)
+        ts_out = (out.get("ts") if out.get("ts") is not None else np.zeros((n, TRANSCRIPT_BYTES), np.uint8)) if want_transcripts else None
+        keep = [ts, np.ascontiguousarray(secrets), inst if inst_stride else np.ascontiguousarray(inst), np.ascontiguousarray(common),
+                None if entropy is None else np.ascontiguousarray(entropy), chal, resp, coms, ts_out]
+        h = ctypes.c_void_p()
+        rc = lib().zkp_prove_batch_submit(self._h, st._h, n, flags, _p(keep[0]), _p(keep[1]), _p(keep[2]), inst_stride or n, _p(keep[3]), _p(keep[4]),
+                                          _p(ts_out), _p(chal), _p(resp), _p(coms), ctypes.byref(h))
+        self._submit(rc, h, "zkp_prove_batch_submit")
+        return Job(h, keep, (chal, resp, coms) + ((ts_out,) if want_transcripts else ()), "prove")
+
+    def submit_batch_verify_many(self, st: Statement, n_batches: int, n_each: int, transcripts, inst, common, commitments, responses, weights16=None,
+                                 want_transcripts=False, inst_stride: Optional[int] = None, weights_stride: Optional[int] = None) -> Job:
+        """zkp_batch_verify_many_submit -> Job whose outputs are (verdicts[n_batches] (0 = Ok, 1 = VerificationFailure)[, ts])."""
+        n = n_batches * n_each
+        ts, flags = self._ts(transcripts, n)
+        verdicts = np.ones(n_batches, np.int32)
+        ts_out = np.zeros((n, TRANSCRIPT_BYTES), np.uint8) if want_transcripts else None
+        keep = [ts, inst if inst_stride else np.ascontiguousarray(inst), np.ascontiguousarray(common), np.ascontiguousarray(commitments),
+                np.ascontiguousarray(responses), None if weights16 is None else (weights16 if weights_stride else np.ascontiguousarray(weights16)), verdicts, ts_out]
+        h = ctypes.c_void_p()
+        rc = lib().zkp_batch_verify_many_submit(self._h, st._h, n_batches, n_each, flags, _p(keep[0]), _p(keep[1]), inst_stride or n, _p(keep[2]), _p(keep[3]),
+                                                _p(keep[4]), _p(keep[5]), weights_stride or n, _p(ts_out), _p(verdicts), ctypes.byref(h))
+        self._submit(rc, h, "zkp_batch_verify_many_submit")
+        return Job(h, keep, (verdicts,) + ((ts_out,) if want_transcripts else ()), "batch_verify_many")
+
+    def submit_verify_compact(self, st: Statement, n: int, transcripts, inst, common, challenges, responses, want_transcripts=False,
+                              inst_stride: Optional[int] = None) -> Job:
+        ts, flags = self._ts(transcripts, n)
+        res = np.ones(n, np.uint8)
+        ts_out = np.zeros((n, TRANSCRIPT_BYTES), np.uint8) if want_transcripts else None
+        keep = [ts, inst if inst_stride else np.ascontiguousarray(inst), np.ascontiguousarray(common), np.ascontiguousarray(challenges),
+                np.ascontiguousarray(responses), res, ts_out]
+        h = ctypes.c_void_p()
+        rc = lib().zkp_verify_compact_batch_submit(self._h, st._h, n, flags, _p(keep[0]), _p(keep[1]), inst_stride or n, _p(keep[2]), _p(keep[3]), _p(keep[4]),
+                                                   _p(ts_out), _p(res), ctypes.byref(h))
+        self._submit(rc, h, "zkp_verify_compact_batch_submit")
+        return Job(h, keep, (res,) + ((ts_out,) if want_transcripts else ()), "verify_compact")
+
+    def submit_verify_batchable_each(self, st: Statement, n: int, transcripts, inst, common, commitments, responses, weights16=None,
+                                     want_transcripts=False, inst_stride: Optional[int] = None) -> Job:
+        ts, flags = self._ts(transcripts, n)
+        res = np.ones(n, np.uint8)
+        ts_out = np.zeros((n, TRANSCRIPT_BYTES), np.uint8) if want_transcripts else None
+        keep = [ts, inst if inst_stride else np.ascontiguousarray(inst), np.ascontiguousarray(common), np.ascontiguousarray(commitments),
+                np.ascontiguousarray(responses), None if weights16 is None else np.ascontiguousarray(weights16), res, ts_out]
+        h = ctypes.c_void_p()
+        rc = lib().zkp_verify_batchable_each_submit(self._h, st._h, n, flags, _p(keep[0]), _p(keep[1]), inst_stride or n, _p(keep[2]), _p(keep[3]), _p(keep[4]),
+                                                    _p(keep[5]), _p(ts_out), _p(res), ctypes.byref(h))
+        self._submit(rc, h, "zkp_verify_batchable_each_submit")
+        return Job(h, keep, (res,) + ((ts_out,) if want_transcripts else ()), "verify_batchable_each")
+
+    # -- synchronous calls sharded over every context (one host thread per listed device) ------------------------------
+    def prove_batch(self, st: Statement, transcripts: np.ndarray, secrets, inst, common, entropy=None):
+        n = len(transcripts)
+        _check_batch_shapes(st, n, inst, common, None, secrets)
+        chal = np.zeros((n, 32), np.uint8)
+        resp = np.zeros((n, st.m, 32), np.uint8)
+        coms = np.zeros((n, st.nc, 32), np.uint8)
+        rc = lib().zkp_pipe_prove_batch(self._h, st._h, n, _p(transcripts), _p(np.ascontiguousarray(secrets)), _p(np.ascontiguousarray(inst)),
+                                        _p(np.ascontiguousarray(common)), _p(None if entropy is None else np.ascontiguousarray(entropy)), _p(chal), _p(resp), _p(coms))
+        _raise(rc, "zkp_pipe_prove_batch")
+        return chal, resp, coms
+
+    def verify_compact_batch(self, st, transcripts, inst, common, challenges, responses) -> np.ndarray:
+        n = len(transcripts)
+        _check_batch_shapes(st, n, inst, common, None, responses)
+        res = np.ones(n, np.uint8)
+        rc = lib().zkp_pipe_verify_compact_batch(self._h, st._h, n, _p(transcripts), _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                                 _p(np.ascontiguousarray(challenges)), _p(np.ascontiguousarray(responses)), _p(res))
+        _raise(rc, "zkp_pipe_verify_compact_batch")
+        return res
+
+    def verify_batchable_each(self, st, transcripts, inst, common, commitments, responses, weights16=None) -> np.ndarray:
+        n = len(transcripts)
+        _check_batch_shapes(st, n, inst, common, commitments, responses, weights16, per_proof_weights=True)
+        res = np.ones(n, np.uint8)
+        rc = lib().zkp_pipe_verify_batchable_each(self._h, st._h, n, _p(transcripts), _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                                  _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
+                                                  _p(None if weights16 is None else np.ascontiguousarray(weights16)), _p(res))
+        _raise(rc, "zkp_pipe_verify_batchable_each")
+        return res
+
+    def batch_verify(self, st, transcripts, inst, common, commitments, responses, weights16=None) -> None:
+        """Raises VerificationFailure unless every range of the batch verifies (host AND of the per-context verdicts)."""
+        n = len(commitments)
+        _check_batch_shapes(st, n, inst, common, commitments, responses, weights16)
+        rc = lib().zkp_pipe_batch_verify(self._h, st._h, n, len(transcripts), _p(transcripts), _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                         _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
+                                         _p(None if weights16 is None else np.ascontiguousarray(weights16)))
+        _raise(rc, "zkp_pipe_batch_verify")
+
+    def batch_verify_many(self, st, n_batches: int, transcripts, inst, common, commitments, responses, weights16=None) -> np.ndarray:
+        n = len(commitments)
+        if n_batches <= 0 or n % n_batches:
+            raise ValueError("the number of proofs must be a positive multiple of n_batches")
+        _check_batch_shapes(st, n, inst, common, commitments, responses, weights16)
+        verdicts = np.ones(n_batches, np.int32)
+        rc = lib().zkp_pipe_batch_verify_many(self._h, st._h, n_batches, n // n_batches, len(transcripts), _p(transcripts), _p(np.ascontiguousarray(inst)),
+                                              _p(np.ascontiguousarray(common)), _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
+                                              _p(None if weights16 is None else np.ascontiguousarray(weights16)), _p(verdicts))
+        _raise(rc, "zkp_pipe_batch_verify_many")
+        return verdicts
+
+    def batch_verify_locate(self, st, transcripts, inst, common, commitments, responses, weights16=None):
+        n = len(commitments)
+        _check_batch_shapes(st, n, inst, common, commitments, responses, weights16)
+        res = np.ones(n, np.uint8)
+        rc = lib().zkp_pipe_batch_verify_locate(self._h, st._h, n, len(transcripts), _p(transcripts), _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
+                                                _p(np.ascontiguousarray(commitments)), _p(np.ascontiguousarray(responses)),
+                                                _p(None if weights16 is None else np.ascontiguousarray(weights16)), _p(res))
+        if rc not in (0, 1):
+            _raise(rc, "zkp_pipe_batch_verify_locate")
+        return rc == 0, res
 
 
 def prove_phase_a(st, transcripts, secrets, inst, common, entropy, threads: int = 0):

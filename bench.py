@@ -398,6 +398,8 @@ def run_workload(cx, args, cfg, n, steps, warmup, K, n_streams, primary):
         for e_ in engines:
             e_.synchronize()
         torch.cuda.synchronize()
+        if getattr(dist, "in_process", False):
+            dist.barrier()         # ranks that are threads of one process: nobody starts a stream capture while another is still inside a device synchronize
 
     def batches_ok(b):
         return int(b["bst"].abs().sum().item()) == 0 and not bool(b["out"].any().item())
@@ -575,7 +577,85 @@ def e2e_host_buffers(eng, n=4096, reps=3):
             best = cur
     return {"proofs": n, "prove_ms": best[0] * 1e3, "batch_verify_ms": best[1] * 1e3, "proofs_per_s": n / sum(best),
             "note": "zkp_prove_batch + zkp_batch_verify (fused route) on host buffers: PCIe copies, OS entropy for the blindings (prover.rs:82) and "
-                    "ChaCha20 weights (batch_verifier.rs:179) included; one synchronous call each, nothing pipelined"}
+                    "ChaCha20 weights (batch_verifier.rs:179) included; one synchronous call each, nothing pipelined (see `pipelined`)"}
+
+
+def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,)):
+    """The CMZ step through the BOUNDARY a Rust caller would bind, pipelined (include/zkp_toolbox.h: zkp_pipe): host buffers in, host
+    buffers out, `jobs` prove jobs of K batches of n proofs each (zkp_prove_batch_submit) and, for every finished prove job, one
+    zkp_batch_verify_many_submit over the proofs it returned (K verdicts) -- at most `contexts` jobs in flight per device, entropy
+    (prover.rs:82) and weights (batch_verifier.rs:179) drawn inside the calls (getrandom seed per job, ChaCha20 on the device), every
+    proof starting from Transcript::new(b"Benchmark") as in the reference's bench loop.  pinned = the caller's buffers live in pinned
+    memory (zkp_host_alloc); otherwise they are ordinary numpy arrays and the pipe stages them through its own pinned rings."""
+    import collections
+    import numpy as np
+    from zkp_amd import toolbox as T
+    from zkp_amd.engine import Engine
+    mod = T.cmz_module(10)
+    st = mod.statement
+    nn = n * K
+    eng = Engine(devices[0])
+    secrets, inst, common = make_instance(eng, cmz_statement(), nn, np.random.default_rng(78))
+    eng.close()
+    t0s = T.Transcript(LABEL).state
+    mk = T.pinned_copy if pinned else np.ascontiguousarray
+    empty = T.pinned_empty if pinned else (lambda shape: np.zeros(shape, np.uint8))
+    a_sec, a_inst, a_com, a_t0 = mk(secrets), mk(inst), mk(common), mk(t0s)
+    in_flight = contexts * len(devices)
+    free_out = collections.deque(dict(chal=empty((nn, 32)), resp=empty((nn, st.m, 32)), coms=empty((nn, st.nc, 32))) for _ in range(2 * in_flight + 2))
+    with T.Pipe(tuple(devices), contexts) as pipe:
+        host = {"submit_s": 0.0, "wait_s": 0.0}
+        phases = {"P": [0.0, 0.0, 0.0, 0], "V": [0.0, 0.0, 0.0, 0]}
+        if os.environ.get("ZKP_BENCH_JOB_TIMING"):
+            pipe.set_profiling(True)
+
+        def run(n_jobs):
+            pending, to_verify = collections.deque(), collections.deque()
+            submitted = verified = 0
+            while verified < n_jobs:
+                ta = time.perf_counter()
+                if to_verify and len(pending) < in_flight:
+                    o = to_verify.popleft()
+                    pending.append(("V", o, pipe.submit_batch_verify_many(st, K, n, a_t0, a_inst, a_com, o["coms"], o["resp"])))
+                    host["submit_s"] += time.perf_counter() - ta
+                elif submitted < n_jobs and len(pending) < in_flight and free_out:
+                    o = free_out.popleft()          # (first in, first out: the warm-up pass touches every buffer set once)
+                    pending.append(("P", o, pipe.submit_prove(st, nn, a_t0, a_sec, a_inst, a_com, out=o)))
+                    submitted += 1
+                    host["submit_s"] += time.perf_counter() - ta
+                else:
+                    kind, o, job = pending.popleft()
+                    outs = job.wait()
+                    host["wait_s"] += time.perf_counter() - ta
+                    if os.environ.get("ZKP_BENCH_JOB_TIMING"):
+                        ms = pipe.job_timing(job.context)
+                        for q in range(3):
+                            phases[kind][q] += ms[q]
+                        phases[kind][3] += 1
+                    if kind == "P":
+                        to_verify.append(o)
+                    else:
+                        assert os.environ.get("ZKP_X_SKIP") or not outs[0].any(), "a batch of fresh proofs did not verify"
+                        free_out.append(o)
+                        verified += 1
+        run(len(free_out) + in_flight)                  # plans compiled, workspaces and staging rings sized, fixed-base tables built, every buffer touched
+        host["submit_s"] = host["wait_s"] = 0.0
+        t0 = time.perf_counter()
+        run(jobs)
+        el = time.perf_counter() - t0
+        # a corrupted proof must fail exactly its own batch
+        o = free_out[0]
+        job = pipe.submit_prove(st, nn, a_t0, a_sec, a_inst, a_com, out=o)
+        job.wait()
+        o["resp"][(K // 2) * n + 7, 3, 0] ^= 1
+        (v,) = pipe.submit_batch_verify_many(st, K, n, a_t0, a_inst, a_com, o["coms"], o["resp"]).wait()
+        assert os.environ.get("ZKP_X_SKIP") or [int(x) for x in v] == [1 if b == K // 2 else 0 for b in range(K)], "a corrupted proof must fail exactly its own batch"
+    h2d = jobs * (2 * a_inst.nbytes + a_sec.nbytes + o["coms"].nbytes + o["resp"].nbytes + 2 * (a_com.nbytes + 208))
+    d2h = jobs * (o["chal"].nbytes + o["resp"].nbytes + o["coms"].nbytes)
+    return {"proofs_per_s": jobs * nn / el, "proofs": jobs * nn, "elapsed_ms": el * 1e3, "proofs_per_batch": n, "batches_per_submit": K, "jobs_in_flight": in_flight,
+            "job_stream_ms": {k: {"h2d": v[0] / max(v[3], 1), "kernels": v[1] / max(v[3], 1), "d2h": v[2] / max(v[3], 1)} for k, v in phases.items()} if os.environ.get("ZKP_BENCH_JOB_TIMING") else None,
+            "devices": list(devices), "host_buffers": "pinned (zkp_host_alloc)" if pinned else "ordinary memory, staged through the pipe's pinned rings",
+            "h2d_GBps": h2d / el / 1e9, "d2h_GBps": d2h / el / 1e9, "host_ms_in_submit": host["submit_s"] * 1e3, "host_ms_in_wait": host["wait_s"] * 1e3, "bytes_per_proof": {"h2d": h2d / (jobs * nn), "d2h": d2h / (jobs * nn)}}
 
 
 def main():
@@ -598,11 +678,15 @@ def main():
     ap.add_argument("--multi-total5", type=int, default=1 << 18, help="--gpus > 1: total proofs of the configs[4] sub-record (2^18 W64 proofs over the GPUs)")
     ap.add_argument("--pmc-json", default=None, help="rocprofv3 --pmc summary (tools/pmc_summary.py); default profiles/r03_pmc_counters_cfg<config>_k<batches per call>.json; "
                                                      "used only if its source hash and workload shape match")
+    ap.add_argument("--in-process", action="store_true", help="--gpus N > 1 WITHOUT torchrun / gloo / RCCL: this one process drives the N GPUs, one host "
+                                                             "thread and one set of engine contexts per GPU, the verdict AND is taken on the host "
+                                                             "(the C-ABI counterpart is zkp_pipe over N devices); same JSON line")
+    ap.add_argument("--pipe-contexts", type=int, default=6, help="e2e_host_buffers.pipelined: contexts (= jobs in flight) of the zkp_pipe")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
                     help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "RANK" not in os.environ:
+    if args.gpus > 1 and "RANK" not in os.environ and not args.in_process:
         # convenience: self-launch one process per GPU exactly as the driver would
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
@@ -619,15 +703,83 @@ def main():
             raise SystemExit("--batches-per-call applies to --config 2 (the other workloads are one wide batch per step)")
         K, n_streams = 1, max(1, min(args.streams or def_streams or pick_streams(args.steps), max(1, args.steps)))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(max(n_streams, 8 if args.gpus > 1 else 1), args.max_hw_queues))))   # default is 4
+    import torch
+
+    if args.in_process and args.gpus > 1 and "RANK" not in os.environ:
+        # one process, one host thread per GPU ("one host thread + stream per device ... AND of G verdict bits -- on the host")
+        import threading
+        torch.cuda.init()
+        tg = ThreadGroup(args.gpus)
+        errors = []
+
+        def worker(r):
+            try:
+                tg.bind(r)
+                rank_main(args, desc, n, K, n_streams, r, 0 if os.environ.get("ZKP_BENCH_DRYRUN_ONE_GPU") else r, args.gpus, tg)
+            except BaseException as e:      # noqa: BLE001 -- a dead rank must not leave the others waiting at a barrier forever
+                errors.append(e)
+                tg.abort()
+        th = [threading.Thread(target=worker, args=(r,)) for r in range(1, args.gpus)]
+        for t_ in th:
+            t_.start()
+        worker(0)
+        for t_ in th:
+            t_.join()
+        if errors:
+            raise errors[0]
+        return
+    rank_main(args, desc, n, K, n_streams, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), None)
+
+
+class ThreadGroup:
+    """What bench.py needs of torch.distributed, for ranks that are THREADS of one process (--in-process): barrier and all_reduce of
+    small CPU tensors.  No sockets, no gloo, no RCCL -- the only cross-GPU exchange of this path is the AND of verdict bits."""
+
+    in_process = True
+
+    class ReduceOp:
+        MIN, MAX, SUM = "min", "max", "sum"
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self._bar = threading.Barrier(world)
+        self._slots = [None] * world
+        self._tls = threading.local()
+
+    def bind(self, rank):
+        self._tls.rank = rank
+
+    def abort(self):
+        self._bar.abort()
+
+    def barrier(self):
+        self._bar.wait()
+
+    def all_reduce(self, t, op=None, group=None):
+        import torch
+        self._slots[self._tls.rank] = t.detach().cpu().clone()
+        self._bar.wait()
+        v = torch.stack(self._slots)
+        res = v.min(0).values if op == "min" else (v.max(0).values if op == "max" else v.sum(0))
+        self._bar.wait()
+        t.copy_(res)
+
+    def destroy_process_group(self):
+        pass
+
+
+def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_group):
     import numpy as np
     import torch
 
     cx = Ctx()
-    cx.rank = int(os.environ.get("RANK", "0"))
-    cx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    cx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    cx.rank, cx.local_rank, cx.world = rank_, local_rank_, world_
     cx.dist, cx.group, dinfo = None, None, {"collective": None, "backend_world_size": 1, "rccl_error": None}
-    if cx.world > 1:
+    if thread_group is not None:
+        cx.dist, cx.group = thread_group, None
+        dinfo = {"collective": "host-and (in-process: one thread per GPU, no process group)", "backend_world_size": world_, "rccl_error": None}
+    elif cx.world > 1:
         if os.environ.get("ZKP_BENCH_DRYRUN_ONE_GPU"):
             cx.local_rank = 0
         else:
@@ -648,6 +800,11 @@ def main():
         e2e = e2e_host_buffers(eng)
     for e_ in r["engines"]:
         e_.close()
+    if e2e is not None:
+        # the same flows through the zkp_pipe of include/zkp_toolbox.h: jobs of K batches, several in flight, host buffers both ways
+        torch.cuda.empty_cache()
+        e2e["pipelined"] = e2e_pipelined(n=n, K=5, contexts=args.pipe_contexts, jobs=24, pinned=True)
+        e2e["pipelined_staged"] = e2e_pipelined(n=n, K=5, contexts=args.pipe_contexts, jobs=24, pinned=False)
     if world > 1 and args.config == "2" and not args.no_multi_configs:
         multi = {}
         for key, cfg, total, cap, streams_cap in (("4", "4share", args.multi_total4, 1 << 19, 2), ("5", "5share", args.multi_total5, 1 << 15, 8)):
@@ -666,6 +823,13 @@ def main():
                           "ms_per_call": rr["elapsed"] * 1e3 / csteps, "per_rank_elapsed_ms": {"min": float(tmin.item()) * 1e3, "max": float(tmax.item()) * 1e3},
                           "collective": dinfo["collective"], "verdict": "every batch of every rank verified (asserted)"}
 
+    if thread_group is not None and args.config == "2" and not args.no_flow_lines:
+        # the same N GPUs through the C-ABI boundary a Rust caller binds: ONE zkp_pipe over all devices, host buffers both ways
+        dist.barrier()
+        if rank == 0:
+            devs = [0] * world if os.environ.get("ZKP_BENCH_DRYRUN_ONE_GPU") else list(range(world))
+            e2e = {"pipelined": e2e_pipelined(n=n, K=min(5, K) if n < 4096 else 5, contexts=3, jobs=8 * world, pinned=True, devices=devs)}
+        dist.barrier()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

@@ -342,6 +342,10 @@ int zkp_fused_verify_batchable_submit(zkp_ctx* ctx, const zkp_fused_statement* s
 int zkp_ctx_job_wait(zkp_ctx* ctx);      /* no job pending: ZKP_OK at once */
 int zkp_ctx_job_poll(zkp_ctx* ctx);      /* 1 = zkp_ctx_job_wait would not block, 0 = still running */
 int zkp_ctx_job_pending(zkp_ctx* ctx);   /* 1 = a job was submitted and not yet waited for */
+/* With zkp_ctx_set_profiling(ctx, 1): where the last finished job spent its time ON ITS STREAM, from HIP events recorded on that stream --
+ * ms[0] host -> device copies (+ on-device randomness), ms[1] the flow's kernels, ms[2] device -> host copies.  Under load these include the
+ * time the stream waited for the chip / the copy engines, which is what a pipelining caller wants to see. */
+int zkp_ctx_job_timing(zkp_ctx* ctx, float ms[3]);
 
 /* Pinned host memory for the jobs above (hipHostMalloc / hipHostRegister, visible to every GPU of the process).  zkp_host_is_pinned: 1 if p
  * points into such memory.  Registering costs ~12 us per MiB (profiles/r04_pcie_copy_rates.txt): register long-lived buffers once. */

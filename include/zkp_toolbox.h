@@ -194,6 +194,7 @@ int zkp_batch_verify_many_submit(zkp_pipe* pipe, const zkp_statement* st, uint32
                                  const uint8_t* common_points, const uint8_t* commitments, const uint8_t* responses,
                                  const uint8_t* weights16 /*[nc][weights_stride][16]*/, uint32_t weights_stride, uint8_t* transcripts_out,
                                  int* verdicts /*[n_batches]: ZKP_TB_OK | ZKP_TB_VERIFICATION_FAILURE after zkp_job_wait*/, zkp_job** job);
+int zkp_job_context_index(const zkp_job* job);   /* which context of the pipe carries the job (zkp_pipe_context; profiling: zkp_ctx_job_timing) */
 int zkp_job_done(const zkp_job* job);    /* 1 = zkp_job_wait would not block */
 int zkp_job_wait(zkp_job* job);          /* the synchronous call's return code; frees the job */
 

@@ -163,6 +163,7 @@ extern "C" {
     pub fn zkp_ctx_job_wait(ctx: *mut zkp_ctx) -> c_int;
     pub fn zkp_ctx_job_poll(ctx: *mut zkp_ctx) -> c_int;
     pub fn zkp_ctx_job_pending(ctx: *mut zkp_ctx) -> c_int;
+    pub fn zkp_ctx_job_timing(ctx: *mut zkp_ctx, ms: *mut f32) -> c_int;
     pub fn zkp_host_alloc(out: *mut *mut c_void, bytes: usize) -> c_int;
     pub fn zkp_host_free(p: *mut c_void);
     pub fn zkp_host_register(p: *mut c_void, bytes: usize) -> c_int;
@@ -239,6 +240,7 @@ extern "C" {
                                         transcripts: *const u8, inst_points: *const u8, inst_stride: u32, common_points: *const u8,
                                         commitments: *const u8, responses: *const u8, weights16: *const u8, weights_stride: u32,
                                         transcripts_out: *mut u8, verdicts: *mut c_int, job: *mut *mut zkp_job) -> c_int;
+    pub fn zkp_job_context_index(job: *const zkp_job) -> c_int;
     pub fn zkp_job_done(job: *const zkp_job) -> c_int;
     pub fn zkp_job_wait(job: *mut zkp_job) -> c_int;
     pub fn zkp_pipe_prove_batch(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, transcripts: *mut u8, secrets: *const u8,

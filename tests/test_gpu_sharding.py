@@ -107,3 +107,29 @@ def test_bench_eight_rank_control_flow_on_one_gpu():
     assert c5["proofs_total"] == 1024 and c5["proofs_per_gpu"] == 128 and c5["value"] > 0
     assert c4["per_rank_elapsed_ms"]["min"] <= c4["per_rank_elapsed_ms"]["max"] <= c4["elapsed_ms"] * 1.001 + 1e-6
     assert c4["collective"] == "gloo-fallback"
+
+
+def test_bench_in_process_multi_gpu_control_flow_on_one_gpu():
+    """bench.py --gpus 3 --in-process: ONE process, one host thread per rank, no torchrun / gloo / RCCL (all three ranks on this box's
+    single GPU): thread barriers, host AND of the verdicts, MAX of the elapsed times, the configs[3] / configs[4] sub-records and the
+    zkp_pipe line over the same devices.  Not a measurement."""
+    import json
+    import subprocess
+    env = dict(os.environ, ZKP_BENCH_DRYRUN_ONE_GPU="1")
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--in-process", "--steps", "4", "--warmup", "1", "--batch", "256", "--batches-per-call", "2",
+           "--streams", "2", "--multi-total4", "1536", "--multi-total5", "768", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 3 and j["steps"] == 4 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["backend_world_size"] == 3 and j["config"]["collective"].startswith("host-and")
+    assert abs(j["value"] - 3 * 256 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]
+    c4, c5 = j["configs"]["4"], j["configs"]["5"]
+    assert c4["proofs_total"] == 1536 and c4["proofs_per_gpu"] == 512 and c5["proofs_total"] == 768 and c4["value"] > 0 and c5["value"] > 0
+    pl = j["e2e_host_buffers"]["pipelined"]
+    assert pl["devices"] == [0, 0, 0] and pl["jobs_in_flight"] == 9 and pl["proofs_per_s"] > 0

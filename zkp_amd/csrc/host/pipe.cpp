@@ -441,6 +441,7 @@ int zkp_batch_verify_many_submit(zkp_pipe* p, const zkp_statement* st, uint32_t 
                               weights_stride, transcripts_out, verdicts, job);
 }
 
+int zkp_job_context_index(const zkp_job* j) { return j ? j->slot : -1; }
 int zkp_job_done(const zkp_job* j) {
   if (!j) return 1;
   if (j->immediate) return 1;

@@ -83,10 +83,18 @@ int job_begin(zkp_ctx* c, size_t pin_bytes) {
     c->job.pin = static_cast<uint8_t*>(p);
     c->job.pin_bytes = pin_bytes + 256;
   }
+  c->job.timed = c->profiling;
+  if (c->job.timed) {
+    for (auto& e : c->job.tev) if (!e) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(c->job.tev[0], c->stream));
+  }
   return ZKP_OK;
 }
+// profiling (zkp_ctx_set_profiling): where a job's time on its stream goes -- copies in, kernels, copies out
+void job_mark(zkp_ctx* c, int i) { if (c->job.timed) (void)hipEventRecord(c->job.tev[i], c->stream); }
 // the job is on the stream: remember what zkp_ctx_job_wait has to derive from the pinned words
 int job_commit(zkp_ctx* c, char kind, uint32_t K, int* verdicts, int* invalid_point) {
+  job_mark(c, 3);
   HIP_TRY(hipEventRecord(c->job.done, c->stream));
   c->job.kind = kind;
   c->job.K = K;
@@ -190,8 +198,10 @@ int prove_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t fl
   ZKP_JOB_TRY(h2d_rows(c, w.base + o_tbl + 32 * (size_t)s.ns, inst, s.ni, (size_t)N * 32, (size_t)inst_stride * 32));
   if (entropy) ZKP_JOB_TRY(h2d(c, w.base + o_ent, entropy, (size_t)N * 32));
   else ZKP_JOB_TRY(chacha_fill(c, rng_seed, 0, w.base + o_ent, (size_t)N * 32));
+  job_mark(c, 1);
   ZKP_JOB_TRY(prove_core(c, *pl, o, w.u8(o_ts), w.u8(o_sec), w.u8(o_tbl), w.u8(o_ent), w.u8(o_chal), w.u8(o_resp), w.u8(o_coms), w.u8(o_st), /*overlap=*/sync_variant,
                          /*throughput=*/!sync_variant));
+  job_mark(c, 2);
   if (hipMemsetAsync(w.base + o_flag, 0, 4, c->stream) != hipSuccess) return job_abort(c, fail(ZKP_ERR_HIP, "hipMemsetAsync failed"));
   if (nc) hipLaunchKernelGGL(k_any_nonzero_bytes, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, (size_t)N * nc, w.u8(o_st), w.u32(o_flag));
   ZKP_JOB_TRY(d2h(c, challenges, w.base + o_chal, (size_t)N * 32));
@@ -240,7 +250,9 @@ int verify_compact_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, ui
   ZKP_JOB_TRY(h2d_rows(c, w.base + o_tbl + 32 * (size_t)s.ns, inst, s.ni, (size_t)N * 32, (size_t)inst_stride * 32));
   ZKP_JOB_TRY(h2d(c, w.base + o_claim, challenges, (size_t)N * 32));
   if (m) ZKP_JOB_TRY(h2d(c, w.base + o_resp, responses, (size_t)N * m * 32));
+  job_mark(c, 1);
   ZKP_JOB_TRY(verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res), /*overlap=*/sync_variant, /*throughput=*/!sync_variant));
+  job_mark(c, 2);
   ZKP_JOB_TRY(d2h(c, results, w.base + o_res, (size_t)N));
   if (transcripts_out) ZKP_JOB_TRY(d2h(c, transcripts_out, w.base + o_ts, (size_t)N * 208));
   ZKP_JOB_TRY(job_commit(c, 'V', 0, nullptr, nullptr));
@@ -301,7 +313,9 @@ int batch_verify_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t K, uint
     }
     if (m) ZKP_JOB_TRY(h2d(c, w.base + o_resp, responses, (size_t)N * m * 32));
   }
+  job_mark(c, 1);
   ZKP_JOB_TRY(batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st), /*throughput=*/!sync_variant, K));
+  job_mark(c, 2);
   if (debug_scalars) ZKP_JOB_TRY(d2h(c, debug_scalars, w.base + o.sc, n_sc * 32));
   ZKP_JOB_TRY(d2h(c, c->job.pin, w.base + o_out, (size_t)K * 32));
   ZKP_JOB_TRY(d2h(c, c->job.pin + (size_t)K * 32, w.base + o_st, (size_t)K * 8));
@@ -354,7 +368,9 @@ int verify_batchable_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, 
     else ZKP_JOB_TRY(chacha_fill(c, rng_seed, 0, w.base + o_w, (size_t)N * nc * 16));
   }
   if (m) ZKP_JOB_TRY(h2d(c, w.base + o_resp, responses, (size_t)N * m * 32));
+  job_mark(c, 1);
   ZKP_JOB_TRY(each_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_resp), w.u8(o_w), w.u8(o_res), /*overlap=*/sync_variant || c->dev_overlap));
+  job_mark(c, 2);
   if (debug_scalars) ZKP_JOB_TRY(d2h(c, debug_scalars, w.base + o.sc, (size_t)N * K * 32));
   ZKP_JOB_TRY(d2h(c, results, w.base + o_res, (size_t)N));
   if (transcripts_out) ZKP_JOB_TRY(d2h(c, transcripts_out, w.base + o_ts, (size_t)N * 208));
@@ -461,6 +477,11 @@ int zkp_fused_verify_batchable(zkp_ctx* c, const zkp_fused_statement* st, uint32
   return zkp_fused_verify_batchable_coeffs(c, st, N, transcripts, inst, common, commitments, responses, weights16, results, nullptr);
 }
 
+int zkp_ctx_job_timing(zkp_ctx* c, float ms[3]) {
+  if (!c || !ms) return fail(ZKP_ERR_ARG, "NULL pointer");
+  memcpy(ms, c->job.ms, sizeof(c->job.ms));
+  return ZKP_OK;
+}
 int zkp_ctx_job_pending(zkp_ctx* c) { return c && c->job.kind ? 1 : 0; }
 int zkp_ctx_job_poll(zkp_ctx* c) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
@@ -482,6 +503,8 @@ int zkp_ctx_job_wait(zkp_ctx* c) {
     if (kind == 'P' && c->job.invalid_point) *c->job.invalid_point = 1;
     return fail(ZKP_ERR_HIP, std::string("job failed on the device: ") + hipGetErrorString(e));
   }
+  if (c->job.timed)
+    for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&c->job.ms[i], c->job.tev[i], c->job.tev[i + 1]);
   if (kind == 'P') {
     uint32_t any;
     memcpy(&any, c->job.pin, 4);

@@ -1213,6 +1213,9 @@ struct zkp_ctx {
     uint32_t K = 0;
     int* verdicts = nullptr;           // 'B': [K], the caller's
     int* invalid_point = nullptr;      // 'P': the caller's
+    hipEvent_t tev[4] = {};            // profiling: job start | inputs on the device | flow done | outputs on the host
+    bool timed = false;
+    float ms[3] = {};                  // host -> device copies, kernels, device -> host copies of the last job (zkp_ctx_job_timing)
   } job;
   size_t ws_limit = 0;                 // ZKP_OPT_WS_LIMIT_BYTES: a call that would need a larger workspace fails with ZKP_ERR_OOM (0 = no cap)
   bool hot_registry_uploaded = false;  // the device copy of the fixed-base registry matches hot_key[]
@@ -1686,6 +1689,7 @@ void zkp_ctx_destroy(zkp_ctx* c) {
   if (c->capturing) { hipGraph_t g = nullptr; hipStreamEndCapture(c->stream, &g); if (g) hipGraphDestroy(g); c->capturing = false; }
   hipStreamSynchronize(c->stream);
   if (c->job.done) hipEventDestroy(c->job.done);
+  for (auto& e : c->job.tev) if (e) hipEventDestroy(e);
   if (c->job.pin) hipHostFree(c->job.pin);
   if (c->ws) hipFree(c->ws);
   if (c->hot_tables) hipFree(c->hot_tables);

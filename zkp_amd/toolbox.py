@@ -42,7 +42,7 @@ EXPORTS = (
     "zkp_proof_batchable_encode", "zkp_proof_batchable_decode", "zkp_batch_verify_locate", "zkp_batch_verify_many",
     "zkp_pipe_create", "zkp_pipe_destroy", "zkp_pipe_num_contexts", "zkp_pipe_num_devices", "zkp_pipe_context", "zkp_pipe_context_device",
     "zkp_pipe_jobs_in_flight", "zkp_pipe_last_error", "zkp_prove_batch_submit", "zkp_verify_compact_batch_submit",
-    "zkp_verify_batchable_each_submit", "zkp_batch_verify_many_submit", "zkp_job_done", "zkp_job_wait", "zkp_pipe_prove_batch",
+    "zkp_verify_batchable_each_submit", "zkp_batch_verify_many_submit", "zkp_job_done", "zkp_job_wait", "zkp_job_context_index", "zkp_pipe_prove_batch",
     "zkp_pipe_verify_compact_batch", "zkp_pipe_verify_batchable_each", "zkp_pipe_batch_verify", "zkp_pipe_batch_verify_many",
     "zkp_pipe_batch_verify_locate",
 )
@@ -108,6 +108,7 @@ def lib() -> ctypes.CDLL:
         _lib.zkp_verify_batchable_each_submit.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp, pj]
         _lib.zkp_batch_verify_many_submit.argtypes = [vp, vp, u32, u32, u32, vp, vp, u32, vp, vp, vp, vp, u32, vp, vp, pj]
         _lib.zkp_job_done.argtypes = [vp]
+        _lib.zkp_job_context_index.argtypes = [vp]
         _lib.zkp_job_wait.argtypes = [vp]
         _lib.zkp_pipe_prove_batch.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib.zkp_pipe_verify_compact_batch.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp]
@@ -477,6 +478,7 @@ class Job:
 
     def __init__(self, handle, keep, outputs, kind):
         self._h, self._keep, self.outputs, self.kind = handle, keep, outputs, kind
+        self.context = int(lib().zkp_job_context_index(handle))
 
     def done(self) -> bool:
         return self._h is None or bool(lib().zkp_job_done(self._h))
@@ -532,6 +534,19 @@ class Pipe:
 
     def last_error(self) -> str:
         return lib().zkp_pipe_last_error(self._h).decode()
+
+    def set_profiling(self, on: bool) -> None:
+        hip = load_library()
+        for i in range(self.num_contexts):
+            hip.zkp_ctx_set_profiling(lib().zkp_pipe_context(self._h, i), 1 if on else 0)
+
+    def job_timing(self, context: int):
+        """(ms of host -> device copies, kernels, device -> host copies) of the last job that finished on that context (profiling on)"""
+        hip = load_library()
+        hip.zkp_ctx_job_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        ms = (ctypes.c_float * 3)()
+        hip.zkp_ctx_job_timing(lib().zkp_pipe_context(self._h, context), ms)
+        return tuple(float(x) for x in ms)
 
     def set_option(self, option: int, value: int, context: Optional[int] = None) -> None:
         """zkp_ctx_set_option on one context of the pipe, or on all of them"""

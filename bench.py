@@ -624,7 +624,10 @@ def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,)):
                     submitted += 1
                     host["submit_s"] += time.perf_counter() - ta
                 else:
-                    kind, o, job = pending.popleft()
+                    # retire a job that is done if there is one (jobs on different contexts finish in any order), else wait for the oldest
+                    idx = next((i for i, e in enumerate(pending) if e[2].done()), 0)
+                    kind, o, job = pending[idx]
+                    del pending[idx]
                     outs = job.wait()
                     host["wait_s"] += time.perf_counter() - ta
                     if os.environ.get("ZKP_BENCH_JOB_TIMING"):
@@ -635,7 +638,7 @@ def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,)):
                     if kind == "P":
                         to_verify.append(o)
                     else:
-                        assert os.environ.get("ZKP_X_SKIP") or not outs[0].any(), "a batch of fresh proofs did not verify"
+                        assert not outs[0].any(), "a batch of fresh proofs did not verify"
                         free_out.append(o)
                         verified += 1
         run(len(free_out) + in_flight)                  # plans compiled, workspaces and staging rings sized, fixed-base tables built, every buffer touched
@@ -649,7 +652,7 @@ def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,)):
         job.wait()
         o["resp"][(K // 2) * n + 7, 3, 0] ^= 1
         (v,) = pipe.submit_batch_verify_many(st, K, n, a_t0, a_inst, a_com, o["coms"], o["resp"]).wait()
-        assert os.environ.get("ZKP_X_SKIP") or [int(x) for x in v] == [1 if b == K // 2 else 0 for b in range(K)], "a corrupted proof must fail exactly its own batch"
+        assert [int(x) for x in v] == [1 if b == K // 2 else 0 for b in range(K)], "a corrupted proof must fail exactly its own batch"
     h2d = jobs * (2 * a_inst.nbytes + a_sec.nbytes + o["coms"].nbytes + o["resp"].nbytes + 2 * (a_com.nbytes + 208))
     d2h = jobs * (o["chal"].nbytes + o["resp"].nbytes + o["coms"].nbytes)
     return {"proofs_per_s": jobs * nn / el, "proofs": jobs * nn, "elapsed_ms": el * 1e3, "proofs_per_batch": n, "batches_per_submit": K, "jobs_in_flight": in_flight,
@@ -681,7 +684,7 @@ def main():
     ap.add_argument("--in-process", action="store_true", help="--gpus N > 1 WITHOUT torchrun / gloo / RCCL: this one process drives the N GPUs, one host "
                                                              "thread and one set of engine contexts per GPU, the verdict AND is taken on the host "
                                                              "(the C-ABI counterpart is zkp_pipe over N devices); same JSON line")
-    ap.add_argument("--pipe-contexts", type=int, default=6, help="e2e_host_buffers.pipelined: contexts (= jobs in flight) of the zkp_pipe")
+    ap.add_argument("--pipe-contexts", type=int, default=8, help="e2e_host_buffers.pipelined: contexts (= jobs in flight) of the zkp_pipe")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
                     help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
     args = ap.parse_args()
@@ -702,7 +705,10 @@ def main():
         if args.batches_per_call > 1:
             raise SystemExit("--batches-per-call applies to --config 2 (the other workloads are one wide batch per step)")
         K, n_streams = 1, max(1, min(args.streams or def_streams or pick_streams(args.steps), max(1, args.steps)))
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(max(n_streams, 8 if args.gpus > 1 else 1), args.max_hw_queues))))   # default is 4
+    # one hardware queue per stream in flight (the runtime's default is 4): the call chains of the timed loop, and the 8 contexts of the zkp_pipe
+    # behind e2e_host_buffers.pipelined (a context whose stream shares a hardware queue with another's is serialised behind it)
+    want_q = max(n_streams, 8 if (args.gpus > 1 or (args.config == "2" and not args.no_flow_lines)) else 1)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(want_q, args.max_hw_queues))))
     import torch
 
     if args.in_process and args.gpus > 1 and "RANK" not in os.environ:

@@ -38,7 +38,7 @@ Other workloads (one JSON line each, same keys):
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  Everything in it is measured in this run, except the PMC-derived fields (roofline.traffic,
-*_valu_issue_frac, step_valu), which need a rocprofv3 --pmc pass: they are taken from --pmc-json only when that file was
+*_valu_busy, step_valu), which need a rocprofv3 --pmc pass: they are taken from --pmc-json only when that file was
 collected from exactly these kernel sources (sha256 of zkp_amd/csrc), and say so in "pmc_source"; otherwise they are null.
 """
 import argparse
@@ -55,11 +55,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = "proofs/sec + batch-verifies/sec, CMZ13 10-attr credential, 1/2/4/8 MI355X"
-VALU_PEAK = 34.5e12           # 4-cycle-class VALU lane-instructions / s (v_mad_u64_u32 ...), measured: profiles/r01_valu_rates_microbench.txt
+# The VALU ceiling is CYCLE-WEIGHTED (round 4): every kernel's static opcode mix is priced with the measured issue rate of each opcode
+# (2-cycle class ~60-68e12, 4-cycle class ~34-38e12 lane-instructions / s: profiles/r04_valu_rates_microbench.txt) by tools/opcode_mix.py ->
+# profiles/r04_opcode_mix.json (keyed to the kernel sources): valu_busy = SQ_INSTS_VALU x seconds_per_wave_instruction / duration <= 1.
+OPCODE_MIX = os.path.join("profiles", "r04_opcode_mix.json")
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
 LABEL = b"Benchmark"
 BASE = bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76")
-PMC_PATTERN = os.path.join("profiles", "r03_pmc_counters_cfg%s_k%d.json")   # one counter file per workload and batches-per-call (tools/collect_profiles.sh)
+PMC_PATTERN = os.path.join("profiles", "r04_pmc_counters_cfg%s_k%d.json")   # one counter file per workload and batches-per-call (tools/collect_profiles.sh)
 # what the HIP-event timing kinds of zkp_ctx_last_timing are, per flow: (kernel names as rocprofv3 prints them, launches per call).
 # roofline.kernel is chosen among the GROUPS below by kernel name, summed across flows (k_transcript_run* = 3 launches per step).
 KERNELS = {
@@ -517,7 +520,7 @@ def run_workload(cx, args, cfg, n, steps, warmup, K, n_streams, primary):
     # ---- per-kernel timing with HIP events on the engine's stream (separate, profiled passes on one stream) -------------
     eng.set_profiling(True)
     reps = 5 if total_n * K <= (1 << 16) else 2
-    kms, samples = {}, {}
+    kms, samples, launched = {}, {}, {}
     flows_timed = sorted({f for p in ps for f in p.flows}) + ([] if args.no_flow_lines or cfg == "3" else ["verify_compact", "verify_batchable"])
     with torch.cuda.stream(streams[0]):
         for _ in range(reps):
@@ -541,6 +544,7 @@ def run_workload(cx, args, cfg, n, steps, warmup, K, n_streams, primary):
                     km, tot = eng.last_timing()
                     d = samples.setdefault((flow, id(p)), [])
                     d.append(dict(km, total=tot))
+                    launched.setdefault(flow, {}).update(eng.last_kernels())     # the variants the library picked, by their rocprofv3 names
     eng.set_profiling(False)
     # per (flow, part): the repetition with the median total -- one host hiccup between two launches (a busy node: 10 ms seen) would
     # otherwise show up as kernel time of whatever phase it fell into; then summed over the parts of the workload
@@ -550,6 +554,7 @@ def run_workload(cx, args, cfg, n, steps, warmup, K, n_streams, primary):
         for k, v in pick.items():
             d[k] = d.get(k, 0.0) + v
     res["kms"] = kms                           # ms per CALL (K steps) on a lone stream
+    res["launched"] = launched                 # {flow: {timing kind: [kernel names]}} as reported by zkp_ctx_last_kernels
     res["engines"] = engines
     return res
 
@@ -848,18 +853,17 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
     algo = {"prove": sum((64.0 * p.T + 32.0 * p.nc) * p.n for p in ps if "prove" in p.flows),                 # 64 B per term in + 32 B per MSM out
             "batch_verify": sum(64.0 * p.n_bv_each * p.K for p in ps if "batch_verify" in p.flows)}           #              64 B per operand of every MSM of the call
     step_flows = sorted({f for p in ps for f in p.flows})
+    # kernel names: the size- / option-dependent variants come from the library itself (zkp_ctx_last_kernels, exact rocprofv3 names), the
+    # fixed ones from KERNELS; launches per call of the transcript kind = programs the flow runs on their own (program A may ride in the tables' launch)
     names = dict(KERNELS)
-    call_n = n * K
-    if args.config in ("2", "4share") and call_n * 31 >= 250000:      # a call that fills the chip on its own: ladder for Q, grouped comb walk
-        names[("prove", "terms")] = ("k_terms_split<true, 16, true>", 1)
-    if call_n >= 65536:                                                # ... and one transcript lane per proof
-        names[("prove", "transcript")] = ("k_transcript_run1", 2)
-        names[("batch_verify", "transcript")] = ("k_transcript_run1", 1)
-    elif call_n >= 8192 and args.config != "5share":                   # mid-size calls: transcript program A rides in the comb tables' launch
-        names[("prove", "tables")] = ("k_tables_transcript<16> (comb tables + transcript program A)", 1)
-        names[("prove", "transcript")] = ("k_transcript_run", 1)
-    if args.config == "5share":                 # every point of the wide statement is a common generator: fixed-base blocks only, no ladder blocks
-        names[("prove", "terms")] = ("k_terms_split<true, T, false> (fixed-base blocks only)", 1)
+    for f, kinds in r["launched"].items():
+        for kind, ks in kinds.items():
+            if (f, kind) not in names:
+                continue
+            launches = names[(f, kind)][1]
+            if kind == "transcript" and f == "prove" and any("k_tables_transcript" in x for x in kinds.get("tables", [])):
+                launches = 1
+            names[(f, kind)] = (" + ".join(ks), launches)
     groups = {}
     for f in step_flows:
         for k, ms in kms[f].items():
@@ -882,11 +886,12 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
                                       % (dom["kernels"], dom["launches_per_call"], "" if dom["launches_per_call"] == 1 else "es", K, "" if K == 1 else "es", 100 * dom["share"]),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": achieved * 1e9 * dom["avg_launch_ms"] * 1e-3, "launch_ms": dom["avg_launch_ms"],
-            "launch_ms_note": "HIP events on the engine's stream around the launch, one call chain in flight (the kernel alone on the chip), the repetition with the median call time: rocprofv3's average for the same "
-                              "shape with ONE stream agrees (profiles/r03_kernel_stats_cfg2_k5_one_stream.txt); in the timed loop four chains share the chip and "
-                              "a launch takes correspondingly longer (profiles/r03_kernel_stats_cfg2_k<K>.txt: average over lone and overlapped launches)",
+            "launch_ms_note": "HIP events on the engine's stream around the launch, one call chain in flight (the kernel alone on the chip), the repetition with the median call time; "
+                              "launch_ms_rocprof_one_stream (when pmc_source is set) = rocprofv3's average for the same kernel and shape on ONE stream "
+                              "(profiles/r04_kernel_stats_cfg<config>_k<K>_one_stream.txt), a few per cent longer -- the profiler's own dispatch overhead; in the timed loop "
+                              "several chains share the chip and a launch takes correspondingly longer (profiles/r04_kernel_stats_cfg<config>_k<K>.txt)",
             "note": "integer-VALU bound by construction (SURVEY.md 8(d)): algorithmic bytes = 64 B per (scalar, point) term + 32 B per output, "
-                    "so the HBM fraction of ANY kernel of this path is ~1e-3; the binding roofline is step_valu / *_valu_issue_frac (PMC)",
+                    "so the HBM fraction of ANY kernel of this path is ~1e-3; the binding roofline is step_valu / *_valu_busy (PMC, cycle-weighted)",
             "by_kernel": by_kernel}
     # ---- PMC-derived fields: only from a counter file collected from exactly these sources and this call shape ---------------------------
     sha = source_sha256()
@@ -900,27 +905,49 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
             if pj.get("_source_sha256") == sha and shape.get("batch") == n and shape.get("batches_per_call") == K and shape.get("config") == args.config:
                 pmc_source = "%s: rocprofv3 --pmc passes of `python bench.py --config %s --steps %s` at kernel-source sha256 %s (tools/collect_profiles.sh)" % (
                     pmc_rel, args.config, shape.get("steps"), sha[:12])
-                pmc_prefix = {"k_terms_split": "k_terms_split<true", "k_comb_tables_lane": "zkp::k_comb_tables_lane<16", "k_transcript_run1": "zkp::k_transcript_run1",
-                              "k_tables_transcript": "zkp::k_tables_transcript<16",
-                              "k_transcript_run": "zkp::k_transcript_run", "k_pip_prepare": "k_pip_prepare<", "k_pip_vmap": "k_pip_bucket_part",
-                              "k_encode_prepare": "k_encode_prepare"}
-                key = next((v for k_, v in sorted(pmc_prefix.items(), key=lambda kv: -len(kv[0])) if dom["kernels"].startswith(k_)), None)
-                kname = next((k_ for k_ in pj if key and k_.startswith(key)), None)
-                if kname:
-                    roof["traffic"] = pj[kname].get("hbm_bytes_per_launch")
-                    roof["dominant_kernel_valu_issue_frac"] = pj[kname]["SQ_INSTS_VALU"] * 64.0 / (dom["avg_launch_ms"] * 1e-3) / VALU_PEAK
-                tname = next((k_ for k_ in pj if k_.startswith("k_terms_split<true")), None)
-                if tname and kms.get("prove", {}).get("terms"):
-                    roof["terms_kernel_valu_issue_frac"] = pj[tname]["SQ_INSTS_VALU"] * 64.0 / (kms["prove"]["terms"] * 1e-3) / VALU_PEAK
-                    roof["terms_kernel_traffic"] = pj[tname].get("hbm_bytes_per_launch")
+                def rows_of(label):
+                    """PMC rows of a kernel group by EXACT name (the names come from zkp_ctx_last_kernels / KERNELS); a label that is a description
+                    rather than a name (the fixed multi-kernel kinds of KERNELS) matches by the bare kernel names it lists"""
+                    rows = []
+                    for part in label.split(" + "):
+                        part = part.strip()
+                        if part in pj:
+                            rows.append(pj[part])
+                        else:
+                            base = part.split(" ")[0].split("<")[0]
+                            rows += [v for k_, v in pj.items() if isinstance(v, dict) and k_.split("<")[0].split("::")[-1] == base.split("::")[-1] and "SQ_INSTS_VALU" in v]
+                    return rows
+
+                def busy(rows, launch_s):
+                    """cycle-weighted: the rows' VALU work priced at measured per-opcode issue rates (tools/opcode_mix.py) / the time they took"""
+                    if not rows or any("valu_seconds_per_launch" not in v for v in rows):
+                        return None
+                    return sum(v["valu_seconds_per_launch"] for v in rows) / launch_s
+                drows = rows_of(dom["kernels"])
+                if drows:
+                    roof["traffic"] = sum(v.get("hbm_bytes_per_launch", 0.0) for v in drows) or None
+                    roof["dominant_kernel_valu_busy"] = busy(drows, dom["avg_launch_ms"] * 1e-3 * len(drows))
+                    if all("avg_us_one_stream" in v for v in drows):
+                        roof["launch_ms_rocprof_one_stream"] = sum(v["avg_us_one_stream"] for v in drows) / len(drows) / 1e3
+                tname = next((x for x in r["launched"].get("prove", {}).get("terms", [])), None)
+                if tname and tname in pj and kms.get("prove", {}).get("terms"):
+                    tv = pj[tname]
+                    roof["terms_kernel"] = tname
+                    roof["terms_kernel_valu_busy"] = busy([tv], kms["prove"]["terms"] * 1e-3)
+                    if "avg_us_one_stream" in tv:
+                        roof["terms_kernel_valu_busy_rocprof_time"] = busy([tv], tv["avg_us_one_stream"] * 1e-6)
+                        roof["terms_kernel_launch_ms"] = {"hip_events_this_run": kms["prove"]["terms"], "rocprof_one_stream": tv["avg_us_one_stream"] / 1e3}
+                    roof["terms_kernel_traffic"] = tv.get("hbm_bytes_per_launch")
                     roof["terms_kernel_algorithmic_bytes"] = algo["prove"]
-                tot = pj.get("_step_totals", {}).get("valu_wave_instructions_per_step")
-                if tot:
-                    lane = tot * 64.0
-                    step_valu = {"wave_instructions_per_step": tot, "lane_instructions_per_s": lane / (ms_per_step * 1e-3),
-                                 "peak_lane_instructions_per_s": VALU_PEAK, "frac": lane / (ms_per_step * 1e-3) / VALU_PEAK,
-                                 "note": "PMC SQ_INSTS_VALU summed over all kernels of a step (from pmc_source) / this run's ms_per_step, "
-                                         "against the measured issue peak of the 4-cycle VALU class"}
+                    roof["terms_kernel_share_int64"] = {"static": tv.get("share_int64_static"), "dynamic_pmc": tv.get("share_int64_dynamic")}
+                st_tot = pj.get("_step_totals", {})
+                if st_tot.get("valu_wave_instructions_per_step"):
+                    secs = st_tot.get("valu_seconds_per_step")
+                    step_valu = {"wave_instructions_per_step": st_tot["valu_wave_instructions_per_step"],
+                                 "valu_floor_ms_per_step": secs * 1e3 if secs else None, "frac": (secs / (ms_per_step * 1e-3)) if secs else None,
+                                 "note": "frac = cycle-weighted VALU busy fraction of the timed step: every kernel's SQ_INSTS_VALU (PMC, from pmc_source) priced with the measured "
+                                         "issue rate of each opcode of its static mix (profiles/r04_opcode_mix.json; 2-cycle class ~60-68e12, 4-cycle class ~34-38e12 "
+                                         "lane-instr/s), summed over the step's kernels, / this run's ms_per_step.  Rounds 1-3 divided raw counts by 34.5e12 and overstated this."}
         except Exception:                       # noqa: BLE001 -- a reported extra, never the measurement
             pmc_source = None
     out = {

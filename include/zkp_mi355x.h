@@ -387,6 +387,13 @@ enum {
   ZKP_K_COUNT = 9
 };
 int zkp_ctx_last_timing(zkp_ctx* ctx, float* kernel_ms /*[ZKP_K_COUNT]*/, float* total_ms);
+/* With profiling on: which VARIANT of a kind's kernel the last call launched, by the name rocprofv3 prints -- the kernels whose template
+ * arguments depend on the call's size, flags or options (ZKP_K_TERMS: "k_terms_split<true, 16, true, false>", ZKP_K_TABLES:
+ * "zkp::k_comb_tables_lane<16>" / "zkp::k_tables_transcript<16>", ZKP_K_TRANSCRIPT: "zkp::k_transcript_run" / "...run1", ZKP_K_DECODE of the
+ * large-MSM path: "k_pip_prepare<11>"); several names are joined with ';', kinds whose kernels never vary give "".  Writes a NUL-terminated
+ * string of at most cap - 1 characters and returns the untruncated length.  Profiles and benchmarks label kernels from THIS, not from a
+ * copy of the dispatch thresholds. */
+int zkp_ctx_last_kernels(zkp_ctx* ctx, int kind, char* buf, size_t cap);
 /* Enable (1) / disable (0) per-kernel event timing (off by default: events add launch gaps). */
 int zkp_ctx_set_profiling(zkp_ctx* ctx, int enabled);
 

@@ -174,6 +174,7 @@ extern "C" {
     pub fn zkp_decode_check(ctx: *mut zkp_ctx, n: u64, points: *const u8, status: *mut u8, xyzt: *mut u8) -> c_int;
     pub fn zkp_encode_many(ctx: *mut zkp_ctx, n: u64, xyzt: *const u8, out: *mut u8) -> c_int;
     pub fn zkp_ctx_last_timing(ctx: *mut zkp_ctx, kernel_ms: *mut f32, total_ms: *mut f32) -> c_int;
+    pub fn zkp_ctx_last_kernels(ctx: *mut zkp_ctx, kind: c_int, buf: *mut c_char, cap: usize) -> c_int;
     pub fn zkp_ctx_set_profiling(ctx: *mut zkp_ctx, enabled: c_int) -> c_int;
 
     // ---- zkp_toolbox.h: Merlin transcripts, scalars ---------------------------------------------------------------------

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Static VALU opcode mix of every kernel in the shipped code object, priced with the MEASURED issue rate of each opcode
+(profiles/r04_valu_rates_microbench.txt) -> profiles/r04_opcode_mix.json.
+
+Why: rounds 1 - 3 divided raw SQ_INSTS_VALU counts by ONE peak, 34.5e12 lane-instructions/s -- the rate of the
+4-cycle class (v_mad_u64_u32, carries, 64-bit shifts, v_cndmask ...).  A third of the instructions of these kernels are 2-cycle-class
+opcodes (v_and / v_add_u32 / v_sub_u32 / v_lshrrev_b32 / v_mov / v_xor / v_bitop3: ~60 - 68e12 lane-instr/s), so "fractions" above
+1.0 appeared (k_responses 105 %).  The hardware has no cycle-weighted VALU counter on gfx950 (SQ_ACTIVE_INST_VALU counts instructions:
+calibrated on the single-opcode kernels of tools/microbench/valu_rates.hip, it reads the same for every opcode), so the ceiling is
+modelled:
+
+    seconds_per_wave_instruction(kernel) = sum over opcodes  f_op * 64 / rate_op          f_op = the opcode's share of the kernel's VALU instructions
+    valu_busy(kernel)                    = SQ_INSTS_VALU * seconds_per_wave_instruction / kernel duration           (<= 1 by construction of the rates)
+
+f_op is the STATIC share in the disassembly (the dynamic share is not observable; the kernels are straight-line field arithmetic inside
+fixed-trip loops, and the one class the PMC can count dynamically -- SQ_INSTS_VALU_INT64 -- is reported next to the static share by
+tools/pmc_summary.py as a check).  Opcodes without a measurement (< 1 % of any kernel) are priced as 4-cycle-class.
+
+    python tools/opcode_mix.py [OUT.json]        (needs /opt/rocm/lib/llvm/bin/{llvm-objcopy,clang-offload-bundler,llvm-objdump} and c++filt)
+"""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LLVM = "/opt/rocm/lib/llvm/bin"
+RATES_FILE = os.path.join(ROOT, "profiles", "r04_valu_rates_microbench.txt")
+DEFAULT_RATE = 36.0e12            # unmeasured opcodes: the 4-cycle class
+
+
+def measured_rates():
+    """opcode -> lane-instructions / s, chip-wide, from the microbenchmark table (the VCC-hazard artefact rows are skipped)"""
+    rates = {}
+    for line in open(RATES_FILE):
+        m = re.match(r"^(v_\w+)(\([^)]*\))?\s+[\d.]+\s+([\d.]+)\s+[\d.]+\s*$", line)
+        if not m:
+            continue
+        op, variant, g = m.group(1), m.group(2) or "", float(m.group(3)) * 1e9
+        if op == "v_cndmask_b32" and "sgpr" not in variant:
+            continue
+        rates[op] = max(rates.get(op, 0.0), g)
+    return rates
+
+
+def normalise(mnemonic):
+    """v_and_b32_e32 -> v_and_b32 ; any DPP form -> priced as v_mov_b32_dpp (the DPP path is 4-cycle class) ; SDWA likewise"""
+    if mnemonic.endswith("_dpp"):
+        return "v_mov_b32_dpp"
+    m = re.sub(r"_(e32|e64|sdwa)$", "", mnemonic)
+    alias = {"v_subrev_u32": "v_sub_u32", "v_subrev_co_u32": "v_add_co_u32", "v_sub_co_u32": "v_add_co_u32", "v_subb_co_u32": "v_addc_co_u32",
+             "v_subbrev_co_u32": "v_addc_co_u32", "v_not_b32": "v_xor_b32", "v_lshrrev_b16": "v_lshrrev_b32", "v_min_u32": "v_max_u32",
+             "v_cmp_ne_u32": "v_cmp_eq_u32", "v_cmp_gt_u32": "v_cmp_eq_u32", "v_cmp_lt_u32": "v_cmp_eq_u32", "v_cmp_le_u32": "v_cmp_eq_u32",
+             "v_cmp_ge_u32": "v_cmp_eq_u32", "v_cmp_ne_u64": "v_cmp_eq_u32", "v_cmp_eq_u64": "v_cmp_eq_u32", "v_cmp_gt_u64": "v_cmp_eq_u32",
+             "v_cmp_lt_u64": "v_cmp_eq_u32", "v_cmp_gt_i32": "v_cmp_eq_u32", "v_cmp_lt_i32": "v_cmp_eq_u32", "v_cmp_ne_u16": "v_cmp_eq_u32",
+             "v_readfirstlane_b32": "v_readlane_b32", "v_and_b16": "v_and_b32", "v_or_b16": "v_or_b32", "v_xad_u32": "v_and_or_b32", "v_mul_lo_u16": "v_mul_u32_u24"}
+    return alias.get(m, m)
+
+
+def disassemble(lib_path):
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "a.fat"), os.path.join(d, "a.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat,
+                               "--output=" + co, "--unbundle"])
+        return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
+
+
+def kernel_mixes(asm):
+    cur, hist = None, collections.defaultdict(collections.Counter)
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.match(r"^\s+(\w+)", line)
+        if m and cur:
+            hist[cur][m.group(1)] += 1
+    names = list(hist)
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    out = {}
+    for mangled, d in zip(names, dem):
+        out[d.split("(")[0].replace("void ", "")] = hist[mangled]
+    return out
+
+
+def main():
+    from zkp_amd import engine
+    import bench
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_opcode_mix.json")
+    rates = measured_rates()
+    res = {"_source_sha256": bench.source_sha256(), "_rates_file": os.path.relpath(RATES_FILE, ROOT), "_default_rate": DEFAULT_RATE,
+           "_note": "per kernel: static VALU mix of the shipped code object priced with per-opcode measured issue rates; "
+                    "seconds_per_wave_instruction x SQ_INSTS_VALU / duration = valu_busy"}
+    for kernel, h in sorted(kernel_mixes(disassemble(engine.LIB_PATH)).items()):
+        valu = collections.Counter()
+        for op, c in h.items():
+            if op.startswith("v_"):
+                valu[normalise(op)] += c
+        n = sum(valu.values())
+        if not n:
+            continue
+        spw = sum(c / n * 64.0 / rates.get(op, DEFAULT_RATE) for op, c in valu.items())
+        unmeasured = sum(c for op, c in valu.items() if op not in rates) / n
+        two_cycle = sum(c for op, c in valu.items() if rates.get(op, DEFAULT_RATE) > 50e12) / n
+        int64 = sum(c for op, c in valu.items() if op in ("v_mad_u64_u32", "v_lshl_add_u64", "v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64", "v_mov_b64")) / n
+        res[kernel] = {"valu_instructions_static": n, "all_instructions_static": sum(h.values()), "seconds_per_wave_instruction": spw,
+                       "equivalent_peak_lane_instr_per_s": 64.0 / spw, "share_2cycle_class": two_cycle, "share_unmeasured": unmeasured, "share_int64_static": int64,
+                       "top": [[op, round(c / n, 4)] for op, c in valu.most_common(8)]}
+    json.dump(res, open(out_path, "w"), indent=1)
+    print("%-62s %8s %10s %8s %8s" % ("kernel", "valu", "peak T/s", "2-cycle", "unmeas."))
+    for k, v in sorted(res.items(), key=lambda kv: -(kv[1].get("valu_instructions_static", 0) if isinstance(kv[1], dict) else 0)):
+        if isinstance(v, dict):
+            print("%-62s %8d %10.1f %8.3f %8.3f" % (k[:62], v["valu_instructions_static"], v["equivalent_peak_lane_instr_per_s"] / 1e12, v["share_2cycle_class"], v["share_unmeasured"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,17 +17,38 @@ import sys
 UNIT = {"2": ("k_terms_split<true", None), "4share": ("k_terms_split<true", 1.0), "5share": ("k_terms_split<true", 1.0), "3": ("k_pip_combine", 0.5)}
 
 
+def kname(r):
+    return r["Kernel_Name"].split("(")[0].replace("void ", "")
+
+
 def main():
     out, line, files = sys.argv[1], sys.argv[2], sys.argv[3:]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sha = bench.source_sha256()
     bl = json.loads([l for l in open(line).read().splitlines() if l.startswith("{")][-1])
     cfg = bl["config"]["baseline_config"]
     k_per_call = bl["config"].get("batches_per_call", 1)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    one_stream = collections.defaultdict(list)          # kernel -> durations (ns) from a kernel trace of the same command on ONE stream
     for fn in files:
-        for r in csv.DictReader(open(fn)):
-            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        rows = list(csv.DictReader(open(fn)))
+        if rows and "Counter_Name" not in rows[0]:       # a *_kernel_trace.csv: durations of lone launches
+            for r in rows:
+                one_stream[kname(r)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            continue
+        for r in rows:
+            agg[kname(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # cycle-weighted VALU ceiling: the static opcode mix of each kernel priced with measured per-opcode issue rates (tools/opcode_mix.py)
+    mix = {}
+    mix_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bench.OPCODE_MIX)
+    if os.path.exists(mix_path):
+        mj = json.load(open(mix_path))
+        if mj.get("_source_sha256") == sha:
+            mix = mj
     res = {}
-    print("# workload: --config %s, %d proofs per batch, %d batch(es) per call, %d timed steps" % (cfg, bl["config"]["batch_per_gpu"], k_per_call, bl["steps"]))
+    print("# workload: --config %s, %d proofs per batch, %d batch(es) per call, %d timed steps; kernel sources sha256 %s" % (cfg, bl["config"]["batch_per_gpu"], k_per_call, bl["steps"], sha[:16]))
+    print("# valu_busy = SQ_INSTS_VALU x seconds_per_wave_instruction (%s, %s) / avg_us_one_stream  -- cycle-weighted, <= 1" % (bench.OPCODE_MIX, "sha matches" if mix else "MISSING or stale: no valu_busy"))
     print("%-34s %s" % ("kernel", "counter averages per launch (n launches)"))
     for k in sorted(agg):
         if "k_" not in k:
@@ -36,6 +57,16 @@ def main():
         row["launches"] = max(len(v) for v in agg[k].values())
         if "FETCH_SIZE" in row and "WRITE_SIZE" in row:
             row["hbm_bytes_per_launch"] = (2.0 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024.0
+        if one_stream.get(k):
+            row["avg_us_one_stream"] = sum(one_stream[k]) / len(one_stream[k]) / 1e3
+        m = mix.get(k)
+        if m and "SQ_INSTS_VALU" in row:
+            row["valu_seconds_per_launch"] = row["SQ_INSTS_VALU"] * m["seconds_per_wave_instruction"]
+            row["share_int64_static"] = m["share_int64_static"]
+            if "avg_us_one_stream" in row:
+                row["valu_busy_one_stream"] = row["valu_seconds_per_launch"] / (row["avg_us_one_stream"] * 1e-6)
+        if "SQ_INSTS_VALU_INT64" in row and row.get("SQ_INSTS_VALU"):
+            row["share_int64_dynamic"] = row["SQ_INSTS_VALU_INT64"] / row["SQ_INSTS_VALU"]
         res[k] = row
         print("%-34s %s" % (k[-34:], "  ".join("%s=%.4g" % (c, v) for c, v in sorted(row.items()))))
     # whole-step totals: every kernel's per-launch average x its launches, divided by the number of bench steps the trace holds
@@ -49,13 +80,30 @@ def main():
         if cfg == "3":
             setup = ("k_hot_",) + tuple(p for p in ("k_terms_", "k_reduce_encode", "k_use_count", "k_class_", "k_comb_", "k_encode_", "k_stmt_", "k_blind_", "k_responses", "k_decode_affine"))
         tot = sum(v["SQ_INSTS_VALU"] * v["launches"] for k, v in res.items() if "SQ_INSTS_VALU" in v and not any(k.startswith(p) or k.startswith("zkp::" + p) for p in setup)) / steps
+        step_kernels = [(k, v) for k, v in res.items() if "SQ_INSTS_VALU" in v and not any(k.startswith(p) or k.startswith("zkp::" + p) for p in setup)]
+        secs = sum(v["valu_seconds_per_launch"] * v["launches"] for k, v in step_kernels if "valu_seconds_per_launch" in v) / steps
+        covered = sum(v["SQ_INSTS_VALU"] * v["launches"] for k, v in step_kernels if "valu_seconds_per_launch" in v) / steps
         res["_step_totals"] = {"steps": steps, "valu_wave_instructions_per_step": tot,
-                               "note": "sum over the step's kernels of SQ_INSTS_VALU x launches / steps in the trace (set-up kernels excluded by name)"}
-        print("%-34s valu wave-instructions per bench step = %.4g  (%g steps in the trace)" % ("_step_totals", tot, steps))
+                               "valu_seconds_per_step": secs if mix and covered > 0.999 * tot else None,
+                               "note": "sum over the step's kernels of SQ_INSTS_VALU x launches / steps in the trace (set-up kernels excluded by name); "
+                                       "valu_seconds_per_step = the same sum with every kernel's instructions priced by its opcode mix: the time the step's VALU "
+                                       "work takes at the measured per-opcode issue rates (cycle-weighted floor of ms_per_step)"}
+        print("%-34s valu wave-instructions per bench step = %.4g, cycle-weighted VALU floor = %s ms per step  (%g steps in the trace)"
+              % ("_step_totals", tot, "%.4f" % (secs * 1e3) if res["_step_totals"]["valu_seconds_per_step"] else "n/a", steps))
+    # efficiency table on one stream (what tools/kernel_efficiency.sh printed in round 3, now with the cycle-weighted busy fraction)
+    rows = [(k, v) for k, v in res.items() if isinstance(v, dict) and "avg_us_one_stream" in v]
+    if rows:
+        tot_t = sum(v["avg_us_one_stream"] * v["launches"] for _, v in rows)
+        print()
+        print("# per-kernel efficiency on ONE stream (a kernel's own duration; cycle-weighted busy; MeanOccupancyPerCU: 32 = full)")
+        print("%-46s %6s %10s %7s %12s %8s %8s %9s" % ("kernel", "calls", "avg_us", "time%", "valu_instr", "busy%", "occ/CU", "waves"))
+        for k, v in sorted(rows, key=lambda kv: -kv[1]["avg_us_one_stream"] * kv[1]["launches"]):
+            print("%-46s %6d %10.1f %7.2f %12.4g %8s %8.2f %9.0f" % (k[:46], v["launches"], v["avg_us_one_stream"], 100.0 * v["avg_us_one_stream"] * v["launches"] / tot_t,
+                                                                       v.get("SQ_INSTS_VALU", float("nan")),
+                                                                       "%.1f" % (100 * v["valu_busy_one_stream"]) if "valu_busy_one_stream" in v else "n/a",
+                                                                       v.get("MeanOccupancyPerCU", float("nan")), v.get("SQ_WAVES", float("nan"))))
     # key the counters to the kernel sources and the workload shape they were collected from (bench.py reports them only on a match)
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
-    res["_source_sha256"] = bench.source_sha256()
+    res["_source_sha256"] = sha
     res["_workload"] = {"config": cfg, "batch": bl["config"]["batch_per_gpu"], "batches_per_call": k_per_call, "steps": bl["steps"], "streams": bl["config"]["streams"]}
     json.dump(res, open(out, "w"), indent=1)
 

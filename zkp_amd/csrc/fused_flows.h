@@ -904,6 +904,7 @@ void run_program(zkp_ctx* c, const prog_dev& p_in, uint32_t N, const tr_bufs& bu
   if (!p_in.n) return;
   prog_dev p = p_in;
   if (owns_failed) p.tail |= 0x80000000u;          // the kernel writes every proof's rejection flag, 0 included
+  prof_note(c, ZKP_K_TRANSCRIPT, transcript_single_lane(c, N, throughput) ? "zkp::k_transcript_run1" : "zkp::k_transcript_run");
   if (transcript_single_lane(c, N, throughput)) {
     hipLaunchKernelGGL(k_transcript_run1, dim3((N + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, c->stream, p.ops, p.n, p.tables, N, bufs, d_ts, d_saved, d_failed, p.tail);
   } else {

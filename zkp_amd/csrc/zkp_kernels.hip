@@ -1193,6 +1193,7 @@ struct zkp_ctx {
   int n_ev = 0;
   float kernel_ms[ZKP_K_COUNT] = {};
   float total_ms = 0;
+  std::string kernel_names[ZKP_K_COUNT];   // profiling: which variant of a kind's size- / option-dependent kernel the last call launched (zkp_ctx_last_kernels)
   // fixed-base tables (hot_tables.h): HOT_SLOTS slots, LRU
   dev_niels* hot_tables = nullptr;
   uint32_t* hot_reg_words = nullptr;       // device [HOT_SLOTS][8]: encodings of the registered points, densely packed
@@ -1253,8 +1254,15 @@ int ensure_ws(zkp_ctx* c, size_t bytes) {
   return ZKP_OK;
 }
 
+// profiling: the name (as rocprofv3 prints it) of a kernel whose variant is picked at run time, filed under its timing kind
+void prof_note(zkp_ctx* c, int kind, const std::string& name) {
+  if (!c->profiling || c->capturing || c->prof_suspended) return;
+  std::string& s = c->kernel_names[kind];
+  if ((";" + s + ";").find(";" + name + ";") == std::string::npos) s += (s.empty() ? "" : ";") + name;
+}
 void prof_begin(zkp_ctx* c) {
   c->n_ev = 0;
+  if (c->profiling && !c->capturing) for (auto& s : c->kernel_names) s.clear();
   if (c->profiling && !c->capturing) { hipEventRecord(c->ev[0], c->stream); c->ev_kind[0] = -1; c->n_ev = 1; }
 }
 void prof_mark(zkp_ctx* c, int kind) {
@@ -1353,6 +1361,7 @@ void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_sca
     stride = (grid.x / 2) / lb;
     if (stride < 2) stride = 0;
   }
+  prof_note(c, ZKP_K_TERMS, std::string("k_terms_split<") + (CT ? "true" : "false") + ", " + std::to_string(TEETH) + ", " + (ladder ? "true" : "false") + ", " + (SCAN ? "true" : "false") + ">");
   if (ladder)
     hipLaunchKernelGGL((k_terms_split<CT, TEETH, true, SCAN>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
                        c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
@@ -1433,6 +1442,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
           hipLaunchKernelGGL(k_tables_transcript<16>, dim3(tr_blocks + (k.max_tables + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, c->stream, tr_blocks, t.ops, t.n_ops,
                              t.tables, t.N, t.bufs, t.ts, t.saved, t.failed, t.tail, n_slots, k.max_tables, slot_pt, pts, comb);
           c->pending_tr.active = false;
+          prof_note(c, ZKP_K_TABLES, "zkp::k_tables_transcript<16>");
         } else if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables_lane<16>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
         else hipLaunchKernelGGL(k_comb_tables_lane<4>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       } else {
@@ -1440,6 +1450,8 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
         else hipLaunchKernelGGL(k_comb_tables<4>, grid1((size_t)k.max_tables * 4, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       }
     }
+    if ((phase & PH_POINTS) && k.max_tables && c->kernel_names[ZKP_K_TABLES].find("k_tables_transcript") == std::string::npos)
+      prof_note(c, ZKP_K_TABLES, std::string((c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) ? "zkp::k_comb_tables_lane<" : "zkp::k_comb_tables<") + (k.teeth == 16 ? "16>" : "4>"));
     if (phase & PH_POINTS) prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 4 + HOT_SLOTS));     // every class starts a new block
     // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l
@@ -1556,6 +1568,7 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
 
   if (!shared_flags) HIP_TRY(hipMemsetAsync(invalid, 0, (size_t)K * 4, c->stream));
+  prof_note(c, ZKP_K_DECODE, "k_pip_prepare<" + std::to_string(C) + ">");
   hipLaunchKernelGGL(k_pip_prepare<C>, dim3((n + 255) / 256, K), dim3(256), 0, c->stream, n, seg, d_scalars, d_points, niels, digits, invalid);
   prof_mark(c, ZKP_K_DECODE);
   hipLaunchKernelGGL(k_pip_tile_hist<C>, dim3(tiles, (unsigned)WK), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist);
@@ -1864,6 +1877,15 @@ int zkp_ctx_last_timing(zkp_ctx* c, float* kernel_ms, float* total_ms) {
   if (kernel_ms) memcpy(kernel_ms, c->kernel_ms, sizeof(c->kernel_ms));
   if (total_ms) *total_ms = c->total_ms;
   return ZKP_K_COUNT;
+}
+
+int zkp_ctx_last_kernels(zkp_ctx* c, int kind, char* buf, size_t cap) {
+  if (!c || !buf || !cap || kind < 0 || kind >= ZKP_K_COUNT) return fail(ZKP_ERR_ARG, "bad argument");
+  const std::string& s = c->kernel_names[kind];
+  const size_t n = std::min(s.size(), cap - 1);
+  memcpy(buf, s.data(), n);
+  buf[n] = 0;
+  return (int)s.size();
 }
 
 int zkp_ctx_prepare_fixed_points(zkp_ctx* c, uint32_t n, const uint8_t* encodings) {

@@ -30,7 +30,7 @@ EXPORTS = (
     "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_verify_batchable_dev", "zkp_fused_batch_verify_dev",
     "zkp_fused_verify_batchable_coeffs", "zkp_fused_batch_verify_many", "zkp_fused_batch_verify_many_dev", "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_ctx_capture_abort", "zkp_graph_launch", "zkp_graph_destroy",
     "zkp_fused_prove_submit", "zkp_fused_verify_compact_submit", "zkp_fused_batch_verify_many_submit", "zkp_fused_verify_batchable_submit",
-    "zkp_ctx_job_wait", "zkp_ctx_job_poll", "zkp_ctx_job_pending", "zkp_ctx_job_timing", "zkp_host_alloc", "zkp_host_free", "zkp_host_register", "zkp_host_unregister",
+    "zkp_ctx_job_wait", "zkp_ctx_job_poll", "zkp_ctx_job_pending", "zkp_ctx_job_timing", "zkp_ctx_last_kernels", "zkp_host_alloc", "zkp_host_free", "zkp_host_register", "zkp_host_unregister",
     "zkp_host_is_pinned", "zkp_chacha20_fill_dev",
 )
 TEST_HOOK_EXPORTS = ("zkp_debug_quad_selftest", "zkp_debug_wave_cycles")      # only in libzkp_mi355x_testhooks.so
@@ -309,6 +309,16 @@ class Engine:
         if rc < 0:
             _check(rc, "zkp_ctx_last_timing")
         return {k: float(arr[i]) for i, k in enumerate(K_NAMES)}, float(tot.value)
+
+    def last_kernels(self):
+        """{timing kind: [kernel names as rocprofv3 prints them]} for the kinds whose kernel variant the last call picked at run time"""
+        out = {}
+        buf = ctypes.create_string_buffer(512)
+        self._lib.zkp_ctx_last_kernels.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        for i, k in enumerate(K_NAMES):
+            if self._lib.zkp_ctx_last_kernels(self._h, i, buf, 512) > 0:
+                out[k] = buf.value.decode().split(";")
+        return out
 
 
 class _Capture:

@@ -3,8 +3,9 @@
  * GPU is entered once per phase for a whole batch of proofs instead of once per 2-term MSM.
  *
  * Layering:  this library (libzkp_toolbox.so, C++/g++)  ->  zkp_mi355x.h (libzkp_mi355x.so, HIP).
- * Everything that touches group arithmetic goes through the zkp_mi355x.h entry points; there is no CPU
- * fallback.  Host work (STROBE/Keccak transcripts, scalar arithmetic mod l, coefficient build) runs on
+ * Group arithmetic goes through the zkp_mi355x.h entry points, except for TINY calls and calls without a context (ctx == NULL), which
+ * run the same field / group headers on the host (zkp_toolbox_set_host_max_terms below) -- a backend choice by size, never a silent
+ * fallback: a call that needs the GPU and cannot have it fails with a negative code.  Host work (STROBE/Keccak transcripts, scalar arithmetic mod l, coefficient build) runs on
  * `n_threads` host threads (0 = all hardware threads).
  *
  * Reference mapping (what each call replaces, for N proofs of ONE statement at a time):
@@ -221,6 +222,14 @@ int zkp_pipe_batch_verify_locate(zkp_pipe* pipe, const zkp_statement* st, uint32
  * host threads and use the GPU for the group arithmetic only.  Both routes produce the same bytes.  Default 32 (the measured crossover for the CMZ statement);
  * 0 = always fused, UINT32_MAX = never. */
 void zkp_toolbox_set_fused_min_batch(uint32_t n);
+/* Host backend (zkp_amd/csrc/host/host_backend.cpp: the kernels' own field / group headers compiled for the host).  Every call above accepts
+ * ctx == NULL: the whole call then runs on the host cores -- no GPU needed (BASELINE configs[0]: "DLEQ proof single prove + verify on CPU").
+ * With a context, calls whose group arithmetic is at most `n` (scalar, point) terms do the same, because a GPU call is a ~1 ms chain of
+ * launches whatever its size and a 2-term multiscalar multiplication is ~0.1 ms on one core.  Default 16 (a single DLEQ proof: 2 terms to
+ * prove, 4 to verify); 0 = never with a context.  Same bytes either way (canonical encodings); the prover's multiplications stay constant
+ * time on the host (masked table look-ups, no skipped digits). */
+void zkp_toolbox_set_host_max_terms(uint32_t n);
+uint32_t zkp_toolbox_get_host_max_terms(void);
 uint32_t zkp_toolbox_get_fused_min_batch(void);
 
 /* The ChaCha20 block function (RFC 8439 section 2.3; state words 12-13 = counter, 14-15 = nonce) behind the default

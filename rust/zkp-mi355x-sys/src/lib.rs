@@ -262,6 +262,8 @@ extern "C" {
     pub fn zkp_pipe_batch_verify_locate(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, n_transcripts: u32, transcripts: *mut u8,
                                         inst_points: *const u8, common_points: *const u8, commitments: *const u8, responses: *const u8,
                                         weights16: *const u8, results: *mut u8) -> c_int;
+    pub fn zkp_toolbox_set_host_max_terms(n: u32);
+    pub fn zkp_toolbox_get_host_max_terms() -> u32;
     pub fn zkp_toolbox_set_fused_min_batch(n: u32);
     pub fn zkp_toolbox_get_fused_min_batch() -> u32;
     pub fn zkp_chacha20_block(key: *const u8, counter: u64, nonce: u64, out: *mut u8);

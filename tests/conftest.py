@@ -20,3 +20,21 @@ def pytest_configure(config):
                 torch.cuda.init()
         except Exception:
             pass
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _gpu_tests_use_the_gpu(request):
+    """The host toolbox serves calls of a handful of terms on the host backend (zkp_toolbox_set_host_max_terms, default 16) even when it
+    has a GPU context.  The -m gpu tests are there to exercise the DEVICE path at every size, tiny ones included, so they switch that
+    off; tests/test_host_backend.py covers the host backend (and, on the GPU box, host == device)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from zkp_amd import toolbox as T
+    old = T.get_host_max_terms()
+    T.set_host_max_terms(0)
+    yield
+    T.set_host_max_terms(old)

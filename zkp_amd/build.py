@@ -67,7 +67,7 @@ def build_host(force: bool = False, verbose: bool = False):
     deps = _deps(host_dir, os.path.join(HERE, "..", "include"))
     force = force or bool(os.environ.get("ZKP_FORCE_BUILD"))
     if force or _stale(HOST_LIB, deps):
-        cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall", "-I", os.path.join(HERE, "..", "include")] + srcs + [
+        cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall", "-Wno-unknown-pragmas", "-I", os.path.join(HERE, "..", "include")] + srcs + [
             "-o", HOST_LIB, "-L", HERE, "-lzkp_mi355x", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -26,11 +26,29 @@
 using zkp::host::Scalar;
 using zkp::host::Transcript;
 
+#include "host_backend.hpp"
 #include "toolbox_internal.hpp"
 
 using namespace zkp::host;
 
 static std::atomic<uint32_t> g_fused_min_batch{32};
+// calls whose group arithmetic is at most this many (scalar, point) terms run on the host cores (host_backend.cpp) instead of paying the
+// ~1 ms launch chain of the GPU; a NULL context always does (no GPU needed at all)
+static std::atomic<uint32_t> g_host_max_terms{16};
+
+namespace {
+inline bool on_host(const zkp_ctx* ctx, uint64_t terms) { return !ctx || terms <= g_host_max_terms.load(); }
+// the engine entry points of the host-transcript route, on the GPU or -- tiny calls, or no context -- on the host
+int be_msm_many(zkp_ctx* ctx, uint32_t n_msm, const uint32_t* off, const uint8_t* scalars, const uint32_t* pidx, const uint8_t* points, uint32_t n_points, int flags,
+                uint8_t* out, uint8_t* status) {
+  if (on_host(ctx, n_msm ? off[n_msm] : 0)) return zkp::hostbk::msm_many(n_msm, off, scalars, pidx, points, n_points, flags, out, status);
+  return zkp_msm_many(ctx, n_msm, off, scalars, pidx, points, n_points, flags, out, status);
+}
+int be_decode_check(zkp_ctx* ctx, bool host, uint64_t n, const uint8_t* points, uint8_t* status) {
+  if (host) return zkp::hostbk::decode_check(n, points, status);
+  return zkp_decode_check(ctx, n, points, status, nullptr);
+}
+}  // namespace
 
 namespace zkp {
 namespace host {
@@ -197,6 +215,8 @@ void zkp_chacha20_block(const uint8_t key[32], uint64_t counter, uint64_t nonce,
   std::memcpy(k, key, 32);
   chacha20_block(k, counter, nonce, out);
 }
+void zkp_toolbox_set_host_max_terms(uint32_t n) { g_host_max_terms = n; }
+uint32_t zkp_toolbox_get_host_max_terms(void) { return g_host_max_terms.load(); }
 void zkp_toolbox_set_fused_min_batch(uint32_t n) { g_fused_min_batch = n; }
 uint32_t zkp_toolbox_get_fused_min_batch(void) { return g_fused_min_batch.load(); }
 
@@ -405,9 +425,9 @@ int zkp_prove_phase_b(const zkp_statement* stp, uint32_t N, uint8_t* ts, const u
 int zkp_prove_batch(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* ts, const uint8_t* secrets,
                     const uint8_t* inst, const uint8_t* common, const uint8_t* entropy, int n_threads, uint8_t* challenges,
                     uint8_t* responses, uint8_t* commitments) {
-  if (!ctx || !st) return ZKP_TB_BAD_STATEMENT;
+  if (!st) return ZKP_TB_BAD_STATEMENT;                                  // (ctx == NULL: the host backend, host_backend.cpp)
   if (N == 0) return ZKP_TB_OK;
-  if (ts && use_fused(ts, N)) {
+  if (ctx && ts && use_fused(ts, N)) {
     std::vector<uint8_t> own_entropy;
     if (!entropy) { own_entropy.resize(32 * (size_t)N); if (!os_random(own_entropy.data(), own_entropy.size())) return ZKP_TB_NO_ENTROPY; entropy = own_entropy.data(); }
     if (st->ns && N >= 32) { const int rc = zkp_ctx_prepare_fixed_points(ctx, st->ns, common); if (rc) return rc; }
@@ -423,10 +443,10 @@ int zkp_prove_batch(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* 
   int rc = zkp_prove_phase_a(st, N, ts, secrets, inst, common, entropy, n_threads, blind.data(), off.data(), scalars.data(), pidx.data());
   if (rc) return rc;
   const std::vector<uint8_t> tbl = point_table(*st, N, inst, common);
-  if (st->ns && N >= 32) { rc = zkp_ctx_prepare_fixed_points(ctx, st->ns, common); if (rc) return rc; }   // common points: fixed-base tables
+  if (ctx && st->ns && N >= 32) { rc = zkp_ctx_prepare_fixed_points(ctx, st->ns, common); if (rc) return rc; }   // common points: fixed-base tables
   // prover.rs:94 RistrettoPoint::multiscalar_mul for every constraint of every proof, + compress (mod.rs:204)
-  rc = zkp_msm_many(ctx, N * nc, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32), ZKP_CT,
-                    commitments, status.data());
+  rc = be_msm_many(ctx, N * nc, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32), ZKP_CT,
+                   commitments, status.data());
   if (rc) return rc;
   for (uint8_t s : status)
     if (s) return ZKP_TB_INVALID_POINT;     // the reference prover holds decoded points; an undecodable input is a caller bug
@@ -450,10 +470,10 @@ static void build_verifiers(const zkp_statement& st, uint32_t N, uint8_t* ts, co
 int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* inst,
                              const uint8_t* common, const uint8_t* challenges, const uint8_t* responses, int n_threads,
                              uint8_t* results) {
-  if (!ctx || !stp || !ts || !results || !challenges || (!stp->secrets.empty() && !responses)) return ZKP_TB_BAD_STATEMENT;
+  if (!stp || !ts || !results || !challenges || (!stp->secrets.empty() && !responses)) return ZKP_TB_BAD_STATEMENT;
   if (N == 0) return ZKP_TB_OK;
   const zkp_statement& st = *stp;
-  if (use_fused(ts, N)) {
+  if (ctx && use_fused(ts, N)) {
     if (st.ns && N >= 32) { const int rc = zkp_ctx_prepare_fixed_points(ctx, st.ns, common); if (rc) return rc; }
     FusedView fv(st);
     return zkp_fused_verify_compact(ctx, &fv.fs, N, ts, inst, common, challenges, responses, results);
@@ -483,10 +503,11 @@ int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N,
   });
   off[(size_t)N * nc] = (uint32_t)((size_t)N * T1);
   const std::vector<uint8_t> tbl = point_table(st, N, inst, common);
-  int rc = (st.ns && N >= 32) ? zkp_ctx_prepare_fixed_points(ctx, st.ns, common) : 0;
+  int rc = (ctx && st.ns && N >= 32) ? zkp_ctx_prepare_fixed_points(ctx, st.ns, common) : 0;
   if (rc) return rc;
-  rc = zkp_msm_many(ctx, N * nc, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32),
-                    ZKP_VARTIME, coms.data(), status.data());
+  const bool host = on_host(ctx, (uint64_t)N * T1);
+  rc = be_msm_many(ctx, N * nc, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32),
+                   ZKP_VARTIME, coms.data(), status.data());
   if (rc) return rc;
   // verifier.rs:87-92 decompresses EVERY allocated point, also those no constraint uses
   const std::vector<uint32_t> unref = unreferenced_points(st);
@@ -498,7 +519,7 @@ int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N,
       else for (uint32_t j = 0; j < N; ++j) { const uint8_t* e = point_enc(st, p, j, N, inst, common); encs.insert(encs.end(), e, e + 32); owner.emplace_back(j, 0); }
     }
     st8.resize(owner.size());
-    rc = zkp_decode_check(ctx, owner.size(), encs.data(), st8.data(), nullptr);
+    rc = be_decode_check(ctx, host, owner.size(), encs.data(), st8.data());
     if (rc) return rc;
     for (size_t i = 0; i < owner.size(); ++i)
       if (st8[i]) {
@@ -529,13 +550,13 @@ int zkp_verify_compact_batch(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N,
 int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, uint8_t* ts, const uint8_t* inst,
                               const uint8_t* common, const uint8_t* commitments, const uint8_t* responses,
                               const uint8_t* weights16, int n_threads, uint8_t* results) {
-  if (!ctx || !stp || !ts || !results || (!stp->cons.empty() && !commitments) || (!stp->secrets.empty() && !responses)) return ZKP_TB_BAD_STATEMENT;
+  if (!stp || !ts || !results || (!stp->cons.empty() && !commitments) || (!stp->secrets.empty() && !responses)) return ZKP_TB_BAD_STATEMENT;
   if (N == 0) return ZKP_TB_OK;
   const zkp_statement& st = *stp;
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), np = (uint32_t)st.points.size();
   std::vector<uint8_t> own_w;
   if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
-  if (use_fused(ts, N)) {
+  if (ctx && use_fused(ts, N)) {
     if (st.ns && N >= 32) { const int rc = zkp_ctx_prepare_fixed_points(ctx, st.ns, common); if (rc) return rc; }
     FusedView fv(st);
     return zkp_fused_verify_batchable(ctx, &fv.fs, N, ts, inst, common, commitments, responses, weights16, results);
@@ -579,10 +600,10 @@ int zkp_verify_batchable_each(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N
     }
   });
   off[N] = N * K;
-  int rc = (st.ns && N >= 32) ? zkp_ctx_prepare_fixed_points(ctx, st.ns, common) : 0;
+  int rc = (ctx && st.ns && N >= 32) ? zkp_ctx_prepare_fixed_points(ctx, st.ns, common) : 0;
   if (rc) return rc;
-  rc = zkp_msm_many(ctx, N, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32), ZKP_VARTIME,
-                    out.data(), status.data());
+  rc = be_msm_many(ctx, N, off.data(), scalars.data(), pidx.data(), tbl.data(), (uint32_t)(tbl.size() / 32), ZKP_VARTIME,
+                   out.data(), status.data());
   if (rc) return rc;
   static const uint8_t zero[32] = {0};
   for (uint32_t j = 0; j < N; ++j)                                     // verifier.rs:162-172
@@ -659,10 +680,25 @@ int zkp_batch_verify_build(const zkp_statement* stp, uint32_t N, uint32_t n_tran
 int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
                             const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
                             int n_threads, uint8_t* coeffs) {
-  if (!ctx || !stp) return ZKP_TB_BAD_STATEMENT;
+  if (!stp) return ZKP_TB_BAD_STATEMENT;
   if (n_transcripts != N) return ZKP_TB_BATCH_SIZE_MISMATCH;           // batch_verifier.rs:72-74
   const zkp_statement& st = *stp;
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), ni = st.ni, ns = st.ns;
+  if (on_host(ctx, (uint64_t)ns + ((uint64_t)ni + nc) * N)) {
+    // tiny batch (or no GPU context): batch_verifier.rs:67-235 entirely on the host -- the operand list of :219-228 from
+    // zkp_batch_verify_build, the MSM from the host backend
+    const size_t total = (size_t)ns + ((size_t)ni + nc) * N;
+    std::vector<uint8_t> sc(32 * (total ? total : 1)), pts(32 * (total ? total : 1));
+    const int rcb = zkp_batch_verify_build(stp, N, n_transcripts, ts, inst, common, commitments, responses, weights16, n_threads, sc.data(), pts.data());
+    if (rcb) return rcb;
+    if (coeffs) std::memcpy(coeffs, sc.data(), 32 * total);
+    uint8_t out[32];
+    int status = 1;
+    const int rcm = zkp::hostbk::msm_optional(total, sc.data(), pts.data(), out, &status);
+    if (rcm) return rcm;
+    static const uint8_t zero32[32] = {0};
+    return (!status && std::memcmp(out, zero32, 32) == 0) ? ZKP_TB_OK : ZKP_TB_VERIFICATION_FAILURE;      // :230-234
+  }
   if (ts && use_fused(ts, N)) {
     std::vector<uint8_t> own_w;
     if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
@@ -721,7 +757,7 @@ int zkp_batch_verify(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t
 int zkp_batch_verify_many(zkp_ctx* ctx, const zkp_statement* stp, uint32_t K, uint32_t N_each, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
                           const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16, int n_threads,
                           int* verdicts) {
-  if (!ctx || !stp || !verdicts || K == 0 || N_each == 0 || (uint64_t)K * N_each > 0x7fffffffull) return ZKP_TB_BAD_STATEMENT;
+  if (!stp || !verdicts || K == 0 || N_each == 0 || (uint64_t)K * N_each > 0x7fffffffull) return ZKP_TB_BAD_STATEMENT;
   const uint32_t N = K * N_each;
   if (n_transcripts != N) return ZKP_TB_BATCH_SIZE_MISMATCH;           // batch_verifier.rs:72-74
   if (!ts) return ZKP_TB_BAD_STATEMENT;
@@ -729,7 +765,7 @@ int zkp_batch_verify_many(zkp_ctx* ctx, const zkp_statement* stp, uint32_t K, ui
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), ni = st.ni;
   std::vector<uint8_t> own_w;
   if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
-  if (use_fused(ts, N)) {
+  if (ctx && use_fused(ts, N)) {
     FusedView fv(st);
     const int rc = zkp_fused_batch_verify_many(ctx, &fv.fs, K, N_each, ts, inst, common, commitments, responses, weights16, verdicts, nullptr);
     if (rc) return rc;
@@ -753,7 +789,7 @@ int zkp_batch_verify_many(zkp_ctx* ctx, const zkp_statement* stp, uint32_t K, ui
 int zkp_batch_verify_locate(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint32_t n_transcripts, uint8_t* ts, const uint8_t* inst,
                             const uint8_t* common, const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16,
                             int n_threads, uint8_t* results) {
-  if (!ctx || !st || !results || (N && !ts)) return ZKP_TB_BAD_STATEMENT;
+  if (!st || !results || (N && !ts)) return ZKP_TB_BAD_STATEMENT;
   if (n_transcripts != N) return ZKP_TB_BATCH_SIZE_MISMATCH;           // batch_verifier.rs:72-74
   std::memset(results, 0, N);
   const std::vector<uint8_t> saved(ts, ts + TB * (size_t)N);           // the per-proof pass starts where the batch check started

@@ -44,7 +44,7 @@ EXPORTS = (
     "zkp_pipe_jobs_in_flight", "zkp_pipe_last_error", "zkp_prove_batch_submit", "zkp_verify_compact_batch_submit",
     "zkp_verify_batchable_each_submit", "zkp_batch_verify_many_submit", "zkp_job_done", "zkp_job_wait", "zkp_job_context_index", "zkp_pipe_prove_batch",
     "zkp_pipe_verify_compact_batch", "zkp_pipe_verify_batchable_each", "zkp_pipe_batch_verify", "zkp_pipe_batch_verify_many",
-    "zkp_pipe_batch_verify_locate",
+    "zkp_pipe_batch_verify_locate", "zkp_toolbox_set_host_max_terms", "zkp_toolbox_get_host_max_terms",
 )
 ZKP_JOB_SHARED_TRANSCRIPT = 1
 ZKP_TB_PIPE_FULL = 3
@@ -122,6 +122,25 @@ def lib() -> ctypes.CDLL:
 def set_fused_min_batch(n: int) -> None:
     """Batches of >= n proofs run transcripts, scalars and MSMs on the device; smaller ones hash on the host threads."""
     lib().zkp_toolbox_set_fused_min_batch(ctypes.c_uint32(n))
+
+
+def set_host_max_terms(n: int) -> None:
+    """Calls of at most n (scalar, point) terms run on the host backend even with a GPU context (0 = never); ctx = None always does."""
+    lib().zkp_toolbox_set_host_max_terms(ctypes.c_uint32(n))
+
+
+def get_host_max_terms() -> int:
+    f = lib().zkp_toolbox_get_host_max_terms
+    f.restype = ctypes.c_uint32
+    return int(f())
+
+
+class HostEngine:
+    """Stands where an Engine stands in the calls of this module and selects the host backend (ctx == NULL in the C ABI): no GPU needed."""
+    _h = None
+
+    def close(self):
+        pass
 
 
 def get_fused_min_batch() -> int:

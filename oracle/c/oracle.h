@@ -50,6 +50,11 @@ void orc_sc_neg(uint8_t out[32], const uint8_t a[32]);
 void orc_sc_add(uint8_t out[32], const uint8_t a[32], const uint8_t b[32]);
 void orc_sc_sub(uint8_t out[32], const uint8_t a[32], const uint8_t b[32]);
 
+/* The MSM entry points below on AVX-512 IFMA vectors (simd_ifma.c: dalek's simd_backend design, 4 lanes = the 4 coordinates of a point).
+ * orc_set_simd(1) switches them over and returns 1 -- or 0 when the build or the CPU lacks AVX-512 IFMA + VL (nothing changes then). */
+int orc_simd_available(void);
+int orc_set_simd(int on);
+
 /* ---- the three dalek MSM entry points ---------------------------------------------------- */
 /* constant-time Straus, radix 16  (RistrettoPoint::multiscalar_mul) */
 void orc_msm_straus_ct(ge_ext* r, size_t n, const uint8_t* scalars, const ge_ext* points);

@@ -50,6 +50,16 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def simd_available() -> bool:
+    """the build and this CPU have AVX-512 IFMA + VL (oracle/c/simd_ifma.c)"""
+    return bool(lib().orc_simd_available())
+
+
+def set_simd(on: bool) -> bool:
+    """MSM inner loops on the vector backend (dalek's simd_backend design); returns whether it is on now"""
+    return bool(lib().orc_set_simd(1 if on else 0))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 

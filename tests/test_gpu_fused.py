@@ -620,3 +620,40 @@ def test_verify_batchable_straus_lane_counts_agree(n):
             assert (got == want).all(), (opt, np.nonzero(got != want)[0][:8])
     finally:
         T.set_fused_min_batch(32)
+
+
+def test_verify_batchable_straus_more_lanes_than_operands_dleq():
+    """ZKP_OPT_EACH_STRAUS = 8 lanes per proof on a DLEQ-sized statement (K = 4 points + 2 commitments = 6 operands): lanes
+    without an operand used to fetch an unwritten LDS word and gather past the proof's table; the lane count is clamped to K now.  Every
+    option value gives the oracle's verdicts, for valid and for tampered proofs."""
+    from zkp_amd.engine import Engine
+    n = 200
+    mod, x, A, B, H = _dleq_batch(n, 17)
+    st = mod.statement
+    inst = np.stack([A, B, H])
+    G = np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32)
+    label = b"straus-dleq"
+    rng = np.random.default_rng(18)
+    e0 = Engine(0)
+    chal, resp, coms = T.prove_batch(e0, st, _fresh(label, n), x, inst, G, rng.integers(0, 256, size=(n, 32), dtype=np.uint8))
+    e0.close()
+    w = rng.integers(0, 256, size=(n, st.nc, 16), dtype=np.uint8)
+    resp, coms = resp.copy(), coms.copy()
+    resp[3, 0, 1] ^= 2
+    coms[50, 1] = coms[51, 1]
+    coms[199, 0] = 0
+    want = np.zeros(n, np.uint8)
+    want[[3, 50, 199]] = 1
+    cst = C.Statement.from_model(M.dleq_statement())
+    for j in (0, 3, 50, 199):
+        assert C.verify_batchable(cst, label, np.concatenate([inst[:, j], G]), coms[j], resp[j], w[j]) == want[j]
+    T.set_fused_min_batch(0)
+    try:
+        for opt in (2**64 - 1, 0, 1, 5, 6, 7, 8, 0x202, 0x240):
+            e = Engine(0)
+            e.set_option(10, opt)
+            got = T.verify_batchable_each(e, st, _fresh(label, n), inst, G, coms, resp, w)
+            e.close()
+            assert (got == want).all(), (opt, np.nonzero(got != want)[0][:8])
+    finally:
+        T.set_fused_min_batch(32)

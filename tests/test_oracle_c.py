@@ -382,3 +382,58 @@ print("sanitizer run complete")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "sanitizer run complete" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+
+
+def test_simd_msm_equals_scalar_port():
+    """oracle/c/simd_ifma.c (AVX-512 IFMA, the four coordinates of a point in four lanes -- the design of curve25519-dalek's simd_backend): the
+    three MSM algorithms, whole proofs and a batch verification must give the bytes of the scalar 5 x 51 port.  Skipped where the build or the CPU
+    has no AVX-512 IFMA (the vector code is then not even compiled / refused at run time)."""
+    if not C.simd_available():
+        assert C.set_simd(True) is False
+        pytest.skip("no AVX-512 IFMA on this CPU / in this build")
+    rng = np.random.default_rng(2024)
+    base = np.frombuffer(bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"), np.uint8).reshape(1, 32)
+    try:
+        for n, algos in ((1, ("straus_ct", "straus_vartime")), (2, ("straus_ct", "straus_vartime")), (11, ("straus_ct", "straus_vartime", "pippenger")),
+                         (37, ("straus_ct", "straus_vartime", "pippenger")), (600, ("pippenger",)), (900, ("pippenger",))):
+            ks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+            ks[:, 31] &= 0x0f
+            C.set_simd(False)
+            pts, st = C.msm_many(np.arange(n + 1, dtype=np.uint32), ks, np.zeros(n, np.uint32), base, 0)
+            assert not st.any()
+            sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+            sc[0] = 0                                                   # a zero scalar
+            if n > 1:
+                sc[1] = np.frombuffer((M.L - 1).to_bytes(32, "little"), np.uint8)
+            if n > 2:
+                sc[2] = 0xff                                            # 2^256 - 1: reduced mod l by both backends
+            for algo in algos:
+                C.set_simd(False)
+                want = C.msm_algo(algo, sc, pts)
+                assert C.set_simd(True)
+                got = C.msm_algo(algo, sc, pts)
+                assert got == want, (n, algo)
+        # whole flows: prover (constant-time Straus), verifiers (NAF Straus), batch verifier (Pippenger)
+        from tests.test_gpu_toolbox import _cmz_batch                 # (CPU only: the instance is made with the oracle's own arithmetic)
+        cst = C.Statement.from_model(M.cmz_statement(10))
+        C.set_simd(False)
+        n = 40
+        mod, secrets, inst, common = _cmz_batch(n, 77)
+        ent = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        w = rng.integers(0, 256, size=(11, n, 16), dtype=np.uint8)
+        proofs = {}
+        for simd in (False, True):
+            assert C.set_simd(simd) == simd
+            out = [C.prove(cst, b"simd", secrets[j], np.concatenate([inst[:, j], common]), ent[j].tobytes())[:3] for j in range(n)]
+            proofs[simd] = out
+            coms = np.stack([o[2] for o in out])
+            resp = np.stack([o[1] for o in out])
+            assert C.batch_verify(cst, b"simd", n, inst, common, coms, resp, w) == 0                    # 12 + 24 * 40 = 972 terms: Pippenger w = 8
+            bad = resp.copy()
+            bad[7, 3, 0] ^= 1
+            assert C.batch_verify(cst, b"simd", n, inst, common, coms, bad, w) == 1
+            assert C.verify_compact(cst, b"simd", np.concatenate([inst[:, 3], common]), out[3][0], out[3][1]) == 0
+        for a, b in zip(proofs[False], proofs[True]):
+            assert a[0].tobytes() == b[0].tobytes() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    finally:
+        C.set_simd(False)

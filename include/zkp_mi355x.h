@@ -110,18 +110,12 @@ const char* zkp_version(void);
  *     instead of all starting first (fewer per-lane ladder tables in flight together: -20 % HBM fetch in that kernel); 0 = all first;
  *     UINT64_MAX = default: spread when the launch has 256 or more ladder blocks (65,536 single-use points), where it also is ~1 % faster --
  *     in a lone smaller launch the later start of the last ladder block lengthens the kernel (profiles/r03_ab_experiments.txt, block l).
- *   ZKP_OPT_TERMS_TWO_LAUNCHES: 1 = the per-proof comb tables are built by the first blocks of the launch that serves the fixed-base terms (which
- *     need none), and the terms on per-proof points follow in a second launch of the term kernel: the table builder -- a 256-doubling chain per
- *     table on a few hundred wavefronts, 16 % of a lone call of 20,480 CMZ proofs -- leaves the call's chain and runs under ~1,600 fixed-base
- *     blocks.  0 = tables first (in the transcript's launch where that applies), then one term launch.  UINT64_MAX = default = 0: measured, the
- *     table chains stay the long pole of their launch (0.9 ms for 20,480 proofs) and the transcript program that used to share the table
- *     launch is exposed instead -- lone prove call 2.98 -> 3.07 ms, pipelined +-1 % (profiles/r04_ab_experiments.txt, block c).
  *   ZKP_OPT_WS_LIMIT_BYTES: the largest device workspace this context may allocate (it grows with the largest call it has served: ~75 KB per CMZ
  *     proof of a prove call).  A call that would need more returns ZKP_ERR_OOM instead of allocating -- the way to keep several contexts of a
  *     zkp_pipe (zkp_toolbox.h) inside one GPU's memory.  0 / UINT64_MAX = no cap (default).
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
-       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12, ZKP_OPT_TERMS_TWO_LAUNCHES = 13 };
+       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~35 short kernels (75 in round 1); enqueueing them one by one costs the host ~0.1 ms per

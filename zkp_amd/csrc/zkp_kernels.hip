@@ -159,26 +159,15 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
               const uint32_t* __restrict__ blk_start, const uint32_t* __restrict__ list, const dev_niels* __restrict__ tables,
               const dev_affine* __restrict__ pts, dev_ext* __restrict__ ladder_rw, uint32_t max_ladder, dev_ext* __restrict__ partial,
-              uint32_t ladder_stride, uint32_t phase, uint32_t tab_blocks, const uint32_t* __restrict__ n_slots, uint32_t max_tables,
-              const uint32_t* __restrict__ slot_pt, dev_ext* __restrict__ comb_rw) {
-  // Two-launch form (ZKP_OPT_TERMS_TWO_LAUNCHES): phase bit 1 = the fixed-base blocks, bit 0 = the cold classes (ladder, comb, grouped comb);
-  // tab_blocks > 0: the first tab_blocks blocks of this launch BUILD the comb tables (one lane per table, a 256-doubling chain each) next to
-  // the fixed-base blocks, which need no table of theirs -- the narrow table kernel leaves the call's chain, the second launch (cold classes)
-  // finds the tables ready.  phase = 3, tab_blocks = 0: everything in one launch, tables built beforehand.
-  uint32_t bx = blockIdx.x;
-  if (tab_blocks) {
-    if (bx < tab_blocks) { comb_table_lane<TEETH>(bx * 256u + threadIdx.x, n_slots, max_tables, slot_pt, pts, comb_rw); return; }
-    bx -= tab_blocks;
-  }
-  const bool cold = (phase & 1u) != 0, fixed = (phase & 2u) != 0;
+              uint32_t ladder_stride) {
   // A block of fixed-base terms serves ONE table; its rows pass through LDS one window at a time, in 16 copies, so that every
   // lane reads the entry its digit names from banks of its own (hot_tables.h): no masked scan, no bank conflict, the same
   // LDS cycles for every scalar.
   __shared__ uint4 hot_lds[HOT_ROW_CHUNKS * HOT_COPIES > GROUP_LDS_UINT4 ? HOT_ROW_CHUNKS * HOT_COPIES : GROUP_LDS_UINT4];
   uint32_t* ecol = reinterpret_cast<uint32_t*>(hot_lds) + threadIdx.x;      // (ladder and comb blocks: the recoded scalars)
-  const uint32_t n_hot = class_start[CLASS_COMB], n_comb = cold ? class_start[CLASS_LADDER] - n_hot : 0u;
-  const uint32_t n_ladder = (LADDER && cold) ? class_start[CLASS_GROUP] - class_start[CLASS_LADDER] : 0u;
-  const uint32_t n_group = (CT && TEETH == 16 && cold) ? class_start[HOT_CLASSES] - class_start[CLASS_GROUP] : 0u;
+  const uint32_t n_hot = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - n_hot;
+  const uint32_t n_ladder = LADDER ? class_start[CLASS_GROUP] - class_start[CLASS_LADDER] : 0u;
+  const uint32_t n_group = (CT && TEETH == 16) ? class_start[HOT_CLASSES] - class_start[CLASS_GROUP] : 0u;
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
   const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
   const uint32_t group_blocks = (n_group + blockDim.x - 1) / blockDim.x;
@@ -186,11 +175,11 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   // ladder blocks over the front of the grid (ladder block i sits at position i * stride) instead of starting them all at once: a ladder
   // lane scans its own 1.1 KB table 65 times, and only as many of those tables as are in flight together have to fit the L2s
   // (one block in `stride` instead of every block of the first wave of the launch).  The mapping depends on the launch shape only.
-  uint32_t vb = bx;
+  uint32_t vb = blockIdx.x;
   if (LADDER && ladder_stride > 1) {
-    const uint32_t q = bx / ladder_stride, r = bx - q * ladder_stride;
+    const uint32_t q = blockIdx.x / ladder_stride, r = blockIdx.x - q * ladder_stride;
     if (r == 0 && q < ladder_blocks) vb = q;
-    else vb = ladder_blocks + bx - min((bx + ladder_stride - 1) / ladder_stride, ladder_blocks);
+    else vb = ladder_blocks + blockIdx.x - min((blockIdx.x + ladder_stride - 1) / ladder_stride, ladder_blocks);
   }
   ZKP_WAVE_T0
   if (LADDER && vb < ladder_blocks) {
@@ -220,7 +209,7 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
     ZKP_WAVE_T1(3);
   } else {
     const uint32_t hb = vb - ladder_blocks - comb_blocks - group_blocks;
-    if (!fixed || hb >= blk_start[HOT_SLOTS]) return;             // (uniform in the block)
+    if (hb >= blk_start[HOT_SLOTS]) return;                       // (uniform in the block)
     uint32_t c = 0;
     while (blk_start[c + 1] <= hb) ++c;                           // class = table slot of this block
     const uint4* src = reinterpret_cast<const uint4*>(tables + (size_t)c * HOT_SLOT_NIELS);
@@ -1165,7 +1154,6 @@ struct zkp_ctx {
   int fuse_tables_transcript = -1;       // ZKP_OPT_FUSE_TABLES_TRANSCRIPT: -1 = asynchronous _dev calls below kVeryWideCallProofs proofs, 0 = never, 1 = always
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
-  int terms_two_launches = -1;       // ZKP_OPT_TERMS_TWO_LAUNCHES: comb tables built inside the fixed-base launch of the term kernel, cold classes in a second launch
   int ladder_interleave = -1;        // ZKP_OPT_LADDER_INTERLEAVE: the term kernel's ladder blocks spread over the front of its grid instead of all first
                                      // (-1 = by size: from kInterleaveLadderBlocks ladder blocks up, where the later start of the last one no longer shows)
   static constexpr uint32_t kInterleaveLadderBlocks = 256;
@@ -1362,27 +1350,24 @@ inline bool terms_batched_encode(const zkp_ctx* c, uint32_t n_terms, uint32_t n_
   return n_terms >= 1024 && (uint64_t)n_msm >= ((throughput && !c->batch_encode_user) ? kThroughputEncodeMin : c->batch_encode_min);
 }
 
-// what a launch of the term kernel covers (see k_terms_split): everything, or -- two-launch form -- the fixed-base blocks together with the
-// comb-table builder, then the cold classes
-struct terms_phase { uint32_t phase = 3, tab_blocks = 0; const uint32_t* n_slots = nullptr; uint32_t max_tables = 0; const uint32_t* slot_pt = nullptr; dev_ext* comb_rw = nullptr; };
 template <bool CT, int TEETH, bool SCAN = false>
 void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
                         const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
-                        const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part, const terms_phase& ph = terms_phase()) {
+                        const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part) {
   // ladder blocks spread over the first half of the grid (ZKP_OPT_LADDER_INTERLEAVE), or all at the front
   uint32_t stride = 0;
   const uint32_t lb = (max_ladder + 255) / 256;
-  if (ladder && lb && (ph.phase & 1u) && !ph.tab_blocks && (c->ladder_interleave < 0 ? lb >= zkp_ctx::kInterleaveLadderBlocks : c->ladder_interleave != 0)) {
+  if (ladder && lb && (c->ladder_interleave < 0 ? lb >= zkp_ctx::kInterleaveLadderBlocks : c->ladder_interleave != 0)) {
     stride = (grid.x / 2) / lb;
     if (stride < 2) stride = 0;
   }
   prof_note(c, ZKP_K_TERMS, std::string("k_terms_split<") + (CT ? "true" : "false") + ", " + std::to_string(TEETH) + ", " + (ladder ? "true" : "false") + ", " + (SCAN ? "true" : "false") + ">");
   if (ladder)
     hipLaunchKernelGGL((k_terms_split<CT, TEETH, true, SCAN>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
-                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride, ph.phase, ph.tab_blocks, ph.n_slots, ph.max_tables, ph.slot_pt, ph.comb_rw);
+                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
   else
     hipLaunchKernelGGL((k_terms_split<CT, TEETH, false, SCAN>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
-                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride, ph.phase, ph.tab_blocks, ph.n_slots, ph.max_tables, ph.slot_pt, ph.comb_rw);
+                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
 }
 
 // phase: everything (default), or only the part that does not look at the scalars (decode, classification, comb tables:
@@ -1449,13 +1434,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
                        cursor, list);
     prof_mark(c, ZKP_K_SORT);          // path A: term classification
     }
-    // Two-launch form of the term kernel: the comb tables are built by the first blocks of the launch that serves the fixed-base terms
-    // (which need no comb table), the cold classes follow in a second launch -- for calls that build their tables with one lane per point
-    // (the throughput schedule) and have fixed-base terms to hide the table chains behind
-    const bool lane_tables = c->tables_lane < 0 ? k.throughput : c->tables_lane != 0;
-    const bool two_launches = k.max_tables && lane_tables && c->hot_nreg && !(flags == ZKP_CT && c->ct_masked_scans) &&
-                              (c->terms_two_launches < 0 ? false : c->terms_two_launches != 0);      // measured: no gain (profiles/r04_ab_experiments.txt, block c)
-    if ((phase & PH_POINTS) && k.max_tables && !two_launches) {
+    if ((phase & PH_POINTS) && k.max_tables) {
       if (c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) {
         if (k.teeth == 16 && c->pending_tr.active) {               // the flow's transcript program shares the launch
           const auto& t = c->pending_tr;
@@ -1471,7 +1450,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
         else hipLaunchKernelGGL(k_comb_tables<4>, grid1((size_t)k.max_tables * 4, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       }
     }
-    if ((phase & PH_POINTS) && k.max_tables && !two_launches && c->kernel_names[ZKP_K_TABLES].find("k_tables_transcript") == std::string::npos)
+    if ((phase & PH_POINTS) && k.max_tables && c->kernel_names[ZKP_K_TABLES].find("k_tables_transcript") == std::string::npos)
       prof_note(c, ZKP_K_TABLES, std::string((c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) ? "zkp::k_comb_tables_lane<" : "zkp::k_comb_tables<") + (k.teeth == 16 ? "16>" : "4>"));
     if (phase & PH_POINTS) prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
     const dim3 grid((unsigned)((n_terms + 255) / 256 + 4 + HOT_SLOTS));     // every class starts a new block
@@ -1487,28 +1466,12 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
       if (flags == ZKP_CT && c->ct_masked_scans) {
         if (k.teeth == 16) launch_terms_split<true, 16, true>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
         else launch_terms_split<true, 4, true>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+      } else if (flags == ZKP_CT) {
+        if (k.teeth == 16) launch_terms_split<true, 16>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        else launch_terms_split<true, 4>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
       } else {
-        // one launch, or: fixed-base blocks + table builder, then the cold classes
-        terms_phase first, second;
-        dim3 g1 = grid, g2 = grid;
-        if (two_launches) {
-          first.phase = 2; first.tab_blocks = (k.max_tables + 255) / 256; first.n_slots = n_slots; first.max_tables = k.max_tables; first.slot_pt = slot_pt; first.comb_rw = comb;
-          second.phase = 1;
-          g1 = dim3(grid.x + first.tab_blocks);
-          g2 = dim3((unsigned)((n_terms + 255) / 256 + 4));
-        }
-        for (int pass = 0; pass < (two_launches ? 2 : 1); ++pass) {
-          const terms_phase& ph = pass == 0 ? first : second;
-          const dim3 g = pass == 0 ? g1 : g2;
-          if (flags == ZKP_CT) {
-            if (k.teeth == 16) launch_terms_split<true, 16>(c, g, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part, ph);
-            else launch_terms_split<true, 4>(c, g, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part, ph);
-          } else {
-            if (k.teeth == 16) launch_terms_split<false, 16>(c, g, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part, ph);
-            else launch_terms_split<false, 4>(c, g, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part, ph);
-          }
-          if (two_launches && pass == 0) prof_mark(c, ZKP_K_TABLES);        // (the launch that carries the table builder is filed under "tables")
-        }
+        if (k.teeth == 16) launch_terms_split<false, 16>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+        else launch_terms_split<false, 4>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
       }
     }
   } else {
@@ -1793,7 +1756,6 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;
     case ZKP_OPT_LADDER_INTERLEAVE: c->ladder_interleave = value == ~0ull ? -1 : value != 0; return ZKP_OK;
-    case ZKP_OPT_TERMS_TWO_LAUNCHES: c->terms_two_launches = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_WS_LIMIT_BYTES: c->ws_limit = value == ~0ull ? 0 : (size_t)value; return ZKP_OK;
     case ZKP_OPT_EACH_STRAUS:
     {

@@ -4,7 +4,10 @@
 //!  * [`Engine`]: one context per GPU, error mapping (every non-zero code is an `Err`: fail closed);
 //!  * [`multiscalar`]: replacements for the three dalek trait calls the reference's toolbox makes (the per-call route);
 //!  * [`Statement`] + [`prove_batch`] / [`verify_compact_batch`] / [`batch_verify`]: the batched route, where transcripts,
-//!    scalar arithmetic and MSMs of a whole batch of proofs of one statement run on the device.
+//!    scalar arithmetic and MSMs of a whole batch of proofs of one statement run on the device;
+//!  * [`Pipe`]: engine contexts over one or several GPUs -- asynchronous jobs on host buffers ([`Pipe::submit_prove`],
+//!    [`Pipe::submit_batch_verify_many`], [`Job::wait`]) and the synchronous calls sharded over every context
+//!    ([`Pipe::prove_batch`], [`Pipe::batch_verify`]: one verdict, the AND of the per-GPU batch checks).
 //! Layouts are the ones `include/zkp_toolbox.h` documents: secrets / responses `[N][m][32]`, instance points
 //! `[n_inst][N][32]` (row = variable, column = proof, like `BatchVerifier::allocate_instance_point`), common points
 //! `[n_common][32]`, commitments `[N][n_constraints][32]`, transcripts `[N][208]`.
@@ -322,6 +325,119 @@ pub fn batch_verify_locate(eng: &Engine, st: &Statement, transcripts: &mut [Tran
         0 => Ok(Ok(())),
         sys::ZKP_TB_VERIFICATION_FAILURE => Ok(Err(results.into_iter().map(|r| r != 0).collect())),
         _ => check(rc).map(|_| Ok(())),
+    }
+}
+
+/// `zkp_pipe` (include/zkp_toolbox.h): `contexts_per_device` engine contexts on each listed GPU.  One process drives the GPUs of a
+/// node: no process group, no collective -- the only cross-GPU exchange of this path is the AND of verdict bits, taken on the host.
+/// Not `Sync`: a pipe and its jobs belong to one thread at a time.
+pub struct Pipe(*mut sys::zkp_pipe);
+impl Pipe {
+    pub fn new(device_ids: &[i32], contexts_per_device: usize) -> Result<Pipe, Error> {
+        let mut p = ptr::null_mut();
+        check(unsafe { sys::zkp_pipe_create(&mut p, device_ids.as_ptr(), device_ids.len() as c_int, contexts_per_device as c_int) })?;
+        Ok(Pipe(p))
+    }
+    pub fn jobs_in_flight(&self) -> usize { unsafe { sys::zkp_pipe_jobs_in_flight(self.0) as usize } }
+    fn err(&self, rc: c_int) -> Error {
+        match rc {
+            sys::ZKP_TB_VERIFICATION_FAILURE => Error::VerificationFailure,
+            sys::ZKP_TB_BATCH_SIZE_MISMATCH => Error::BatchSizeMismatch,
+            rc => Error::Backend(rc, unsafe { CStr::from_ptr(sys::zkp_pipe_last_error(self.0)) }.to_string_lossy().into_owned()),
+        }
+    }
+
+    /// `prove_batch` over every context: contiguous proof ranges, one host thread per listed GPU; the bytes of the single-context call.
+    pub fn prove_batch(&self, st: &Statement, transcripts: &mut [Transcript], secrets: &[Scalar], inst_points: &[CompressedRistretto],
+                       common_points: &[CompressedRistretto]) -> Result<Proofs, Error> {
+        let n = transcripts.len();
+        st.check_shapes(n, inst_points.len(), common_points.len(), &[("secrets", secrets.len(), st.m())])?;
+        let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
+        let sec: Vec<u8> = secrets.iter().flat_map(|s| s.as_bytes().iter().copied()).collect();
+        let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+        let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+        let mut out = Proofs { challenges: vec![0; 32 * n], responses: vec![0; 32 * n * st.m()], commitments: vec![0; 32 * n * st.nc()] };
+        let rc = unsafe {
+            sys::zkp_pipe_prove_batch(self.0, st.0, n as u32, ts.as_mut_ptr(), sec.as_ptr(), inst.as_ptr(), com.as_ptr(), ptr::null(),
+                                      out.challenges.as_mut_ptr(), out.responses.as_mut_ptr(), out.commitments.as_mut_ptr())
+        };
+        if rc != 0 { return Err(self.err(rc)); }
+        for (t, chunk) in transcripts.iter_mut().zip(ts.chunks(sys::ZKP_TRANSCRIPT_BYTES)) { t.0.copy_from_slice(chunk); }
+        Ok(out)
+    }
+
+    /// `BatchVerifier::verify_batchable` over every context: each contiguous range is a batch check of its own (own weights, own sums of
+    /// the static coefficients, batch_verifier.rs:173-206 per range); `Ok(())` iff every range verifies.
+    pub fn batch_verify(&self, st: &Statement, transcripts: &mut [Transcript], inst_points: &[CompressedRistretto],
+                        common_points: &[CompressedRistretto], commitments: &[u8], responses: &[u8]) -> Result<(), Error> {
+        let n = (commitments.len() / 32).checked_div(st.nc()).unwrap_or(transcripts.len());
+        st.check_shapes(n, inst_points.len(), common_points.len(), &[("commitments", commitments.len(), 32 * st.nc()), ("responses", responses.len(), 32 * st.m())])?;
+        let mut ts: Vec<u8> = transcripts.iter().flat_map(|t| t.0.iter().copied()).collect();
+        let inst: Vec<u8> = inst_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+        let com: Vec<u8> = common_points.iter().flat_map(|p| p.as_bytes().iter().copied()).collect();
+        let rc = unsafe {
+            sys::zkp_pipe_batch_verify(self.0, st.0, n as u32, transcripts.len() as u32, ts.as_mut_ptr(), inst.as_ptr(), com.as_ptr(),
+                                       commitments.as_ptr(), responses.as_ptr(), ptr::null())
+        };
+        for (t, chunk) in transcripts.iter_mut().zip(ts.chunks(sys::ZKP_TRANSCRIPT_BYTES)) { t.0.copy_from_slice(chunk); }
+        if rc != 0 { Err(self.err(rc)) } else { Ok(()) }
+    }
+
+    /// Asynchronous `prove_batch`: every proof starts from `start` (the reference's callers write `Transcript::new(label)` per proof); the
+    /// per-proof entropy of prover.rs:82 is a ChaCha20 stream keyed from the OS and expanded on the device.  The buffers are borrowed until
+    /// [`Job::wait`]; `Err(PipeFull)`-style back-pressure is `Error::Backend(ZKP_TB_PIPE_FULL, ..)`: wait for the oldest job first.
+    pub fn submit_prove<'a>(&'a self, st: &'a Statement, n: usize, start: &'a Transcript, secrets: &'a [u8], inst_points: &'a [u8], common_points: &'a [u8],
+                            out: &'a mut Proofs) -> Result<Job<'a>, Error> {
+        st.check_shapes(n, inst_points.len() / 32, common_points.len() / 32, &[("secrets", secrets.len(), 32 * st.m())])?;
+        if out.challenges.len() != 32 * n || out.responses.len() != 32 * n * st.m() || out.commitments.len() != 32 * n * st.nc() {
+            return Err(Error::Shape("output buffers do not match the statement and batch size"));
+        }
+        let mut job = ptr::null_mut();
+        let rc = unsafe {
+            sys::zkp_prove_batch_submit(self.0, st.0, n as u32, sys::ZKP_JOB_SHARED_TRANSCRIPT, start.0.as_ptr(), secrets.as_ptr(), inst_points.as_ptr(), n as u32,
+                                        common_points.as_ptr(), ptr::null(), ptr::null_mut(), out.challenges.as_mut_ptr(), out.responses.as_mut_ptr(),
+                                        out.commitments.as_mut_ptr(), &mut job)
+        };
+        if rc != 0 { return Err(self.err(rc)); }
+        Ok(Job { job, pipe: self, verdicts: None })
+    }
+
+    /// Asynchronous K batch verifications (K x batch_verifier.rs:67-235) over proofs lying next to each other; weights drawn on the device.
+    pub fn submit_batch_verify_many<'a>(&'a self, st: &'a Statement, n_batches: usize, n_each: usize, start: &'a Transcript, inst_points: &'a [u8],
+                                        common_points: &'a [u8], commitments: &'a [u8], responses: &'a [u8]) -> Result<Job<'a>, Error> {
+        let n = n_batches * n_each;
+        st.check_shapes(n, inst_points.len() / 32, common_points.len() / 32, &[("commitments", commitments.len(), 32 * st.nc()), ("responses", responses.len(), 32 * st.m())])?;
+        let mut verdicts = vec![1 as c_int; n_batches].into_boxed_slice();      // boxed: the C side keeps the address until the job is waited for
+        let mut job = ptr::null_mut();
+        let rc = unsafe {
+            sys::zkp_batch_verify_many_submit(self.0, st.0, n_batches as u32, n_each as u32, sys::ZKP_JOB_SHARED_TRANSCRIPT, start.0.as_ptr(), inst_points.as_ptr(),
+                                              n as u32, common_points.as_ptr(), commitments.as_ptr(), responses.as_ptr(), ptr::null(), n as u32, ptr::null_mut(),
+                                              verdicts.as_mut_ptr(), &mut job)
+        };
+        if rc != 0 { return Err(self.err(rc)); }
+        Ok(Job { job, pipe: self, verdicts: Some(verdicts) })
+    }
+}
+impl Drop for Pipe {
+    fn drop(&mut self) {
+        unsafe { sys::zkp_pipe_destroy(self.0) }      // waits for jobs in flight
+    }
+}
+
+/// A submitted call.  Dropping a job without waiting leaves it to `Pipe`'s destructor (which waits); the borrow of its buffers ends with it.
+pub struct Job<'a> {
+    job: *mut sys::zkp_job,
+    pipe: &'a Pipe,
+    verdicts: Option<Box<[c_int]>>,
+}
+impl<'a> Job<'a> {
+    pub fn done(&self) -> bool { unsafe { sys::zkp_job_done(self.job) != 0 } }
+    /// What the synchronous call would have returned; for a batch-verification job the per-batch verdicts.
+    pub fn wait(mut self) -> Result<Vec<Result<(), Error>>, Error> {
+        let rc = unsafe { sys::zkp_job_wait(self.job) };
+        self.job = ptr::null_mut();
+        if rc != 0 { return Err(self.pipe.err(rc)); }      // negative: the job failed closed, nothing it wrote may be used
+        Ok(self.verdicts.take().map(|v| v.iter().map(|&x| if x == 0 { Ok(()) } else { Err(Error::VerificationFailure) }).collect()).unwrap_or_default())
     }
 }
 

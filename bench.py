@@ -613,6 +613,8 @@ def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,)):
         phases = {"P": [0.0, 0.0, 0.0, 0], "V": [0.0, 0.0, 0.0, 0]}
         if os.environ.get("ZKP_BENCH_JOB_TIMING"):
             pipe.set_profiling(True)
+        if os.environ.get("ZKP_X_DEFER") is not None:          # (tools/x/ab_defer.py: A/B of ZKP_OPT_JOB_DEFER_D2H)
+            pipe.set_option(13, int(os.environ["ZKP_X_DEFER"]))
 
         def run(n_jobs):
             pending, to_verify = collections.deque(), collections.deque()
@@ -689,7 +691,7 @@ def main():
     ap.add_argument("--in-process", action="store_true", help="--gpus N > 1 WITHOUT torchrun / gloo / RCCL: this one process drives the N GPUs, one host "
                                                              "thread and one set of engine contexts per GPU, the verdict AND is taken on the host "
                                                              "(the C-ABI counterpart is zkp_pipe over N devices); same JSON line")
-    ap.add_argument("--pipe-contexts", type=int, default=8, help="e2e_host_buffers.pipelined: contexts (= jobs in flight) of the zkp_pipe")
+    ap.add_argument("--pipe-contexts", type=int, default=6, help="e2e_host_buffers.pipelined: contexts (= jobs in flight) of the zkp_pipe")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
                     help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
     args = ap.parse_args()
@@ -711,7 +713,7 @@ def main():
             raise SystemExit("--batches-per-call applies to --config 2 (the other workloads are one wide batch per step)")
         K, n_streams = 1, max(1, min(args.streams or def_streams or pick_streams(args.steps), max(1, args.steps)))
     # one hardware queue per stream in flight (the runtime's default is 4): the call chains of the timed loop, and the 8 contexts of the zkp_pipe
-    # behind e2e_host_buffers.pipelined (a context whose stream shares a hardware queue with another's is serialised behind it)
+    # behind e2e_host_buffers.pipelined (6 by default; a context whose stream shares a hardware queue with another's is serialised behind it)
     want_q = max(n_streams, 8 if (args.gpus > 1 or (args.config == "2" and not args.no_flow_lines)) else 1)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(want_q, args.max_hw_queues))))
     import torch

@@ -110,12 +110,17 @@ const char* zkp_version(void);
  *     instead of all starting first (fewer per-lane ladder tables in flight together: -20 % HBM fetch in that kernel); 0 = all first;
  *     UINT64_MAX = default: spread when the launch has 256 or more ladder blocks (65,536 single-use points), where it also is ~1 % faster --
  *     in a lone smaller launch the later start of the last ladder block lengthens the kernel (profiles/r03_ab_experiments.txt, block l).
+ *   ZKP_OPT_JOB_DEFER_D2H: when the device -> host copies of a host-buffer job (section 2d) are issued.  1 (default) = by zkp_ctx_job_poll /
+ *     zkp_ctx_job_wait once the job's kernels are finished; 0 = queued behind the kernels at submit.  The copy engines serve ONE queue in order:
+ *     a copy that waits in it for its job's kernels (milliseconds) holds up the copies IN of every job submitted after it -- measured with six
+ *     contexts, a job's inputs take 3.7 ms to arrive instead of 1.4, and the pipelined rate through pinned buffers is 4.5 instead of 5.4 M proofs/s
+ *     (profiles/r04_ab_experiments.txt, block e).
  *   ZKP_OPT_WS_LIMIT_BYTES: the largest device workspace this context may allocate (it grows with the largest call it has served: ~75 KB per CMZ
  *     proof of a prove call).  A call that would need more returns ZKP_ERR_OOM instead of allocating -- the way to keep several contexts of a
  *     zkp_pipe (zkp_toolbox.h) inside one GPU's memory.  0 / UINT64_MAX = no cap (default).
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
-       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12 };
+       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12, ZKP_OPT_JOB_DEFER_D2H = 13 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~35 short kernels (75 in round 1); enqueueing them one by one costs the host ~0.1 ms per
@@ -340,7 +345,8 @@ int zkp_fused_verify_batchable_submit(zkp_ctx* ctx, const zkp_fused_statement* s
                                       const uint8_t* responses, const uint8_t* weights16 /*[N][n_constraints][16]*/, const uint8_t* rng_seed,
                                       uint8_t* transcripts_out, uint8_t* results /*[N]*/);
 int zkp_ctx_job_wait(zkp_ctx* ctx);      /* no job pending: ZKP_OK at once */
-int zkp_ctx_job_poll(zkp_ctx* ctx);      /* 1 = zkp_ctx_job_wait would not block, 0 = still running */
+int zkp_ctx_job_poll(zkp_ctx* ctx);      /* 1 = zkp_ctx_job_wait would not block, 0 = still running.  Polling also moves the job along: its copies
+                                          * out are issued by the first poll (or wait) that finds its kernels finished -- see ZKP_OPT_JOB_DEFER_D2H */
 int zkp_ctx_job_pending(zkp_ctx* ctx);   /* 1 = a job was submitted and not yet waited for */
 /* With zkp_ctx_set_profiling(ctx, 1): where the last finished job spent its time ON ITS STREAM, from HIP events recorded on that stream --
  * ms[0] host -> device copies (+ on-device randomness), ms[1] the flow's kernels, ms[2] device -> host copies.  Under load these include the

@@ -209,10 +209,18 @@ const char* zkp_pipe_last_error(const zkp_pipe* p) { return p ? p->last_error.c_
 
 namespace {
 
+// Jobs whose kernels have finished get their copies out started (zkp_ctx_job_poll issues them: zkp_mi355x.h 2d): called whenever the caller
+// is in the pipe anyway, so that a finished job's outputs are already travelling when somebody waits for it.
+void kick_all(zkp_pipe* p) {
+  for (auto& s : p->slots)
+    if (s->busy) (void)zkp_ctx_job_poll(s->ctx);
+}
+
 // what every submit starts with; *slot_out < 0 with rc == 0 never happens
 int begin_job(zkp_pipe* p, const zkp_statement* st, zkp_job** job, int want_slot, std::unique_ptr<zkp_job>& j, Slot** slot_out) {
   if (!p || !st || !job) return ZKP_TB_BAD_STATEMENT;
   *job = nullptr;
+  if (want_slot < 0) kick_all(p);                        // (the sharded synchronous calls run one thread per device: each looks after its own)
   int k = want_slot;
   if (k < 0) k = p->find_free();
   else if ((size_t)k >= p->slots.size() || p->slots[k]->busy) k = -1;
@@ -453,6 +461,7 @@ int zkp_job_wait(zkp_job* jp) {
   std::unique_ptr<zkp_job> j(jp);
   if (j->immediate) return j->immediate_rc;
   Slot* s = j->pipe->slots[j->slot].get();
+  if (j->use_pool) kick_all(j->pipe);                    // (use_pool = false: a per-device thread of a sharded call -- other threads own the other slots)
   const int rc = zkp_ctx_job_wait(s->ctx);
   s->busy = false;
   if (rc) {

@@ -70,6 +70,7 @@ k_any_nonzero_bytes(size_t n, const uint8_t* __restrict__ flags, uint32_t* __res
 namespace {
 
 // ---- pinned scratch and the pending-job record of a context -------------------------------------------------------------
+inline bool job_defers(const zkp_ctx* c) { return c->defer_d2h != 0; }
 int job_begin(zkp_ctx* c, size_t pin_bytes) {
   if (c->job.kind) return fail(ZKP_ERR_ARG, "a submitted job is pending on this context: zkp_ctx_job_wait first");
   if (c->capturing) return fail(ZKP_ERR_ARG, "graph capture: host-buffer jobs cannot be recorded (their copies name the caller's buffers)");
@@ -83,6 +84,9 @@ int job_begin(zkp_ctx* c, size_t pin_bytes) {
     c->job.pin = static_cast<uint8_t*>(p);
     c->job.pin_bytes = pin_bytes + 256;
   }
+  c->job.outs.clear();
+  c->job.copies_issued = false;
+  if (!c->job.copied) HIP_TRY(hipEventCreateWithFlags(&c->job.copied, hipEventDisableTiming));
   c->job.timed = c->profiling;
   if (c->job.timed) {
     for (auto& e : c->job.tev) if (!e) HIP_TRY(hipEventCreate(&e));
@@ -94,8 +98,8 @@ int job_begin(zkp_ctx* c, size_t pin_bytes) {
 void job_mark(zkp_ctx* c, int i) { if (c->job.timed) (void)hipEventRecord(c->job.tev[i], c->stream); }
 // the job is on the stream: remember what zkp_ctx_job_wait has to derive from the pinned words
 int job_commit(zkp_ctx* c, char kind, uint32_t K, int* verdicts, int* invalid_point) {
-  job_mark(c, 3);
-  HIP_TRY(hipEventRecord(c->job.done, c->stream));
+  if (!job_defers(c)) job_mark(c, 3);
+  HIP_TRY(hipEventRecord(c->job.done, c->stream));      // deferred copies out: this marks the end of the KERNELS
   c->job.kind = kind;
   c->job.K = K;
   c->job.verdicts = verdicts;
@@ -110,6 +114,7 @@ int job_abort(zkp_ctx* c, int rc) {
   (void)hipGetLastError();
   c->pending_tr.offered = c->pending_tr.active = false;
   c->job.kind = 0;
+  c->job.outs.clear();
   g_last_error = msg;
   return rc;
 }
@@ -123,7 +128,9 @@ int h2d_rows(zkp_ctx* c, void* dst, const void* src, size_t rows, size_t row_byt
 }
 int h2d(zkp_ctx* c, void* dst, const void* src, size_t bytes) { return h2d_rows(c, dst, src, 1, bytes, bytes); }
 int d2h(zkp_ctx* c, void* dst, const void* src, size_t bytes) {
-  if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  if (!bytes) return ZKP_OK;
+  if (job_defers(c)) { c->job.outs.push_back({dst, src, bytes}); return ZKP_OK; }       // issued by zkp_ctx_job_wait, after the kernels
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   return ZKP_OK;
 }
 // `bytes` of the ChaCha20 stream (key = seed[0..32), nonce = seed[32..40) little endian) into a 64-byte-granular device buffer
@@ -483,19 +490,44 @@ int zkp_ctx_job_timing(zkp_ctx* c, float ms[3]) {
   return ZKP_OK;
 }
 int zkp_ctx_job_pending(zkp_ctx* c) { return c && c->job.kind ? 1 : 0; }
+// the kernels of the pending job are done: issue its copies out (asynchronously) and mark their end
+static hipError_t job_issue_copies(zkp_ctx* c) {
+  hipError_t e = hipSuccess;
+  for (const auto& o : c->job.outs)
+    if (e == hipSuccess) e = hipMemcpyAsync(o.dst, o.src, o.bytes, hipMemcpyDeviceToHost, c->stream);
+  if (c->job.timed) (void)hipEventRecord(c->job.tev[3], c->stream);
+  if (e == hipSuccess) e = hipEventRecord(c->job.copied, c->stream);
+  c->job.copies_issued = true;
+  return e;
+}
 int zkp_ctx_job_poll(zkp_ctx* c) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   if (!c->job.kind) return 1;
-  const hipError_t e = hipEventQuery(c->job.done);
+  (void)hipSetDevice(c->device);
+  if (!c->job.copies_issued) {
+    const hipError_t e = hipEventQuery(c->job.done);
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    if (e != hipSuccess || c->job.outs.empty()) return 1;              // failed (zkp_ctx_job_wait reports it), or nothing to copy: done
+    if (job_issue_copies(c) != hipSuccess) return 1;
+    return 0;                                                          // the copies out are on their way
+  }
+  const hipError_t e = hipEventQuery(c->job.copied);
   if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
-  return 1;                                                          // done, or failed: zkp_ctx_job_wait reports which
+  return 1;                                                            // done, or failed: zkp_ctx_job_wait reports which
 }
 int zkp_ctx_job_wait(zkp_ctx* c) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   if (!c->job.kind) return ZKP_OK;
   const char kind = c->job.kind;
   (void)hipSetDevice(c->device);
-  const hipError_t e = hipEventSynchronize(c->job.done);
+  hipError_t e = hipSuccess;
+  if (!c->job.copies_issued) {
+    e = hipEventSynchronize(c->job.done);
+    // the kernels are done: now the copies out -- nothing waits inside the copy engine's queue (see job_t::outs)
+    if (e == hipSuccess && !c->job.outs.empty()) e = job_issue_copies(c);
+  }
+  if (e == hipSuccess && c->job.copies_issued) e = hipEventSynchronize(c->job.copied);
+  c->job.outs.clear();
   c->job.kind = 0;
   if (e != hipSuccess) {
     // fail closed: whatever reached the caller's buffers must not be read as "verified" / "proven"

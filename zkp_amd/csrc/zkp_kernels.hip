@@ -1217,7 +1217,14 @@ struct zkp_ctx {
     hipEvent_t tev[4] = {};            // profiling: job start | inputs on the device | flow done | outputs on the host
     bool timed = false;
     float ms[3] = {};                  // host -> device copies, kernels, device -> host copies of the last job (zkp_ctx_job_timing)
+    // Device -> host copies are issued by zkp_ctx_job_wait once the kernels are done, not queued behind them at submit: a copy that sits in
+    // the copy engine's queue waiting for its kernels blocks every later copy of every other context behind it (host_jobs.h).
+    struct out_copy { void* dst; const void* src; size_t bytes; };
+    std::vector<out_copy> outs;
+    hipEvent_t copied = nullptr;       // recorded behind the deferred copies once they are issued
+    bool copies_issued = false;
   } job;
+  int defer_d2h = -1;                  // ZKP_OPT_JOB_DEFER_D2H: -1 = default (1), 0 = queue the copies out at submit
   size_t ws_limit = 0;                 // ZKP_OPT_WS_LIMIT_BYTES: a call that would need a larger workspace fails with ZKP_ERR_OOM (0 = no cap)
   bool hot_registry_uploaded = false;  // the device copy of the fixed-base registry matches hot_key[]
 };
@@ -1702,6 +1709,7 @@ void zkp_ctx_destroy(zkp_ctx* c) {
   if (c->capturing) { hipGraph_t g = nullptr; hipStreamEndCapture(c->stream, &g); if (g) hipGraphDestroy(g); c->capturing = false; }
   hipStreamSynchronize(c->stream);
   if (c->job.done) hipEventDestroy(c->job.done);
+  if (c->job.copied) hipEventDestroy(c->job.copied);
   for (auto& e : c->job.tev) if (e) hipEventDestroy(e);
   if (c->job.pin) hipHostFree(c->job.pin);
   if (c->ws) hipFree(c->ws);
@@ -1756,6 +1764,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;
     case ZKP_OPT_LADDER_INTERLEAVE: c->ladder_interleave = value == ~0ull ? -1 : value != 0; return ZKP_OK;
+    case ZKP_OPT_JOB_DEFER_D2H: c->defer_d2h = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_WS_LIMIT_BYTES: c->ws_limit = value == ~0ull ? 0 : (size_t)value; return ZKP_OK;
     case ZKP_OPT_EACH_STRAUS:
     {

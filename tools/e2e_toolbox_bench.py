@@ -44,3 +44,27 @@ for n in sizes:
             for k, (d, tot) in km.items():
                 print("           device %-14s %7.3f ms: " % (k, tot) + ", ".join("%s %.3f" % (a, b) for a, b in d.items() if b > 0))
 T.set_fused_min_batch(32)
+# round 4: the same synchronous calls over a zkp_pipe of C contexts on this GPU (contiguous proof ranges, copies of one range under the
+# kernels of the others; on a node: zkp_pipe over the 8 device ids)
+for n in sizes:
+    if n < 4096:
+        continue
+    mod, secrets, inst, common = _cmz_batch(n, 11)
+    entropy = np.random.default_rng(1).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    for C in (2, 4, 8):
+        if n // C < 1024:
+            continue
+        with T.Pipe((0,), C) as pipe:
+            best = {}
+            for rep in range(4):
+                ts = np.stack([T.Transcript(label).state] * n)
+                t0 = time.perf_counter(); chal, resp, coms = pipe.prove_batch(mod.statement, ts, secrets, inst, common, entropy); t1 = time.perf_counter()
+                ts = np.stack([T.Transcript(label).state] * n)
+                t2 = time.perf_counter(); pipe.batch_verify(mod.statement, ts, inst, common, coms, resp); t3 = time.perf_counter()
+                ts = np.stack([T.Transcript(label).state] * n)
+                t4 = time.perf_counter(); res = pipe.verify_compact_batch(mod.statement, ts, inst, common, chal, resp); t5 = time.perf_counter()
+                assert not res.any()
+                if rep:
+                    for k, v in (("prove", t1 - t0), ("batch_verify", t3 - t2), ("verify_compact", t5 - t4)):
+                        best[k] = min(best.get(k, 1e9), v)
+        print("N %7d %-16s | " % (n, "pipe x %d ctx" % C) + " | ".join("%s %8.2f ms = %9.0f proofs/s" % (k, v * 1e3, n / v) for k, v in best.items()))

@@ -55,9 +55,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = "proofs/sec + batch-verifies/sec, CMZ13 10-attr credential, 1/2/4/8 MI355X"
-# The VALU ceiling is CYCLE-WEIGHTED (round 4): every kernel's static opcode mix is priced with the measured issue rate of each opcode
-# (2-cycle class ~60-68e12, 4-cycle class ~34-38e12 lane-instructions / s: profiles/r04_valu_rates_microbench.txt) by tools/opcode_mix.py ->
-# profiles/r04_opcode_mix.json (keyed to the kernel sources): valu_busy = SQ_INSTS_VALU x seconds_per_wave_instruction / duration <= 1.
+# The VALU ceiling is CYCLE-WEIGHTED (round 4): every kernel's static opcode mix is priced in SIMD issue cycles (2-cycle class: v_and / v_add_u32 /
+# v_mov / v_xor ..., 4-cycle class: v_mad_u64_u32, carries, 64-bit ops, v_cndmask ...: tools/opcode_mix.py -> profiles/r04_opcode_mix.json, keyed to
+# the kernel sources) and divided by the clock cycles that went by: valu_busy = SQ_INSTS_VALU x cycles per instruction / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+# per kernel (one PMC pass, the chip's own clock), and issue cycles / (1024 x 2.4 GHz nameplate x ms_per_step) for the timed step -- <= 1 by construction.
 OPCODE_MIX = os.path.join("profiles", "r04_opcode_mix.json")
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
 LABEL = b"Benchmark"
@@ -920,36 +921,42 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
                             rows += [v for k_, v in pj.items() if isinstance(v, dict) and k_.split("<")[0].split("::")[-1] == base.split("::")[-1] and "SQ_INSTS_VALU" in v]
                     return rows
 
-                def busy(rows, launch_s):
-                    """cycle-weighted: the rows' VALU work priced at measured per-opcode issue rates (tools/opcode_mix.py) / the time they took"""
-                    if not rows or any("valu_seconds_per_launch" not in v for v in rows):
+                def busy(rows):
+                    """cycle-weighted: issue cycles of the rows' VALU instructions / SIMD clock cycles that went by while they ran (both from the PMC pass)"""
+                    if not rows or any("valu_busy" not in v for v in rows):
                         return None
-                    return sum(v["valu_seconds_per_launch"] for v in rows) / launch_s
+                    return sum(v["valu_issue_cycles"] for v in rows) / sum(v["valu_issue_cycles"] / v["valu_busy"] for v in rows)
                 drows = rows_of(dom["kernels"])
                 if drows:
                     roof["traffic"] = sum(v.get("hbm_bytes_per_launch", 0.0) for v in drows) or None
-                    roof["dominant_kernel_valu_busy"] = busy(drows, dom["avg_launch_ms"] * 1e-3 * len(drows))
+                    roof["dominant_kernel_valu_busy"] = busy(drows)
                     if all("avg_us_one_stream" in v for v in drows):
                         roof["launch_ms_rocprof_one_stream"] = sum(v["avg_us_one_stream"] for v in drows) / len(drows) / 1e3
                 tname = next((x for x in r["launched"].get("prove", {}).get("terms", [])), None)
                 if tname and tname in pj and kms.get("prove", {}).get("terms"):
                     tv = pj[tname]
                     roof["terms_kernel"] = tname
-                    roof["terms_kernel_valu_busy"] = busy([tv], kms["prove"]["terms"] * 1e-3)
+                    roof["terms_kernel_valu_busy"] = busy([tv])
+                    roof["terms_kernel_sclk_ghz"] = tv.get("sclk_ghz")
                     if "avg_us_one_stream" in tv:
-                        roof["terms_kernel_valu_busy_rocprof_time"] = busy([tv], tv["avg_us_one_stream"] * 1e-6)
-                        roof["terms_kernel_launch_ms"] = {"hip_events_this_run": kms["prove"]["terms"], "rocprof_one_stream": tv["avg_us_one_stream"] / 1e3}
+                        roof["terms_kernel_launch_ms"] = {"hip_events_this_run": kms["prove"]["terms"], "rocprof_one_stream": tv["avg_us_one_stream"] / 1e3,
+                                                          "rocprof_pmc_pass": tv.get("us_in_pmc_pass", 0.0) / 1e3 or None}
                     roof["terms_kernel_traffic"] = tv.get("hbm_bytes_per_launch")
                     roof["terms_kernel_algorithmic_bytes"] = algo["prove"]
                     roof["terms_kernel_share_int64"] = {"static": tv.get("share_int64_static"), "dynamic_pmc": tv.get("share_int64_dynamic")}
                 st_tot = pj.get("_step_totals", {})
                 if st_tot.get("valu_wave_instructions_per_step"):
-                    secs = st_tot.get("valu_seconds_per_step")
-                    step_valu = {"wave_instructions_per_step": st_tot["valu_wave_instructions_per_step"],
-                                 "valu_floor_ms_per_step": secs * 1e3 if secs else None, "frac": (secs / (ms_per_step * 1e-3)) if secs else None,
-                                 "note": "frac = cycle-weighted VALU busy fraction of the timed step: every kernel's SQ_INSTS_VALU (PMC, from pmc_source) priced with the measured "
-                                         "issue rate of each opcode of its static mix (profiles/r04_opcode_mix.json; 2-cycle class ~60-68e12, 4-cycle class ~34-38e12 "
-                                         "lane-instr/s), summed over the step's kernels, / this run's ms_per_step.  Rounds 1-3 divided raw counts by 34.5e12 and overstated this."}
+                    floor, floor_obs = st_tot.get("valu_floor_ms_per_step_nameplate_clock"), st_tot.get("valu_floor_ms_per_step_observed_clock")
+                    step_valu = {"wave_instructions_per_step": st_tot["valu_wave_instructions_per_step"], "issue_cycles_per_step": st_tot.get("valu_issue_cycles_per_step"),
+                                 "valu_floor_ms_per_step": floor, "frac": floor / ms_per_step if floor else None,
+                                 "sclk_ghz_observed": st_tot.get("sclk_ghz_observed"),
+                                 "valu_floor_ms_per_step_at_observed_sclk": floor_obs, "frac_at_observed_sclk": floor_obs / ms_per_step if floor_obs else None,
+                                 "note": "cycle-weighted VALU busy fraction of the timed step: every kernel's SQ_INSTS_VALU (PMC, from pmc_source) x the 2- or 4-cycle issue weight "
+                                         "of its static opcode mix (profiles/r04_opcode_mix.json), summed over the step's kernels, / (1024 SIMDs x clock x this run's ms_per_step).  "
+                                         "frac uses the 2.4 GHz nameplate clock: a hard bound, <= 1 whatever the chip does.  Under this load the chip clocks lower "
+                                         "(sclk_ghz_observed = GRBM_GUI_ACTIVE / duration of the step's long kernels in the PMC pass), so frac_at_observed_sclk is the share of the "
+                                         "issue cycles that were really there -- an estimate: the clock of the four-stream run is not observable from HIP.  "
+                                         "Rounds 1-3 divided raw counts by 34.5e12 lane-instr/s and overstated this."}
         except Exception:                       # noqa: BLE001 -- a reported extra, never the measurement
             pmc_source = None
     out = {

@@ -16,8 +16,10 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 
-constexpr int ITER = 4096;
+constexpr int ITER = 2048;
 constexpr int CHAINS = 8;
+constexpr int REP = 4;       // the 8-chain group is repeated REP times per loop iteration: 32 VALU instructions per s_add / s_cmp / s_cbranch
+#define R8(ASM) ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)
 
 // 32-bit chains: x_k = OP(x_k, a, b)
 #define KERNEL32(NAME, ASM)                                                            \
@@ -27,7 +29,7 @@ __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t a, uint32_t 
   uint32_t va = a + threadIdx.x, vb = b ^ threadIdx.x;                                 \
   asm volatile("s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x55555555\n s_mov_b32 vcc_lo, 0x33333333\n s_mov_b32 vcc_hi, 0x33333333" ::: "s20", "s21", "vcc"); \
   for (int i = 0; i < ITER; ++i) {                                                     \
-    asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)               \
+    asm volatile(R8(ASM) R8(ASM) R8(ASM) R8(ASM)                                  \
       : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) \
         : "v"(va), "v"(vb) : "vcc", "s20", "s21", "s22");                                                     \
   }                                                                                    \
@@ -42,7 +44,7 @@ __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t a, uint32_t 
   uint32_t va = a + threadIdx.x, vb = b ^ threadIdx.x;                                 \
   asm volatile("s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x55555555\n s_mov_b32 vcc_lo, 0x33333333\n s_mov_b32 vcc_hi, 0x33333333" ::: "s20", "s21", "vcc"); \
   for (int i = 0; i < ITER; ++i) {                                                     \
-    asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)               \
+    asm volatile(R8(ASM) R8(ASM) R8(ASM) R8(ASM)                                  \
       : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) \
         : "v"(va), "v"(vb) : "vcc", "s20", "s21", "s22");                                                     \
   }                                                                                    \
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t a, uint32_t 
   double va = 1.0 + 1e-9 * a, vb = 1e-9 * b;                                           \
   asm volatile("s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x55555555\n s_mov_b32 vcc_lo, 0x33333333\n s_mov_b32 vcc_hi, 0x33333333" ::: "s20", "s21", "vcc"); \
   for (int i = 0; i < ITER; ++i) {                                                     \
-    asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)               \
+    asm volatile(R8(ASM) R8(ASM) R8(ASM) R8(ASM)                                  \
       : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) \
         : "v"(va), "v"(vb) : "vcc", "s20", "s21", "s22");                                                     \
   }                                                                                    \
@@ -224,8 +226,8 @@ int main() {
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (rep == 0) continue;
-      const double lane_instr = (double)blocks * 256 * ITER * CHAINS;
-      const double wave_instr_per_simd = (double)blocks * 4 / (cus * 4.0) * ITER * CHAINS;  // waves per SIMD * instr
+      const double lane_instr = (double)blocks * 256 * ITER * CHAINS * REP;
+      const double wave_instr_per_simd = (double)blocks * 4 / (cus * 4.0) * ITER * CHAINS * REP;  // waves per SIMD * instr
       const double cyc = ms * 1e-3 * clk_ghz * 1e9 / wave_instr_per_simd;
       printf("%-30s %10.3f %14.1f %16.2f\n", e.name, ms, lane_instr / (ms * 1e-3) * 1e-9, cyc);
     }

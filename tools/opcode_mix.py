@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""Static VALU opcode mix of every kernel in the shipped code object, priced with the MEASURED issue rate of each opcode
-(profiles/r04_valu_rates_microbench.txt) -> profiles/r04_opcode_mix.json.
+"""Static VALU opcode mix of every kernel in the shipped code object, priced in SIMD ISSUE CYCLES (2 or 4 per wave64 instruction, by opcode)
+-> profiles/r04_opcode_mix.json.
 
 Why: rounds 1 - 3 divided raw SQ_INSTS_VALU counts by ONE peak, 34.5e12 lane-instructions/s -- the rate of the
 4-cycle class (v_mad_u64_u32, carries, 64-bit shifts, v_cndmask ...).  A third of the instructions of these kernels are 2-cycle-class
-opcodes (v_and / v_add_u32 / v_sub_u32 / v_lshrrev_b32 / v_mov / v_xor / v_bitop3: ~60 - 68e12 lane-instr/s), so "fractions" above
-1.0 appeared (k_responses 105 %).  The hardware has no cycle-weighted VALU counter on gfx950 (SQ_ACTIVE_INST_VALU counts instructions:
-calibrated on the single-opcode kernels of tools/microbench/valu_rates.hip, it reads the same for every opcode), so the ceiling is
-modelled:
+opcodes (v_and / v_add_u32 / v_sub_u32 / v_lshrrev_b32 / v_mov / v_xor / v_bitop3), so "fractions" above 1.0 appeared (k_responses 105 %).
+The hardware has no cycle-weighted VALU counter on gfx950 (SQ_ACTIVE_INST_VALU counts instructions: on the single-opcode kernels of
+tools/microbench/valu_rates.hip it reads the same for every opcode), so the weights come from the disassembly:
 
-    seconds_per_wave_instruction(kernel) = sum over opcodes  f_op * 64 / rate_op          f_op = the opcode's share of the kernel's VALU instructions
-    valu_busy(kernel)                    = SQ_INSTS_VALU * seconds_per_wave_instruction / kernel duration           (<= 1 by construction of the rates)
+    issue_cycles_per_wave_instruction(kernel) = sum over opcodes  f_op * cycles_op     cycles_op = 2 or 4, f_op = the opcode's share of the kernel's VALU instructions
+    valu_busy(kernel) = SQ_INSTS_VALU * issue_cycles_per_wave_instruction / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)        both counters from ONE rocprofv3 --pmc pass
+
+i.e. issue cycles used / issue cycles that went by, in the chip's own clock (which is NOT the 2.4 GHz nameplate under this load: the term
+kernel runs at 2.06 - 2.16 GHz) -- no modelled rate, no duration from another pass, <= 1 by construction.  The class of an opcode is read
+off the microbenchmark (profiles/r04_valu_rates_microbench.txt: a pure stream reaches > 50e12 lane-instr/s => 2 cycles, else 4;
+profiles/r04_valu_issue_cycles_pmc.txt has the same kernels in GRBM_GUI_ACTIVE cycles).  Round 4's first version priced the mix with
+the microbenchmark's sustained RATES instead (seconds_per_wave_instruction, still written): those rates carry the microbenchmark's own clock
+(2.14 - 2.26 GHz) and loop overhead, and a kernel that clocks higher than the microbenchmark did (k_responses at K = 50: 2.35 GHz) came out at 1.009.
 
 f_op is the STATIC share in the disassembly (the dynamic share is not observable; the kernels are straight-line field arithmetic inside
 fixed-trip loops, and the one class the PMC can count dynamically -- SQ_INSTS_VALU_INT64 -- is reported next to the static share by
@@ -45,6 +51,12 @@ def measured_rates():
             continue
         rates[op] = max(rates.get(op, 0.0), g)
     return rates
+
+
+def issue_cycles(rate):
+    """SIMD issue cycles of one wave64 instruction: the two classes of the microbenchmark, 2 cycles (a pure stream reaches > 50e12 lane-instr/s)
+    and 4 cycles (everything else incl. unmeasured opcodes); profiles/r04_valu_issue_cycles_pmc.txt has them in hardware clock cycles"""
+    return 2.0 if rate > 50e12 else 4.0
 
 
 def normalise(mnemonic):
@@ -94,8 +106,9 @@ def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_opcode_mix.json")
     rates = measured_rates()
     res = {"_source_sha256": bench.source_sha256(), "_rates_file": os.path.relpath(RATES_FILE, ROOT), "_default_rate": DEFAULT_RATE,
-           "_note": "per kernel: static VALU mix of the shipped code object priced with per-opcode measured issue rates; "
-                    "seconds_per_wave_instruction x SQ_INSTS_VALU / duration = valu_busy"}
+           "_note": "per kernel: static VALU mix of the shipped code object priced in SIMD issue cycles (2 or 4 per opcode); "
+                    "issue_cycles_per_wave_instruction (2 or 4 per opcode) x SQ_INSTS_VALU / (SIMDs x GRBM_GUI_ACTIVE per XCD) = valu_busy; "
+                    "seconds_per_wave_instruction = the same mix at the microbenchmark's sustained rates (clock-throttled, loop overhead included)"}
     for kernel, h in sorted(kernel_mixes(disassemble(engine.LIB_PATH)).items()):
         valu = collections.Counter()
         for op, c in h.items():
@@ -105,10 +118,11 @@ def main():
         if not n:
             continue
         spw = sum(c / n * 64.0 / rates.get(op, DEFAULT_RATE) for op, c in valu.items())
+        cyc = sum(c / n * issue_cycles(rates.get(op, DEFAULT_RATE)) for op, c in valu.items())
         unmeasured = sum(c for op, c in valu.items() if op not in rates) / n
         two_cycle = sum(c for op, c in valu.items() if rates.get(op, DEFAULT_RATE) > 50e12) / n
         int64 = sum(c for op, c in valu.items() if op in ("v_mad_u64_u32", "v_lshl_add_u64", "v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64", "v_mov_b64")) / n
-        res[kernel] = {"valu_instructions_static": n, "all_instructions_static": sum(h.values()), "seconds_per_wave_instruction": spw,
+        res[kernel] = {"valu_instructions_static": n, "all_instructions_static": sum(h.values()), "seconds_per_wave_instruction": spw, "issue_cycles_per_wave_instruction": cyc,
                        "equivalent_peak_lane_instr_per_s": 64.0 / spw, "share_2cycle_class": two_cycle, "share_unmeasured": unmeasured, "share_int64_static": int64,
                        "top": [[op, round(c / n, 4)] for op, c in valu.most_common(8)]}
     json.dump(res, open(out_path, "w"), indent=1)

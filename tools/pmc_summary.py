@@ -6,7 +6,12 @@
 BENCH_LINE.json = the JSON line the profiled `python bench.py ...` command printed (workload shape: config, batch, batches per
 call, steps).  HBM traffic per launch follows MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB of fabric
 requests; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) streaming reads, so reads are counted as
-2 x FETCH_SIZE (an upper bound for kernels whose reads are narrower gathers)."""
+2 x FETCH_SIZE (an upper bound for kernels whose reads are narrower gathers).
+
+valu_busy (cycle-weighted, tools/opcode_mix.py): SQ_INSTS_VALU x issue cycles per wave instruction of the kernel's opcode mix (2 or 4 each) /
+(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) -- issue cycles used / clock cycles that went by, both counted in the same pass.  GRBM_GUI_ACTIVE covers a
+little more than the kernel (tens of microseconds of dispatch around it): the busy fraction of kernels shorter than ~100 us is understated, and
+sclk_ghz = GRBM_GUI_ACTIVE / 8 / the dispatch's duration in that pass is only printed as a clock for longer ones."""
 import collections
 import csv
 import json
@@ -14,6 +19,7 @@ import os
 import sys
 
 # the kernel that runs once per CALL of a workload's step loop, and how many bench steps one such launch stands for
+SIMDS, XCDS, NAMEPLATE_GHZ = 1024, 8, 2.4            # 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs; hipDeviceProp.clockRate
 UNIT = {"2": ("k_terms_split<true", None), "4share": ("k_terms_split<true", 1.0), "5share": ("k_terms_split<true", 1.0), "3": ("k_pip_combine", 0.5)}
 
 
@@ -30,6 +36,7 @@ def main():
     cfg = bl["config"]["baseline_config"]
     k_per_call = bl["config"].get("batches_per_call", 1)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    gui_ns = collections.defaultdict(list)              # kernel -> durations (ns) of its dispatches in the pass that counted GRBM_GUI_ACTIVE
     one_stream = collections.defaultdict(list)          # kernel -> durations (ns) from a kernel trace of the same command on ONE stream
     for fn in files:
         rows = list(csv.DictReader(open(fn)))
@@ -39,7 +46,9 @@ def main():
             continue
         for r in rows:
             agg[kname(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    # cycle-weighted VALU ceiling: the static opcode mix of each kernel priced with measured per-opcode issue rates (tools/opcode_mix.py)
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):
+                gui_ns[kname(r)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    # cycle-weighted VALU ceiling: the static opcode mix of each kernel priced in issue cycles (tools/opcode_mix.py)
     mix = {}
     mix_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bench.OPCODE_MIX)
     if os.path.exists(mix_path):
@@ -48,7 +57,8 @@ def main():
             mix = mj
     res = {}
     print("# workload: --config %s, %d proofs per batch, %d batch(es) per call, %d timed steps; kernel sources sha256 %s" % (cfg, bl["config"]["batch_per_gpu"], k_per_call, bl["steps"], sha[:16]))
-    print("# valu_busy = SQ_INSTS_VALU x seconds_per_wave_instruction (%s, %s) / avg_us_one_stream  -- cycle-weighted, <= 1" % (bench.OPCODE_MIX, "sha matches" if mix else "MISSING or stale: no valu_busy"))
+    print("# valu_busy = SQ_INSTS_VALU x issue_cycles_per_wave_instruction (%s, %s) / (%d SIMDs x GRBM_GUI_ACTIVE / %d)  -- issue cycles used / clock cycles elapsed, one PMC pass, <= 1"
+          % (bench.OPCODE_MIX, "sha matches" if mix else "MISSING or stale: no valu_busy", SIMDS, XCDS))
     print("%-34s %s" % ("kernel", "counter averages per launch (n launches)"))
     for k in sorted(agg):
         if "k_" not in k:
@@ -61,10 +71,13 @@ def main():
             row["avg_us_one_stream"] = sum(one_stream[k]) / len(one_stream[k]) / 1e3
         m = mix.get(k)
         if m and "SQ_INSTS_VALU" in row:
-            row["valu_seconds_per_launch"] = row["SQ_INSTS_VALU"] * m["seconds_per_wave_instruction"]
+            row["valu_issue_cycles"] = row["SQ_INSTS_VALU"] * m["issue_cycles_per_wave_instruction"]        # summed over all SIMDs
             row["share_int64_static"] = m["share_int64_static"]
-            if "avg_us_one_stream" in row:
-                row["valu_busy_one_stream"] = row["valu_seconds_per_launch"] / (row["avg_us_one_stream"] * 1e-6)
+            if row.get("GRBM_GUI_ACTIVE"):
+                row["valu_busy"] = row["valu_issue_cycles"] / (SIMDS * row["GRBM_GUI_ACTIVE"] / XCDS)
+                if gui_ns.get(k):
+                    row["us_in_pmc_pass"] = sum(gui_ns[k]) / len(gui_ns[k]) / 1e3
+                    row["sclk_ghz"] = row["GRBM_GUI_ACTIVE"] / XCDS / (row["us_in_pmc_pass"] * 1e3)
         if "SQ_INSTS_VALU_INT64" in row and row.get("SQ_INSTS_VALU"):
             row["share_int64_dynamic"] = row["SQ_INSTS_VALU_INT64"] / row["SQ_INSTS_VALU"]
         res[k] = row
@@ -81,27 +94,38 @@ def main():
             setup = ("k_hot_",) + tuple(p for p in ("k_terms_", "k_reduce_encode", "k_use_count", "k_class_", "k_comb_", "k_encode_", "k_stmt_", "k_blind_", "k_responses", "k_decode_affine"))
         tot = sum(v["SQ_INSTS_VALU"] * v["launches"] for k, v in res.items() if "SQ_INSTS_VALU" in v and not any(k.startswith(p) or k.startswith("zkp::" + p) for p in setup)) / steps
         step_kernels = [(k, v) for k, v in res.items() if "SQ_INSTS_VALU" in v and not any(k.startswith(p) or k.startswith("zkp::" + p) for p in setup)]
-        secs = sum(v["valu_seconds_per_launch"] * v["launches"] for k, v in step_kernels if "valu_seconds_per_launch" in v) / steps
-        covered = sum(v["SQ_INSTS_VALU"] * v["launches"] for k, v in step_kernels if "valu_seconds_per_launch" in v) / steps
+        cyc = sum(v["valu_issue_cycles"] * v["launches"] for k, v in step_kernels if "valu_issue_cycles" in v) / steps
+        covered = sum(v["SQ_INSTS_VALU"] * v["launches"] for k, v in step_kernels if "valu_issue_cycles" in v) / steps
+        ok = bool(mix) and covered > 0.999 * tot
+        # the clock these kernels really ran at: issue-cycle-weighted over the kernels long enough for GRBM_GUI_ACTIVE / duration to be a clock
+        long_k = [(v["valu_issue_cycles"] * v["launches"], v["sclk_ghz"]) for k, v in step_kernels if v.get("us_in_pmc_pass", 0) >= 200.0 and "valu_issue_cycles" in v]
+        sclk = sum(w * f for w, f in long_k) / sum(w for w, _ in long_k) if long_k else None
         res["_step_totals"] = {"steps": steps, "valu_wave_instructions_per_step": tot,
-                               "valu_seconds_per_step": secs if mix and covered > 0.999 * tot else None,
-                               "note": "sum over the step's kernels of SQ_INSTS_VALU x launches / steps in the trace (set-up kernels excluded by name); "
-                                       "valu_seconds_per_step = the same sum with every kernel's instructions priced by its opcode mix: the time the step's VALU "
-                                       "work takes at the measured per-opcode issue rates (cycle-weighted floor of ms_per_step)"}
-        print("%-34s valu wave-instructions per bench step = %.4g, cycle-weighted VALU floor = %s ms per step  (%g steps in the trace)"
-              % ("_step_totals", tot, "%.4f" % (secs * 1e3) if res["_step_totals"]["valu_seconds_per_step"] else "n/a", steps))
+                               "valu_issue_cycles_per_step": cyc if ok else None,
+                               "valu_floor_ms_per_step_nameplate_clock": cyc / SIMDS / (NAMEPLATE_GHZ * 1e6) if ok else None,
+                               "sclk_ghz_observed": sclk,
+                               "valu_floor_ms_per_step_observed_clock": cyc / SIMDS / (sclk * 1e6) if ok and sclk else None,
+                               "note": "sums over the step's kernels x launches / steps in the trace (set-up kernels excluded by name).  valu_issue_cycles_per_step = "
+                                       "SQ_INSTS_VALU x the 2- or 4-cycle weight of every kernel's opcode mix; / 1024 SIMDs / clock = the time the step's VALU work needs "
+                                       "with every SIMD issuing every cycle: at the 2.4 GHz nameplate clock (a hard floor of ms_per_step) and at the clock the kernels "
+                                       "were observed to run at under this load (GRBM_GUI_ACTIVE / duration, kernels of >= 200 us, weighted by issue cycles)"}
+        print("%-34s valu wave-instructions per bench step = %.4g, issue cycles = %s; VALU floor %s ms per step at %.1f GHz, %s ms at the observed %s GHz  (%g steps in the trace)"
+              % ("_step_totals", tot, "%.4g" % cyc if ok else "n/a", "%.4f" % res["_step_totals"]["valu_floor_ms_per_step_nameplate_clock"] if ok else "n/a", NAMEPLATE_GHZ,
+                 "%.4f" % res["_step_totals"]["valu_floor_ms_per_step_observed_clock"] if ok and sclk else "n/a", "%.3f" % sclk if sclk else "n/a", steps))
     # efficiency table on one stream (what tools/kernel_efficiency.sh printed in round 3, now with the cycle-weighted busy fraction)
     rows = [(k, v) for k, v in res.items() if isinstance(v, dict) and "avg_us_one_stream" in v]
     if rows:
         tot_t = sum(v["avg_us_one_stream"] * v["launches"] for _, v in rows)
         print()
-        print("# per-kernel efficiency on ONE stream (a kernel's own duration; cycle-weighted busy; MeanOccupancyPerCU: 32 = full)")
-        print("%-46s %6s %10s %7s %12s %8s %8s %9s" % ("kernel", "calls", "avg_us", "time%", "valu_instr", "busy%", "occ/CU", "waves"))
+        print("# per-kernel efficiency: duration and time share on ONE stream (a kernel's own duration); busy% = valu_busy (issue cycles / GRBM_GUI_ACTIVE cycles of the PMC pass);")
+        print("# sclk = clock observed in that pass (kernels >= 100 us); MeanOccupancyPerCU: 32 = full")
+        print("%-46s %6s %10s %7s %12s %8s %7s %8s %9s" % ("kernel", "calls", "avg_us", "time%", "valu_instr", "busy%", "sclk", "occ/CU", "waves"))
         for k, v in sorted(rows, key=lambda kv: -kv[1]["avg_us_one_stream"] * kv[1]["launches"]):
-            print("%-46s %6d %10.1f %7.2f %12.4g %8s %8.2f %9.0f" % (k[:46], v["launches"], v["avg_us_one_stream"], 100.0 * v["avg_us_one_stream"] * v["launches"] / tot_t,
-                                                                       v.get("SQ_INSTS_VALU", float("nan")),
-                                                                       "%.1f" % (100 * v["valu_busy_one_stream"]) if "valu_busy_one_stream" in v else "n/a",
-                                                                       v.get("MeanOccupancyPerCU", float("nan")), v.get("SQ_WAVES", float("nan"))))
+            print("%-46s %6d %10.1f %7.2f %12.4g %8s %7s %8.2f %9.0f" % (k[:46], v["launches"], v["avg_us_one_stream"], 100.0 * v["avg_us_one_stream"] * v["launches"] / tot_t,
+                                                                           v.get("SQ_INSTS_VALU", float("nan")),
+                                                                           "%.1f" % (100 * v["valu_busy"]) if "valu_busy" in v else "n/a",
+                                                                           "%.2f" % v["sclk_ghz"] if v.get("us_in_pmc_pass", 0) >= 100.0 else "-",
+                                                                           v.get("MeanOccupancyPerCU", float("nan")), v.get("SQ_WAVES", float("nan"))))
     # key the counters to the kernel sources and the workload shape they were collected from (bench.py reports them only on a match)
     res["_source_sha256"] = sha
     res["_workload"] = {"config": cfg, "batch": bl["config"]["batch_per_gpu"], "batches_per_call": k_per_call, "steps": bl["steps"], "streams": bl["config"]["streams"]}

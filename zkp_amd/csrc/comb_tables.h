@@ -459,9 +459,47 @@ __device__ __forceinline__ void comb_group_block(uint32_t i0, uint32_t n_g, cons
 // verify_compact; CMZ's Q in the prover): signed radix-16 ladder over P's own eight multiples, 256 doublings + 65
 // additions instead of the radix-4 ladder's 256 + 128.  The multiples live in the term's slot of the ladder scratch.
 // CT: the eight multiples are scanned with masks (prover.rs:94 semantics); otherwise the entry is loaded directly.
+// Ladder tables are WAVE-INTERLEAVED (round 4): the 64 ladder lanes of a wavefront share one 72 KB group, chunk q of entry e of lane l at
+// 16-byte slot (9 e + q) * 64 + l.  A wavefront's load of one chunk is then one contiguous KB (8 cache lines, every byte used) instead of 64
+// lines of which 16 bytes each are used (lane-contiguous tables, 1,152 B apart): the texture addresser handles a quarter of the lines per
+// constant-time scan (72 loads per addition) and the L1 sees every line once instead of eight times.  Variable-time look-ups (one entry per
+// lane, the entry differing between lanes) touch at most the 64 lines they touched before.
+constexpr uint32_t LADDER_GROUP_UINT4 = 64u * LADDER_ENTRIES * 9u;          // 16-byte slots per wavefront group
+__device__ __forceinline__ void ladder_store_entry(uint4* __restrict__ g, int e, const ge_cached& c) {
+  uint32_t w[36];
+  fe_get(w, c.YmX); fe_get(w + 9, c.YpX); fe_get(w + 18, c.Z2); fe_get(w + 27, c.T2d);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) g[(9 * e + q) * 64] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+__device__ __forceinline__ void ladder_load_entry(ge_cached& c, const uint4* __restrict__ g, uint32_t e) {
+  uint32_t w[36];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const uint4 v = g[(9u * e + (uint32_t)q) * 64u];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+  fe_set(c.YmX, w); fe_set(c.YpX, w + 9); fe_set(c.Z2, w + 18); fe_set(c.T2d, w + 27);
+}
+template <bool CT>
+__device__ __forceinline__ void ladder_select(ge_cached& sel, const uint4* __restrict__ g, uint32_t mag) {
+  ge_cached_identity(sel);
+  if (CT) {
+#pragma unroll 1
+    for (uint32_t h = 0; h < 4; ++h) {
+      ge_cached c0, c1;
+      ladder_load_entry(c0, g, 2 * h + 0);
+      ladder_load_entry(c1, g, 2 * h + 1);
+      ge_cached_cmov(sel, c0, (uint32_t)(mag == 2 * h + 1));
+      ge_cached_cmov(sel, c1, (uint32_t)(mag == 2 * h + 2));
+    }
+  } else if (mag) {
+    ladder_load_entry(sel, g, mag - 1);
+  }
+}
+
 template <bool CT>
 __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restrict__ scalars, const dev_affine* __restrict__ pt,
-                                              dev_ext* __restrict__ tbl, dev_ext* __restrict__ partial, uint32_t* ecol) {
+                                              uint4* __restrict__ tbl /* this lane's slot 0 of its wavefront group */, dev_ext* __restrict__ partial, uint32_t* ecol) {
   uint32_t s[8], e[8], top;
   load_vec<2>(s, scalars + 32 * (size_t)t);
   sc_add_pattern(e, top, s, 0x88888888u);                       // signed radix-16 digits: nibble - 8 in [-8, 7]
@@ -473,21 +511,21 @@ __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restr
     ge_cached c1, c;
     load_affine(P, pt);
     ge_to_cached(c1, P);
-    store_comb_entry(tbl + 0, c1);
+    ladder_store_entry(tbl, 0, c1);
     ge_double<true>(m2, P);
-    ge_to_cached(c, m2); store_comb_entry(tbl + 1, c);
+    ge_to_cached(c, m2); ladder_store_entry(tbl, 1, c);
     ge_add_cached(m3, m2, c1);
-    ge_to_cached(c, m3); store_comb_entry(tbl + 2, c);
+    ge_to_cached(c, m3); ladder_store_entry(tbl, 2, c);
     ge_double<true>(m4, m2);
-    ge_to_cached(c, m4); store_comb_entry(tbl + 3, c);
+    ge_to_cached(c, m4); ladder_store_entry(tbl, 3, c);
     ge_add_cached(m, m4, c1);
-    ge_to_cached(c, m); store_comb_entry(tbl + 4, c);
+    ge_to_cached(c, m); ladder_store_entry(tbl, 4, c);
     ge_double<true>(m, m3);
-    ge_to_cached(c, m); store_comb_entry(tbl + 5, c);
+    ge_to_cached(c, m); ladder_store_entry(tbl, 5, c);
     ge_add_cached(m, m, c1);
-    ge_to_cached(c, m); store_comb_entry(tbl + 6, c);
+    ge_to_cached(c, m); ladder_store_entry(tbl, 6, c);
     ge_double<true>(m, m4);
-    ge_to_cached(c, m); store_comb_entry(tbl + 7, c);
+    ge_to_cached(c, m); ladder_store_entry(tbl, 7, c);
     ge_cached sel;                                              // carry out of bit 255: one more P at the top
     ge_cached_identity(sel);
     ge_cached_cmov(sel, c1, top);
@@ -505,7 +543,7 @@ __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restr
       const uint32_t neg = (uint32_t)(nib < 8u);
       const uint32_t mag = neg ? 8u - nib : nib - 8u;           // 0..8
       ge_cached sel;
-      comb_select<CT>(sel, tbl, mag);
+      ladder_select<CT>(sel, tbl, mag);
       ge_cached_cneg(sel, neg);
       ge_add_cached(acc, acc, sel);
     }

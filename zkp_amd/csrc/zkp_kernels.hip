@@ -188,7 +188,7 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
       if (i < n_ladder && i < max_ladder) {                       // (max_ladder bounds n_ladder by construction)
         const uint32_t t = list[n_hot + n_comb + i];
         const uint32_t pi = pidx[t];                              // < n_points (out-of-range indices are classed with the comb terms)
-        term_ladder16<CT>(t, scalars, pts + pi, ladder_rw + (size_t)i * LADDER_ENTRIES, partial, ecol);
+        term_ladder16<CT>(t, scalars, pts + pi, reinterpret_cast<uint4*>(ladder_rw) + (size_t)(i >> 6) * LADDER_GROUP_UINT4 + (i & 63u), partial, ecol);
       }
     }
     ZKP_WAVE_T1(1);
@@ -1338,7 +1338,7 @@ terms_layout terms_carve(size_t start, uint32_t n_points, uint32_t n_terms, uint
   o.slot_pt = cv.take(split ? (size_t)k.max_tables * 4 : 0);
   o.gstart = cv.take(split ? (size_t)n_points * 4 : 0);            // grouped comb terms: list range of a point
   o.comb = cv.take(split ? (size_t)k.max_tables * comb_entries(k.teeth) * sizeof(dev_ext) : 0);
-  o.ladder = cv.take(split ? (size_t)k.max_ladder * LADDER_ENTRIES * sizeof(dev_ext) : 0);
+  o.ladder = cv.take(split ? (((size_t)k.max_ladder + 63) / 64) * LADDER_GROUP_UINT4 * sizeof(uint4) : 0);   // wave-interleaved groups of 64 tables (comb_tables.h)
   const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
   o.half = cv.take(split ? (size_t)n_terms * 32 : 0);            // (batched encoder: reserved whenever it could be chosen)
   o.states = cv.take(split ? (size_t)n_msm * 54 * 4 : 0);

@@ -222,7 +222,8 @@ int zkp_pipe_batch_verify_locate(zkp_pipe* pipe, const zkp_statement* st, uint32
  * host threads and use the GPU for the group arithmetic only.  Both routes produce the same bytes.  Default 32 (the measured crossover for the CMZ statement);
  * 0 = always fused, UINT32_MAX = never. */
 void zkp_toolbox_set_fused_min_batch(uint32_t n);
-/* Host backend (zkp_amd/csrc/host/host_backend.cpp: the kernels' own field / group headers compiled for the host).  Every call above accepts
+/* Host backend (zkp_amd/csrc/host/host_backend.cpp: the kernels' own point formulas and ristretto codec compiled for the host over a
+ * 5 x 51-bit field, host/fe51.h).  Every call above accepts
  * ctx == NULL: the whole call then runs on the host cores -- no GPU needed (BASELINE configs[0]: "DLEQ proof single prove + verify on CPU").
  * With a context, calls whose group arithmetic is at most `n` (scalar, point) terms do the same, because a GPU call is a ~1 ms chain of
  * launches whatever its size and a 2-term multiscalar multiplication is ~0.1 ms on one core.  Default 16 (a single DLEQ proof: 2 terms to

@@ -1,7 +1,8 @@
 // Host build of the DEVICE field/group headers (same source the HIP kernels compile), exposed through
 // a tiny C interface so pytest can compare every primitive with the big-integer oracle on CPU.
-// Built twice by tests/test_host_field.py: plain, and with -DZKP_FE_TRACK (interval bound tracker:
-// aborts if any lazy add/sub chain could overflow a 64-bit column or a 32-bit limb).
+// Built three times by tests/test_host_field.py: plain, with -DZKP_FE_TRACK (interval bound tracker:
+// aborts if any lazy add/sub chain could overflow a 64-bit column or a 32-bit limb), and with -DZKP_HOST_FE51 (the same point
+// formulas and codec over the host backend's 5 x 51-bit field, zkp_amd/csrc/host/fe51.h).
 #include "../../zkp_amd/csrc/ge25519.h"
 #include "../../zkp_amd/csrc/sc25519.h"
 #include <cstring>
@@ -30,6 +31,20 @@ void t_fe_binop(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
 }
 int t_fe_canonical(const uint8_t* a) { uint32_t w[8]; memcpy(w, a, 32); return (int)fe_words_canonical(w); }
 // raw limbs in, canonical bytes out: exercises fe_towords on non-normalised limbs
+#ifdef ZKP_HOST_FE51
+int t_is_fe51(void) { return 1; }
+void t_fe51_towords_raw(const uint64_t* limbs, uint8_t* out) {          // the host backend's field: five limbs, any value below 2^63 each
+  fe x; for (int i = 0; i < 5; ++i) x.v[i] = limbs[i];
+  store(out, x);
+}
+// constants travel as 9 x 29-bit limbs (fe_constants.h): the repacking, byte for byte
+void t_fe51_const(int which, uint8_t* out) {
+  fe x;
+  fe_from_const(x, which == 0 ? FE_D : which == 1 ? FE_D2 : which == 2 ? FE_SQRT_M1 : FE_INVSQRT_A_MINUS_D);
+  store(out, x);
+}
+#else
+int t_is_fe51(void) { return 0; }
 void t_fe_towords_raw(const uint32_t* limbs, uint8_t* out) {
   fe x; for (int i = 0; i < 9; ++i) x.v[i] = limbs[i];
 #ifdef ZKP_FE_TRACK
@@ -37,6 +52,7 @@ void t_fe_towords_raw(const uint32_t* limbs, uint8_t* out) {
 #endif
   store(out, x);
 }
+#endif
 int t_decode(const uint8_t* enc, uint8_t* xyzt /*4x32*/) {
   uint32_t w[8]; memcpy(w, enc, 32);
   ge_p3 p; const int ok = (int)ristretto_decode(p, w);

@@ -16,18 +16,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "host", "fe_host_lib.cpp")
 
 
-def _build(track: bool):
-    out = os.path.join(HERE, "host", "fe_host_lib_track.so" if track else "fe_host_lib.so")
-    deps = [SRC] + [os.path.join(HERE, "..", "zkp_amd", "csrc", f) for f in ("fe25519.h", "ge25519.h", "fe_constants.h", "sc25519.h")]
+def _build(variant: str):
+    out = os.path.join(HERE, "host", {"plain": "fe_host_lib.so", "bound-tracked": "fe_host_lib_track.so", "host-fe51": "fe_host_lib_fe51.so"}[variant])
+    deps = [SRC] + [os.path.join(HERE, "..", "zkp_amd", "csrc", f) for f in ("fe25519.h", "ge25519.h", "fe_constants.h", "sc25519.h", os.path.join("host", "fe51.h"))]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         cmd = ["g++", "-O1", "-std=c++17", "-shared", "-fPIC", SRC, "-o", out]
-        if track:
+        if variant == "bound-tracked":
             cmd.insert(1, "-DZKP_FE_TRACK")
+        if variant == "host-fe51":                     # the field of the host backend (zkp_amd/csrc/host/fe51.h) under the same point formulas
+            cmd.insert(1, "-DZKP_HOST_FE51")
         subprocess.check_call(cmd)
     return ctypes.CDLL(out)
 
 
-@pytest.fixture(scope="module", params=[False, True], ids=["plain", "bound-tracked"])
+@pytest.fixture(scope="module", params=["plain", "bound-tracked", "host-fe51"])
 def lib(request):
     return _build(request.param)
 
@@ -60,6 +62,18 @@ def test_fe_canonical_and_towords(lib):
     for x in [M.P - 1, M.P, M.P + 1, (1 << 255) - 1, 1 << 255, (1 << 256) - 1, 0, M.P - 19, (1 << 255) - 19 + 18]:
         assert lib.t_fe_canonical(x.to_bytes(32, "little")) == int(x < M.P)
     out = ctypes.create_string_buffer(32)
+    if lib.t_is_fe51():
+        Limbs5 = ctypes.c_uint64 * 5
+        m51 = (1 << 51) - 1
+        cases5 = [[(1 << 63) - 1] * 5, [(1 << 52) - 38] + [(1 << 52) - 2] * 4, [m51] * 5, [m51 - 18] + [m51] * 4, [m51 - 19] + [m51] * 4, [m51 + 19] + [m51] * 4, [0] * 5]
+        cases5 += [[rng.randrange(1 << 63) for _ in range(5)] for _ in range(300)] + [[rng.randrange(1 << 52) for _ in range(5)] for _ in range(300)]
+        for limbs in cases5:
+            lib.t_fe51_towords_raw(Limbs5(*limbs), out)
+            assert out.raw == fe_bytes(sum(l << (51 * i) for i, l in enumerate(limbs))), limbs
+        for which, val in enumerate([M.D, 2 * M.D % M.P, M.SQRT_M1, M.INVSQRT_A_MINUS_D]):
+            lib.t_fe51_const(which, out)
+            assert out.raw == fe_bytes(val), which
+        return
     Limbs = ctypes.c_uint32 * 9
     cases = [[0xfffffff0] * 9, [0x3fffffda] + [0x3ffffffe] * 7 + [0x00fffffe], [(1 << 29) - 1] * 8 + [(1 << 23) - 1],
              [(1 << 29) - 19] + [(1 << 29) - 1] * 7 + [(1 << 23) - 1], [(1 << 29) - 20] + [(1 << 29) - 1] * 7 + [(1 << 23) - 1]]

@@ -64,7 +64,8 @@ def build_host(force: bool = False, verbose: bool = False):
     srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp")]
     if not srcs:
         return None
-    deps = _deps(host_dir, os.path.join(HERE, "..", "include"))
+    # (host_backend.cpp compiles the kernels' point formulas for the host: ge25519.h and what it includes)
+    deps = _deps(host_dir, os.path.join(HERE, "..", "include"), exts=(".h", ".hpp", ".cpp")) + [os.path.join(CSRC, f) for f in ("ge25519.h", "fe25519.h", "fe_constants.h")]
     force = force or bool(os.environ.get("ZKP_FORCE_BUILD"))
     if force or _stale(HOST_LIB, deps):
         cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall", "-Wno-unknown-pragmas", "-I", os.path.join(HERE, "..", "include")] + srcs + [

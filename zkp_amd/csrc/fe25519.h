@@ -29,6 +29,11 @@
 #define ZKP_HD inline
 #endif
 
+#if defined(ZKP_HOST_FE51) && !defined(__HIPCC__)
+// the host backend's translation unit: same interface over 5 x 51-bit limbs (host/fe51.h says why and what the contract is)
+#include "host/fe51.h"
+#else
+
 #ifdef ZKP_FE_TRACK
 #include <cassert>
 #include <cstdio>
@@ -402,3 +407,5 @@ ZKP_HD void fe_from_const(fe& r, const fe_const& c) {
 }
 
 }  // namespace zkp
+
+#endif  // ZKP_HOST_FE51

@@ -3,8 +3,9 @@
 //
 // A single DLEQ verification through the GPU is a chain of ~10 kernel launches, ~1 ms whatever the size; the reference needs ~0.1 ms
 // on one core (benches/dleq.rs:49-90).  For calls below a handful of terms the host toolbox therefore runs the group arithmetic HERE:
-// the very headers the kernels are compiled from -- fe25519.h (9 x 29-bit limbs), ge25519.h (extended coordinates, ristretto255
-// codec), compiled for the host by g++ -- behind the same zkp_toolbox.h calls, and also when no GPU context is given at all
+// the very header the kernels' point arithmetic is compiled from -- ge25519.h (extended coordinates, ristretto255 codec) -- compiled for
+// the host by g++ over a field of 5 x 51-bit limbs with the same interface as the device's 9 x 29-bit one (host/fe51.h: a 64-bit core
+// needs 25 products per multiplication instead of 98) -- behind the same zkp_toolbox.h calls, and also when no GPU context is given at all
 // (ctx == NULL).  Same bytes as the device path (outputs are canonical encodings), checked by tests/test_host_backend.py against the
 // oracle and by tests/test_gpu_toolbox.py against the GPU route.  This is product code: nothing under oracle/ is involved.
 //
@@ -19,6 +20,7 @@
 #include <cstring>
 #include <vector>
 
+#define ZKP_HOST_FE51 1        // this translation unit (and no other of the library) gets the 5 x 51-bit field under the device's point formulas
 #include "../ge25519.h"
 
 namespace zkp {

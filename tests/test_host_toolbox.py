@@ -105,6 +105,25 @@ def test_engine_fails_loudly_without_gpu():
         engine.Engine(0)
 
 
+def test_pipe_fails_loudly_without_gpu_and_refuses_bad_arguments():
+    """zkp_pipe is a GPU object: without a device it cannot be created (the host backend is chosen with ctx == NULL on the plain calls,
+    never behind a pipe); an empty device list or zero contexts is an argument error everywhere."""
+    import ctypes
+    import torch
+    lib = T.lib()
+    h = ctypes.c_void_p()
+    assert lib.zkp_pipe_create(ctypes.byref(h), None, 0, 1) != 0 and not h.value
+    ids = (ctypes.c_int * 1)(0)
+    assert lib.zkp_pipe_create(ctypes.byref(h), ids, 1, 0) != 0 and not h.value
+    assert lib.zkp_pipe_create(ctypes.byref(h), ids, 1, 2000) != 0 and not h.value        # more than 1024 contexts
+    assert lib.zkp_pipe_num_contexts(None) == 0 and lib.zkp_pipe_jobs_in_flight(None) == 0
+    lib.zkp_pipe_destroy(None)                                                             # no-op
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(engine.ZkpError):
+        T.Pipe((0,), 1)
+
+
 def test_transcript_kat_and_random_traffic():
     t = T.Transcript(b"test protocol")
     t.append_message(b"some label", b"some data")

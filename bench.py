@@ -1048,13 +1048,15 @@ def cpu_baseline(ps, label, sample):
         proofs.append((chal, resp, coms))
         notes.append("%d proofs of \"%s\": proven one by one %.3f s%s, one batch verification %.3f s (%d-term Pippenger incl. decompression)"
                      % (m, p.fst._label.decode(), t1 - t0, "" if "prove" in p.flows else " (set-up, not counted)", t2 - t1, p.ns + (p.ni + p.nc) * m))
-    # the same sample with the MSM inner loops on AVX-512 IFMA vectors (oracle/c/simd_ifma.c: the design of curve25519-dalek's simd_backend,
-    # which north_star names and which cannot be built here): a MEASURED number instead of a recalled factor -- where the host CPU has IFMA
-    simd = {"value": None, "isa": None, "note": "this host CPU (or the oracle's build) has no AVX-512 IFMA: not measured"}
-    if C.simd_available() and len(ps) == 1 and "prove" in ps[0].flows:
-        p = ps[0]
-        m = min(p.n, sample)
-        assert C.set_simd(True)
+    # the same sample with the MSM inner loops on vectors (oracle/c/simd_ifma.c + simd_x4.inc: the design of curve25519-dalek's simd_backend, which
+    # north_star names and which cannot be built here): a MEASURED number instead of a recalled factor -- on the best instruction set the host CPU has
+    # (AVX-512 IFMA, else AVX2); where IFMA exists, AVX2 is timed too, on a sub-sample
+    ISA_TEXT = {"avx512ifma": "AVX-512 IFMA (vpmadd52, radix 2^51, 4 x 64-bit lanes = the four coordinates of a point)",
+                "avx2": "AVX2 (vpmuludq, radix 2^25.5 with one limb per vector, 4 x 64-bit lanes = the four coordinates of a point)"}
+    simd = {"value": None, "isa": None, "note": "this host CPU (or the oracle's build) has neither AVX-512 IFMA nor AVX2: not measured"}
+
+    def simd_run(isa, m):
+        assert C.set_simd(isa)
         try:
             t0 = time.perf_counter()
             equal = True
@@ -1062,20 +1064,31 @@ def cpu_baseline(ps, label, sample):
                 ec, er, ek, _ = C.prove(cst, label, p.secrets[j], np.stack([p.common[com_rank[i]] if i in com_rank else p.inst[inst_rank[i], j] for i in range(len(points))]), ent[j].tobytes())
                 equal = equal and bool((er == resp[j]).all()) and bool((ek == coms[j]).all())
             t1 = time.perf_counter()
-            rc = C.batch_verify(cst, label, m, np.ascontiguousarray(p.inst[:, :m]), p.common, coms, resp, w)
+            rc = C.batch_verify(cst, label, m, np.ascontiguousarray(p.inst[:, :m]), p.common, np.ascontiguousarray(coms[:m]), np.ascontiguousarray(resp[:m]), np.ascontiguousarray(w[:, :m]))
             t2 = time.perf_counter()
         finally:
             C.set_simd(False)
-        assert rc == 0 and equal, "the vector backend of the CPU baseline disagrees with the scalar port"
-        simd = {"value": m / (t2 - t0), "unit": "proofs/s", "cores": 1, "isa": "AVX-512 IFMA (vpmadd52, 4 x 64-bit lanes = the four coordinates of a point)",
-                "prove_proofs_per_s": m / (t1 - t0), "batch_verifies_per_s": m / (t2 - t1), "equal_to_scalar_port": True,
-                "note": "MSM inner loops (point addition / doubling in the 4-way parallel formulas, constant-time and NAF Straus, Pippenger) vectorised as in "
-                        "curve25519-dalek's simd_backend; decompression, compression, Merlin and scalar arithmetic stay scalar, as there"}
+        assert rc == 0 and equal, "the vector backend (%s) of the CPU baseline disagrees with the scalar port" % isa
+        return {"value": m / (t2 - t0), "unit": "proofs/s", "cores": 1, "isa": ISA_TEXT[isa], "proofs": m, "prove_proofs_per_s": m / (t1 - t0), "batch_verifies_per_s": m / (t2 - t1),
+                "equal_to_scalar_port": True}
+
+    isas = C.simd_isas()
+    if isas and len(ps) == 1 and "prove" in ps[0].flows:
+        p = ps[0]
+        m = min(p.n, sample)
+        simd = simd_run(isas[0], m)
+        simd["note"] = ("MSM inner loops (point addition / doubling in the 4-way parallel formulas, constant-time and NAF Straus, Pippenger) vectorised as in "
+                        "curve25519-dalek's simd_backend; decompression, compression, Merlin and scalar arithmetic stay scalar, as there")
+        if len(isas) > 1:
+            simd["avx2"] = simd_run("avx2", min(m, 512))
+            simd["avx2"]["note"] = ("the same backend on AVX2 for hosts without IFMA, timed on the first %d proofs of the sample.  One limb per vector (ten vectors per four field "
+                                    "elements), not dalek's packed 2625x4 layout: on a core with a fast 64-bit multiplier it does not beat the scalar port -- reported, never the baseline"
+                                    % min(m, 512))
     outd = {"value": n_done / (t_prove + t_bv), "unit": "proofs/s", "cores": 1, "kind": "port", "simd": simd,
             "sample": "; ".join(notes) + "; Merlin + radix-16 constant-time Straus + responses / Merlin + coefficients + Pippenger; gcc -O3 -march=native, 5x51-bit limbs",
             "batch_verifies_per_s": n_done / t_bv,
             "note": "scalar u64-style port of the reference's flows (dalek's u64_backend algorithms); the reference's own Rust cannot be built on this box; "
-                    "`simd` = the same port with the MSM inner loops on AVX-512 IFMA vectors in the design of dalek's simd_backend (Cargo.toml:37-40), measured here"}
+                    "`simd` = the same port with the MSM inner loops on AVX-512 IFMA (else AVX2) vectors in the design of dalek's simd_backend (Cargo.toml:37-40), measured here"}
     if t_prove:
         outd["prove_proofs_per_s"] = n_done / t_prove
     return outd, proofs
@@ -1092,7 +1105,7 @@ def cpu_baseline_all_cores():
         outs = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--per", "1024", "--simd"], cwd=ROOT, capture_output=True, text=True, timeout=240)
         js = json.loads(outs.stdout.strip().splitlines()[-1])
         j["simd"] = {"value": js["value"] if js.get("isa") != "scalar u64" else None, "isa": js.get("isa"), "cores": js["cores"],
-                     "note": "the vector backend (oracle/c/simd_ifma.c) on every usable host thread"}
+                     "note": "the vector backend (oracle/c/simd_ifma.c, best instruction set of the host) on every usable host thread"}
         return j
     except Exception as e:      # a reported baseline, never the measurement: do not fail the bench line over it
         return {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}

@@ -87,13 +87,16 @@ static int to_radix_2w(int8_t* digits /*>= 65*/, const uint8_t s[32], int w) {
   return count;
 }
 
-/* the same three algorithms on AVX-512 IFMA vectors (dalek's simd_backend design), selected by orc_set_simd(1) */
+/* the same three algorithms on AVX-512 IFMA or AVX2 vectors (dalek's simd_backend design), selected by orc_set_simd() */
 #include "simd_ifma.c"
 
 /* ---- constant-time Straus (dalek straus.rs, MultiscalarMul) --------------------------------- */
 void orc_msm_straus_ct(ge_ext* r, size_t n, const uint8_t* scalars, const ge_ext* points) {
 #if ORC_HAVE_IFMA
-  if (g_orc_simd) { simd_straus_ct(r, n, scalars, points); return; }
+  if (g_orc_simd == 1) { simd_straus_ct_ifma(r, n, scalars, points); return; }
+#endif
+#if ORC_HAVE_AVX2
+  if (g_orc_simd == 2) { simd_straus_ct_avx2(r, n, scalars, points); return; }
 #endif
   ge_pniels* tables = (ge_pniels*)malloc(sizeof(ge_pniels) * 8 * (n ? n : 1));
   int8_t* digits = (int8_t*)malloc(64 * (n ? n : 1));
@@ -126,7 +129,10 @@ void orc_msm_straus_ct(ge_ext* r, size_t n, const uint8_t* scalars, const ge_ext
 /* ---- vartime Straus, NAF-5 (dalek straus.rs, VartimeMultiscalarMul) ------------------------- */
 void orc_msm_straus_vartime(ge_ext* r, size_t n, const uint8_t* scalars, const ge_ext* points) {
 #if ORC_HAVE_IFMA
-  if (g_orc_simd) { simd_straus_vartime(r, n, scalars, points); return; }
+  if (g_orc_simd == 1) { simd_straus_vartime_ifma(r, n, scalars, points); return; }
+#endif
+#if ORC_HAVE_AVX2
+  if (g_orc_simd == 2) { simd_straus_vartime_avx2(r, n, scalars, points); return; }
 #endif
   ge_pniels* tables = (ge_pniels*)malloc(sizeof(ge_pniels) * 8 * (n ? n : 1));
   int8_t* nafs = (int8_t*)malloc(256 * (n ? n : 1));
@@ -158,7 +164,10 @@ void orc_msm_straus_vartime(ge_ext* r, size_t n, const uint8_t* scalars, const g
 /* ---- vartime Pippenger (dalek pippenger.rs) -------------------------------------------------- */
 void orc_msm_pippenger(ge_ext* r, size_t n, const uint8_t* scalars, const ge_ext* points) {
 #if ORC_HAVE_IFMA
-  if (g_orc_simd) { simd_pippenger(r, n, scalars, points); return; }
+  if (g_orc_simd == 1) { simd_pippenger_ifma(r, n, scalars, points); return; }
+#endif
+#if ORC_HAVE_AVX2
+  if (g_orc_simd == 2) { simd_pippenger_avx2(r, n, scalars, points); return; }
 #endif
   const int w = n < 500 ? 6 : (n < 800 ? 7 : 8);
   const int buckets_count = (1 << w) / 2;

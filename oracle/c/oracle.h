@@ -50,10 +50,13 @@ void orc_sc_neg(uint8_t out[32], const uint8_t a[32]);
 void orc_sc_add(uint8_t out[32], const uint8_t a[32], const uint8_t b[32]);
 void orc_sc_sub(uint8_t out[32], const uint8_t a[32], const uint8_t b[32]);
 
-/* The MSM entry points below on AVX-512 IFMA vectors (simd_ifma.c: dalek's simd_backend design, 4 lanes = the 4 coordinates of a point).
- * orc_set_simd(1) switches them over and returns 1 -- or 0 when the build or the CPU lacks AVX-512 IFMA + VL (nothing changes then). */
+/* The MSM entry points below on vectors (simd_ifma.c + simd_x4.inc: dalek's simd_backend design, 4 lanes = the 4 coordinates of a point).
+ * orc_simd_available(): 1 = AVX-512 IFMA + VL, 2 = AVX2 only, 0 = neither (build or CPU).  orc_set_simd(1) switches to the best of them,
+ * orc_set_simd(2) to AVX2 even where IFMA exists, orc_set_simd(0) back to the scalar port; the return value (and orc_simd_mode()) is what
+ * runs from now on: 0 scalar, 1 IFMA, 2 AVX2 -- 0 after a request the CPU or the build cannot serve (nothing changes then). */
 int orc_simd_available(void);
-int orc_set_simd(int on);
+int orc_set_simd(int mode);
+int orc_simd_mode(void);
 
 /* ---- the three dalek MSM entry points ---------------------------------------------------- */
 /* constant-time Straus, radix 16  (RistrettoPoint::multiscalar_mul) */

@@ -50,14 +50,38 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+SIMD_ISA = {0: None, 1: "avx512ifma", 2: "avx2"}
+
+
 def simd_available() -> bool:
-    """the build and this CPU have AVX-512 IFMA + VL (oracle/c/simd_ifma.c)"""
+    """the build and this CPU have a vector instruction set the backend of oracle/c/simd_ifma.c runs on (AVX-512 IFMA + VL, or AVX2)"""
     return bool(lib().orc_simd_available())
 
 
-def set_simd(on: bool) -> bool:
-    """MSM inner loops on the vector backend (dalek's simd_backend design); returns whether it is on now"""
-    return bool(lib().orc_set_simd(1 if on else 0))
+def simd_isas():
+    """the instruction sets set_simd() accepts here, best first"""
+    best = int(lib().orc_simd_available())
+    return {0: [], 1: ["avx512ifma", "avx2"], 2: ["avx2"]}[best]
+
+
+def set_simd(on) -> bool:
+    """MSM inner loops on the vector backend (dalek's simd_backend design): True = the best instruction set this CPU has, "avx2" = AVX2 even
+    where IFMA exists, "avx512ifma", False = the scalar port.  Returns whether a vector backend is on now (False: refused)."""
+    if on in (False, None, 0):
+        lib().orc_set_simd(0)
+        return False
+    if on == "avx2":
+        return int(lib().orc_set_simd(2)) == 2
+    got = int(lib().orc_set_simd(1))
+    if on == "avx512ifma" and got != 1:
+        lib().orc_set_simd(0)
+        return False
+    return got != 0
+
+
+def simd_mode():
+    """which backend the MSM entry points run on right now: None (scalar port), "avx512ifma" or "avx2" """
+    return SIMD_ISA[int(lib().orc_simd_mode())]
 
 
 def _p(a):

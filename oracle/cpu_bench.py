@@ -57,7 +57,7 @@ def cmz_instance(n, seed):
 def _work(args):
     simd, per, data = args
     secrets, inst, common, entropy, weights = data
-    C.set_simd(bool(simd))
+    C.set_simd(simd or False)                       # False, True (best instruction set) or "avx2"
     cst = C.Statement.from_model(M.cmz_statement(10))
     coms = np.zeros((per, 11, 32), np.uint8)
     resp = np.zeros((per, 21, 32), np.uint8)
@@ -85,20 +85,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workers", type=int, default=usable_cpus())
     ap.add_argument("--per", type=int, default=96)
-    ap.add_argument("--simd", action="store_true", help="MSM inner loops on AVX-512 IFMA vectors (oracle/c/simd_ifma.c), where the CPU has them")
+    ap.add_argument("--simd", action="store_true", help="MSM inner loops on the vector backend (oracle/c/simd_ifma.c): AVX-512 IFMA where the CPU has it, else AVX2")
+    ap.add_argument("--simd-isa", choices=["avx512ifma", "avx2"], default=None, help="the vector backend on this instruction set (implies --simd)")
     a = ap.parse_args()
     C.build()
     data = cmz_instance(a.per, 7)            # every worker handles an identical range: same work, no data skew
     warm = cmz_instance(2, 8)
     ctx = mp.get_context("fork")
     with ctx.Pool(a.workers) as pool:
-        simd = 1 if (a.simd and C.simd_available()) else 0
+        simd = False
+        if a.simd_isa:
+            simd = a.simd_isa if a.simd_isa in C.simd_isas() else False
+        elif a.simd and C.simd_available():
+            simd = C.simd_isas()[0]
         pool.map(_work, [(simd, 2, warm)] * a.workers)       # start the workers, load the library
         t0 = time.perf_counter()
         res = pool.map(_work, [(simd, a.per, data)] * a.workers)
         wall = time.perf_counter() - t0
     assert not any(rc for rc, _ in res), "a sample batch did not verify"
-    print(json.dumps({"value": a.workers * a.per / wall, "unit": "proofs/s", "cores": a.workers, "kind": "port", "isa": "avx512ifma" if simd else "scalar u64",
+    print(json.dumps({"value": a.workers * a.per / wall, "unit": "proofs/s", "cores": a.workers, "kind": "port", "isa": simd or "scalar u64",
                       "sample": "%d worker processes (usable CPUs: affinity %d, cgroup quota applied; %d visible) x %d proofs, each proven one by one "
                                 "and batch-verified by its worker; %.2f s wall, slowest worker %.2f s; gcc -O3 -march=native, 5x51-bit limbs"
                                 % (a.workers, len(os.sched_getaffinity(0)), os.cpu_count() or 0, a.per, wall, max(t for _, t in res))}))

@@ -384,13 +384,15 @@ print("sanitizer run complete")
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
 
 
-def test_simd_msm_equals_scalar_port():
-    """oracle/c/simd_ifma.c (AVX-512 IFMA, the four coordinates of a point in four lanes -- the design of curve25519-dalek's simd_backend): the
-    three MSM algorithms, whole proofs and a batch verification must give the bytes of the scalar 5 x 51 port.  Skipped where the build or the CPU
-    has no AVX-512 IFMA (the vector code is then not even compiled / refused at run time)."""
-    if not C.simd_available():
-        assert C.set_simd(True) is False
-        pytest.skip("no AVX-512 IFMA on this CPU / in this build")
+@pytest.mark.parametrize("isa", ["avx512ifma", "avx2"])
+def test_simd_msm_equals_scalar_port(isa):
+    """oracle/c/simd_ifma.c + simd_x4.inc (the four coordinates of a point in four lanes -- the design of curve25519-dalek's simd_backend -- on
+    AVX-512 IFMA in radix 2^51 and on AVX2 in radix 2^25.5): the three MSM algorithms, whole proofs and a batch verification must give the bytes
+    of the scalar 5 x 51 port.  Skipped where the build or the CPU lacks the instruction set (the vector code is then not even compiled /
+    refused at run time)."""
+    if isa not in C.simd_isas():
+        assert C.set_simd(isa) is False and C.simd_mode() is None
+        pytest.skip("no %s on this CPU / in this build" % isa)
     rng = np.random.default_rng(2024)
     base = np.frombuffer(bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"), np.uint8).reshape(1, 32)
     try:
@@ -410,7 +412,7 @@ def test_simd_msm_equals_scalar_port():
             for algo in algos:
                 C.set_simd(False)
                 want = C.msm_algo(algo, sc, pts)
-                assert C.set_simd(True)
+                assert C.set_simd(isa) and C.simd_mode() == isa
                 got = C.msm_algo(algo, sc, pts)
                 assert got == want, (n, algo)
         # whole flows: prover (constant-time Straus), verifiers (NAF Straus), batch verifier (Pippenger)
@@ -422,8 +424,8 @@ def test_simd_msm_equals_scalar_port():
         ent = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
         w = rng.integers(0, 256, size=(11, n, 16), dtype=np.uint8)
         proofs = {}
-        for simd in (False, True):
-            assert C.set_simd(simd) == simd
+        for simd in (False, isa):
+            assert C.set_simd(simd) == bool(simd)
             out = [C.prove(cst, b"simd", secrets[j], np.concatenate([inst[:, j], common]), ent[j].tobytes())[:3] for j in range(n)]
             proofs[simd] = out
             coms = np.stack([o[2] for o in out])
@@ -433,7 +435,7 @@ def test_simd_msm_equals_scalar_port():
             bad[7, 3, 0] ^= 1
             assert C.batch_verify(cst, b"simd", n, inst, common, coms, bad, w) == 1
             assert C.verify_compact(cst, b"simd", np.concatenate([inst[:, 3], common]), out[3][0], out[3][1]) == 0
-        for a, b in zip(proofs[False], proofs[True]):
+        for a, b in zip(proofs[False], proofs[isa]):
             assert a[0].tobytes() == b[0].tobytes() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
     finally:
         C.set_simd(False)

@@ -55,10 +55,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 METRIC = "proofs/sec + batch-verifies/sec, CMZ13 10-attr credential, 1/2/4/8 MI355X"
-# The VALU ceiling is CYCLE-WEIGHTED (round 4): every kernel's static opcode mix is priced in SIMD issue cycles (2-cycle class: v_and / v_add_u32 /
-# v_mov / v_xor ..., 4-cycle class: v_mad_u64_u32, carries, 64-bit ops, v_cndmask ...: tools/opcode_mix.py -> profiles/r04_opcode_mix.json, keyed to
-# the kernel sources) and divided by the clock cycles that went by: valu_busy = SQ_INSTS_VALU x cycles per instruction / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
-# per kernel (one PMC pass, the chip's own clock), and issue cycles / (1024 x 2.4 GHz nameplate x ms_per_step) for the timed step -- <= 1 by construction.
+# The VALU ceiling is counted in ISSUE SLOTS (round 4): a SIMD issues one VALU instruction per 4-cycle slot, or two when both are of the 2-cycle class
+# (v_and / v_add_u32 / v_mov ...) -- SQ_ACTIVE_INST_VALU2 counts those second instructions; an isolated 2-cycle instruction between v_mad_u64_u32 costs a
+# whole slot (profiles/r04_valu_mix_microbench.txt).  valu_busy = 4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) per kernel
+# (one PMC pass, the chip's own clock), and issue cycles / (1024 x 2.4 GHz nameplate x ms_per_step) for the timed step -- <= 1 by construction.
+# profiles/r04_opcode_mix.json (tools/opcode_mix.py) is the static opcode mix of every kernel, keyed to the kernel sources: information, not the weights.
 OPCODE_MIX = os.path.join("profiles", "r04_opcode_mix.json")
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
 LABEL = b"Benchmark"
@@ -894,7 +895,7 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
                               "(profiles/r04_kernel_stats_cfg<config>_k<K>_one_stream.txt), a few per cent longer -- the profiler's own dispatch overhead; in the timed loop "
                               "several chains share the chip and a launch takes correspondingly longer (profiles/r04_kernel_stats_cfg<config>_k<K>.txt)",
             "note": "integer-VALU bound by construction (SURVEY.md 8(d)): algorithmic bytes = 64 B per (scalar, point) term + 32 B per output, "
-                    "so the HBM fraction of ANY kernel of this path is ~1e-3; the binding roofline is step_valu / *_valu_busy (PMC, cycle-weighted)",
+                    "so the HBM fraction of ANY kernel of this path is ~1e-3; the binding roofline is step_valu / *_valu_busy (PMC, VALU issue slots)",
             "by_kernel": by_kernel}
     # ---- PMC-derived fields: only from a counter file collected from exactly these sources and this call shape ---------------------------
     sha = source_sha256()
@@ -922,7 +923,7 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
                     return rows
 
                 def busy(rows):
-                    """cycle-weighted: issue cycles of the rows' VALU instructions / SIMD clock cycles that went by while they ran (both from the PMC pass)"""
+                    """VALU issue slots the rows' instructions took (4 cycles each; co-issued 2-cycle instructions share one) / SIMD clock cycles that went by (one PMC pass)"""
                     if not rows or any("valu_busy" not in v for v in rows):
                         return None
                     return sum(v["valu_issue_cycles"] for v in rows) / sum(v["valu_issue_cycles"] / v["valu_busy"] for v in rows)
@@ -951,12 +952,13 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
                                  "valu_floor_ms_per_step": floor, "frac": floor / ms_per_step if floor else None,
                                  "sclk_ghz_observed": st_tot.get("sclk_ghz_observed"),
                                  "valu_floor_ms_per_step_at_observed_sclk": floor_obs, "frac_at_observed_sclk": floor_obs / ms_per_step if floor_obs else None,
-                                 "note": "cycle-weighted VALU busy fraction of the timed step: every kernel's SQ_INSTS_VALU (PMC, from pmc_source) x the 2- or 4-cycle issue weight "
-                                         "of its static opcode mix (profiles/r04_opcode_mix.json), summed over the step's kernels, / (1024 SIMDs x clock x this run's ms_per_step).  "
-                                         "frac uses the 2.4 GHz nameplate clock: a hard bound, <= 1 whatever the chip does.  Under this load the chip clocks lower "
+                                 "note": "VALU busy fraction of the timed step in issue slots: every kernel's 4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) (PMC, from pmc_source: one "
+                                         "slot of 4 cycles per instruction, two co-issued 2-cycle-class instructions share one), summed over the step's kernels, / (1024 SIMDs x clock x "
+                                         "this run's ms_per_step).  frac uses the 2.4 GHz nameplate clock: a hard bound, <= 1 whatever the chip does.  Under this load the chip clocks lower "
                                          "(sclk_ghz_observed = GRBM_GUI_ACTIVE / duration of the step's long kernels in the PMC pass), so frac_at_observed_sclk is the share of the "
                                          "issue cycles that were really there -- an estimate: the clock of the four-stream run is not observable from HIP.  "
-                                         "Rounds 1-3 divided raw counts by 34.5e12 lane-instr/s and overstated this."}
+                                         "Rounds 1-3 charged 4 cycles to every instruction at one assumed clock; this round first charged 2 to every 2-cycle-class opcode "
+                                         "(too few: isolated ones cost 4, profiles/r04_valu_mix_microbench.txt)."}
         except Exception:                       # noqa: BLE001 -- a reported extra, never the measurement
             pmc_source = None
     out = {

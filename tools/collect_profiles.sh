@@ -16,7 +16,7 @@ B="python bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline --n
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${S}_prof -o kt -- $B > $O/${S}_kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${S}_prof -o fetch -- $B > $O/${S}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${S}_prof -o write -- $B > $O/${S}_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/${S}_prof -o sq -- $B > $O/${S}_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/${S}_prof -o sq -- $B > $O/${S}_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $O/${S}_prof -o sq2 -- $B > $O/${S}_sq2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 MeanOccupancyPerCU --output-format csv -d $O/${S}_prof -o sq3 -- $B > $O/${S}_sq3.log 2>&1
 # the same command on ONE stream: a kernel's own duration (nothing overlaps it) -- the time base of the time-share column and of roofline.launch_ms_rocprof_one_stream

@@ -1,26 +1,20 @@
 #!/usr/bin/env python3
-"""Static VALU opcode mix of every kernel in the shipped code object, priced in SIMD ISSUE CYCLES (2 or 4 per wave64 instruction, by opcode)
--> profiles/r04_opcode_mix.json.
+"""Static VALU opcode mix of every kernel in the shipped code object -> profiles/r04_opcode_mix.json (keyed to the kernel sources).  INFORMATION
+about the code (share of 2-cycle-class opcodes, of 64-bit integer opcodes, the top opcodes), not the weights of the VALU ceiling any more.
 
-Why: rounds 1 - 3 divided raw SQ_INSTS_VALU counts by ONE peak, 34.5e12 lane-instructions/s -- the rate of the
-4-cycle class (v_mad_u64_u32, carries, 64-bit shifts, v_cndmask ...).  A third of the instructions of these kernels are 2-cycle-class
-opcodes (v_and / v_add_u32 / v_sub_u32 / v_lshrrev_b32 / v_mov / v_xor / v_bitop3), so "fractions" above 1.0 appeared (k_responses 105 %).
-The hardware has no cycle-weighted VALU counter on gfx950 (SQ_ACTIVE_INST_VALU counts instructions: on the single-opcode kernels of
-tools/microbench/valu_rates.hip it reads the same for every opcode), so the weights come from the disassembly:
+History: rounds 1 - 3 divided raw SQ_INSTS_VALU counts by ONE peak, 34.5e12 lane-instructions/s -- 4 issue cycles per instruction at
+one assumed clock -- and kernels made of 2-cycle-class opcodes (k_responses: 63 % v_mov / v_and / v_add_u32 ...) came out above 1.0.  This round first
+charged every opcode its class weight from the single-opcode microbenchmark (2 or 4 cycles: issue_cycles_per_wave_instruction below, still written) --
+which UNDER-charges: a SIMD issues one VALU instruction per 4-cycle slot and a second one in the same slot only if both are of the 2-cycle class, so a
+2-cycle instruction between v_mad_u64_u32 costs a whole slot (tools/microbench/valu_mix.hip -> profiles/r04_valu_mix_microbench.txt: the alternating
+pattern runs at 4.03 cycles per instruction, not 3.0).  The hardware counts the co-issued second instructions (SQ_ACTIVE_INST_VALU2: 0.48 per instruction
+on a pure 2-cycle stream, 0.00 on a pure 4-cycle one), so the ceiling is now counted, not modelled (tools/pmc_summary.py, bench.py):
 
-    issue_cycles_per_wave_instruction(kernel) = sum over opcodes  f_op * cycles_op     cycles_op = 2 or 4, f_op = the opcode's share of the kernel's VALU instructions
-    valu_busy(kernel) = SQ_INSTS_VALU * issue_cycles_per_wave_instruction / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)        both counters from ONE rocprofv3 --pmc pass
+    valu_busy(kernel) = 4 * (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)        all three counters from ONE rocprofv3 --pmc pass
 
-i.e. issue cycles used / issue cycles that went by, in the chip's own clock (which is NOT the 2.4 GHz nameplate under this load: the term
-kernel runs at 2.06 - 2.16 GHz) -- no modelled rate, no duration from another pass, <= 1 by construction.  The class of an opcode is read
-off the microbenchmark (profiles/r04_valu_rates_microbench.txt: a pure stream reaches > 50e12 lane-instr/s => 2 cycles, else 4;
-profiles/r04_valu_issue_cycles_pmc.txt has the same kernels in GRBM_GUI_ACTIVE cycles).  Round 4's first version priced the mix with
-the microbenchmark's sustained RATES instead (seconds_per_wave_instruction, still written): those rates carry the microbenchmark's own clock
-(2.14 - 2.26 GHz) and loop overhead, and a kernel that clocks higher than the microbenchmark did (k_responses at K = 50: 2.35 GHz) came out at 1.009.
-
-f_op is the STATIC share in the disassembly (the dynamic share is not observable; the kernels are straight-line field arithmetic inside
-fixed-trip loops, and the one class the PMC can count dynamically -- SQ_INSTS_VALU_INT64 -- is reported next to the static share by
-tools/pmc_summary.py as a check).  Opcodes without a measurement (< 1 % of any kernel) are priced as 4-cycle-class.
+i.e. issue slots used / clock cycles that went by, in the chip's own clock (which is NOT the 2.4 GHz nameplate under this load: the term kernel runs at
+1.97 - 2.10 GHz).  The class of an opcode here is read off profiles/r04_valu_rates_microbench.txt (a pure stream reaches > 50e12 lane-instr/s => 2-cycle
+class); opcodes without a measurement (< 1 % of any kernel) count as 4-cycle class.
 
     python tools/opcode_mix.py [OUT.json]        (needs /opt/rocm/lib/llvm/bin/{llvm-objcopy,clang-offload-bundler,llvm-objdump} and c++filt)
 """
@@ -107,8 +101,9 @@ def main():
     rates = measured_rates()
     res = {"_source_sha256": bench.source_sha256(), "_rates_file": os.path.relpath(RATES_FILE, ROOT), "_default_rate": DEFAULT_RATE,
            "_note": "per kernel: static VALU mix of the shipped code object priced in SIMD issue cycles (2 or 4 per opcode); "
-                    "issue_cycles_per_wave_instruction (2 or 4 per opcode) x SQ_INSTS_VALU / (SIMDs x GRBM_GUI_ACTIVE per XCD) = valu_busy; "
-                    "seconds_per_wave_instruction = the same mix at the microbenchmark's sustained rates (clock-throttled, loop overhead included)"}
+                    "share_2cycle_class = opcodes that CAN share an issue slot with another of their class; whether they do is counted by SQ_ACTIVE_INST_VALU2 "
+                    "(tools/pmc_summary.py: valu_busy = 4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / (SIMDs x GRBM_GUI_ACTIVE per XCD)); issue_cycles_per_wave_instruction "
+                    "(2 or 4 per opcode) is the lower bound a perfectly paired schedule would reach"}
     for kernel, h in sorted(kernel_mixes(disassemble(engine.LIB_PATH)).items()):
         valu = collections.Counter()
         for op, c in h.items():

@@ -8,8 +8,11 @@ call, steps).  HBM traffic per launch follows MI355X_MICROARCH.md section HBM: F
 requests; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) streaming reads, so reads are counted as
 2 x FETCH_SIZE (an upper bound for kernels whose reads are narrower gathers).
 
-valu_busy (cycle-weighted, tools/opcode_mix.py): SQ_INSTS_VALU x issue cycles per wave instruction of the kernel's opcode mix (2 or 4 each) /
-(1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) -- issue cycles used / clock cycles that went by, both counted in the same pass.  GRBM_GUI_ACTIVE covers a
+valu_busy (cycle-weighted): 4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) -- VALU issue slots used / clock
+cycles that went by, all three counters from ONE pass.  A SIMD issues one VALU instruction per 4-cycle slot, or TWO when both belong to the
+2-cycle class (v_and / v_add_u32 / v_mov ...): SQ_ACTIVE_INST_VALU2 counts those second instructions (0.48 per instruction on a pure 2-cycle stream, 0
+on a pure 4-cycle one, 0.02 - 0.07 on alternating patterns, whose 2-cycle instructions then cost a full slot each: profiles/r04_valu_mix_microbench.txt).
+The static share of 2-cycle opcodes (tools/opcode_mix.py) is printed next to the co-issued share for information only.  GRBM_GUI_ACTIVE covers a
 little more than the kernel (tens of microseconds of dispatch around it): the busy fraction of kernels shorter than ~100 us is understated, and
 sclk_ghz = GRBM_GUI_ACTIVE / 8 / the dispatch's duration in that pass is only printed as a clock for longer ones."""
 import collections
@@ -48,7 +51,7 @@ def main():
             agg[kname(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
             if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):
                 gui_ns[kname(r)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    # cycle-weighted VALU ceiling: the static opcode mix of each kernel priced in issue cycles (tools/opcode_mix.py)
+    # static opcode mix of each kernel (tools/opcode_mix.py): printed for information, the busy fractions are counted in issue slots by the hardware
     mix = {}
     mix_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bench.OPCODE_MIX)
     if os.path.exists(mix_path):
@@ -57,8 +60,8 @@ def main():
             mix = mj
     res = {}
     print("# workload: --config %s, %d proofs per batch, %d batch(es) per call, %d timed steps; kernel sources sha256 %s" % (cfg, bl["config"]["batch_per_gpu"], k_per_call, bl["steps"], sha[:16]))
-    print("# valu_busy = SQ_INSTS_VALU x issue_cycles_per_wave_instruction (%s, %s) / (%d SIMDs x GRBM_GUI_ACTIVE / %d)  -- issue cycles used / clock cycles elapsed, one PMC pass, <= 1"
-          % (bench.OPCODE_MIX, "sha matches" if mix else "MISSING or stale: no valu_busy", SIMDS, XCDS))
+    print("# valu_busy = 4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / (%d SIMDs x GRBM_GUI_ACTIVE / %d)  -- VALU issue slots used / clock cycles elapsed, one PMC pass, <= 1   (static opcode mix: %s, %s)"
+          % (SIMDS, XCDS, bench.OPCODE_MIX, "sha matches" if mix else "missing or stale"))
     print("%-34s %s" % ("kernel", "counter averages per launch (n launches)"))
     for k in sorted(agg):
         if "k_" not in k:
@@ -70,9 +73,13 @@ def main():
         if one_stream.get(k):
             row["avg_us_one_stream"] = sum(one_stream[k]) / len(one_stream[k]) / 1e3
         m = mix.get(k)
-        if m and "SQ_INSTS_VALU" in row:
-            row["valu_issue_cycles"] = row["SQ_INSTS_VALU"] * m["issue_cycles_per_wave_instruction"]        # summed over all SIMDs
+        if m:
             row["share_int64_static"] = m["share_int64_static"]
+            row["share_2cycle_static"] = m["share_2cycle_class"]
+        if "SQ_INSTS_VALU" in row and "SQ_ACTIVE_INST_VALU2" in row:
+            # issue slots: one per instruction, minus the instructions that shared a slot with another 2-cycle-class instruction
+            row["valu_issue_cycles"] = 4.0 * (row["SQ_INSTS_VALU"] - row["SQ_ACTIVE_INST_VALU2"])            # summed over all SIMDs
+            row["share_co_issued"] = row["SQ_ACTIVE_INST_VALU2"] / row["SQ_INSTS_VALU"] if row["SQ_INSTS_VALU"] else 0.0
             if row.get("GRBM_GUI_ACTIVE"):
                 row["valu_busy"] = row["valu_issue_cycles"] / (SIMDS * row["GRBM_GUI_ACTIVE"] / XCDS)
                 if gui_ns.get(k):
@@ -96,7 +103,7 @@ def main():
         step_kernels = [(k, v) for k, v in res.items() if "SQ_INSTS_VALU" in v and not any(k.startswith(p) or k.startswith("zkp::" + p) for p in setup)]
         cyc = sum(v["valu_issue_cycles"] * v["launches"] for k, v in step_kernels if "valu_issue_cycles" in v) / steps
         covered = sum(v["SQ_INSTS_VALU"] * v["launches"] for k, v in step_kernels if "valu_issue_cycles" in v) / steps
-        ok = bool(mix) and covered > 0.999 * tot
+        ok = covered > 0.999 * tot
         # the clock these kernels really ran at: issue-cycle-weighted over the kernels long enough for GRBM_GUI_ACTIVE / duration to be a clock
         long_k = [(v["valu_issue_cycles"] * v["launches"], v["sclk_ghz"]) for k, v in step_kernels if v.get("us_in_pmc_pass", 0) >= 200.0 and "valu_issue_cycles" in v]
         sclk = sum(w * f for w, f in long_k) / sum(w for w, _ in long_k) if long_k else None
@@ -106,7 +113,7 @@ def main():
                                "sclk_ghz_observed": sclk,
                                "valu_floor_ms_per_step_observed_clock": cyc / SIMDS / (sclk * 1e6) if ok and sclk else None,
                                "note": "sums over the step's kernels x launches / steps in the trace (set-up kernels excluded by name).  valu_issue_cycles_per_step = "
-                                       "SQ_INSTS_VALU x the 2- or 4-cycle weight of every kernel's opcode mix; / 1024 SIMDs / clock = the time the step's VALU work needs "
+                                       "4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2): VALU issue slots; / 1024 SIMDs / clock = the time the step's VALU work needs "
                                        "with every SIMD issuing every cycle: at the 2.4 GHz nameplate clock (a hard floor of ms_per_step) and at the clock the kernels "
                                        "were observed to run at under this load (GRBM_GUI_ACTIVE / duration, kernels of >= 200 us, weighted by issue cycles)"}
         print("%-34s valu wave-instructions per bench step = %.4g, issue cycles = %s; VALU floor %s ms per step at %.1f GHz, %s ms at the observed %s GHz  (%g steps in the trace)"
@@ -119,13 +126,15 @@ def main():
         print()
         print("# per-kernel efficiency: duration and time share on ONE stream (a kernel's own duration); busy% = valu_busy (issue cycles / GRBM_GUI_ACTIVE cycles of the PMC pass);")
         print("# sclk = clock observed in that pass (kernels >= 100 us); MeanOccupancyPerCU: 32 = full")
-        print("%-46s %6s %10s %7s %12s %8s %7s %8s %9s" % ("kernel", "calls", "avg_us", "time%", "valu_instr", "busy%", "sclk", "occ/CU", "waves"))
+        print("# 2cyc% s/co = share of 2-cycle-class opcodes in the disassembly / share of instructions that were CO-ISSUED with another one (SQ_ACTIVE_INST_VALU2 / SQ_INSTS_VALU: at most 50)")
+        print("%-46s %6s %10s %7s %12s %8s %7s %8s %9s %11s" % ("kernel", "calls", "avg_us", "time%", "valu_instr", "busy%", "sclk", "occ/CU", "waves", "2cyc% s/co"))
         for k, v in sorted(rows, key=lambda kv: -kv[1]["avg_us_one_stream"] * kv[1]["launches"]):
-            print("%-46s %6d %10.1f %7.2f %12.4g %8s %7s %8.2f %9.0f" % (k[:46], v["launches"], v["avg_us_one_stream"], 100.0 * v["avg_us_one_stream"] * v["launches"] / tot_t,
+            print("%-46s %6d %10.1f %7.2f %12.4g %8s %7s %8.2f %9.0f %11s" % (k[:46], v["launches"], v["avg_us_one_stream"], 100.0 * v["avg_us_one_stream"] * v["launches"] / tot_t,
                                                                            v.get("SQ_INSTS_VALU", float("nan")),
                                                                            "%.1f" % (100 * v["valu_busy"]) if "valu_busy" in v else "n/a",
                                                                            "%.2f" % v["sclk_ghz"] if v.get("us_in_pmc_pass", 0) >= 100.0 else "-",
-                                                                           v.get("MeanOccupancyPerCU", float("nan")), v.get("SQ_WAVES", float("nan"))))
+                                                                           v.get("MeanOccupancyPerCU", float("nan")), v.get("SQ_WAVES", float("nan")),
+                                                                           "%.0f / %.1f" % (100 * v["share_2cycle_static"], 100 * v["share_co_issued"]) if "share_2cycle_static" in v and "share_co_issued" in v else "-"))
     # key the counters to the kernel sources and the workload shape they were collected from (bench.py reports them only on a match)
     res["_source_sha256"] = sha
     res["_workload"] = {"config": cfg, "batch": bl["config"]["batch_per_gpu"], "batches_per_call": k_per_call, "steps": bl["steps"], "streams": bl["config"]["streams"]}

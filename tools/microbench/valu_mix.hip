@@ -37,6 +37,19 @@ KERNEL(k_MMMAMMMA, M(0) M(1) M(2) A(4) M(3) M(0) M(1) A(5), 8)
 KERNEL(k_MAAAMAAA, M(0) A(4) A(5) A(6) M(1) A(7) A(4) A(5), 8)
 KERNEL(k_MMMMAAAA, M(0) M(1) M(2) M(3) A(4) A(5) A(6) A(7), 8)
 KERNEL(k_MMMMMMMA, M(0) M(1) M(2) M(3) M(0) M(1) M(2) A(4), 8)
+// run length: how long must a run of 2-cycle instructions be before they share slots?  (names: M<count>A<count>)
+#define M4 M(0) M(1) M(2) M(3)
+#define A4 A(4) A(5) A(6) A(7)
+// B = v_add_u32, S = v_lshrrev_b32: other opcodes of the 2-cycle class, mixed into a run
+#define B(k) "v_add_u32 %" #k ", %8, %" #k "\n"
+#define S(k) "v_lshrrev_b32 %" #k ", 3, %" #k "\n"
+KERNEL(k_M4A8, M4 A4 A4, 12)
+KERNEL(k_M8A8, M4 M4 A4 A4, 16)
+KERNEL(k_M8A16, M4 M4 A4 A4 A4 A4, 24)
+KERNEL(k_M16A16, M4 M4 M4 M4 A4 A4 A4 A4, 32)
+KERNEL(k_M16A32, M4 M4 M4 M4 A4 A4 A4 A4 A4 A4 A4 A4, 48)
+KERNEL(k_M8X8, M4 M4 A(4) B(5) S(6) A(7) B(4) S(5) A(6) B(7), 16)
+KERNEL(k_X8, A(4) B(5) S(6) A(7) B(4) S(5) A(6) B(7), 8)
 
 typedef void (*kern_t)(uint32_t*, uint32_t, uint32_t);
 struct Entry { const char* name; kern_t k; int n2, n4; };
@@ -47,7 +60,9 @@ int main() {
   const int blocks = cus * 8;
   uint32_t* out; CK(hipMalloc(&out, (size_t)blocks * 256 * 4));
   Entry es[] = {{"MMMMMMMM", k_MMMMMMMM, 0, 8}, {"AAAAAAAA", k_AAAAAAAA, 8, 0}, {"MAMAMAMA", k_MAMAMAMA, 4, 4}, {"MMAAMMAA", k_MMAAMMAA, 4, 4}, {"MMMAMMMA", k_MMMAMMMA, 2, 6},
-                {"MAAAMAAA", k_MAAAMAAA, 6, 2}, {"MMMMAAAA", k_MMMMAAAA, 4, 4}, {"MMMMMMMA", k_MMMMMMMA, 1, 7}};
+                {"MAAAMAAA", k_MAAAMAAA, 6, 2}, {"MMMMAAAA", k_MMMMAAAA, 4, 4}, {"MMMMMMMA", k_MMMMMMMA, 1, 7},
+                {"M4A8", k_M4A8, 8, 4}, {"M8A8", k_M8A8, 8, 8}, {"M8A16", k_M8A16, 16, 8}, {"M16A16", k_M16A16, 16, 16}, {"M16A32", k_M16A32, 32, 16},
+                {"M8X8", k_M8X8, 8, 8}, {"X8", k_X8, 8, 0}};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("%-10s %8s %8s %10s %22s\n", "pattern", "2-cycle", "4-cycle", "ms", "weighted cycles/instr");
   for (auto& e : es) {
@@ -56,7 +71,7 @@ int main() {
       hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, 3u, 5u);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      if (rep) printf("%-10s %8d %8d %10.3f %22.2f\n", e.name, e.n2, e.n4, ms, (2.0 * e.n2 + 4.0 * e.n4) / 8.0);
+      if (rep) printf("%-10s %8d %8d %10.3f %22.2f\n", e.name, e.n2, e.n4, ms, (2.0 * e.n2 + 4.0 * e.n4) / (e.n2 + e.n4));
     }
   }
   CK(hipFree(out));

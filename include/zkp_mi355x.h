@@ -281,7 +281,9 @@ int zkp_fused_verify_batchable_coeffs(zkp_ctx* ctx, const zkp_fused_statement* s
  *     zkp_fused_batch_verify_dev: d_points [n_static + (n_instance + n_constraints) * N][32] with the static points
  *     and instance rows filled in (the commitment rows are written by the call); d_status [2] words: decode failure
  *     in the MSM | a point or commitment rejected by the transcript protocol (identity encoding); the batch verifies
- *     iff both are 0 and d_out_point holds 32 zero bytes. */
+ *     iff both are 0 and d_out_point holds 32 zero bytes (= the canonical encoding of the identity; for any other sum the 32 bytes are a
+ *     non-zero marker, not its encoding: batch_verifier.rs:230-234 asks is_identity() and nothing else, and the test -- X = 0 or Y = 0 --
+ *     needs no inverse square root at the end of the MSM's 253-doubling chain). */
 int zkp_fused_prove_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint32_t strobe_pos, uint8_t* d_transcripts,
                         const uint8_t* d_secrets, const uint8_t* d_table, const uint8_t* d_entropy, uint8_t* d_challenges,
                         uint8_t* d_responses, uint8_t* d_commitments, uint8_t* d_status);
@@ -302,7 +304,7 @@ int zkp_fused_verify_batchable_dev(zkp_ctx* ctx, const zkp_fused_statement* st, 
 /* zkp_fused_batch_verify_many on device buffers: d_points [n_static + (n_instance + n_constraints) * N][32] (N = n_batches *
  * N_each; static points and instance rows filled in, commitment rows written by the call), d_out_points [n_batches][32],
  * d_status [n_batches][2] words (decode failure in batch b's MSM | a point, commitment or response of batch b rejected):
- * batch b verifies iff both are 0 and d_out_points[b] is 32 zero bytes. */
+ * batch b verifies iff both are 0 and d_out_points[b] is 32 zero bytes (otherwise a non-zero marker, as above). */
 int zkp_fused_batch_verify_many_dev(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t n_batches, uint32_t N_each, uint32_t strobe_pos,
                                     uint8_t* d_transcripts, uint8_t* d_points, const uint8_t* d_commitments, const uint8_t* d_responses,
                                     const uint8_t* d_weights16, uint8_t* d_out_points, uint32_t* d_status);

@@ -242,6 +242,38 @@ def pick_call_shape(steps, want_k=0, want_streams=0):
     return k, max(1, min(s, calls))
 
 
+_HIP = None
+
+
+def _priority_stream(dev, priority):
+    """a torch stream object over hipStreamCreateWithPriority(non-blocking, priority): torch's own pools offer "high" and "normal" only"""
+    import ctypes
+    import torch
+    global _HIP
+    if _HIP is None:
+        _HIP = ctypes.CDLL("libamdhip64.so")
+    torch.cuda.set_device(dev)
+    h = ctypes.c_void_p()
+    rc = _HIP.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))
+    if rc != 0:
+        raise RuntimeError("hipStreamCreateWithPriority(%d) -> %d" % (priority, rc))
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
+def _sleep_cycles_per_ms(dev):
+    """torch.cuda._sleep counts in the device's own clock ticks: calibrate once"""
+    import torch
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    n = 2_000_000
+    a.record()
+    torch.cuda._sleep(n)
+    b.record()
+    torch.cuda.synchronize()
+    return n / max(a.elapsed_time(b), 1e-3)
+
+
 def source_sha256():
     """sha256 over the kernel sources: keys PMC counter files to the code they were collected from"""
     h = hashlib.sha256()
@@ -311,7 +343,17 @@ def run_workload(cx, args, cfg, n, steps, warmup, K, n_streams, primary):
     calls = steps // K
     n_streams = max(1, min(n_streams, calls))
     engines = [Engine(cx.local_rank) for _ in range(n_streams)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    prios = [int(x) for x in args.stream_priorities.split(",")] if getattr(args, "stream_priorities", "") else []
+    if prios:
+        # call chains on streams of different HIP priorities (-1 high, 0 normal, 1 low; cycled over the streams): identical chains that start together
+        # stay in phase -- their narrow kernels coincide -- unless the dispatcher prefers one queue's wide kernel over the others'
+        streams = [_priority_stream(dev, prios[k % len(prios)]) for k in range(n_streams)]
+    else:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    stagger_cycles = [0] * n_streams
+    if getattr(args, "stagger_ms", 0.0) > 0.0 and n_streams > 1:
+        per_ms = _sleep_cycles_per_ms(dev)
+        stagger_cycles = [int(k * args.stagger_ms * per_ms) for k in range(n_streams)]
     for e_, s_ in zip(engines, streams):
         e_.set_stream(s_.cuda_stream)          # engine work and the torch copies of one call share one HIP stream
         for kv in args.engine_opt:
@@ -381,6 +423,8 @@ def run_workload(cx, args, cfg, n, steps, warmup, K, n_streams, primary):
         """one call (= K steps) on stream k: per part, fresh transcripts and its flows (or only the flow `which`)"""
         e_ = engines[k]
         with torch.cuda.stream(streams[k]):
+            if stagger_cycles[k]:
+                torch.cuda._sleep(stagger_cycles[k])           # (--stagger-ms: chain k starts k x stagger late; one idle wavefront, inside the timed region)
             for p in ps:
                 b = p.bufs[k]
                 for flow in ((which,) if which else p.flows):
@@ -680,6 +724,8 @@ def main():
     ap.add_argument("--batches-per-call", type=int, default=0, help="--config 2: K steps (batches) travel in one call chain -- one wide prove call + "
                                                                      "one K-batch verification; must divide --steps (0 = automatic, 1 = one batch per call)")
     ap.add_argument("--streams", type=int, default=0, help="independent call chains in flight, each on its own HIP stream / engine context (0 = automatic)")
+    ap.add_argument("--stream-priorities", default="", help="experiment: HIP stream priorities of the call chains, cycled over the streams (-1 high, 0 normal, 1 low), e.g. -1,0,0,1")
+    ap.add_argument("--stagger-ms", type=float, default=0.0, help="experiment: call chain k starts k x this many ms late (a one-wavefront sleep at the head of its stream, inside the timed region)")
     ap.add_argument("--max-hw-queues", type=int, default=8, help="cap of GPU_MAX_HW_QUEUES (one hardware queue per stream up to this)")
     ap.add_argument("--no-graphs", action="store_true", help="enqueue every kernel of every call from the host instead of replaying one "
                                                             "HIP graph per stream")
@@ -693,6 +739,8 @@ def main():
     ap.add_argument("--in-process", action="store_true", help="--gpus N > 1 WITHOUT torchrun / gloo / RCCL: this one process drives the N GPUs, one host "
                                                              "thread and one set of engine contexts per GPU, the verdict AND is taken on the host "
                                                              "(the C-ABI counterpart is zkp_pipe over N devices); same JSON line")
+    ap.add_argument("--pipe-batches", type=int, default=10, help="e2e_host_buffers.pipelined: batches of --batch proofs per submitted job (rounds 3-4 measured 5: "
+                                                                 "profiles/r04_ab_experiments.txt block n has 5 / 10 / 20 side by side)")
     ap.add_argument("--pipe-contexts", type=int, default=6, help="e2e_host_buffers.pipelined: contexts (= jobs in flight) of the zkp_pipe")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
                     help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
@@ -818,8 +866,8 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
     if e2e is not None:
         # the same flows through the zkp_pipe of include/zkp_toolbox.h: jobs of K batches, several in flight, host buffers both ways
         torch.cuda.empty_cache()
-        e2e["pipelined"] = e2e_pipelined(n=n, K=5, contexts=args.pipe_contexts, jobs=24, pinned=True)
-        e2e["pipelined_staged"] = e2e_pipelined(n=n, K=5, contexts=args.pipe_contexts, jobs=24, pinned=False)
+        e2e["pipelined"] = e2e_pipelined(n=n, K=args.pipe_batches, contexts=args.pipe_contexts, jobs=24, pinned=True)
+        e2e["pipelined_staged"] = e2e_pipelined(n=n, K=args.pipe_batches, contexts=args.pipe_contexts, jobs=24, pinned=False)
     if world > 1 and args.config == "2" and not args.no_multi_configs:
         multi = {}
         for key, cfg, total, cap, streams_cap in (("4", "4share", args.multi_total4, 1 << 19, 2), ("5", "5share", args.multi_total5, 1 << 15, 8)):

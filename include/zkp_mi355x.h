@@ -75,7 +75,9 @@ const char* zkp_version(void);
  *     chip on its own), tables otherwise.
  *   ZKP_OPT_DEV_OVERLAP: 1 = zkp_fused_prove_dev / _verify_compact_dev / _verify_batchable_dev run the half of their work that does not depend on the
  *     transcripts (decoding, classification, comb tables) on a second stream of the context, as the synchronous entry points
- *     always do: a shorter call, more cross-stream dependencies.  Default 0.
+ *     always do: a shorter call, more cross-stream dependencies.  Default 0.  (Measured again in round 4 on a LONE call chain: 2.87 -> 3.17 ms per
+ *     prove call of 20,480 proofs -- no gain there either.)  In a process that owns one hardware queue (GPU_MAX_HW_QUEUES=1) a capture records the
+ *     flow without the fork: ROCm 7.2.0 crashes in hipGraphLaunch on a forked graph under that setting.
  *   ZKP_OPT_GROUPED_COMB: 1 = constant-time calls list the terms of every point with 8 or more uses next to each other and
  *     walk that point's 16-teeth comb table through LDS (each lane reads the entry its digit names from an LDS column of its
  *     own: no masked scan, 20 % fewer instructions per addition, less independent work per lane); 0 = every comb term scans

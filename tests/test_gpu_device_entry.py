@@ -441,3 +441,65 @@ def test_masked_scan_safe_mode_gives_the_same_proofs(eng):
         assert (a == b).all()
     ts = np.stack([T.Transcript(b"safe-mode").state] * n)
     T.batch_verify(eng, mod.statement, ts, inst, common, out[1][2], out[1][1])
+
+
+_ONE_QUEUE_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+torch.cuda.init()
+from zkp_amd.engine import Engine
+from zkp_amd import toolbox as T
+from tests.test_gpu_toolbox import _cmz_batch
+from tests.test_gpu_device_entry import _cmz_fused_statement, _dev
+n = 96
+mod, secrets, inst, common = _cmz_batch(n, 8)
+fst = _cmz_fused_statement()
+e = Engine(0)
+e.set_option(5, 1)                                  # ZKP_OPT_DEV_OVERLAP: the _dev flows fork onto the side stream
+stream = torch.cuda.Stream()
+e.set_stream(stream.cuda_stream)
+e.prepare_fixed_points(common)
+t0 = T.Transcript(b"one-queue").state
+pos = int(t0[200]) | int(t0[201]) << 8 | int(t0[202]) << 16
+rng = np.random.default_rng(5)
+entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+d_ts0, d_ent, d_sec = _dev(np.stack([t0] * n)), _dev(entropy), _dev(secrets)
+d_tbl = _dev(np.concatenate([common, inst.reshape(-1, 32)]))
+z8 = lambda *s: torch.zeros(s, dtype=torch.uint8, device="cuda:0")
+ts, chal, resp, coms, st = z8(n, 208), z8(n, 32), z8(n, 21, 32), z8(n, 11, 32), z8(11 * n)
+def chain():
+    with torch.cuda.stream(stream):
+        ts.copy_(d_ts0, non_blocking=True)
+        e.fused_prove_dev(fst, n, pos, ts.data_ptr(), d_sec.data_ptr(), d_tbl.data_ptr(), d_ent.data_ptr(), chal.data_ptr(), resp.data_ptr(), coms.data_ptr(), st.data_ptr())
+chain()
+e.synchronize(); torch.cuda.synchronize()
+want = [x.clone() for x in (chal, resp, coms)]
+with e.capture() as cap:
+    chain()
+for x in (chal, resp, coms):
+    x.zero_()
+for _ in range(3):
+    cap.graph.launch()
+e.synchronize(); torch.cuda.synchronize()
+assert all(bool((a == b).all().item()) for a, b in zip(want, (chal, resp, coms)))
+ts_h = np.stack([t0] * n)
+chal_h, resp_h, coms_h = T.prove_batch(e, mod.statement, ts_h, secrets, inst, common, entropy)
+assert (chal.cpu().numpy() == chal_h).all() and (resp.cpu().numpy() == resp_h).all() and (coms.cpu().numpy() == coms_h).all()
+print("ONE-QUEUE-OK")
+"""
+
+
+def test_forked_flow_in_a_graph_with_one_hardware_queue():
+    """GPU_MAX_HW_QUEUES=1 (what a one-stream profiler run sets) + ZKP_OPT_DEV_OVERLAP + graph replay: ROCm 7.2.0 crashes in hipGraphLaunch on a
+    graph with a forked branch when the process owns a single hardware queue, so a capture recorded under that setting keeps the flow on the
+    context's stream (fused_flows.h: side_forks).  Own process: the variable is read when the HIP runtime initialises."""
+    import os
+    import subprocess
+    import sys
+    _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    r = subprocess.run([sys.executable, "-c", _ONE_QUEUE_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ONE-QUEUE-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

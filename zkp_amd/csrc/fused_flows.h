@@ -932,8 +932,17 @@ void run_program_pending(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_buf
 // call in flight per context: latency matters, prove 1.71 -> 1.45 ms per 4096 CMZ proofs); the asynchronous _dev entry
 // points do not (their callers pipeline many contexts, and cross-stream events between 2 x 16 streams cost more
 // throughput than the overlap returns: 0.99 -> 1.9 ms per step).
+// A graph with a forked branch, replayed by a process that owns ONE hardware queue (GPU_MAX_HW_QUEUES=1: what a profiler run that wants every
+// kernel of a trace serialised sets), crashes inside hipGraphLaunch on ROCm 7.2.0.  While a capture is recording under that setting the work stays
+// on the context's stream -- one queue would run the two branches one after the other anyway.  (capturing is constant between a flow's
+// side_begin and its side_join, so the three calls agree.)
+inline bool side_forks(const zkp_ctx* c, bool overlap) {
+  static const bool one_queue = [] { const char* e = getenv("GPU_MAX_HW_QUEUES"); return e && atoi(e) == 1; }();
+  return overlap && !(c->capturing && one_queue);
+}
 int side_begin(zkp_ctx* c, hipStream_t* main_out, bool overlap) {
   *main_out = c->stream;
+  overlap = side_forks(c, overlap);
   if (!overlap) return ZKP_OK;
   if (!c->side_stream) {
     HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
@@ -947,14 +956,14 @@ int side_begin(zkp_ctx* c, hipStream_t* main_out, bool overlap) {
   return ZKP_OK;
 }
 int side_end(zkp_ctx* c, hipStream_t main, bool overlap) {
-  if (!overlap) return ZKP_OK;
+  if (!side_forks(c, overlap)) return ZKP_OK;
   c->prof_suspended = false;
   c->stream = main;
   HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
   return ZKP_OK;
 }
 int side_join(zkp_ctx* c, bool overlap) {
-  if (overlap) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  if (side_forks(c, overlap)) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   return ZKP_OK;
 }
 

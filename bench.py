@@ -631,6 +631,85 @@ def e2e_host_buffers(eng, n=4096, reps=3):
                     "ChaCha20 weights (batch_verifier.rs:179) included; one synchronous call each, nothing pipelined (see `pipelined`)"}
 
 
+def e2e_threads(n=4096, K=10, threads=6, jobs=24, mem="pageable", opts=((14, 1),), device=0):
+    """The same step issued the plainest way a service would: `threads` host threads, each with its OWN context, calling the SYNCHRONOUS
+    zkp_prove_batch + zkp_batch_verify_many of include/zkp_toolbox.h on K x n proofs (ordinary memory allocated once per thread and reused, OS entropy
+    and weights inside the calls).  opts = zkp_ctx_set_option pairs for every context (14 = ZKP_OPT_SYNC_SCHEDULE: 1 = the synchronous calls run the
+    jobs' throughput schedule).  mem = "fresh": the Python wrappers, which allocate their outputs per call."""
+    import ctypes
+    import threading
+    import numpy as np
+    from zkp_amd import toolbox as T
+    from zkp_amd.engine import Engine
+    L, _p = T.lib(), T._p
+    st = T.cmz_module(10).statement
+    nn = n * K
+    e0 = Engine(device)
+    secrets, inst, common = make_instance(e0, cmz_statement(), nn, np.random.default_rng(78))
+    e0.close()
+    ts0 = np.stack([T.Transcript(LABEL).state] * nn)
+    engines = [Engine(device) for _ in range(threads)]
+    for e in engines:
+        for k, v in opts:
+            e.set_option(int(k), int(v))
+    bufs = {}
+    if mem != "fresh":
+        mk = T.pinned_copy if mem == "pinned" else (lambda x: np.array(x, copy=True, order="C"))
+        for e in engines:
+            bufs[id(e)] = dict(ts0=mk(ts0), ts=mk(ts0), sec=mk(secrets), inst=mk(inst), com=mk(common), chal=mk(np.ones((nn, 32), np.uint8)),
+                               resp=mk(np.ones((nn, st.m, 32), np.uint8)), coms=mk(np.ones((nn, st.nc, 32), np.uint8)), v=(ctypes.c_int * K)())
+    todo, lock, errors = {"left": 0}, threading.Lock(), []
+
+    def worker(e):
+        try:
+            while True:
+                with lock:
+                    if todo["left"] <= 0:
+                        return
+                    todo["left"] -= 1
+                if mem == "fresh":
+                    ts = ts0.copy()
+                    chal, resp, coms = T.prove_batch(e, st, ts, secrets, inst, common)
+                    ts = ts0.copy()
+                    v = T.batch_verify_many(e, st, K, ts, inst, common, coms, resp)
+                else:
+                    b = bufs[id(e)]
+                    b["ts"][...] = b["ts0"]
+                    rc = L.zkp_prove_batch(e._h, st._h, ctypes.c_uint32(nn), _p(b["ts"]), _p(b["sec"]), _p(b["inst"]), _p(b["com"]), None, 0, _p(b["chal"]), _p(b["resp"]), _p(b["coms"]))
+                    assert rc == 0, "zkp_prove_batch -> %d" % rc
+                    b["ts"][...] = b["ts0"]
+                    rc = L.zkp_batch_verify_many(e._h, st._h, ctypes.c_uint32(K), ctypes.c_uint32(n), ctypes.c_uint32(nn), _p(b["ts"]), _p(b["inst"]), _p(b["com"]), _p(b["coms"]),
+                                                 _p(b["resp"]), None, 0, b["v"])
+                    assert rc == 0, "zkp_batch_verify_many -> %d" % rc
+                    v = np.array(list(b["v"]))
+                assert not v.any(), "a batch of fresh proofs did not verify"
+        except Exception as ex:          # noqa: BLE001
+            errors.append(ex)
+
+    def run(n_jobs):
+        todo["left"] = n_jobs
+        th = [threading.Thread(target=worker, args=(e,)) for e in engines]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    try:
+        run(2 * threads)                                # plans, workspaces, tables
+        el = run(jobs)
+    finally:
+        for e in engines:
+            e.close()
+    if errors:
+        raise errors[0]
+    return {"proofs_per_s": jobs * nn / el, "threads": threads, "proofs_per_batch": n, "batches_per_call": K, "calls": 2 * jobs, "elapsed_ms": el * 1e3, "host_buffers": mem,
+            "engine_options": {str(k): int(v) for k, v in opts},
+            "note": "synchronous zkp_prove_batch + zkp_batch_verify_many from `threads` host threads, one context each (no zkp_pipe, no jobs); ZKP_OPT_SYNC_SCHEDULE = 1 "
+                    "puts the synchronous calls on the throughput schedule"}
+
+
 def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,)):
     """The CMZ step through the BOUNDARY a Rust caller would bind, pipelined (include/zkp_toolbox.h: zkp_pipe): host buffers in, host
     buffers out, `jobs` prove jobs of K batches of n proofs each (zkp_prove_batch_submit) and, for every finished prove job, one
@@ -868,6 +947,7 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
         torch.cuda.empty_cache()
         e2e["pipelined"] = e2e_pipelined(n=n, K=args.pipe_batches, contexts=args.pipe_contexts, jobs=24, pinned=True)
         e2e["pipelined_staged"] = e2e_pipelined(n=n, K=args.pipe_batches, contexts=args.pipe_contexts, jobs=24, pinned=False)
+        e2e["threads"] = e2e_threads(n=n, K=args.pipe_batches, threads=args.pipe_contexts, jobs=24)
     if world > 1 and args.config == "2" and not args.no_multi_configs:
         multi = {}
         for key, cfg, total, cap, streams_cap in (("4", "4share", args.multi_total4, 1 << 19, 2), ("5", "5share", args.multi_total5, 1 << 15, 8)):

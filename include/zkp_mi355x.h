@@ -117,12 +117,16 @@ const char* zkp_version(void);
  *     a copy that waits in it for its job's kernels (milliseconds) holds up the copies IN of every job submitted after it -- measured with six
  *     contexts, a job's inputs take 3.7 ms to arrive instead of 1.4, and the pipelined rate through pinned buffers is 4.5 instead of 5.4 M proofs/s
  *     (profiles/r04_ab_experiments.txt, block e).
+ *   ZKP_OPT_SYNC_SCHEDULE: which schedule the SYNCHRONOUS host-pointer entry points (section 2c) run.  0 / UINT64_MAX (default) = the low-latency one (second
+ *     stream for the point phase, comb tables built by four lanes per point, single-use points on tables): one call at a time per process, the caller sees
+ *     the call's duration.  1 = the throughput schedule of the asynchronous jobs (section 2d): for callers that issue synchronous calls from several host
+ *     threads at once, one context per thread -- every call is a little longer, the chip does less work per proof (profiles/r04_ab_experiments.txt, block r).
  *   ZKP_OPT_WS_LIMIT_BYTES: the largest device workspace this context may allocate (it grows with the largest call it has served: ~75 KB per CMZ
  *     proof of a prove call).  A call that would need more returns ZKP_ERR_OOM instead of allocating -- the way to keep several contexts of a
  *     zkp_pipe (zkp_toolbox.h) inside one GPU's memory.  0 / UINT64_MAX = no cap (default).
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
-       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12, ZKP_OPT_JOB_DEFER_D2H = 13 };
+       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12, ZKP_OPT_JOB_DEFER_D2H = 13, ZKP_OPT_SYNC_SCHEDULE = 14 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~35 short kernels (75 in round 1); enqueueing them one by one costs the host ~0.1 ms per

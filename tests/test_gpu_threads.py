@@ -21,8 +21,8 @@ def _t0(n):
     return np.stack([T.Transcript(LABEL).state] * n)
 
 
-@pytest.mark.parametrize("n_threads", [4, 8])
-def test_concurrent_contexts_give_the_bytes_of_a_lone_thread(n_threads):
+@pytest.mark.parametrize("n_threads,sync_schedule", [(4, 0), (8, 0), (6, 1)])
+def test_concurrent_contexts_give_the_bytes_of_a_lone_thread(n_threads, sync_schedule):
     from zkp_amd.engine import Engine, ZkpError
     n = 160
     jobs = []
@@ -65,6 +65,8 @@ def test_concurrent_contexts_give_the_bytes_of_a_lone_thread(n_threads):
         assert bytes(want[0][0][jx]) == bytes(ec) and want[0][1][jx].tobytes() == bytes(er) and want[0][2][jx].tobytes() == bytes(ek)
 
     engines = [Engine(0) for _ in range(n_threads)]
+    for e in engines:
+        e.set_option(14, sync_schedule)             # ZKP_OPT_SYNC_SCHEDULE: 1 = the synchronous calls run the jobs' throughput schedule (same bytes)
     got, errors = [None] * n_threads, []
     start = threading.Barrier(n_threads + 1)
 

@@ -22,6 +22,6 @@ for f in ("1gpu_steps20","1gpu","cfg3","cfg4share","cfg5share"):
         j=json.loads(open("gpurun_out/r04_bench_%s.json"%f).read().strip().splitlines()[-1])
         sv=j.get("step_valu") or {}
         print(f, "value",round(j["value"]), "ms/step",round(j["ms_per_step"],3), "step_valu.frac", sv.get("frac"), "dom", j["roofline"]["kernel"][:50], "busy", j["roofline"].get("dominant_kernel_valu_busy"), "traffic", j["roofline"].get("traffic"), "pmc", bool(j["pmc_source"]))
-        if "e2e_host_buffers" in j: print("   e2e", round(j["e2e_host_buffers"]["proofs_per_s"]), round(j["e2e_host_buffers"]["pipelined"]["proofs_per_s"]), round(j["e2e_host_buffers"]["pipelined_staged"]["proofs_per_s"]))
+        if "e2e_host_buffers" in j: print("   e2e", round(j["e2e_host_buffers"]["proofs_per_s"]), round(j["e2e_host_buffers"]["pipelined"]["proofs_per_s"]), round(j["e2e_host_buffers"]["pipelined_staged"]["proofs_per_s"]), "threads", round(j["e2e_host_buffers"].get("threads", {}).get("proofs_per_s", 0)))
     except Exception as e: print(f,"ERR",e)
 PY

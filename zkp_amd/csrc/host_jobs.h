@@ -454,21 +454,23 @@ int zkp_fused_verify_batchable_submit(zkp_ctx* c, const zkp_fused_statement* st,
 
 // ---- the synchronous host-pointer entry points of zkp_mi355x.h (2c): the same jobs with the low-latency schedule, then wait ----------
 static int job_finish(zkp_ctx* c, int rc) { return rc ? rc : zkp_ctx_job_wait(c); }
+// ZKP_OPT_SYNC_SCHEDULE: 0 (default) = a synchronous call runs the low-latency schedule (the caller sees one call's duration); 1 = the jobs' throughput schedule
+static bool sync_latency(const zkp_ctx* c) { return !(c && c->sync_throughput); }
 int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets, const uint8_t* inst, const uint8_t* common,
                     const uint8_t* entropy, uint8_t* challenges, uint8_t* responses, uint8_t* commitments, int* invalid_point) {
   if (c && N && !entropy) return fail(ZKP_ERR_ARG, "NULL pointer");
-  return job_finish(c, prove_job(c, st, N, 0, transcripts, secrets, inst, N, common, entropy, nullptr, transcripts, challenges, responses, commitments, invalid_point, true));
+  return job_finish(c, prove_job(c, st, N, 0, transcripts, secrets, inst, N, common, entropy, nullptr, transcripts, challenges, responses, commitments, invalid_point, sync_latency(c)));
 }
 int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst, const uint8_t* common,
                              const uint8_t* challenges, const uint8_t* responses, uint8_t* results) {
-  return job_finish(c, verify_compact_job(c, st, N, 0, transcripts, inst, N, common, challenges, responses, transcripts, results, true));
+  return job_finish(c, verify_compact_job(c, st, N, 0, transcripts, inst, N, common, challenges, responses, transcripts, results, sync_latency(c)));
 }
 int zkp_fused_batch_verify_many(zkp_ctx* c, const zkp_fused_statement* st, uint32_t K, uint32_t N_each, uint8_t* transcripts, const uint8_t* inst, const uint8_t* common,
                                 const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16, int* verdicts, uint8_t* debug_scalars) {
   if (c && (K == 0 || (K != 1 && N_each == 0))) return fail(ZKP_ERR_ARG, "n_batches and N_each must be positive");
   if (c && K * N_each && st && st->shape.n_constraints && !weights16) return fail(ZKP_ERR_ARG, "NULL pointer");
   return job_finish(c, batch_verify_job(c, st, K, N_each, 0, transcripts, inst, K * N_each, common, commitments, responses, weights16, K * N_each, nullptr, transcripts, verdicts,
-                                        debug_scalars, true));
+                                        debug_scalars, sync_latency(c)));
 }
 int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst, const uint8_t* common,
                            const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16, int* verdict, uint8_t* debug_scalars) {
@@ -477,7 +479,7 @@ int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N
 int zkp_fused_verify_batchable_coeffs(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst, const uint8_t* common,
                                       const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16, uint8_t* results, uint8_t* debug_scalars) {
   if (c && N && st && st->shape.n_constraints && !weights16) return fail(ZKP_ERR_ARG, "NULL pointer");
-  return job_finish(c, verify_batchable_job(c, st, N, 0, transcripts, inst, N, common, commitments, responses, weights16, nullptr, transcripts, results, debug_scalars, true));
+  return job_finish(c, verify_batchable_job(c, st, N, 0, transcripts, inst, N, common, commitments, responses, weights16, nullptr, transcripts, results, debug_scalars, sync_latency(c)));
 }
 int zkp_fused_verify_batchable(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst, const uint8_t* common,
                                const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16, uint8_t* results) {

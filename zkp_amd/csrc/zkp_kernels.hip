@@ -1244,6 +1244,7 @@ struct zkp_ctx {
     bool copies_issued = false;
   } job;
   int defer_d2h = -1;                  // ZKP_OPT_JOB_DEFER_D2H: -1 = default (1), 0 = queue the copies out at submit
+  bool sync_throughput = false;        // ZKP_OPT_SYNC_SCHEDULE: the synchronous host-pointer entry points run the jobs' throughput schedule (callers with a thread per context)
   size_t ws_limit = 0;                 // ZKP_OPT_WS_LIMIT_BYTES: a call that would need a larger workspace fails with ZKP_ERR_OOM (0 = no cap)
   bool hot_registry_uploaded = false;  // the device copy of the fixed-base registry matches hot_key[]
 };
@@ -1784,6 +1785,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;
     case ZKP_OPT_LADDER_INTERLEAVE: c->ladder_interleave = value == ~0ull ? -1 : value != 0; return ZKP_OK;
     case ZKP_OPT_JOB_DEFER_D2H: c->defer_d2h = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
+    case ZKP_OPT_SYNC_SCHEDULE: c->sync_throughput = value != 0 && value != ~0ull; return ZKP_OK;
     case ZKP_OPT_WS_LIMIT_BYTES: c->ws_limit = value == ~0ull ? 0 : (size_t)value; return ZKP_OK;
     case ZKP_OPT_EACH_STRAUS:
     {

@@ -167,3 +167,28 @@ def test_host_backend_equals_device_path():
     finally:
         T.set_host_max_terms(16)
         eng.close()
+
+
+def test_c_example_links_the_libraries_and_matches_the_python_layer(host, tmp_path):
+    """examples/dleq_c_abi.c: plain C99 against include/zkp_toolbox.h and the two shared libraries (what a `-sys` crate links), host backend: builds
+    warning-free, every check of the example passes, and the proof it prints is the proof of the Python object layer (= the oracle's, first test of this
+    file) for the same secret, points and entropy."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "dleq_c_abi")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "dleq_c_abi.c"),
+                           "-L", os.path.join(root, "zkp_amd"), "-lzkp_toolbox", "-lzkp_mi355x", "-Wl,-rpath," + os.path.join(root, "zkp_amd"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "all checks passed (host backend, N = 1)" in out.stdout, (out.stdout, out.stderr)
+    printed = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines() if " " in l and not l.startswith("all"))
+    x, A, B, G, H = R._capi_points()
+    prover = T.Prover(b"DLEQProof", T.Transcript(LABEL), host)
+    var_x = prover.allocate_scalar(b"x", x)
+    var_B, _ = prover.allocate_point(b"B", B)
+    var_H, _ = prover.allocate_point(b"H", H)
+    var_A, _ = prover.allocate_point(b"A", A)
+    var_G, _ = prover.allocate_point(b"G", G)
+    R.dleq_statement(prover, var_x, var_A, var_G, var_B, var_H)
+    proof = prover.prove_compact(entropy=bytes(range(32)))
+    assert printed["challenge"].strip() == proof.challenge.hex() and printed["response"].strip() == proof.responses[0].hex()

@@ -41,13 +41,22 @@ fn check(rc: c_int) -> Result<(), Error> {
     }
 }
 
-/// One engine context = one GPU (one process per GPU in multi-GPU jobs).  Not `Sync`: a context is not re-entrant.
+/// One engine context = one GPU (one process per GPU in multi-GPU jobs).  Not `Sync`: a context is not re-entrant.  It is `Send`: a thread pool keeps one
+/// context per worker thread (contexts are independent of each other, as the reference's Prover / Verifier / BatchVerifier objects are).
 pub struct Engine(*mut sys::zkp_ctx);
+unsafe impl Send for Engine {}
 impl Engine {
     pub fn new(device_id: i32) -> Result<Engine, Error> {
         let mut ctx = ptr::null_mut();
         check(unsafe { sys::zkp_ctx_create(&mut ctx, device_id) })?;
         Ok(Engine(ctx))
+    }
+    /// A context for one worker of a thread pool: the synchronous calls run the throughput schedule of the asynchronous jobs (ZKP_OPT_SYNC_SCHEDULE = 1)
+    /// instead of the low-latency one a lone caller wants.  Six such workers reach the rate of `Pipe`'s jobs ("A thread pool of synchronous calls").
+    pub fn for_thread_pool(device_id: i32) -> Result<Engine, Error> {
+        let e = Engine::new(device_id)?;
+        check(unsafe { sys::zkp_ctx_set_option(e.0, sys::ZKP_OPT_SYNC_SCHEDULE, 1) })?;
+        Ok(e)
     }
     /// Hint: the statement's common points (define_proof!'s third list / BatchVerifier's static points) get fixed-base tables.
     pub fn prepare_fixed_points(&self, points: &[CompressedRistretto]) -> Result<(), Error> {

@@ -10,6 +10,7 @@
 //     TEETH = 4  (64 doublings per term, 33-entry table, 4.75 KB)   for points with a few uses,
 //     TEETH = 16 (16 doublings per term, 129-entry table, 18.6 KB)  from about 6 uses per point on (CMZ's P: 1564 -> 1168).
 // The first window's four doublings act on the identity and are skipped (12 doublings per term at TEETH = 16).
+// (The grouped walk through LDS, comb_group_block below, runs two accumulators instead: 16 doublings + 1 addition per term, each staged row serving two additions.)
 // Each row of the TEETH = 16 table is read by exactly one window of a term, so the constant-time scans stream the table
 // once per term instead of cycling 4 rows 16 times through a cache they do not fit (round 1: 556 MB of fabric traffic
 // per launch for 9.6 MB of algorithmic bytes).
@@ -387,64 +388,64 @@ __device__ __forceinline__ void comb_group_block(uint32_t i0, uint32_t n_g, cons
       dlo[w] = lo; dhi[w] = hi;
     }
   }
-  ge_p3 acc;
+  // TWO accumulators (end of round 4): `acc` collects windows 3 and 2, `lo` windows 1 and 0, so that a staged row serves two additions and the table passes
+  // through LDS twice instead of four times -- half the LDS-DMA loads, half the barriers, 42 % less HBM fetch in the term kernel (1,433 -> 834 MiB per launch of
+  // 20,480 CMZ proofs) -- for 16 doublings + 1 addition per term instead of 12 doublings:
+  //   pass 0: acc += T_j[d(j,3)], lo += T_j[d(j,1)] over the teeth j;  acc, lo <- 16 acc, 16 lo;  pass 1: acc += T_j[d(j,2)], lo += T_j[d(j,0)];  result = 256 acc + lo.
+  // Window-major with one accumulator (rounds 2 - 4) issued 15 LDS-DMA loads and two barriers per addition: 21 % of a wavefront's walk was spent issuing them
+  // (profiles/r04_ab_experiments.txt, block t).  The kernel needs 229 VGPRs this way (249 before: the compiler keeps fewer temporaries alive across the shorter
+  // loop body), +2 % on the term kernel at K = 50, +1 - 3 % on the step.  Four accumulators (every row staged once) would need ~72 more registers.
+  ge_p3 acc, lo;
   ge_identity(acc);
+  ge_identity(lo);
   issue(0);
-#ifdef ZKP_PROBE_TIMING
-  uint64_t tp[6] = {0, 0, 0, 0, 0, 0}, t0 = __builtin_readcyclecounter();
-#define ZKP_TP(i) { const uint64_t now_ = __builtin_readcyclecounter(); tp[i] += now_ - t0; t0 = now_; }
-#else
-#define ZKP_TP(i)
-#endif
-#pragma unroll 1
-  for (int w = cfg::WINDOWS - 1; w >= 0; --w) {
-    if (live && w != cfg::WINDOWS - 1) ge_double4(acc);            // (the accumulator is still the identity in the first window)
-    ZKP_TP(5)
-    uint32_t clo = dlo[0], chi = dhi[0];
+  auto pick = [&](uint32_t& c0, uint32_t& c1, ge_cached& sel, uint32_t& neg) {
+    const uint32_t nib = c0 & 15u;
+    c0 = __builtin_amdgcn_alignbit(c1, c0, 4);
+    c1 >>= 4;
+    neg = (uint32_t)(nib < 8u);
+    const uint32_t mag = neg ? 8u - nib : nib - 8u;              // 0..8
+    const uint32_t row = mag ? run * GROUP_ROW_CHUNKS + (mag - 1u) * 9u : (uint32_t)GROUP_IDENT_ROW;
+    const uint4* ent = lds + (size_t)row * 16 + col;
+    uint32_t wd[36];
 #pragma unroll
-    for (int q = 1; q < cfg::WINDOWS; ++q) { clo = (w == q) ? dlo[q] : clo; chi = (w == q) ? dhi[q] : chi; }
+    for (int q = 0; q < 9; ++q) {
+      const uint4 x = ent[q * 16];
+      wd[4 * q + 0] = x.x; wd[4 * q + 1] = x.y; wd[4 * q + 2] = x.z; wd[4 * q + 3] = x.w;
+    }
+    fe_set(sel.YmX, wd); fe_set(sel.YpX, wd + 9); fe_set(sel.Z2, wd + 18); fe_set(sel.T2d, wd + 27);
+  };
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (live && pass) { ge_double4(acc); ge_double4(lo); }
+    uint32_t alo = pass ? dlo[2] : dlo[3], ahi = pass ? dhi[2] : dhi[3];     // the 16 nibbles of the hi accumulator's window
+    uint32_t blo = pass ? dlo[0] : dlo[1], bhi = pass ? dhi[0] : dhi[1];     // ... and of the lo accumulator's
 #pragma unroll 1
     for (int j = 0; j < 16; ++j) {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // this step's rows have landed, for every wavefront's part
-      ZKP_TP(0)
       ge_cached sel;
       uint32_t neg = 0;
       if (live) {
-        const uint32_t nib = clo & 15u;
-        clo = __builtin_amdgcn_alignbit(chi, clo, 4);
-        chi >>= 4;
-        neg = (uint32_t)(nib < 8u);
-        const uint32_t mag = neg ? 8u - nib : nib - 8u;            // 0..8
-        const uint32_t row = mag ? run * GROUP_ROW_CHUNKS + (mag - 1u) * 9u : (uint32_t)GROUP_IDENT_ROW;
-        const uint4* ent = lds + (size_t)row * 16 + col;
-        uint32_t wd[36];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          const uint4 x = ent[q * 16];
-          wd[4 * q + 0] = x.x; wd[4 * q + 1] = x.y; wd[4 * q + 2] = x.z; wd[4 * q + 3] = x.w;
-        }
-        fe_set(sel.YmX, wd); fe_set(sel.YpX, wd + 9); fe_set(sel.Z2, wd + 18); fe_set(sel.T2d, wd + 27);
+        pick(alo, ahi, sel, neg);
+        ge_cached_cneg(sel, neg);
+        ge_add_cached(acc, acc, sel);                                      // (the rows stay: the second look-up reads them too)
+        pick(blo, bhi, sel, neg);
       }
-      ZKP_TP(1)
-      lds_barrier();                                               // every lane holds its entry: the rows may be replaced
-      ZKP_TP(2)
-      if (w != 0 || j != 15) issue((uint32_t)((j + 1) & 15));      // next step's rows arrive during the addition
-      ZKP_TP(3)
+      lds_barrier();                                               // every lane holds its second entry: the rows may be replaced
+      if (pass == 0 || j != 15) issue((uint32_t)((j + 1) & 15));   // next step's rows arrive during the second addition
       if (live) {
         ge_cached_cneg(sel, neg);
-        ge_add_cached(acc, acc, sel);
+        ge_add_cached(lo, lo, sel);
       }
-#ifdef ZKP_PROBE_TIMING
-      asm volatile("" : "+v"(acc.X.v[0]));
-#endif
-      ZKP_TP(4)
     }
   }
-#ifdef ZKP_PROBE_TIMING
-  if (i0 == 0 && tid == 0)
-    printf("[group walk probe] cycles: wait rows %llu | look-up %llu | read barrier %llu | issue DMA %llu | cneg + add %llu | doublings %llu\n",
-           (unsigned long long)tp[0], (unsigned long long)tp[1], (unsigned long long)tp[2], (unsigned long long)tp[3], (unsigned long long)tp[4], (unsigned long long)tp[5]);
-#endif
+  if (live) {
+    ge_double4(acc);
+    ge_double4(acc);                                               // 256 hi
+    ge_cached c;
+    ge_to_cached(c, lo);
+    ge_add_cached(acc, acc, c);
+  }
   if (live) {
     ge_cached sel, c;
     ge_cached_identity(sel);

@@ -498,3 +498,22 @@ def test_debug_transcript_env_dumps_the_op_log():
     quiet = subprocess.run([sys.executable, "-c", code], cwd=root, env={k: v for k, v in os.environ.items() if k != "ZKP_DEBUG_TRANSCRIPT"},
                            capture_output=True, text=True, timeout=120)
     assert quiet.returncode == 0 and "[merlin]" not in quiet.stderr and quiet.stdout == r.stdout
+
+
+def test_option_numbers_agree_between_header_python_and_rust():
+    """zkp_ctx_set_option's option ids are part of the ABI: include/zkp_mi355x.h's enum, zkp_amd/engine.py and rust/zkp-mi355x-sys must say the same."""
+    import re
+    from zkp_amd import engine as E
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "zkp_mi355x.h")).read()
+    enum = {k: int(v) for k, v in re.findall(r"(ZKP_OPT_[A-Z0-9_]+) = (\d+)", header)}
+    assert len(enum) >= 14 and sorted(enum.values()) == list(range(1, len(enum) + 1))
+    for k, v in enum.items():
+        if hasattr(E, k):
+            assert getattr(E, k) == v, k
+        assert re.search(r"ZKP_OPT_[A-Z_]+", k) and ("%s:" % k) in header or k in header
+    rust = open(os.path.join(root, "rust", "zkp-mi355x-sys", "src", "lib.rs")).read()
+    rs = {k: int(v) for k, v in re.findall(r"pub const (ZKP_OPT_[A-Z0-9_]+): c_int = (\d+);", rust)}
+    assert rs == enum
+    for k in enum:                                   # every option is documented in the header's comment block
+        assert (" *   %s:" % k) in header, k

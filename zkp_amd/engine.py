@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libzkp_mi355x.so")
 TESTHOOKS_LIB_PATH = os.path.join(_HERE, "libzkp_mi355x_testhooks.so")     # -DZKP_BUILD_TEST_HOOKS build (tests / A-B tools)
 ZKP_TESTOPT_DUMMY_LAUNCHES, ZKP_TESTOPT_GENERIC_CLASSIFIER, ZKP_TESTOPT_WAVE_CYCLES = 1001, 1002, 1003
 ZKP_OPT_CT_MASKED_SCANS, ZKP_OPT_EACH_STRAUS, ZKP_OPT_LADDER_INTERLEAVE = 9, 10, 11
+ZKP_OPT_WS_LIMIT_BYTES, ZKP_OPT_JOB_DEFER_D2H, ZKP_OPT_SYNC_SCHEDULE = 12, 13, 14
 
 ZKP_VARTIME = 0
 ZKP_CT = 1

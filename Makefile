@@ -3,7 +3,7 @@
 CSRC := zkp_amd/csrc
 HIP_DEPS := $(wildcard $(CSRC)/*.hip $(CSRC)/*.h include/*.h)
 HOST_SRCS := $(sort $(wildcard $(CSRC)/host/*.cpp))
-HOST_DEPS := $(HOST_SRCS) $(wildcard $(CSRC)/host/*.h $(CSRC)/host/*.hpp include/*.h) $(CSRC)/ge25519.h $(CSRC)/fe25519.h $(CSRC)/fe_constants.h
+HOST_DEPS := $(HOST_SRCS) $(wildcard $(CSRC)/host/*.h $(CSRC)/host/*.hpp $(CSRC)/host/*.map include/*.h) $(CSRC)/ge25519.h $(CSRC)/fe25519.h $(CSRC)/fe_constants.h
 
 all: zkp_amd/libzkp_mi355x.so zkp_amd/libzkp_toolbox.so
 
@@ -11,7 +11,7 @@ zkp_amd/libzkp_mi355x.so: $(HIP_DEPS)
 	hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value $(CSRC)/zkp_kernels.hip -o $@
 
 zkp_amd/libzkp_toolbox.so: $(HOST_DEPS) zkp_amd/libzkp_mi355x.so
-	g++ -O3 -std=c++17 -shared -fPIC -pthread -Wall -Wno-unknown-pragmas -I include $(HOST_SRCS) -o $@ -L zkp_amd -lzkp_mi355x -Wl,-rpath,'$$ORIGIN'
+	g++ -O3 -std=c++17 -shared -fPIC -pthread -Wall -Wno-unknown-pragmas -I include $(HOST_SRCS) -o $@ -L zkp_amd -lzkp_mi355x -Wl,-rpath,'$$ORIGIN' -Wl,--version-script=$(CSRC)/host/exports.map
 
 # the reference's DLEQ test in C99 against the two libraries alone: `build/dleq_c_abi` (host backend), `build/dleq_c_abi gpu 4096`
 example: all

@@ -62,9 +62,15 @@ METRIC = "proofs/sec + batch-verifies/sec, CMZ13 10-attr credential, 1/2/4/8 MI3
 # profiles/r04_opcode_mix.json (tools/opcode_mix.py) is the static opcode mix of every kernel, keyed to the kernel sources: information, not the weights.
 OPCODE_MIX = os.path.join("profiles", "r04_opcode_mix.json")
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
+# how the constant-time prover MSMs (prover.rs:94) pick the table entry a secret digit names: ZKP_OPT_CT_LOOKUP (include/zkp_mi355x.h)
+CT_SCHEDULES = {0: "lane crossbar: rows in registers, entries by ds_bpermute_b32 from one half of the wavefront, 8-entry private rows scanned with v_cndmask -- constant time BY CONSTRUCTION "
+                   "(no address, bank or branch depends on a secret; ZKP_OPT_CT_LOOKUP = 0, the default)",
+                1: "masked scans over every row (curve25519-dalek's LookupTable::select) -- constant time by construction (ZKP_OPT_CT_LOOKUP = 1)",
+                2: "rows replicated in LDS and read at the digit's index from banks no other lane of the service group uses -- constant time under the LDS bank model, "
+                   "NOT by construction (ZKP_OPT_CT_LOOKUP = 2, the default of rounds 2 - 4)"}
 LABEL = b"Benchmark"
 BASE = bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76")
-PMC_PATTERN = os.path.join("profiles", "r04_pmc_counters_cfg%s_k%d.json")   # one counter file per workload and batches-per-call (tools/collect_profiles.sh)
+PMC_PATTERN = os.path.join("profiles", "r05_pmc_counters_cfg%s_k%d.json")   # one counter file per workload and batches-per-call (tools/collect_profiles.sh)
 # what the HIP-event timing kinds of zkp_ctx_last_timing are, per flow: (kernel names as rocprofv3 prints them, launches per call).
 # roofline.kernel is chosen among the GROUPS below by kernel name, summed across flows (k_transcript_run* = 3 launches per step).
 KERNELS = {
@@ -139,6 +145,18 @@ def w64_statement():
     gs = [b"G_%d" % i for i in range(64)]
     return _index_form(xs, [(b"Q", False)] + [(g, True) for g in gs], [(b"Q", [(x, g) for x, g in zip(xs, gs)])])
 
+
+def w64_constraints_statement(terms_per_constraint=1):
+    """the OTHER reading of configs[4] ("64-constraint Schnorr"): 64 constraints Q_i = x_i * G_i (+ y_i * G_(i+1 mod 64)), the 64 generators common
+    (one fixed-base table each) -- 64 (128) secrets, 64 instance left-hand sides, 64 commitments per proof; the prover's 64 MSMs have 1 (2) terms each"""
+    xs = [b"x_%d" % i for i in range(64)]
+    ys = [b"y_%d" % i for i in range(64)] if terms_per_constraint == 2 else []
+    points = [(b"Q_%d" % i, False) for i in range(64)] + [(b"G_%d" % i, True) for i in range(64)]
+    cons = [(b"Q_%d" % i, [(b"x_%d" % i, b"G_%d" % i)] + ([(b"y_%d" % i, b"G_%d" % ((i + 1) % 64))] if ys else [])) for i in range(64)]
+    return _index_form(xs + ys, points, cons)
+
+
+W64_FORMS = {"terms": w64_statement, "constraints": lambda: w64_constraints_statement(1), "constraints2": lambda: w64_constraints_statement(2)}
 
 WORKLOADS = {
     # name: (description, [(statement label, statement fn, share of the batch, flows)], default batch, default streams (0 = auto), default steps)
@@ -710,7 +728,7 @@ def e2e_threads(n=4096, K=10, threads=6, jobs=24, mem="pageable", opts=((14, 1),
                     "puts the synchronous calls on the throughput schedule"}
 
 
-def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,)):
+def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,), submit_threads=-1):
     """The CMZ step through the BOUNDARY a Rust caller would bind, pipelined (include/zkp_toolbox.h: zkp_pipe): host buffers in, host
     buffers out, `jobs` prove jobs of K batches of n proofs each (zkp_prove_batch_submit) and, for every finished prove job, one
     zkp_batch_verify_many_submit over the proofs it returned (K verdicts) -- at most `contexts` jobs in flight per device, entropy
@@ -736,6 +754,8 @@ def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,)):
     with T.Pipe(tuple(devices), contexts) as pipe:
         host = {"submit_s": 0.0, "wait_s": 0.0}
         phases = {"P": [0.0, 0.0, 0.0, 0], "V": [0.0, 0.0, 0.0, 0]}
+        if submit_threads >= 0:
+            pipe.set_submit_threads(submit_threads)        # (default: one submitter thread per entry of the device list when there is more than one)
         if os.environ.get("ZKP_BENCH_JOB_TIMING"):
             pipe.set_profiling(True)
         if os.environ.get("ZKP_X_DEFER") is not None:          # (tools/x/ab_defer.py: A/B of ZKP_OPT_JOB_DEFER_D2H)
@@ -789,7 +809,7 @@ def e2e_pipelined(n=4096, K=5, contexts=6, jobs=24, pinned=True, devices=(0,)):
     d2h = jobs * (o["chal"].nbytes + o["resp"].nbytes + o["coms"].nbytes)
     return {"proofs_per_s": jobs * nn / el, "proofs": jobs * nn, "elapsed_ms": el * 1e3, "proofs_per_batch": n, "batches_per_submit": K, "jobs_in_flight": in_flight,
             "job_stream_ms": {k: {"h2d": v[0] / max(v[3], 1), "kernels": v[1] / max(v[3], 1), "d2h": v[2] / max(v[3], 1)} for k, v in phases.items()} if os.environ.get("ZKP_BENCH_JOB_TIMING") else None,
-            "devices": list(devices), "host_buffers": "pinned (zkp_host_alloc)" if pinned else "ordinary memory, staged through the pipe's pinned rings",
+            "devices": list(devices), "submit_threads": (len(devices) > 1) if submit_threads < 0 else bool(submit_threads), "host_buffers": "pinned (zkp_host_alloc)" if pinned else "ordinary memory, staged through the pipe's pinned rings",
             "h2d_GBps": h2d / el / 1e9, "d2h_GBps": d2h / el / 1e9, "host_ms_in_submit": host["submit_s"] * 1e3, "host_ms_in_wait": host["wait_s"] * 1e3, "bytes_per_proof": {"h2d": h2d / (jobs * nn), "d2h": d2h / (jobs * nn)}}
 
 
@@ -821,6 +841,11 @@ def main():
     ap.add_argument("--pipe-batches", type=int, default=10, help="e2e_host_buffers.pipelined: batches of --batch proofs per submitted job (rounds 3-4 measured 5: "
                                                                  "profiles/r04_ab_experiments.txt block n has 5 / 10 / 20 side by side)")
     ap.add_argument("--pipe-contexts", type=int, default=6, help="e2e_host_buffers.pipelined: contexts (= jobs in flight) of the zkp_pipe")
+    ap.add_argument("--w64-form", default="terms", choices=sorted(W64_FORMS), help="--config 5share: the reading of BASELINE configs[4] -- `terms` = ONE constraint of 64 terms "
+                    "(SURVEY section 8), `constraints` = 64 constraints of one term, `constraints2` = 64 constraints of two terms (a per-constraint generator + one shared)")
+    ap.add_argument("--no-sustained", action="store_true", help="--config 2: skip the `sustained` sub-record (4000 more steps at 50 batches per call after 0.6 s under load: "
+                    "the steady-state rate next to the short timed region) and the `ct` sub-record (the same steps on the other look-ups of ZKP_OPT_CT_LOOKUP)")
+    ap.add_argument("--sustained-steps", type=int, default=4000, help="steps of the `sustained` sub-record (a multiple of 50: >= 2 s of GPU time at the default)")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="ID=VALUE",
                     help="zkp_ctx_set_option(ID, VALUE) on every engine context (tuning experiments; results never depend on it)")
     args = ap.parse_args()
@@ -831,6 +856,11 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    if args.w64_form != "terms":
+        d5, p5, b5, s5, t5 = WORKLOADS["5share"]
+        what = "64 constraints of %d term%s: %d + %d N terms in the batch check" % ((1, "", 64, 128) if args.w64_form == "constraints" else (2, "s", 64, 128))
+        WORKLOADS["5share"] = (d5.replace("(64 + 2 N terms)", "(%s)" % what).replace("the 64-term wide statement", "the 64-CONSTRAINT wide statement"),
+                               [(p5[0][0], W64_FORMS[args.w64_form]) + tuple(p5[0][2:])], b5, s5, t5)
     desc, parts, def_batch, def_streams, def_steps = WORKLOADS[args.config]
     if args.steps is None:
         args.steps = def_steps
@@ -942,6 +972,27 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
         e2e = e2e_host_buffers(eng)
     for e_ in r["engines"]:
         e_.close()
+    # ---- what the short timed region cannot show, under the same clock: the steady-state rate, and the same steps on the other look-ups ----
+    sustained, ct = None, None
+    user_lookup = next((int(kv.split("=")[1]) for kv in args.engine_opt if int(kv.split("=")[0]) == 9), 0)
+    if args.config == "2" and not args.no_sustained and not args.no_flow_lines:
+        import copy
+        torch.cuda.empty_cache()
+        ss = max(50, args.sustained_steps // 50 * 50)
+        # 5 warm-up calls per stream = 20 calls of 204,800 proofs ~ 0.6 s under load before the clock starts; the timed part is >= 2 s
+        rs = run_workload(cx, args, "2", n, ss, 5, 50, 4, primary=False)
+        sustained = {"value": rs["value"], "unit": "proofs/s", "steps": ss, "ms_per_step": rs["ms_per_step"], "elapsed_s": rs["elapsed"], "batches_per_call": 50, "streams": rs["streams"],
+                     "warmup_calls_per_stream": 5, "note": "same flows, same statement, same process as `value`: %d more steps in calls of 50 batches on 4 streams, timed after 20 untimed calls "
+                     "(~0.6 s under load: the chip has settled at the clock it holds under these kernels); `value` stays the short region the driver asks for" % ss}
+        torch.cuda.empty_cache()
+        if world == 1 and len(eng.ct_lookups) > 1:       # (-DZKP_HOT_W=6 builds only: the shipped library has the crossbar look-up alone)
+            ct = {}
+            for name, lk in (("secret_indexed_lds_rows", 2), ("masked_scans", 1)):
+                a2 = copy.copy(args)
+                a2.engine_opt = [kv for kv in args.engine_opt if int(kv.split("=")[0]) != 9] + ["9=%d" % lk]
+                rr = run_workload(cx, a2, "2", n, args.steps, args.warmup, K, n_streams, primary=False)
+                ct[name] = rr["value"]
+                torch.cuda.empty_cache()
     if e2e is not None:
         # the same flows through the zkp_pipe of include/zkp_toolbox.h: jobs of K batches, several in flight, host buffers both ways
         torch.cuda.empty_cache()
@@ -1093,8 +1144,9 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
         "metric": METRIC, "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, u64 accumulate)",
         "data": "synthetic", "seed": 1000,                                      # numpy default_rng(seed + rank) drives every witness, point, entropy and weight
-        "config": {"workload": desc % n, "baseline_config": args.config, "batch_per_gpu": n, "batches_per_call": K, "calls": args.steps // K,
+        "config": {"workload": desc % n, "baseline_config": args.config, "w64_form": args.w64_form if args.config == "5share" else None, "batch_per_gpu": n, "batches_per_call": K, "calls": args.steps // K,
                    "streams": r["streams"], "hip_graphs": not args.no_graphs,
+                   "ct_schedule": CT_SCHEDULES[user_lookup],
                    "gpu_max_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "sharding": "independent proof ranges per GPU, AND of verdict bits",
                    "collective": dinfo["collective"], "backend_world_size": dinfo["backend_world_size"],
                    "excluded_from_value": "per-proof entropy (prover.rs:82 thread_rng) and batch weights (batch_verifier.rs:179) are fixed arrays resident in HBM, "
@@ -1108,6 +1160,24 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
         out["config"]["rccl_error"] = dinfo["rccl_error"]
     if step_valu:
         out["step_valu"] = step_valu
+    if sustained is not None:
+        try:                                       # its own VALU busy fraction, from the counter file of ITS call shape (K = 50), same rule: only at this source sha
+            pj50 = json.load(open(os.path.join(ROOT, PMC_PATTERN % ("2", 50))))
+            st50 = pj50.get("_step_totals", {})
+            if pj50.get("_source_sha256") == sha and pj50.get("_workload", {}).get("batch") == n and st50.get("valu_floor_ms_per_step_nameplate_clock"):
+                f50, f50o = st50["valu_floor_ms_per_step_nameplate_clock"], st50.get("valu_floor_ms_per_step_observed_clock")
+                sustained["step_valu"] = {"issue_cycles_per_step": st50.get("valu_issue_cycles_per_step"), "valu_floor_ms_per_step": f50, "frac": f50 / sustained["ms_per_step"],
+                                          "sclk_ghz_observed": st50.get("sclk_ghz_observed"), "frac_at_observed_sclk": f50o / sustained["ms_per_step"] if f50o else None,
+                                          "pmc_source": PMC_PATTERN % ("2", 50)}
+        except Exception:                          # noqa: BLE001 -- a reported extra
+            pass
+        out["sustained"] = sustained
+    if user_lookup in (0, 1):
+        out["value_ct_by_construction"] = value                     # the prover's constant-time promise (prover.rs:94) holds by construction on the schedule `value` ran on
+    if ct is not None:
+        out["ct"] = {"schedule_of_value": CT_SCHEDULES[user_lookup], "by_construction": user_lookup in (0, 1),
+                     "value_by_lookup": dict({"lane_crossbar" if user_lookup == 0 else ("masked_scans" if user_lookup == 1 else "secret_indexed_lds_rows"): value}, **ct),
+                     "note": "the same timed region (same steps, warm-up, call shape) under each look-up of ZKP_OPT_CT_LOOKUP; every one gives the same bytes (tests/test_gpu_device_entry.py)"}
     if multi is not None:
         out["configs"] = multi
     if e2e is not None:

@@ -78,11 +78,11 @@ const char* zkp_version(void);
  *     always do: a shorter call, more cross-stream dependencies.  Default 0.  (Measured again in round 4 on a LONE call chain: 2.87 -> 3.17 ms per
  *     prove call of 20,480 proofs -- no gain there either.)  In a process that owns one hardware queue (GPU_MAX_HW_QUEUES=1) a capture records the
  *     flow without the fork: ROCm 7.2.0 crashes in hipGraphLaunch on a forked graph under that setting.
- *   ZKP_OPT_GROUPED_COMB: 1 = constant-time calls list the terms of every point with 8 or more uses next to each other and
- *     walk that point's 16-teeth comb table through LDS (each lane reads the entry its digit names from an LDS column of its
- *     own: no masked scan, 20 % fewer instructions per addition, less independent work per lane); 0 = every comb term scans
- *     its rows with masks; UINT64_MAX = default: 1 for calls of 400,000 terms or more (asynchronous _dev
- *     calls: 250,000).
+ *   ZKP_OPT_GROUPED_COMB: 1 = constant-time calls list the terms of every point with 11 or more uses next to each other; a wavefront
+ *     then holds the rows of the (at most 8) 16-teeth comb tables its 64 terms need and every lane takes the entry its digit names over
+ *     the lane crossbar (ZKP_OPT_CT_LOOKUP: no masked scan, 20 % fewer instructions per addition, a row fetched once per wavefront instead
+ *     of once per lane); 0 = every comb term scans its rows with masks; UINT64_MAX = default: 1 for calls of 400,000 terms or more
+ *     (asynchronous _dev calls: 250,000).
  *   ZKP_OPT_TABLES_LANE: comb tables are built by one lane per point (1: half the instructions) or by four lanes per point
  *     (0: a quarter of the latency); UINT64_MAX = default: 1 in the asynchronous _dev entry points, 0 in the synchronous ones.
  *   ZKP_OPT_FUSE_TABLES_TRANSCRIPT: 1 = zkp_fused_prove_dev / _verify_compact_dev run their first transcript program in the same
@@ -95,13 +95,21 @@ const char* zkp_version(void);
  *   ZKP_OPT_TRANSCRIPT_LANES: lanes per proof in the Merlin transcript kernel of the fused flows.  2 = a lane pair per proof
  *     (each lane holds one 32-bit half of every STROBE word: half the latency), 1 = one lane per proof (23 % fewer
  *     instructions per Keccak-f), UINT64_MAX = default: 1 in asynchronous _dev calls of 65,536 proofs or more, 2 otherwise.
- *   ZKP_OPT_CT_MASKED_SCANS: 1 = the safe mode of the constant-time schedule.  By default a ZKP_CT call reads fixed-base rows (and, in
- *     wide calls, comb rows) from LDS at an index derived from the secret digit, from banks that no other lane of the ds_read_b128
- *     service group touches -- constant time under the LDS service-group / bank model of the hardware guide, checked with PMC
- *     counters and per-wavefront cycle counts (profiles/r03_constant_time_counters.txt).  With this option every table look-up of a
- *     ZKP_CT call is what curve25519-dalek does on a CPU: all entries of the row are read at fixed addresses and the wanted one is
- *     kept with v_cndmask (fixed-base rows: 32 entries, comb / ladder rows: 8), and the grouped comb walk is off.  Same bytes out;
- *     about 1.6 x the instructions of the term kernel.  Default 0.
+ *   ZKP_OPT_CT_LOOKUP: how a ZKP_CT call picks the table entry a secret digit names.
+ *     0 / UINT64_MAX (default since round 5) = LANE CROSSBAR: constant time by construction.  A wavefront holds the row in registers, one
+ *       entry per lane (fixed-base rows: 32 entries of a 6-bit window; grouped comb rows: 8 tables x 8 entries), and every lane fetches its
+ *       entry with ds_bpermute_b32 -- the digit selects a source LANE, never a memory address, and the layouts keep the sources of every
+ *       instruction inside one 32-lane half, where the crossbar has no bank conflicts whatever the digits are (hot_tables.h, comb_tables.h;
+ *       tools/microbench/bpermute_rate.hip).  Rows of 8 entries that belong to ONE lane (comb tables of points with fewer than 11 uses,
+ *       ladder tables) are scanned completely and the entry kept with v_cndmask, as curve25519-dalek's LookupTable::select does.  This is
+ *       what `RistrettoPoint::multiscalar_mul` promises at prover.rs:94, at the speed of the look-up of value 2 (profiles/r05_ab_experiments.txt).
+ *     1 = MASKED SCANS everywhere (fixed-base rows: 32 entries x 7 LDS reads + 864 selects per addition; no grouped comb walk): the
+ *       round-3 "safe mode"; same bytes, -25 % throughput.  Kept as the reference point of the other two.
+ *     2 = the default of rounds 2 - 4: rows replicated in LDS and read at an index derived from the digit, from banks that no other lane of
+ *       the ds_read_b128 service group touches -- constant time under the LDS bank / service-group model of the hardware guide (checked
+ *       with PMC counters and per-wavefront cycle counts), not by construction.
+ *     Same bytes out for every value (tests/test_gpu_device_entry.py); 1 and 2 exist for the 6-bit fixed-base window only.
+ *   ZKP_OPT_CT_MASKED_SCANS: the name ZKP_OPT_CT_LOOKUP had in rounds 3 - 4 (same id; value 1 still selects the masked scans, value 0 is now the crossbar).
  *   ZKP_OPT_EACH_STRAUS: how zkp_fused_verify_batchable[_dev] computes a proof's MSM over its points and commitments (verifier.rs:162-166).
  *     UINT64_MAX = default: one Straus walk per proof -- 256 shared doublings and one table addition per operand and window; below
  *     65,536 proofs split over 32 lanes per proof by windows (each lane: two windows of every operand; one quad of lanes per proof then
@@ -126,7 +134,7 @@ const char* zkp_version(void);
  *     zkp_pipe (zkp_toolbox.h) inside one GPU's memory.  0 / UINT64_MAX = no cap (default).
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
-       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_MASKED_SCANS = 9, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12, ZKP_OPT_JOB_DEFER_D2H = 13, ZKP_OPT_SYNC_SCHEDULE = 14 };
+       ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_LOOKUP = 9, ZKP_OPT_CT_MASKED_SCANS = 9 /* round-3 name: value 1 still selects the scans */, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12, ZKP_OPT_JOB_DEFER_D2H = 13, ZKP_OPT_SYNC_SCHEDULE = 14 };
 int zkp_ctx_set_option(zkp_ctx* ctx, int option, uint64_t value);
 
 /* HIP graphs.  A batch of proofs is a chain of ~35 short kernels (75 in round 1); enqueueing them one by one costs the host ~0.1 ms per
@@ -333,9 +341,15 @@ int zkp_fused_batch_verify_many_dev(zkp_ctx* ctx, const zkp_fused_statement* st,
  *       keyed with rng_seed[40] = key[32] || nonce[8], which the caller takes from the operating system per job -- what `thread_rng()` is
  *       to the reference (prover.rs:82, verifier.rs:153, batch_verifier.rs:179: rand 0.7's ThreadRng is a ChaCha stream keyed from the OS);
  *       entropy[j] = stream bytes [32 j, 32 j + 32), weights16 = the first 16 * n_constraints * N stream bytes in the array's own order.
- *     Errors: a submit that fails leaves no job pending and has waited for whatever it had queued (the caller's buffers are free again);
- *       zkp_ctx_job_wait < 0 means the device failed underneath the job: verdicts are set to 1 (rejected), *invalid_point to 1, and no
- *       output buffer may be used.  Any other call on a context with a pending job returns ZKP_ERR_ARG. */
+ *     Errors (fail closed): the verdict words of a job -- results[N] of the two per-proof verifiers, verdicts[n_batches] of the batch verifier --
+ *       are set to 1 (rejected) by the submit call itself as soon as its pointers have been checked, and only a job that ran to its end
+ *       overwrites them: a failed submit (which leaves no job pending and has waited for whatever it had queued: the caller's buffers are free
+ *       again) and a failed zkp_ctx_job_wait (< 0: the device failed underneath the job, or a copy out could not be issued by an earlier
+ *       zkp_ctx_job_poll) both leave every verdict at "rejected", *invalid_point at 1, and no output buffer may be used.  The pinned words a
+ *       wait derives verdicts from are poisoned at every submit, so nothing an earlier job left behind can read as "verified".
+ *       Any other call on a context with a pending job returns ZKP_ERR_ARG.
+ *     zkp_ctx_job_discard: for an owner that goes away with a job in flight (zkp_pipe_destroy): waits for the job's kernels, issues no copy
+ *       out that was not already queued (with the default of ZKP_OPT_JOB_DEFER_D2H -- deferred copies --: none) and writes nothing to the caller's memory. */
 #define ZKP_JOB_SHARED_TRANSCRIPT 1u
 int zkp_fused_prove_submit(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts,
                            const uint8_t* secrets, const uint8_t* inst, uint32_t inst_stride, const uint8_t* common,
@@ -356,6 +370,7 @@ int zkp_ctx_job_wait(zkp_ctx* ctx);      /* no job pending: ZKP_OK at once */
 int zkp_ctx_job_poll(zkp_ctx* ctx);      /* 1 = zkp_ctx_job_wait would not block, 0 = still running.  Polling also moves the job along: its copies
                                           * out are issued by the first poll (or wait) that finds its kernels finished -- see ZKP_OPT_JOB_DEFER_D2H */
 int zkp_ctx_job_pending(zkp_ctx* ctx);   /* 1 = a job was submitted and not yet waited for */
+int zkp_ctx_job_discard(zkp_ctx* ctx);   /* forget the pending job without touching the caller's memory (see Errors above) */
 /* With zkp_ctx_set_profiling(ctx, 1): where the last finished job spent its time ON ITS STREAM, from HIP events recorded on that stream --
  * ms[0] host -> device copies (+ on-device randomness), ms[1] the flow's kernels, ms[2] device -> host copies.  Under load these include the
  * time the stream waited for the chip / the copy engines, which is what a pipelining caller wants to see. */
@@ -364,6 +379,13 @@ int zkp_ctx_job_timing(zkp_ctx* ctx, float ms[3]);
 /* Pinned host memory for the jobs above (hipHostMalloc / hipHostRegister, visible to every GPU of the process).  zkp_host_is_pinned: 1 if p
  * points into such memory.  Registering costs ~12 us per MiB (profiles/r04_pcie_copy_rates.txt): register long-lived buffers once. */
 int zkp_host_alloc(void** out, size_t bytes);
+/* The same on the NUMA node of GPU `device` (round 5): on a two-socket host a staging buffer on the far socket sends every copied byte over the
+ * socket interconnect first.  zkp_host_numa_node: the node the device's PCIe root hangs off (sysfs), -1 = unknown; zkp_host_node_of: the node the
+ * page at p lives on, -1 = unknown.  Where the node is unknown or the kernel refuses the memory policy (a container's seccomp filter),
+ * zkp_host_alloc_on is zkp_host_alloc.  zkp_pipe's staging rings are allocated this way (zkp_toolbox.h). */
+int zkp_host_alloc_on(void** out, size_t bytes, int device);
+int zkp_host_numa_node(int device);
+int zkp_host_node_of(const void* p);
 void zkp_host_free(void* p);
 int zkp_host_register(void* p, size_t bytes);
 int zkp_host_unregister(void* p);

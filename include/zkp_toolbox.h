@@ -157,6 +157,14 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, u
  *         (results / verdicts set to "rejected", negative return code from zkp_job_wait);
  *       - batches below the fused threshold or with ragged transcripts run the synchronous call inside submit (same results).
  *     A pipe and its jobs belong to one host thread at a time.
+ *     SUBMITTER THREADS (round 5): a pipe over more than one entry of the device list carries out its submits on one host thread per entry --
+ *     zkp_*_submit reserves a context, queues the call for that device's thread and returns; the thread stages the buffers (its pinned rings
+ *     live on the GPU's NUMA node: zkp_host_alloc_on), enqueues the job, polls the contexts of ITS device so that a finished job's copies
+ *     out start at once, and retires finished jobs (staged outputs copied back, verdicts written); zkp_job_wait picks the result up.  A
+ *     single caller thread no longer pays 0.1 - 0.4 ms of host work per job per GPU (profiles/r05_pipe_host_scaling.txt: one submitting
+ *     thread is host-bound near three GPUs).  Consequences for the caller: errors the submit itself would have returned (a malformed call,
+ *     ZKP_ERR_OOM) arrive from zkp_job_wait; the STATEMENT, like every buffer, must stay alive until zkp_job_wait.  zkp_pipe_set_submit_threads
+ *     forces the mode (1 = threads also for one device, 0 = the caller's thread does everything, -1 = default) while no job is in flight.
  *
  * (b) SYNCHRONOUS CALLS OVER ALL CONTEXTS -- zkp_pipe_prove_batch, _verify_compact_batch, _verify_batchable_each, _batch_verify[_many],
  *     _batch_verify_locate: same arguments and results as the single-context calls, the N proofs sharded as contiguous ranges
@@ -170,12 +178,13 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, u
 typedef struct zkp_pipe zkp_pipe;
 typedef struct zkp_job zkp_job;
 int zkp_pipe_create(zkp_pipe** out, const int* device_ids, int n_devices, int contexts_per_device);
-void zkp_pipe_destroy(zkp_pipe* pipe);                    /* waits for jobs in flight */
+void zkp_pipe_destroy(zkp_pipe* pipe);                    /* jobs nobody waited for are DISCARDED: kernels waited for, nothing written to caller memory */
 int zkp_pipe_num_contexts(const zkp_pipe* pipe);
 int zkp_pipe_num_devices(const zkp_pipe* pipe);
 zkp_ctx* zkp_pipe_context(zkp_pipe* pipe, int i);        /* context i (tuning options, ZKP_OPT_WS_LIMIT_BYTES); do not destroy it */
 int zkp_pipe_context_device(const zkp_pipe* pipe, int i);
 int zkp_pipe_jobs_in_flight(const zkp_pipe* pipe);
+int zkp_pipe_set_submit_threads(zkp_pipe* pipe, int on);  /* -1 default (threads when the device list has more than one entry), 0 off, 1 on */
 const char* zkp_pipe_last_error(const zkp_pipe* pipe);    /* text of the last failure of a pipe call (never NULL) */
 
 int zkp_prove_batch_submit(zkp_pipe* pipe, const zkp_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts,

@@ -44,7 +44,8 @@ pub const ZKP_OPT_DEV_OVERLAP: c_int = 5;
 pub const ZKP_OPT_GROUPED_COMB: c_int = 6;
 pub const ZKP_OPT_TABLES_LANE: c_int = 7;
 pub const ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c_int = 8;
-pub const ZKP_OPT_CT_MASKED_SCANS: c_int = 9;
+pub const ZKP_OPT_CT_LOOKUP: c_int = 9;            // 0 lane crossbar (default), 1 masked scans, 2 LDS rows at the digit's index
+pub const ZKP_OPT_CT_MASKED_SCANS: c_int = 9;      // the round-3 name of the same option
 pub const ZKP_OPT_EACH_STRAUS: c_int = 10;
 pub const ZKP_OPT_LADDER_INTERLEAVE: c_int = 11;
 pub const ZKP_OPT_WS_LIMIT_BYTES: c_int = 12;
@@ -165,8 +166,12 @@ extern "C" {
     pub fn zkp_ctx_job_wait(ctx: *mut zkp_ctx) -> c_int;
     pub fn zkp_ctx_job_poll(ctx: *mut zkp_ctx) -> c_int;
     pub fn zkp_ctx_job_pending(ctx: *mut zkp_ctx) -> c_int;
+    pub fn zkp_ctx_job_discard(ctx: *mut zkp_ctx) -> c_int;
     pub fn zkp_ctx_job_timing(ctx: *mut zkp_ctx, ms: *mut f32) -> c_int;
     pub fn zkp_host_alloc(out: *mut *mut c_void, bytes: usize) -> c_int;
+    pub fn zkp_host_alloc_on(out: *mut *mut c_void, bytes: usize, device: c_int) -> c_int;
+    pub fn zkp_host_numa_node(device: c_int) -> c_int;
+    pub fn zkp_host_node_of(p: *const c_void) -> c_int;
     pub fn zkp_host_free(p: *mut c_void);
     pub fn zkp_host_register(p: *mut c_void, bytes: usize) -> c_int;
     pub fn zkp_host_unregister(p: *mut c_void) -> c_int;
@@ -227,6 +232,7 @@ extern "C" {
     pub fn zkp_pipe_context(pipe: *mut zkp_pipe, i: c_int) -> *mut zkp_ctx;
     pub fn zkp_pipe_context_device(pipe: *const zkp_pipe, i: c_int) -> c_int;
     pub fn zkp_pipe_jobs_in_flight(pipe: *const zkp_pipe) -> c_int;
+    pub fn zkp_pipe_set_submit_threads(pipe: *mut zkp_pipe, on: c_int) -> c_int;
     pub fn zkp_pipe_last_error(pipe: *const zkp_pipe) -> *const c_char;
     pub fn zkp_prove_batch_submit(pipe: *mut zkp_pipe, st: *const zkp_statement, n: u32, flags: u32, transcripts: *const u8, secrets: *const u8,
                                   inst_points: *const u8, inst_stride: u32, common_points: *const u8, entropy: *const u8,

@@ -429,11 +429,14 @@ impl Pipe {
 }
 impl Drop for Pipe {
     fn drop(&mut self) {
-        unsafe { sys::zkp_pipe_destroy(self.0) }      // waits for jobs in flight
+        unsafe { sys::zkp_pipe_destroy(self.0) }      // (every Job<'_> borrows the pipe: none is alive here; a forgotten one is discarded, not written)
     }
 }
 
-/// A submitted call.  Dropping a job without waiting leaves it to `Pipe`'s destructor (which waits); the borrow of its buffers ends with it.
+/// A submitted call.  The C side holds pointers into the job's buffers -- the borrowed inputs and outputs, and the boxed `verdicts` --
+/// until `zkp_job_wait` has returned, so a job that is dropped without `wait()` waits in `Drop` (its result is discarded): no pointer the
+/// library holds ever outlives the memory it names.  (`mem::forget`-ing a job leaks the box and keeps its context busy; it is still not a
+/// use-after-free, because `zkp_pipe_destroy` DISCARDS whatever jobs are pending -- it waits for their kernels and writes nothing.)
 pub struct Job<'a> {
     job: *mut sys::zkp_job,
     pipe: &'a Pipe,
@@ -447,6 +450,14 @@ impl<'a> Job<'a> {
         self.job = ptr::null_mut();
         if rc != 0 { return Err(self.pipe.err(rc)); }      // negative: the job failed closed, nothing it wrote may be used
         Ok(self.verdicts.take().map(|v| v.iter().map(|&x| if x == 0 { Ok(()) } else { Err(Error::VerificationFailure) }).collect()).unwrap_or_default())
+    }
+}
+impl<'a> Drop for Job<'a> {
+    fn drop(&mut self) {
+        if !self.job.is_null() {
+            unsafe { sys::zkp_job_wait(self.job) };        // buffers and `verdicts` are still alive here; the verdicts are dropped unread
+            self.job = ptr::null_mut();
+        }
     }
 }
 

@@ -15,7 +15,8 @@ class _OracleEngine:
 
 
 @pytest.mark.parametrize("st_fn,label", [(bench.cmz_statement, b"CMZ cred show n=10"), (bench.dleq_macro_statement, b"DLEQ proof"),
-                                         (bench.dleq_capi_statement, b"DLEQProof"), (bench.w64_statement, b"W64")])
+                                         (bench.dleq_capi_statement, b"DLEQProof"), (bench.w64_statement, b"W64"),
+                                         (bench.W64_FORMS["constraints"], b"W64"), (bench.W64_FORMS["constraints2"], b"W64")])
 def test_make_instance_gives_provable_statements(st_fn, label):
     C.build()
     st = st_fn()

@@ -273,22 +273,30 @@ def test_hip_graph_replay_equals_direct_calls(eng):
     stale.close()
 
 
-@pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1), (0, "masked"), (1, "masked"), (0, "interleave")])
+@pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1), (0, "masked"), (1, "masked"), (0, "lds"), (1, "lds"), (0, "interleave")])
 def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_tables, grouped):
     """ZKP_OPT_CT_SINGLE_USE_TABLES: a constant-time call serves a point that only one term multiplies either through a comb
     table (default when the call has shared points) or through the masked radix-16 ladder; both must give the oracle's bytes.
     CMZ shape (Q is the single-use point) and a DLEQ-like shape without any shared point (always the ladder).
-    grouped = ZKP_OPT_GROUPED_COMB: the terms of points with 8 or more uses walk the point's comb table through LDS (the
-    default of large calls), forced here at sizes that leave blocks partly filled and columns with 2 and 3 tables."""
+    grouped = ZKP_OPT_GROUPED_COMB: the terms of points with 9 or more uses are listed point by point and a wavefront walks the rows of its
+    (at most 8) tables together (the default of large calls), forced here at sizes that leave blocks partly filled and wavefronts with few and
+    with many tables.  "masked" / "lds" = ZKP_OPT_CT_LOOKUP 1 / 2: the other two ways to pick a table entry (default 0: the lane crossbar)."""
     from zkp_amd.engine import Engine
     import bench
     rng = np.random.default_rng(12)
     e = Engine(0)
+    if grouped in ("masked", "lds") and len(e.ct_lookups) == 1:
+        e.close()
+        pytest.skip("ZKP_OPT_CT_LOOKUP 1 / 2 exist in -DZKP_HOT_W=6 builds only (the shipped library: 7-bit windows, lane crossbar)")
     e.set_option(3, single_use_tables)
     if grouped == "masked":
         # ZKP_OPT_CT_MASKED_SCANS: the safe mode -- every table look-up of the constant-time call is a masked scan over the whole
         # row (fixed-base rows too), and the grouped walk stays off even when asked for
         e.set_option(9, 1)
+        e.set_option(6, 1)
+    elif grouped == "lds":
+        # ZKP_OPT_CT_LOOKUP = 2: the look-up of rounds 2 - 4 (rows replicated in LDS, read at the digit's index), grouped walk through LDS
+        e.set_option(9, 2)
         e.set_option(6, 1)
     elif grouped == "interleave":
         # ZKP_OPT_LADDER_INTERLEAVE: the ladder blocks spread over the front of the term kernel's grid (the default of launches with
@@ -366,9 +374,11 @@ def test_grouped_comb_walk_with_mixed_group_sizes(single_use_tables):
     e = Engine(0)
     e.prepare_fixed_points(pts[[3, 12]])                                 # two of the points are fixed-base points as well
     e.set_option(3, single_use_tables)
-    for grouped, masked in ((1, 0), (0, 0), (1, 1)):
+    for grouped, masked in ((1, 0), (0, 0), (1, 1), (1, 2), (0, 2)):
+        if masked not in e.ct_lookups:
+            continue
         e.set_option(6, grouped)
-        e.set_option(9, masked)                                          # ZKP_OPT_CT_MASKED_SCANS
+        e.set_option(9, masked)                                          # ZKP_OPT_CT_LOOKUP
         got, st = e.msm_many(off, sc, pidx, pts, 1)
         assert (st == wst).all() and (got[wst == 0] == want[wst == 0]).all(), (grouped, masked)
     e.close()
@@ -421,7 +431,7 @@ def test_mid_size_dev_call_variants_give_the_same_proofs(eng, opts):
 
 
 def test_masked_scan_safe_mode_gives_the_same_proofs(eng):
-    """ZKP_OPT_CT_MASKED_SCANS through the fused prover at the size where the wide-call variants (grouped walk, ladder) switch on
+    """ZKP_OPT_CT_LOOKUP (0 lane crossbar, 1 masked scans, 2 LDS rows) through the fused prover at the size where the wide-call variants (grouped walk, ladder) switch on
     by themselves: byte-identical proofs, and the batch of them verifies."""
     from zkp_amd.engine import Engine
     n = 13000                                                            # 403,000 terms: a wide call also for the synchronous entry points
@@ -431,16 +441,23 @@ def test_masked_scan_safe_mode_gives_the_same_proofs(eng):
     inst = np.ascontiguousarray(np.tile(inst, (1, reps, 1))[:, :n])
     entropy = np.random.default_rng(34).integers(0, 256, size=(n, 32), dtype=np.uint8)
     out = {}
-    for masked in (0, 1):
+    for masked in eng.ct_lookups:
         e = Engine(0)
         e.set_option(9, masked)
         ts = np.stack([T.Transcript(b"safe-mode").state] * n)
         out[masked] = T.prove_batch(e, mod.statement, ts, secrets, inst, common, entropy)
         e.close()
-    for a, b in zip(out[0], out[1]):
-        assert (a == b).all()
+    if len(out) == 1:                                                    # the shipped build: nothing to compare with, but unsupported values must be refused
+        e = Engine(0)
+        for v in (1, 2, 3):
+            with pytest.raises(Exception):
+                e.set_option(9, v)
+        e.close()
+    for other in [k for k in out if k != 0]:
+        for a, b in zip(out[0], out[other]):
+            assert (a == b).all(), other
     ts = np.stack([T.Transcript(b"safe-mode").state] * n)
-    T.batch_verify(eng, mod.statement, ts, inst, common, out[1][2], out[1][1])
+    T.batch_verify(eng, mod.statement, ts, inst, common, out[0][2], out[0][1])
 
 
 _ONE_QUEUE_SCRIPT = r"""

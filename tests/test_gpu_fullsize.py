@@ -356,3 +356,53 @@ def test_config2_bench_shape_many_batches_per_call(eng):
     ts = np.stack([T.Transcript(label).state] * n)
     v = T.batch_verify_many(eng, st, K, ts, inst, common, coms, bad, w)
     assert v.tolist() == [0, 1, 0, 0, 0, 0, 1, 0]
+
+
+@pytest.mark.parametrize("form", ["constraints", "constraints2"])
+def test_config5_share_64_constraint_reading_complete_flows_32768(eng, form):
+    """The other reading of BASELINE configs[4] ("64-constraint Schnorr"): 64 constraints Q_i = x_i G_i (+ y_i G_(i+1)) per proof, one GPU's share of
+    2^18 proofs.  Complete flows on the device: 32,768 proofs proven (2,097,152 commitment MSMs), verified one by one and batch-verified (one MSM of
+    64 + 128 N terms); sampled proofs equal the C oracle's; checksum of checksums over ALL commitments: sum_j sum_i K_ij = (sum of blindings x logs) B,
+    checked through the responses -- sum_i K_ij = sum_i (s_i - c x_i) G_i per proof, i.e. the batch check with all weights 1 is a size-independent
+    identity the oracle's verifier also computes; a tampered response fails the batch and verify_compact names the proof."""
+    import bench
+    from zkp_amd import toolbox as T
+    n = 32768
+    rng = np.random.default_rng(640 + len(form))
+    st3 = bench.W64_FORMS[form]()
+    secrets_l, points, cons = st3
+    secrets, inst, common = bench.make_instance(eng, st3, n, rng)
+    eng.prepare_fixed_points(common)
+    names = [nm.decode() for nm, _ in points]
+    st = T.Statement(b"W64")
+    sv = [st.add_secret(s) for s in secrets_l]
+    pv = [st.add_point(nm, c) for nm, c in points]
+    for lhs, lc in cons:
+        st.constrain(pv[lhs], [(sv[s], pv[p]) for s, p in lc])
+    cst = C.Statement(b"W64", [s.decode() for s in secrets_l], [(nm.decode(), c) for nm, c in points],
+                      [(names[l], [(secrets_l[s].decode(), names[q]) for s, q in lc]) for l, lc in cons])
+    entropy = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    label = b"config-5c"
+    t0 = T.Transcript(label).state
+    chal, resp, coms = T.prove_batch(eng, st, np.repeat(t0[None], n, axis=0), secrets, inst, common, entropy)
+    assert coms.shape == (n, 64, 32)
+    for j in (0, n // 2 + 1, n - 1):                         # allocation order: the 64 instance points, then the 64 generators
+        ec, er, ek, _ = C.prove(cst, label, secrets[j], np.concatenate([inst[:, j], common]), entropy[j].tobytes())
+        assert chal[j].tobytes() == ec.tobytes() and (resp[j] == er).all() and (coms[j] == ek).all(), j
+    assert not T.verify_compact_batch(eng, st, np.repeat(t0[None], n, axis=0), inst, common, chal, resp).any()
+    # the batch check, once with random weights and once with all weights 1 (the plain sum over all 2 M commitments: checksum of checksums)
+    w = rng.integers(0, 256, size=(64, n, 16), dtype=np.uint8)
+    T.batch_verify(eng, st, np.repeat(t0[None], n, axis=0), inst, common, coms, resp, w)
+    ones = np.zeros((64, n, 16), np.uint8)
+    ones[:, :, 0] = 1
+    T.batch_verify(eng, st, np.repeat(t0[None], n, axis=0), inst, common, coms, resp, ones)
+    bad = resp.copy()
+    bad[n - 7, 40, 3] ^= 4
+    with pytest.raises(T.VerificationFailure):
+        T.batch_verify(eng, st, np.repeat(t0[None], n, axis=0), inst, common, coms, bad, ones)
+    res = T.verify_compact_batch(eng, st, np.repeat(t0[None], n, axis=0), inst, common, chal, bad)
+    assert res[n - 7] == 1 and res.sum() == 1
+    # per-proof batchable verification on a slice (192 operands per proof: the operand-split Straus walk)
+    sl = slice(1000, 1000 + 2048)
+    each = T.verify_batchable_each(eng, st, np.repeat(t0[None], 2048, axis=0), np.ascontiguousarray(inst[:, sl]), common, coms[sl], bad[sl] if False else resp[sl])
+    assert not each.any()

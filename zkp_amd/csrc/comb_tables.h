@@ -306,7 +306,7 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
 // Per addition and lane: 15 LDS-DMA loads + 9 LDS reads instead of 72 loads + 288 selects.
 constexpr int GROUP_RUNS = 3, GROUP_ROW_CHUNKS = 8 * 9, GROUP_IDENT_ROW = GROUP_RUNS * GROUP_ROW_CHUNKS, GROUP_CHUNK_ROWS = GROUP_IDENT_ROW + 9;
 constexpr int GROUP_LDS_UINT4 = GROUP_CHUNK_ROWS * 16 + (256 + 16 * GROUP_RUNS) / 4;      // rows | slots[256] | colslot[16][3]
-static_assert(GROUP_MIN_USES >= 8, "a column of 16 consecutive grouped terms must span at most GROUP_RUNS points");
+static_assert(GROUP_MIN_USES >= 8, "a column of 16 consecutive grouped terms must span at most GROUP_RUNS points");      // (comb_group_block, ZKP_OPT_CT_LOOKUP = 2)
 
 __device__ __forceinline__ void comb_group_block(uint32_t i0, uint32_t n_g, const uint32_t* __restrict__ list_g, const uint8_t* __restrict__ scalars,
                                                  const uint32_t* __restrict__ pidx, const uint32_t* __restrict__ slot_of,
@@ -442,6 +442,155 @@ __device__ __forceinline__ void comb_group_block(uint32_t i0, uint32_t n_g, cons
   if (live) {
     ge_double4(acc);
     ge_double4(acc);                                               // 256 hi
+    ge_cached c;
+    ge_to_cached(c, lo);
+    ge_add_cached(acc, acc, c);
+  }
+  if (live) {
+    ge_cached sel, c;
+    ge_cached_identity(sel);
+    load_comb_entry(c, comb + (size_t)slot * cfg::ENTRIES + 8 * 16);     // carry out of bit 255: 2^256 * P
+    ge_cached_cmov(sel, c, top);
+    ge_add_cached(acc, acc, sel);
+    store_ext(partial + t, acc);
+  }
+}
+
+// ---- grouped comb terms, look-up on the lane crossbar (round 5): constant time BY CONSTRUCTION ------------------------------------------
+// comb_group_block reads LDS at an index the secret digit names and argues with the bank / service-group model that this takes the same
+// time for every digit.  Here the digit never becomes an address.  A WAVEFRONT takes 64 consecutive entries of the grouped list and holds
+// the row of a (window, tooth) step as 8 tables x 8 entries = 64 (table, entry) pairs: LANE 8 r + (k - 1) HOLDS entry k of the row of the
+// wavefront's r-th table.  The pair travels global -> LDS by LDS-DMA into the holder lane's OWN 144-byte slot (addresses: lane number and
+// table slot, both public), the holder reads its slot back with ds_read_b128 at that same public address, and the lane whose term is on
+// table r with digit magnitude m fetches the 36 words from lane 8 r + m - 1 with ds_bpermute_b32 -- a lane number, not an address.
+// What the crossbar still has is BANKS (hot_tables.h, tools/microbench/bpermute_rate.hip): an instruction is served in two groups of 32
+// lanes and two lanes of a group whose sources are 32 apart cost an extra cycle.  Lanes of one group read from lanes 8 r .. 8 r + 7 of
+// THEIR runs r, and sources 32 apart are entries of runs r and r + 4: with GROUP_MIN_USES >= 11, 32 consecutive list entries span at most
+// 2 + floor(30 / 11) = 4 runs (and 64 at most 2 + floor(62 / 11) = 7 <= XBAR_RUNS), so the runs of a group are four CONSECUTIVE numbers,
+// their source lanes 8 (r mod 4) + k are 32 distinct banks whatever the digits are, and SQ_LDS_BANK_CONFLICT of the walk is zero for every
+// scalar (tools/ct_check.py).  A zero digit fetches entry 1 and is masked to the identity.  No block barrier is left: a wavefront waits only
+// for its own DMA (vmcnt), so the four wavefronts of a block drift apart freely.  Per addition and wavefront: 4.5 LDS-DMA loads + 4.5
+// ds_read_b128 + 36 crossbar moves (comb_group_block: 7.5 + 9, two barriers per two additions); a table row is fetched once per WAVEFRONT
+// that holds terms of its point and pass -- 2 x 1.16 times for CMZ's P (11 terms) against 2 x 1.7 times per 16-lane column before.
+constexpr uint32_t XBAR_RUNS = 8;
+constexpr int XBAR_WAVE_UINT4 = 9 * 64;                         // a wavefront's staged pairs: chunk q of lane l at q * 64 + l
+constexpr int XBAR_LDS_UINT4 = 4 * XBAR_WAVE_UINT4;             // 36 KB per 256-lane block
+static_assert(2 + (64 - 2) / GROUP_MIN_USES <= XBAR_RUNS, "64 consecutive grouped terms must span at most XBAR_RUNS points");
+static_assert(2 + (32 - 2) / GROUP_MIN_USES <= 4, "32 consecutive grouped terms (one crossbar service group) must span at most 4 points: sources 32 lanes apart never meet");
+
+__device__ __forceinline__ void comb_group_xbar(uint32_t i0, uint32_t n_g, const uint32_t* __restrict__ list_g, const uint8_t* __restrict__ scalars,
+                                                const uint32_t* __restrict__ pidx, const uint32_t* __restrict__ slot_of,
+                                                const dev_ext* __restrict__ comb, dev_ext* __restrict__ partial, uint4* lds) {
+  using cfg = comb_cfg<16>;
+  constexpr uint32_t NONE = 0xffffffffu;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  if (i0 + wave * 64u >= n_g) return;                              // (a whole wavefront past the end of the list: nothing waits for it)
+  const uint32_t i = i0 + tid;
+  const bool listed = i < n_g;
+  uint32_t t = 0, slot = NONE;
+  if (listed) { t = list_g[i]; slot = slot_of[pidx[t]]; }           // (a grouped term's point index is in range by construction)
+  // runs of equal table slots in the wavefront (lanes past the end of the list join the last run)
+  const uint32_t before = (uint32_t)__shfl_up((int)slot, 1);
+  const bool change = lane == 0u || (listed && slot != before);
+  const uint64_t cm = __ballot(change);
+  const uint32_t run = (uint32_t)__popcll(cm & ((2ull << lane) - 1ull)) - 1u;
+  const bool live = listed && slot != NONE && run < XBAR_RUNS;      // (run < 8 always: see above)
+  // holder role: this lane keeps entry (lane & 7) + 1 of the table of run lane >> 3
+  int first = -1;
+  {
+    uint64_t mm = cm;
+#pragma unroll
+    for (uint32_t r = 0; r < XBAR_RUNS; ++r) {
+      const int f = mm ? (int)__ffsll((long long)mm) - 1 : -1;
+      if ((lane >> 3) == r) first = f;
+      mm &= mm - 1ull;
+    }
+  }
+  uint32_t hslot = (uint32_t)__shfl((int)slot, first < 0 ? 0 : first);
+  if (first < 0) hslot = NONE;
+  const bool have = hslot != NONE;
+  const uint4* hsrc = reinterpret_cast<const uint4*>(comb + (size_t)(have ? hslot : 0u) * cfg::ENTRIES + (lane & 7u));
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  uint4* wlds = lds + (size_t)wave * XBAR_WAVE_UINT4;
+  const uint4* mine = wlds + lane;
+  auto issue = [&](uint32_t row) {                                 // row = tooth: its 8 entries are dev_ext 8 row .. 8 row + 7 of a table
+    const uint4* p = hsrc + (size_t)row * (8 * 9);
+    if (have) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(p + q), (lptr_t)(wlds + 64 * q), 16, 0, 0);
+    }
+  };
+  // the scalar: signed radix-16 digits nibble - 8; D[w] = the 16 nibbles window w of the 16 teeth, tooth 0 lowest
+  uint32_t dlo[cfg::WINDOWS], dhi[cfg::WINDOWS], top = 0;
+  {
+    uint32_t sc[8], e[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sc[q] = 0;
+    if (live) load_vec<2>(sc, scalars + 32 * (size_t)t);
+    sc_add_pattern(e, top, sc, 0x88888888u);
+#pragma unroll
+    for (int w = 0; w < cfg::WINDOWS; ++w) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {                                // word m holds teeth 2m (low half) and 2m + 1
+        lo |= (((e[m] >> (4 * w)) & 0xfu) | ((e[m] >> (12 + 4 * w)) & 0xf0u)) << (8 * m);
+        hi |= (((e[m + 4] >> (4 * w)) & 0xfu) | ((e[m + 4] >> (12 + 4 * w)) & 0xf0u)) << (8 * m);
+      }
+      dlo[w] = lo; dhi[w] = hi;
+    }
+  }
+  // two accumulators as in comb_group_block: `acc` collects windows 3 and 2, `lo` windows 1 and 0; a staged row serves two additions
+  ge_p3 acc, lo;
+  ge_identity(acc);
+  ge_identity(lo);
+  issue(0);
+  const uint32_t run8 = (run & (XBAR_RUNS - 1u)) * 8u;
+  auto pick = [&](uint32_t& c0, uint32_t& c1, ge_cached& sel, uint32_t& neg) {      // EVERY lane runs this: a crossbar source must be an active lane
+    const uint32_t nib = c0 & 15u;
+    c0 = __builtin_amdgcn_alignbit(c1, c0, 4);
+    c1 >>= 4;
+    neg = (uint32_t)(nib < 8u);
+    const uint32_t mag = neg ? 8u - nib : nib - 8u;              // 0..8
+    const uint32_t nz = (uint32_t)(mag != 0u);
+    const int src = (int)((run8 + mag - nz) << 2);               // lane 8 run + mag - 1 (entry 1 for a zero digit: masked below)
+    uint32_t wd[36];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const uint4 x = mine[q * 64];                              // (public address: this lane's own slot)
+      wd[4 * q + 0] = xbar_fetch(src, x.x); wd[4 * q + 1] = xbar_fetch(src, x.y);
+      wd[4 * q + 2] = xbar_fetch(src, x.z); wd[4 * q + 3] = xbar_fetch(src, x.w);
+    }
+    const uint32_t m = 0u - nz, id = nz ^ 1u;                      // zero digit: the identity in table form (Y-X, Y+X, 2Z, 2dT) = (1, 1, 2, 0)
+#pragma unroll
+    for (int q = 0; q < 36; ++q) wd[q] &= m;
+    wd[0] |= id; wd[9] |= id; wd[18] |= id << 1;
+    fe_set(sel.YmX, wd); fe_set(sel.YpX, wd + 9); fe_set(sel.Z2, wd + 18); fe_set(sel.T2d, wd + 27);
+  };
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) { ge_double4(acc); ge_double4(lo); }
+    uint32_t alo = pass ? dlo[2] : dlo[3], ahi = pass ? dhi[2] : dhi[3];     // the 16 nibbles of the hi accumulator's window
+    uint32_t blo = pass ? dlo[0] : dlo[1], bhi = pass ? dhi[0] : dhi[1];     // ... and of the lo accumulator's
+#pragma unroll 1
+    for (int j = 0; j < 16; ++j) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this step's pairs have landed in this wavefront's slots
+      ge_cached sel;
+      uint32_t neg = 0;
+      pick(alo, ahi, sel, neg);
+      ge_cached_cneg(sel, neg);
+      ge_add_cached(acc, acc, sel);
+      pick(blo, bhi, sel, neg);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // every slot has been read: the next row may overwrite them
+      if (pass == 0 || j != 15) issue((uint32_t)((j + 1) & 15));      // ... and arrives during the second addition
+      ge_cached_cneg(sel, neg);
+      ge_add_cached(lo, lo, sel);
+    }
+  }
+  ge_double4(acc);
+  ge_double4(acc);                                                 // 256 hi
+  {
     ge_cached c;
     ge_to_cached(c, lo);
     ge_add_cached(acc, acc, c);

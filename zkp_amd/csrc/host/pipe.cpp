@@ -14,6 +14,7 @@
 #include <sys/random.h>
 
 #include <algorithm>
+#include <deque>
 #include <memory>
 
 #include "toolbox_internal.hpp"
@@ -25,6 +26,7 @@ namespace {
 struct PinBuf {
   uint8_t* p = nullptr;
   size_t cap = 0;
+  int device = 0;                    // the ring lives on the NUMA node of the GPU it feeds (zkp_host_alloc_on)
   int ensure(size_t n) {
     if (n <= cap) return ZKP_OK;
     if (p) zkp_host_free(p);
@@ -32,7 +34,7 @@ struct PinBuf {
     cap = 0;
     void* q = nullptr;
     const size_t want = n + n / 4 + 4096;
-    const int rc = zkp_host_alloc(&q, want);
+    const int rc = zkp_host_alloc_on(&q, want, device);
     if (rc) return rc;
     p = static_cast<uint8_t*>(q);
     cap = want;
@@ -44,9 +46,24 @@ struct PinBuf {
 struct Slot {
   zkp_ctx* ctx = nullptr;
   int device = 0;                    // HIP ordinal
-  int group = 0;                     // position in the device list the pipe was created over: one host thread per entry in the synchronous calls
-  bool busy = false;
+  int group = 0;                     // position in the device list the pipe was created over: one host thread per entry (synchronous calls, submitter threads)
+  std::atomic<bool> busy{false};     // a job is on the context's stream (set by whoever submitted it, cleared by zkp_job_wait)
+  std::atomic<bool> reserved{false}; // submitter threads: the caller has handed the slot to a job that its device's thread has yet to put on the stream
+  std::mutex ctx_mu;                 // poll / wait on the context: one thread at a time (a kick from another thread just skips a context somebody holds)
+  zkp_job* cur = nullptr;            // submitter threads: the OUTER job whose inner job is on this context (touched by the device's thread only)
   PinBuf in, out;
+};
+
+// One host thread per entry of the device list (round 5): asynchronous submits of a pipe over several GPUs are carried out here -- staging
+// memcpy, ~40 enqueue calls and the fixed-base table check of a job cost the submitting thread 0.1 - 0.4 ms, and ONE caller thread doing
+// that for eight GPUs is host-bound near three of them (profiles/r05_pipe_host_scaling.txt).  Between submits the thread polls the busy
+// contexts of ITS device, so a finished job's copies out start without the caller (what kick_all does on the caller's thread otherwise).
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  bool stop = false;
 };
 
 struct OutCopy { uint8_t* user; const uint8_t* staged; size_t bytes; };
@@ -70,10 +87,13 @@ struct zkp_pipe {
   size_t next = 0;
   std::mutex err_mu;                 // (the per-device threads of the synchronous calls may all report)
   std::string last_error;
+  int threaded = -1;                 // submitter threads: -1 = default (on when the pipe spans more than one entry of the device list), 0 / 1 = zkp_pipe_set_submit_threads
+  std::vector<std::unique_ptr<Worker>> workers;      // one per entry of the device list, started with the first threaded submit
+  bool use_threads() const { return threaded < 0 ? devices.size() > 1 : threaded != 0; }
   int find_free() {
     for (size_t i = 0; i < slots.size(); ++i) {
       const size_t k = (next + i) % slots.size();
-      if (!slots[k]->busy) { next = (k + 1) % slots.size(); return (int)k; }
+      if (!slots[k]->busy.load(std::memory_order_acquire) && !slots[k]->reserved.load(std::memory_order_acquire)) { next = (k + 1) % slots.size(); return (int)k; }
     }
     return -1;
   }
@@ -82,6 +102,13 @@ struct zkp_pipe {
 struct zkp_job {
   zkp_pipe* pipe = nullptr;
   int slot = -1;
+  // submitter threads: the handle the caller holds is an OUTER job; the device's thread performs the submit and leaves the real job in `inner`
+  bool outer = false;
+  zkp_job* inner = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  int state = 0;                     // outer: 0 = queued, 1 = on the stream (inner is set), 2 = the submit failed, 3 = retired by the device's thread: rc holds
+  int rc = 0;                        //        what zkp_job_wait returns (states 2 and 3)
   bool immediate = false;            // the call ran synchronously inside submit (small or ragged batch: host-transcript route)
   int immediate_rc = 0;
   char kind = 0;                     // 'P', 'V', 'E', 'B'
@@ -152,6 +179,16 @@ struct Gathered {
   }
 };
 
+// text for a negative code: the engine's own codes (> -10) come with zkp_last_error(); the toolbox's (<= -10) name themselves
+std::string err_text(int rc) {
+  if (rc > -10) return zkp_last_error();
+  switch (rc) {
+    case ZKP_TB_BAD_STATEMENT: return "malformed statement descriptor or NULL / inconsistent argument";
+    case ZKP_TB_INVALID_POINT: return "a point handed to the prover does not decode";
+    case ZKP_TB_NO_ENTROPY: return "getrandom() failed";
+    default: return "toolbox error " + std::to_string(rc);
+  }
+}
 int fail_pipe(zkp_pipe* p, int rc, const std::string& what) {
   if (p) {
     std::lock_guard<std::mutex> lk(p->err_mu);
@@ -176,6 +213,7 @@ int zkp_pipe_create(zkp_pipe** out, const int* device_ids, int n_devices, int co
       std::unique_ptr<Slot> s(new Slot());
       s->device = device_ids[d];
       s->group = d;
+      s->in.device = s->out.device = device_ids[d];
       const int rc = zkp_ctx_create(&s->ctx, device_ids[d]);
       if (rc) {
         for (auto& q : p->slots) zkp_ctx_destroy(q->ctx);
@@ -189,8 +227,15 @@ int zkp_pipe_create(zkp_pipe** out, const int* device_ids, int n_devices, int co
 
 void zkp_pipe_destroy(zkp_pipe* p) {
   if (!p) return;
+  for (auto& w : p->workers) {                           // queued submits are carried out (their callers may be about to wait), then the threads end
+    { std::lock_guard<std::mutex> lk(w->mu); w->stop = true; }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+  }
+  // Jobs still in flight belong to zkp_job handles nobody waited for; their owners (and the buffers and verdict words the jobs name) may be
+  // gone already.  Discard them: the kernels are waited for, no copy out is issued any more, nothing is written to caller memory.
   for (auto& s : p->slots) {
-    if (s->ctx) { (void)zkp_ctx_job_wait(s->ctx); zkp_ctx_destroy(s->ctx); }
+    if (s->ctx) { (void)zkp_ctx_job_discard(s->ctx); zkp_ctx_destroy(s->ctx); }
   }
   delete p;
 }
@@ -200,8 +245,15 @@ zkp_ctx* zkp_pipe_context(zkp_pipe* p, int i) { return (p && i >= 0 && (size_t)i
 int zkp_pipe_context_device(const zkp_pipe* p, int i) { return (p && i >= 0 && (size_t)i < p->slots.size()) ? p->slots[i]->device : -1; }
 int zkp_pipe_jobs_in_flight(const zkp_pipe* p) {
   int n = 0;
-  if (p) for (auto& s : p->slots) n += s->busy ? 1 : 0;
+  if (p) for (auto& s : p->slots) n += (s->busy.load() || s->reserved.load()) ? 1 : 0;
   return n;
+}
+int zkp_pipe_set_submit_threads(zkp_pipe* p, int on) {
+  if (!p) return ZKP_TB_BAD_STATEMENT;
+  for (auto& s : p->slots)
+    if (s->busy.load() || s->reserved.load()) return fail_pipe(p, ZKP_TB_PIPE_FULL, "zkp_pipe_set_submit_threads: wait for the jobs in flight first");
+  p->threaded = on < 0 ? -1 : (on ? 1 : 0);
+  return ZKP_TB_OK;
 }
 const char* zkp_pipe_last_error(const zkp_pipe* p) { return p ? p->last_error.c_str() : ""; }
 
@@ -211,19 +263,74 @@ namespace {
 
 // Jobs whose kernels have finished get their copies out started (zkp_ctx_job_poll issues them: zkp_mi355x.h 2d): called whenever the caller
 // is in the pipe anyway, so that a finished job's outputs are already travelling when somebody waits for it.
+void kick_slot(Slot* s) {
+  if (!s->busy.load(std::memory_order_acquire)) return;
+  std::unique_lock<std::mutex> lk(s->ctx_mu, std::try_to_lock);     // (somebody is waiting on it or kicking it already)
+  if (lk.owns_lock() && s->busy.load(std::memory_order_acquire)) (void)zkp_ctx_job_poll(s->ctx);
+}
 void kick_all(zkp_pipe* p) {
-  for (auto& s : p->slots)
-    if (s->busy) (void)zkp_ctx_job_poll(s->ctx);
+  for (auto& s : p->slots) kick_slot(s.get());
+}
+int wait_inner(zkp_job* jp);
+void finish_outer(zkp_job* o, int state, int rc) {
+  { std::lock_guard<std::mutex> lk(o->mu); o->rc = rc; o->state = state; }
+  o->cv.notify_all();
+}
+// the device's thread: jobs of this device whose kernels are done get their copies out issued (poll), finished ones are retired completely --
+// staged outputs copied to the caller's buffers, verdict words written -- so that the caller's zkp_job_wait only picks up the result
+void retire_group(zkp_pipe* p, int group) {
+  for (auto& sp : p->slots) {
+    Slot* s = sp.get();
+    if (s->group != group || !s->cur || !s->busy.load(std::memory_order_acquire)) continue;
+    bool done;
+    { std::lock_guard<std::mutex> lk(s->ctx_mu); done = zkp_ctx_job_poll(s->ctx) != 0; }
+    if (!done) continue;
+    zkp_job* o = s->cur;
+    s->cur = nullptr;
+    finish_outer(o, 3, wait_inner(o->inner));
+  }
+}
+
+void worker_loop(zkp_pipe* p, int group, Worker* w) {
+  for (;;) {
+    std::function<void()> fn;
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      // wake for work, or every 200 us to move this device's finished jobs along (their copies out are issued by the first poll after the kernels)
+      w->cv.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || !w->q.empty(); });
+      if (w->q.empty()) {
+        if (w->stop) {
+          bool pending = false;                           // (jobs still on a stream: retired before the thread ends, their callers may be waiting)
+          for (auto& sp : p->slots) pending = pending || (sp->group == group && sp->cur);
+          if (!pending) return;
+        }
+      } else {
+        fn = std::move(w->q.front());
+        w->q.pop_front();
+      }
+    }
+    if (fn) fn();
+    retire_group(p, group);
+  }
+}
+Worker* worker_of(zkp_pipe* p, int group) {
+  if (p->workers.size() != p->devices.size()) {
+    p->workers.clear();
+    for (size_t g = 0; g < p->devices.size(); ++g) p->workers.emplace_back(new Worker());
+  }
+  Worker* w = p->workers[group].get();
+  if (!w->th.joinable()) w->th = std::thread(worker_loop, p, group, w);
+  return w;
 }
 
 // what every submit starts with; *slot_out < 0 with rc == 0 never happens
 int begin_job(zkp_pipe* p, const zkp_statement* st, zkp_job** job, int want_slot, std::unique_ptr<zkp_job>& j, Slot** slot_out) {
   if (!p || !st || !job) return ZKP_TB_BAD_STATEMENT;
   *job = nullptr;
-  if (want_slot < 0) kick_all(p);                        // (the sharded synchronous calls run one thread per device: each looks after its own)
+  if (want_slot < 0) kick_all(p);                        // (the sharded synchronous calls and the submitter threads pass their slot: each looks after its own device)
   int k = want_slot;
   if (k < 0) k = p->find_free();
-  else if ((size_t)k >= p->slots.size() || p->slots[k]->busy) k = -1;
+  else if ((size_t)k >= p->slots.size() || p->slots[k]->busy.load()) k = -1;
   if (k < 0) return fail_pipe(p, ZKP_TB_PIPE_FULL, "every context of the pipe has a job in flight: zkp_job_wait one first");
   j.reset(new zkp_job());
   j->pipe = p;
@@ -239,7 +346,7 @@ int finish_immediate(zkp_job** job, std::unique_ptr<zkp_job>& j, int rc) {
 }
 int finish_submitted(zkp_pipe* p, Slot* s, zkp_job** job, std::unique_ptr<zkp_job>& j, int rc, const char* what) {
   if (rc) return fail_pipe(p, rc, what);
-  s->busy = true;
+  s->busy.store(true, std::memory_order_release);
   *job = j.release();
   return ZKP_TB_OK;
 }
@@ -255,7 +362,7 @@ int prove_submit_on(zkp_pipe* p, int want_slot, bool use_pool, const zkp_stateme
   j->N = N;
   j->use_pool = use_pool;
   if (N == 0) return finish_immediate(job, j, ZKP_TB_OK);
-  if (!ts || (st->ni && inst_stride < N)) return ZKP_TB_BAD_STATEMENT;
+  if (!ts || (st->ni && inst_stride < N)) return fail_pipe(p, ZKP_TB_BAD_STATEMENT, "prove: transcripts == NULL or inst_stride < N");
   const bool shared = (flags & ZKP_JOB_SHARED_TRANSCRIPT) != 0;
   const uint32_t m = (uint32_t)st->secrets.size(), nc = (uint32_t)st->cons.size(), ni = st->ni, ns = st->ns;
   if (!fused_ok(ts, N, shared)) {
@@ -301,7 +408,7 @@ int verify_compact_submit_on(zkp_pipe* p, int want_slot, bool use_pool, const zk
   j->results = results;
   j->use_pool = use_pool;
   if (N == 0) return finish_immediate(job, j, ZKP_TB_OK);
-  if (!ts || !results || (st->ni && inst_stride < N)) return ZKP_TB_BAD_STATEMENT;
+  if (!ts || !results || (st->ni && inst_stride < N)) return fail_pipe(p, ZKP_TB_BAD_STATEMENT, "verify: transcripts / results == NULL or inst_stride < N");
   const bool shared = (flags & ZKP_JOB_SHARED_TRANSCRIPT) != 0;
   const uint32_t m = (uint32_t)st->secrets.size(), ni = st->ni, ns = st->ns;
   if (!fused_ok(ts, N, shared)) {
@@ -342,7 +449,7 @@ int verify_each_submit_on(zkp_pipe* p, int want_slot, bool use_pool, const zkp_s
   j->results = results;
   j->use_pool = use_pool;
   if (N == 0) return finish_immediate(job, j, ZKP_TB_OK);
-  if (!ts || !results || (st->ni && inst_stride < N)) return ZKP_TB_BAD_STATEMENT;
+  if (!ts || !results || (st->ni && inst_stride < N)) return fail_pipe(p, ZKP_TB_BAD_STATEMENT, "verify: transcripts / results == NULL or inst_stride < N");
   const bool shared = (flags & ZKP_JOB_SHARED_TRANSCRIPT) != 0;
   const uint32_t m = (uint32_t)st->secrets.size(), nc = (uint32_t)st->cons.size(), ni = st->ni, ns = st->ns;
   if (!fused_ok(ts, N, shared)) {
@@ -382,14 +489,14 @@ int batch_many_submit_on(zkp_pipe* p, int want_slot, bool use_pool, const zkp_st
   Slot* s = nullptr;
   int rc = begin_job(p, st, job, want_slot, j, &s);
   if (rc) return rc;
-  if (!verdicts || K == 0 || N_each == 0 || (uint64_t)K * N_each > 0x7fffffffull) return ZKP_TB_BAD_STATEMENT;
+  if (!verdicts || K == 0 || N_each == 0 || (uint64_t)K * N_each > 0x7fffffffull) return fail_pipe(p, ZKP_TB_BAD_STATEMENT, "batch verification: verdicts == NULL, or n_batches / N_each out of range");
   const uint32_t N = K * N_each;
   j->kind = 'B';
   j->N = N;
   j->K = K;
   j->verdicts = verdicts;
   j->use_pool = use_pool;
-  if (!ts || (st->ni && inst_stride < N) || (weights16 && w_stride < N)) return ZKP_TB_BAD_STATEMENT;
+  if (!ts || (st->ni && inst_stride < N) || (weights16 && w_stride < N)) return fail_pipe(p, ZKP_TB_BAD_STATEMENT, "batch verification: transcripts == NULL or a stride smaller than the proof count");
   const bool shared = (flags & ZKP_JOB_SHARED_TRANSCRIPT) != 0;
   const uint32_t m = (uint32_t)st->secrets.size(), nc = (uint32_t)st->cons.size(), ni = st->ni, ns = st->ns;
   if (!fused_ok(ts, N, shared)) {
@@ -421,6 +528,37 @@ int batch_many_submit_on(zkp_pipe* p, int want_slot, bool use_pool, const zkp_st
   return finish_submitted(p, s, job, j, rc, "zkp_fused_batch_verify_many_submit");
 }
 
+// submitter threads: the caller reserves a context and gets an OUTER handle at once; the device's thread carries out the submit (do_submit(slot, &inner))
+template <typename F>
+int submit_threaded(zkp_pipe* p, const zkp_statement* st, zkp_job** job, F&& do_submit) {
+  if (!p || !st || !job) return ZKP_TB_BAD_STATEMENT;
+  *job = nullptr;
+  const int k = p->find_free();
+  if (k < 0) return fail_pipe(p, ZKP_TB_PIPE_FULL, "every context of the pipe has a job in flight: zkp_job_wait one first");
+  Slot* s = p->slots[k].get();
+  s->reserved.store(true, std::memory_order_release);
+  zkp_job* o = new zkp_job();
+  o->pipe = p;
+  o->slot = k;
+  o->outer = true;
+  Worker* w = worker_of(p, s->group);
+  {
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->q.emplace_back([s, o, k, fn = std::forward<F>(do_submit)]() mutable {
+      zkp_job* in = nullptr;
+      const int rc = fn(k, &in);
+      if (rc) { finish_outer(o, 2, rc); return; }
+      o->inner = in;
+      if (in->immediate) { finish_outer(o, 3, wait_inner(in)); return; }      // (small or ragged batch: it ran inside the submit)
+      s->cur = o;
+      { std::lock_guard<std::mutex> lk2(o->mu); o->state = 1; }
+    });
+  }
+  w->cv.notify_one();
+  *job = o;
+  return ZKP_TB_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -428,42 +566,87 @@ extern "C" {
 int zkp_prove_batch_submit(zkp_pipe* p, const zkp_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts, const uint8_t* secrets,
                            const uint8_t* inst_points, uint32_t inst_stride, const uint8_t* common_points, const uint8_t* entropy, uint8_t* transcripts_out,
                            uint8_t* challenges, uint8_t* responses, uint8_t* commitments, zkp_job** job) {
+  if (p && p->use_threads())
+    return submit_threaded(p, st, job, [=](int k, zkp_job** in) {
+      return prove_submit_on(p, k, false, st, N, flags, transcripts, secrets, inst_points, inst_stride, common_points, entropy, transcripts_out, challenges, responses, commitments, in);
+    });
   return prove_submit_on(p, -1, true, st, N, flags, transcripts, secrets, inst_points, inst_stride, common_points, entropy, transcripts_out, challenges, responses,
                          commitments, job);
 }
 int zkp_verify_compact_batch_submit(zkp_pipe* p, const zkp_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts, const uint8_t* inst_points,
                                     uint32_t inst_stride, const uint8_t* common_points, const uint8_t* challenges, const uint8_t* responses,
                                     uint8_t* transcripts_out, uint8_t* results, zkp_job** job) {
+  if (p && p->use_threads())
+    return submit_threaded(p, st, job, [=](int k, zkp_job** in) {
+      return verify_compact_submit_on(p, k, false, st, N, flags, transcripts, inst_points, inst_stride, common_points, challenges, responses, transcripts_out, results, in);
+    });
   return verify_compact_submit_on(p, -1, true, st, N, flags, transcripts, inst_points, inst_stride, common_points, challenges, responses, transcripts_out, results, job);
 }
 int zkp_verify_batchable_each_submit(zkp_pipe* p, const zkp_statement* st, uint32_t N, uint32_t flags, const uint8_t* transcripts, const uint8_t* inst_points,
                                      uint32_t inst_stride, const uint8_t* common_points, const uint8_t* commitments, const uint8_t* responses,
                                      const uint8_t* weights16, uint8_t* transcripts_out, uint8_t* results, zkp_job** job) {
+  if (p && p->use_threads())
+    return submit_threaded(p, st, job, [=](int k, zkp_job** in) {
+      return verify_each_submit_on(p, k, false, st, N, flags, transcripts, inst_points, inst_stride, common_points, commitments, responses, weights16, transcripts_out, results, in);
+    });
   return verify_each_submit_on(p, -1, true, st, N, flags, transcripts, inst_points, inst_stride, common_points, commitments, responses, weights16, transcripts_out,
                                results, job);
 }
 int zkp_batch_verify_many_submit(zkp_pipe* p, const zkp_statement* st, uint32_t n_batches, uint32_t N_each, uint32_t flags, const uint8_t* transcripts,
                                  const uint8_t* inst_points, uint32_t inst_stride, const uint8_t* common_points, const uint8_t* commitments,
                                  const uint8_t* responses, const uint8_t* weights16, uint32_t weights_stride, uint8_t* transcripts_out, int* verdicts, zkp_job** job) {
+  if (p && p->use_threads())
+    return submit_threaded(p, st, job, [=](int k, zkp_job** in) {
+      return batch_many_submit_on(p, k, false, st, n_batches, N_each, flags, transcripts, inst_points, inst_stride, common_points, commitments, responses, weights16, weights_stride,
+                                  transcripts_out, verdicts, in);
+    });
   return batch_many_submit_on(p, -1, true, st, n_batches, N_each, flags, transcripts, inst_points, inst_stride, common_points, commitments, responses, weights16,
                               weights_stride, transcripts_out, verdicts, job);
 }
 
 int zkp_job_context_index(const zkp_job* j) { return j ? j->slot : -1; }
-int zkp_job_done(const zkp_job* j) {
-  if (!j) return 1;
+int zkp_job_done(const zkp_job* jc) {
+  if (!jc) return 1;
+  zkp_job* j = const_cast<zkp_job*>(jc);
+  if (j->outer) {                                          // the device's thread moves the job along; the caller only looks at its state
+    std::lock_guard<std::mutex> lk(j->mu);
+    return j->state >= 2 ? 1 : 0;
+  }
   if (j->immediate) return 1;
-  return zkp_ctx_job_poll(j->pipe->slots[j->slot]->ctx);
+  Slot* s = j->pipe->slots[j->slot].get();
+  std::unique_lock<std::mutex> lk(s->ctx_mu, std::try_to_lock);
+  return lk.owns_lock() ? zkp_ctx_job_poll(s->ctx) : 0;
 }
 
 int zkp_job_wait(zkp_job* jp) {
   if (!jp) return ZKP_TB_BAD_STATEMENT;
+  if (!jp->outer) return wait_inner(jp);
+  std::unique_ptr<zkp_job> o(jp);
+  int rc;
+  {
+    std::unique_lock<std::mutex> lk(o->mu);
+    o->cv.wait(lk, [&] { return o->state >= 2; });
+    rc = o->rc;
+  }
+  o->pipe->slots[o->slot]->reserved.store(false, std::memory_order_release);
+  return rc;
+}
+
+}  // extern "C"
+
+namespace {
+// retires a job that is on a context's stream (or ran inside its submit): blocks until it is done, copies staged outputs, writes the verdicts
+int wait_inner(zkp_job* jp) {
   std::unique_ptr<zkp_job> j(jp);
   if (j->immediate) return j->immediate_rc;
   Slot* s = j->pipe->slots[j->slot].get();
-  if (j->use_pool) kick_all(j->pipe);                    // (use_pool = false: a per-device thread of a sharded call -- other threads own the other slots)
-  const int rc = zkp_ctx_job_wait(s->ctx);
-  s->busy = false;
+  if (j->use_pool) kick_all(j->pipe);                    // (use_pool = false: a per-device thread -- other threads own the other slots)
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(s->ctx_mu);
+    rc = zkp_ctx_job_wait(s->ctx);
+    s->busy.store(false, std::memory_order_release);
+  }
   if (rc) {
     // the device failed underneath the job: nothing it wrote may be read as a proof or as "verified"
     if (j->results) std::memset(j->results, 1, j->N);
@@ -475,8 +658,7 @@ int zkp_job_wait(zkp_job* jp) {
   if (j->kind == 'B') for (uint32_t b = 0; b < j->K; ++b) j->verdicts[b] = j->verdicts[b] ? ZKP_TB_VERIFICATION_FAILURE : ZKP_TB_OK;
   return ZKP_TB_OK;
 }
-
-}  // extern "C"
+}  // namespace
 
 // ---- synchronous calls over every context of a pipe: contiguous proof ranges, one host thread per device ------------------
 namespace {
@@ -484,9 +666,13 @@ namespace {
 struct Shard { uint32_t lo, hi; int slot; };
 
 // ranges [g n / G, (g + 1) n / G) over the first G = min(#contexts, n) contexts (SURVEY 8(e) / DESIGN section 8); empty ones dropped
-std::vector<Shard> make_shards(const zkp_pipe* p, uint32_t n) {
+// -- and no more contexts than keep every range on the fused device route (>= fused_min_batch proofs each): a range below it would run the
+// host-transcript route synchronously inside submit, one range after the other (N = 100 over 24 contexts: 24 ranges of 4 proofs, each a full
+// GPU call chain; one range of 100 instead).  `unit` = proofs per schedulable item (a whole batch for the K-batch call).
+std::vector<Shard> make_shards(const zkp_pipe* p, uint32_t n, uint32_t unit = 1) {
   std::vector<Shard> out;
-  const uint32_t G = (uint32_t)std::min<size_t>(p->slots.size(), n);
+  const uint64_t min_items = std::max<uint64_t>(1, ((uint64_t)std::max<uint32_t>(1, zkp_toolbox_get_fused_min_batch()) + unit - 1) / std::max<uint32_t>(1, unit));
+  const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(p->slots.size(), n), n / min_items));
   for (uint32_t g = 0; g < G; ++g) {
     const uint32_t lo = (uint32_t)((uint64_t)g * n / G), hi = (uint32_t)((uint64_t)(g + 1) * n / G);
     if (lo < hi) out.push_back({lo, hi, (int)g});
@@ -500,7 +686,7 @@ template <typename Submit>
 int run_shards(zkp_pipe* p, const std::vector<Shard>& shards, Submit&& submit, std::vector<int>& codes) {
   codes.assign(shards.size(), ZKP_TB_OK);
   for (auto& s : p->slots)
-    if (s->busy) return fail_pipe(p, ZKP_TB_PIPE_FULL, "the synchronous calls of a pipe need all of its contexts: wait for the submitted jobs first");
+    if (s->busy.load() || s->reserved.load()) return fail_pipe(p, ZKP_TB_PIPE_FULL, "the synchronous calls of a pipe need all of its contexts: wait for the submitted jobs first");
   std::vector<int> devs;                                    // entries of the pipe's device list that have work (an ordinal listed twice = two threads)
   for (const Shard& sh : shards) {
     const int d = p->slots[sh.slot]->group;
@@ -513,12 +699,12 @@ int run_shards(zkp_pipe* p, const std::vector<Shard>& shards, Submit&& submit, s
       if (p->slots[shards[i].slot]->group != devs[di]) continue;
       zkp_job* j = nullptr;
       const int rc = submit(shards[i], &j);
-      if (rc) { codes[i] = rc; if (rc < 0) errs[di] = zkp_last_error(); continue; }
+      if (rc) { codes[i] = rc; if (rc < 0) errs[di] = err_text(rc); continue; }
       mine.emplace_back(i, j);
     }
     for (auto& e : mine) {
       codes[e.first] = zkp_job_wait(e.second);
-      if (codes[e.first] < 0) errs[di] = zkp_last_error();
+      if (codes[e.first] < 0) errs[di] = err_text(codes[e.first]);
     }
   };
   if (devs.size() <= 1) {
@@ -631,7 +817,7 @@ int zkp_pipe_batch_verify_many(zkp_pipe* p, const zkp_statement* st, uint32_t K,
   if (n_transcripts != N) return ZKP_TB_BATCH_SIZE_MISMATCH;
   if (!transcripts) return ZKP_TB_BAD_STATEMENT;
   const size_t m = st->secrets.size(), nc = st->cons.size();
-  const std::vector<Shard> shards = make_shards(p, K);
+  const std::vector<Shard> shards = make_shards(p, K, N_each);
   const bool threads = p->devices.size() > 1;
   std::vector<int> codes;
   const int rc = run_shards(p, shards, [&](const Shard& sh, zkp_job** j) {

@@ -86,6 +86,13 @@ int job_begin(zkp_ctx* c, size_t pin_bytes) {
   }
   c->job.outs.clear();
   c->job.copies_issued = false;
+  c->job.copy_err = hipSuccess;
+  c->job.results = nullptr;
+  c->job.n_results = 0;
+  c->job.verdicts = nullptr;
+  c->job.invalid_point = nullptr;
+  // the words zkp_ctx_job_wait turns into verdicts start out as "rejected" / "invalid": whatever an earlier job left here can never read as "verified"
+  if (c->job.pin && pin_bytes) memset(c->job.pin, 0xff, pin_bytes);
   if (!c->job.copied) HIP_TRY(hipEventCreateWithFlags(&c->job.copied, hipEventDisableTiming));
   c->job.timed = c->profiling;
   if (c->job.timed) {
@@ -106,6 +113,14 @@ int job_commit(zkp_ctx* c, char kind, uint32_t K, int* verdicts, int* invalid_po
   c->job.invalid_point = invalid_point;
   return ZKP_OK;
 }
+// the caller's per-proof verdict array of a 'V' / 'E' job, registered right after job_begin: every failure path sets it to "rejected"
+void job_results(zkp_ctx* c, uint8_t* results, size_t n) { c->job.results = results; c->job.n_results = n; }
+// fail closed: nothing a failed job left in the caller's verdict words may read as "verified" / "valid"
+void job_reject_all(zkp_ctx* c, char kind) {
+  if (c->job.results && c->job.n_results) memset(c->job.results, 1, c->job.n_results);
+  if (kind == 'B' && c->job.verdicts) for (uint32_t b = 0; b < c->job.K; ++b) c->job.verdicts[b] = 1;
+  if (c->job.invalid_point) *c->job.invalid_point = 1;
+}
 // A failure after part of a job was queued: the queued copies still name the caller's buffers, so drain the stream before the
 // error goes back (the caller may free them), and leave no job pending.  Outputs are undefined, the code says so (fail closed).
 int job_abort(zkp_ctx* c, int rc) {
@@ -113,8 +128,11 @@ int job_abort(zkp_ctx* c, int rc) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipGetLastError();
   c->pending_tr.offered = c->pending_tr.active = false;
+  job_reject_all(c, 0);                                  // (the 'B' verdicts were preset to 1 by the submitter before anything was queued)
   c->job.kind = 0;
   c->job.outs.clear();
+  c->job.results = nullptr;
+  c->job.n_results = 0;
   g_last_error = msg;
   return rc;
 }
@@ -236,6 +254,7 @@ int verify_compact_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, ui
   if (rc) return rc;
   const fused_shape& s = pl->s;
   if (!challenges || !results || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
+  memset(results, 1, N);                                             // rejected until the job's copy out says otherwise (whatever fails from here on)
   if (s.ni && inst_stride < N) return fail(ZKP_ERR_ARG, "inst_stride is smaller than N");
   const uint32_t m = s.m, n_points = s.ns + s.ni * N;
   if ((uint64_t)N * pl->T1 > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
@@ -251,6 +270,7 @@ int verify_compact_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, ui
   if (rc) return rc;
   rc = job_begin(c, 16);
   if (rc) return rc;
+  job_results(c, results, N);
   const ws_view w{static_cast<char*>(c->ws)};
   ZKP_JOB_TRY(put_transcripts(c, N, shared, transcripts, w.u8(o_ts), w.u8(o_blob)));
   if (s.ns) ZKP_JOB_TRY(h2d(c, w.base + o_tbl, common, (size_t)s.ns * 32));
@@ -349,6 +369,7 @@ int verify_batchable_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, 
   if (rc) return rc;
   const fused_shape& s = pl->s;
   if ((s.nc && (!commitments || (!weights16 && !rng_seed))) || (s.m && !responses) || (s.ni && !inst) || (s.ns && !common)) return fail(ZKP_ERR_ARG, "NULL pointer");
+  memset(results, 1, N);                                             // rejected until the job's copy out says otherwise
   if (s.ni && inst_stride < N) return fail(ZKP_ERR_ARG, "inst_stride is smaller than N");
   const uint32_t m = s.m, nc = s.nc, ns = s.ns, ni = s.ni;
   const size_t n_points = (size_t)ns + (size_t)ni * N + (size_t)N * nc, K = (size_t)s.np + nc;
@@ -365,6 +386,7 @@ int verify_batchable_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, 
   if (rc) return rc;
   rc = job_begin(c, 16);
   if (rc) return rc;
+  job_results(c, results, N);
   const ws_view w{static_cast<char*>(c->ws)};
   ZKP_JOB_TRY(put_transcripts(c, N, shared, transcripts, w.u8(o_ts), w.u8(o_blob)));
   if (ns) ZKP_JOB_TRY(h2d(c, w.base + o_tbl, common, (size_t)ns * 32));
@@ -399,6 +421,66 @@ int zkp_host_alloc(void** out, size_t bytes) {
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(ZKP_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
   return ZKP_OK;
+}
+// The NUMA node a GPU hangs off (its PCIe root complex): hipDeviceAttributeHostNumaId, else /sys/bus/pci/devices/<domain:bus:device.function>/numa_node.  -1 = unknown
+// (no such file, a single-node host, a container that hides it).
+int zkp_host_numa_node(int device) {
+  int v = -1;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeHostNumaId, device) == hipSuccess && v >= 0) return v;       // (the runtime's own answer first)
+  (void)hipGetLastError();
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf) - 1, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  for (char* q = bdf; *q; ++q) *q = (char)tolower((unsigned char)*q);
+  const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+  FILE* f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+// Pinned memory on the NUMA node of `device`: on a two-socket host a staging ring on the far socket sends every byte of every copy over
+// the socket interconnect first.  The pages of a hipHostMalloc are placed when they are pinned, under the calling thread's memory policy:
+// the policy is set to "prefer the GPU's node" around the allocation (hipHostMallocNumaUser: the runtime keeps its hands off the policy) and
+// restored afterwards.  Raw syscalls, no libnuma.  Wherever the node is unknown or the kernel refuses the policy (seccomp in a container)
+// this is zkp_host_alloc: same memory, wherever the first touch lands it.
+int zkp_host_alloc_on(void** out, size_t bytes, int device) {
+  if (!out) return fail(ZKP_ERR_ARG, "NULL pointer");
+  *out = nullptr;
+  if (!bytes) return ZKP_OK;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(ZKP_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= count) return fail(ZKP_ERR_ARG, "zkp_host_alloc_on: no such device");
+  const int node = zkp_host_numa_node(device);
+#if defined(__linux__) && defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
+  if (node >= 0 && node < 1024) {
+    constexpr unsigned long MAXNODE = 1024;
+    unsigned long old_mask[MAXNODE / (8 * sizeof(unsigned long))] = {0}, want[MAXNODE / (8 * sizeof(unsigned long))] = {0};
+    int old_mode = 0;
+    const bool saved = syscall(SYS_get_mempolicy, &old_mode, old_mask, MAXNODE, nullptr, 0ul) == 0;
+    want[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+    if (saved && syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, want, MAXNODE) == 0) {
+      const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable | hipHostMallocNumaUser);
+      (void)syscall(SYS_set_mempolicy, old_mode, old_mask, MAXNODE);
+      if (e == hipSuccess) return ZKP_OK;
+      (void)hipGetLastError();
+      *out = nullptr;                                                // (an older runtime without the flag: fall through to the plain allocation)
+    }
+  }
+#else
+  (void)node;
+#endif
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+  return ZKP_OK;
+}
+// the NUMA node the page at p lives on (-1: unknown / not permitted): get_mempolicy(MPOL_F_NODE | MPOL_F_ADDR)
+int zkp_host_node_of(const void* p) {
+#if defined(__linux__) && defined(SYS_get_mempolicy)
+  int node = -1;
+  if (p && syscall(SYS_get_mempolicy, &node, nullptr, 0ul, const_cast<void*>(p), 3ul /* MPOL_F_NODE | MPOL_F_ADDR */) == 0) return node;
+#endif
+  (void)p;
+  return -1;
 }
 void zkp_host_free(void* p) { if (p) (void)hipHostFree(p); }
 int zkp_host_register(void* p, size_t bytes) {
@@ -499,13 +581,17 @@ static hipError_t job_issue_copies(zkp_ctx* c) {
     if (e == hipSuccess) e = hipMemcpyAsync(o.dst, o.src, o.bytes, hipMemcpyDeviceToHost, c->stream);
   if (c->job.timed) (void)hipEventRecord(c->job.tev[3], c->stream);
   if (e == hipSuccess) e = hipEventRecord(c->job.copied, c->stream);
-  c->job.copies_issued = true;
+  // `copied` stands for THIS job's copies only if it was recorded now: after a failure the event still carries an earlier job's record, and waiting on it
+  // would "succeed" with nothing copied.  The error is kept for zkp_ctx_job_wait, which reports it and rejects every verdict.
+  c->job.copies_issued = e == hipSuccess;
+  c->job.copy_err = e;
   return e;
 }
 int zkp_ctx_job_poll(zkp_ctx* c) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   if (!c->job.kind) return 1;
   (void)hipSetDevice(c->device);
+  if (c->job.copy_err != hipSuccess) return 1;                         // failed: zkp_ctx_job_wait reports it
   if (!c->job.copies_issued) {
     const hipError_t e = hipEventQuery(c->job.done);
     if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
@@ -517,24 +603,30 @@ int zkp_ctx_job_poll(zkp_ctx* c) {
   if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
   return 1;                                                            // done, or failed: zkp_ctx_job_wait reports which
 }
-int zkp_ctx_job_wait(zkp_ctx* c) {
+static int job_retire(zkp_ctx* c, bool discard) {
   if (!c) return fail(ZKP_ERR_ARG, "ctx is NULL");
   if (!c->job.kind) return ZKP_OK;
   const char kind = c->job.kind;
   (void)hipSetDevice(c->device);
-  hipError_t e = hipSuccess;
-  if (!c->job.copies_issued) {
+  hipError_t e = c->job.copy_err;                                      // (a poll may already have failed to issue the copies)
+  if (e == hipSuccess && !c->job.copies_issued) {
     e = hipEventSynchronize(c->job.done);
     // the kernels are done: now the copies out -- nothing waits inside the copy engine's queue (see job_t::outs)
-    if (e == hipSuccess && !c->job.outs.empty()) e = job_issue_copies(c);
+    if (e == hipSuccess && !c->job.outs.empty() && !discard) e = job_issue_copies(c);
   }
   if (e == hipSuccess && c->job.copies_issued) e = hipEventSynchronize(c->job.copied);
   c->job.outs.clear();
   c->job.kind = 0;
+  if (discard) {                                                       // the caller's memory may be gone: nothing is written to it
+    c->job.results = nullptr; c->job.n_results = 0; c->job.verdicts = nullptr; c->job.invalid_point = nullptr;
+    (void)hipGetLastError();
+    return ZKP_OK;
+  }
   if (e != hipSuccess) {
     // fail closed: whatever reached the caller's buffers must not be read as "verified" / "proven"
-    if (kind == 'B') for (uint32_t b = 0; b < c->job.K; ++b) c->job.verdicts[b] = 1;
-    if (kind == 'P' && c->job.invalid_point) *c->job.invalid_point = 1;
+    (void)hipStreamSynchronize(c->stream);                             // (copies that WERE queued still name the caller's buffers)
+    (void)hipGetLastError();
+    job_reject_all(c, kind);
     return fail(ZKP_ERR_HIP, std::string("job failed on the device: ") + hipGetErrorString(e));
   }
   if (c->job.timed)
@@ -554,5 +646,10 @@ int zkp_ctx_job_wait(zkp_ctx* c) {
   }
   return ZKP_OK;
 }
+int zkp_ctx_job_wait(zkp_ctx* c) { return job_retire(c, false); }
+// Forget the pending job: waits for its kernels (and for copies out that were already queued), issues no further copy and writes nothing to
+// the caller's verdict words.  For owners that go away with jobs in flight (zkp_pipe_destroy): with deferred copies out (the default) the
+// caller's output buffers are never touched after this call was entered.
+int zkp_ctx_job_discard(zkp_ctx* c) { return job_retire(c, true); }
 
 }  // extern "C"

@@ -24,21 +24,24 @@
 
 namespace zkp {
 
+// 7 since round 5 (37 additions per term instead of 43; rows of 64 entries are held as two sets of 32 lanes, fixed_base_xbar).  -DZKP_HOT_W=6 builds the
+// round 2 - 4 shape, the only one the look-ups 1 and 2 of ZKP_OPT_CT_LOOKUP exist for (A/B builds: profiles/r05_ab_experiments.txt).
 #ifndef ZKP_HOT_W
-#define ZKP_HOT_W 6
+#define ZKP_HOT_W 7
 #endif
-constexpr int HOT_W = ZKP_HOT_W;                                 // window width in bits (4, 5 or 6)
-constexpr int HOT_WINDOWS = (257 + HOT_W - 1) / HOT_W;           // 65, 52, 43
+constexpr int HOT_W = ZKP_HOT_W;                                 // window width in bits: 6, or 7 (crossbar look-ups only: fixed_base_xbar)
+constexpr int HOT_WINDOWS = (257 + HOT_W - 1) / HOT_W;           // 43, 37
 constexpr int HOT_HALF = 1 << (HOT_W - 1);                       // digits in [-HOT_HALF, HOT_HALF - 1]
 constexpr int HOT_ROW = HOT_HALF + 1;                            // entries per row: k * base for k = 0 (identity) .. HOT_HALF
 constexpr int HOT_SLOTS = 64;
 constexpr int HOT_CLASSES = HOT_SLOTS + 3;                       // class 64 = "cold" terms through a comb table, 65 = cold terms on a ladder,
 constexpr int CLASS_COMB = HOT_SLOTS, CLASS_LADDER = HOT_SLOTS + 1, CLASS_GROUP = HOT_SLOTS + 2;   // 66 = comb terms listed point by point
-constexpr uint32_t GROUP_MIN_USES = 8;                           // a point's terms form a group from this many cold uses on (comb_tables.h)
+constexpr uint32_t GROUP_MIN_USES = 11;                          // a point's terms form a group from this many cold uses on (comb_tables.h: 32 consecutive grouped terms then span <= 4 points, 64 <= 7)
 constexpr size_t HOT_SLOT_NIELS = (size_t)HOT_WINDOWS * HOT_ROW;
 constexpr int HOT_ROW_CHUNKS = HOT_ROW * (int)(sizeof(dev_niels) / 16);   // 16-byte chunks per row
 constexpr int HOT_COPIES = 16;
-static_assert(HOT_W >= 4 && HOT_W <= 6 && HOT_W * HOT_WINDOWS >= 258 && HOT_ROW_CHUNKS <= 256, "fixed-base window shape");
+static_assert(HOT_W >= 6 && HOT_W <= 7 && HOT_W * HOT_WINDOWS >= 258, "fixed-base window shape");
+constexpr bool HOT_LDS_ROWS = HOT_ROW_CHUNKS <= 256;             // the replicated-LDS-row walk (fixed_base_block) stages one chunk per lane: W = 6 only
 
 // word i of the recoding constant sum_w 2^(W w + W - 1)
 constexpr uint32_t hot_pattern_word(int i) {
@@ -467,6 +470,90 @@ __device__ __forceinline__ void fixed_base_block(ge_p3& acc, uint32_t e[9], bool
       ge_niels_cneg(q, neg);
       ge_madd(acc, acc, q);
     }
+  }
+}
+
+// ---- the same walk with the look-up on the lane crossbar (round 5): constant time BY CONSTRUCTION ------------------------------------
+// The secret digit never becomes a memory address -- not even an LDS one.  A wavefront holds the window's row in REGISTERS, one entry per
+// lane, and every lane fetches the entry its digit names with ds_bpermute_b32: the instruction moves VGPR data between lanes over the LDS
+// crossbar and takes a source LANE NUMBER instead of an address.  27 (W = 7: 54) crossbar moves per addition replace the 7 secret-indexed
+// ds_read_b128 of fixed_base_block<false> -- and the 16 ds_write_b128 per lane and the two block barriers per window that kept the
+// replicated rows coherent: a wavefront loads its own row (from L2) and never waits for another one.
+//
+// The crossbar is not free of banks, though (tools/microbench/bpermute_rate.hip, profiles/r05_bpermute_microbench.txt): the hardware serves
+// the instruction like a ds_read_b32 of address 4 x source lane -- two groups of 32 lanes, 32 banks, bank = source lane mod 32 -- and two
+// lanes of a group that name sources 32 apart (same bank, different "address") cost an extra LDS cycle: SQ_LDS_BANK_CONFLICT counts 2 per
+// instruction for random sources over all 64 lanes, and 0 whenever every source of an instruction lies in ONE half of the wavefront
+// (identity, broadcast, l mod 32, l xor 32).  So the layouts below keep the sources of every single instruction inside one half:
+//   a row is held as SETS of 32 entries; in a set, lane l < 32 holds words 0..15 of entry l + 1, lane l + 32 words 16..27 of the same entry
+//   (16 VGPRs per set); words 0..15 come from lane m, words 16..26 from lane m + 32 (m = magnitude - 1 within the set): the 64 lanes of an
+//   instruction all read lanes 0..31, or all read lanes 32..63 -- distinct sources are distinct banks, equal sources broadcast.
+//   W = 6: one set (32 non-zero entries), 27 moves.  W = 7: two sets (entries 1..32 and 33..64), both are fetched and the lane keeps the one
+//   its magnitude lies in (v_cndmask on a value that is secret but never an address or a branch): 54 moves + 27 selects, 37 additions
+//   per term instead of 43.
+// A zero digit reads entry 1 and is masked to the identity (1, 1, 0).  Every lane of the wavefront takes part whether it has a term or not
+// (a crossbar source must be an active lane); lanes without a term walk the scalar 0 and store nothing.
+__device__ __forceinline__ uint32_t xbar_fetch(int src_lane_x4, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane_x4, (int)v); }
+
+__device__ __forceinline__ void fixed_base_xbar(ge_p3& acc, uint32_t e[9], const uint4* __restrict__ rows) {
+  const uint32_t lane = threadIdx.x & 63u;
+  constexpr int SETS = HOT_HALF / 32;                                // 1 (W = 6) or 2 (W = 7)
+  static_assert(HOT_HALF == 32 * SETS && SETS >= 1 && SETS <= 2, "the crossbar walk holds sets of 32 entries");
+  // (entry 0 of a row in memory is the identity: skipped.)  Upper half: chunks 4, 5, 6 of the entry and chunk 6 once more (in bounds)
+  const uint4* my = rows + (size_t)(1u + (lane & 31u)) * 7u + (lane >> 5) * 4u;
+  const uint32_t last = lane < 32u ? 3u : 2u;
+  uint4 r[SETS][4];
+#pragma unroll
+  for (int s = 0; s < SETS; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[s][q] = my[(size_t)s * 32 * 7 + (q < 3 ? (uint32_t)q : last)];
+#pragma unroll 1
+  for (int w = 0; w < HOT_WINDOWS; ++w) {
+    uint32_t mag, neg;
+    hot_next_digit(e, mag, neg);
+    const uint32_t nz = (uint32_t)(mag != 0u);
+    const uint32_t m1 = mag - nz;                                     // magnitude - 1 (0 for a zero digit)
+    const int src = (int)((m1 & 31u) << 2);                          // lane (magnitude - 1) mod 32, x 4: always in the lower half
+    uint32_t wd[28];
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+      uint32_t t[28];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        t[4 * q + 0] = xbar_fetch(src, r[s][q].x); t[4 * q + 1] = xbar_fetch(src, r[s][q].y);
+        t[4 * q + 2] = xbar_fetch(src, r[s][q].z); t[4 * q + 3] = xbar_fetch(src, r[s][q].w);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {                                   // (+ 128: the same lane number in the upper half)
+        t[16 + 4 * q + 0] = xbar_fetch(src + 128, r[s][q].x); t[16 + 4 * q + 1] = xbar_fetch(src + 128, r[s][q].y);
+        t[16 + 4 * q + 2] = xbar_fetch(src + 128, r[s][q].z);
+        if (q < 2) t[16 + 4 * q + 3] = xbar_fetch(src + 128, r[s][q].w);       // (word 27 is the valid flag: not needed)
+      }
+      if (s == 0) {
+#pragma unroll
+        for (int i = 0; i < 27; ++i) wd[i] = t[i];
+      } else {
+        const bool hi = m1 >= 32u;                                    // the entry lies in the second set
+#pragma unroll
+        for (int i = 0; i < 27; ++i) wd[i] = hi ? t[i] : wd[i];
+      }
+    }
+    if (w + 1 < HOT_WINDOWS) {                                        // the next row travels during the addition
+      const uint4* nx = my + (size_t)(w + 1) * HOT_ROW_CHUNKS;
+#pragma unroll
+      for (int s = 0; s < SETS; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[s][q] = nx[(size_t)s * 32 * 7 + (q < 3 ? (uint32_t)q : last)];
+    }
+    const uint32_t m = 0u - nz;                                       // zero digit: the identity (1, 1, 0)
+#pragma unroll
+    for (int i = 0; i < 27; ++i) wd[i] &= m;
+    wd[0] |= nz ^ 1u;
+    wd[9] |= nz ^ 1u;
+    ge_niels q;
+    fe_set(q.ypx, wd); fe_set(q.ymx, wd + 9); fe_set(q.xy2d, wd + 18);
+    ge_niels_cneg(q, neg);
+    ge_madd(acc, acc, q);
   }
 }
 

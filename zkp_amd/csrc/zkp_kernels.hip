@@ -21,6 +21,9 @@
 // Point addition is commutative and the final encoding canonical, so the (non-deterministic)
 // order in which the atomics of k_pip_scatter fill a bucket cannot change a single output bit.
 #include <hip/hip_runtime.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
@@ -152,8 +155,18 @@ __device__ uint32_t g_wave_cycles_cap = 0;
 #define ZKP_WAVE_T1(cls)
 #endif
 
-// SCAN (constant-time calls only): the fixed-base blocks pick their table entries with masked scans (ZKP_OPT_CT_MASKED_SCANS)
-template <bool CT, int TEETH, bool LADDER, bool SCAN = false>
+// LOOKUP: how the fixed-base blocks and the grouped comb blocks pick a table entry (ZKP_OPT_CT_LOOKUP).
+//   LOOKUP_XBAR  the row sits in the wavefront's registers, the entry comes over the lane crossbar (ds_bpermute_b32): no address of any
+//                kind depends on the digit -- constant time by construction; the default of every call, and the only walk of 7-bit windows
+//   LOOKUP_SCAN  masked scans over whole rows (curve25519-dalek's LookupTable::select); the grouped class does not exist, comb terms scan
+//   LOOKUP_LDS   rounds 2 - 4: rows replicated in LDS, ds_read_b128 at an index the digit names, conflict-free under the bank model
+enum : int { LOOKUP_XBAR = 0, LOOKUP_SCAN = 1, LOOKUP_LDS = 2 };
+template <int LOOKUP>
+constexpr int terms_lds_uint4() {
+  if (LOOKUP == LOOKUP_XBAR) return XBAR_LDS_UINT4 > 512 ? XBAR_LDS_UINT4 : 512;          // (512: the comb / ladder blocks' scalar columns, 8 words x 256 lanes)
+  return HOT_ROW_CHUNKS * HOT_COPIES > GROUP_LDS_UINT4 ? HOT_ROW_CHUNKS * HOT_COPIES : GROUP_LDS_UINT4;
+}
+template <bool CT, int TEETH, bool LADDER, int LOOKUP = LOOKUP_XBAR>
 __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
@@ -163,7 +176,8 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   // A block of fixed-base terms serves ONE table; its rows pass through LDS one window at a time, in 16 copies, so that every
   // lane reads the entry its digit names from banks of its own (hot_tables.h): no masked scan, no bank conflict, the same
   // LDS cycles for every scalar.
-  __shared__ uint4 hot_lds[HOT_ROW_CHUNKS * HOT_COPIES > GROUP_LDS_UINT4 ? HOT_ROW_CHUNKS * HOT_COPIES : GROUP_LDS_UINT4];
+  static_assert(LOOKUP == LOOKUP_XBAR || HOT_LDS_ROWS, "7-bit fixed-base windows exist on the crossbar only");
+  __shared__ uint4 hot_lds[terms_lds_uint4<LOOKUP>()];
   uint32_t* ecol = reinterpret_cast<uint32_t*>(hot_lds) + threadIdx.x;      // (ladder and comb blocks: the recoded scalars)
   const uint32_t n_hot = class_start[CLASS_COMB], n_comb = class_start[CLASS_LADDER] - n_hot;
   const uint32_t n_ladder = LADDER ? class_start[CLASS_GROUP] - class_start[CLASS_LADDER] : 0u;
@@ -204,8 +218,12 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
     }
     ZKP_WAVE_T1(2);
   } else if (vb < ladder_blocks + comb_blocks + group_blocks) {
-    if constexpr (CT && TEETH == 16)                              // terms of points with many uses, listed point by point: rows through LDS
-      comb_group_block((vb - ladder_blocks - comb_blocks) * 256u, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
+    if constexpr (CT && TEETH == 16) {                            // terms of points with many uses, listed point by point
+      if constexpr (LOOKUP == LOOKUP_XBAR)
+        comb_group_xbar((vb - ladder_blocks - comb_blocks) * 256u, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
+      else
+        comb_group_block((vb - ladder_blocks - comb_blocks) * 256u, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
+    }
     ZKP_WAVE_T1(3);
   } else {
     const uint32_t hb = vb - ladder_blocks - comb_blocks - group_blocks;
@@ -219,11 +237,20 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
     uint32_t s[8], e[9];
     ge_p3 acc;
     ge_identity(acc);
-    if (live) {
-      load_vec<2>(s, scalars + 32 * (size_t)t);
-      hot_recode(e, s);
+    if constexpr (LOOKUP == LOOKUP_XBAR) {
+      if (hb * 256u + (threadIdx.x & ~63u) - blk_start[c] * 256u >= class_start[c + 1] - class_start[c]) return;    // a wavefront without terms (nothing waits for it)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s[q] = 0;
+      if (live) load_vec<2>(s, scalars + 32 * (size_t)t);
+      hot_recode(e, s);                                            // (lanes without a term walk the scalar 0: they are crossbar sources)
+      fixed_base_xbar(acc, e, src);
+    } else {
+      if (live) {
+        load_vec<2>(s, scalars + 32 * (size_t)t);
+        hot_recode(e, s);
+      }
+      fixed_base_block<LOOKUP == LOOKUP_SCAN>(acc, e, live, src, hot_lds);
     }
-    fixed_base_block<SCAN>(acc, e, live, src, hot_lds);
     if (live) store_ext(partial + t, acc);
     ZKP_WAVE_T1(4);
   }
@@ -1179,7 +1206,7 @@ struct zkp_ctx {
   bool each_straus = true;           // ZKP_OPT_EACH_STRAUS: verify_batchable's per-proof MSMs as one Straus walk per proof (0: one ladder per operand)
   uint32_t each_straus_lanes = 0;    //   ... with this many lanes per proof (0 = by batch size)
   uint32_t each_straus_wins = 0;     //   ... or with this many window parts per proof (0 = by batch size)
-  bool ct_masked_scans = false;      // ZKP_OPT_CT_MASKED_SCANS: constant-time calls pick every table entry with masked scans (no secret-indexed LDS read)
+  int ct_lookup = 0;                 // ZKP_OPT_CT_LOOKUP: how constant-time calls pick a table entry: 0 lane crossbar (default), 1 masked scans, 2 LDS rows read at the digit's index (rounds 2 - 4)
 #ifdef ZKP_BUILD_TEST_HOOKS
   uint64_t* wave_cycles = nullptr;   // ZKP_TESTOPT_WAVE_CYCLES: per-wavefront cycle recorder of the term kernel
   static constexpr uint32_t kWaveCyclesCap = 1u << 20;
@@ -1233,6 +1260,9 @@ struct zkp_ctx {
     uint32_t K = 0;
     int* verdicts = nullptr;           // 'B': [K], the caller's
     int* invalid_point = nullptr;      // 'P': the caller's
+    uint8_t* results = nullptr;        // 'V' / 'E': [n_results], the caller's -- set to 1 (rejected) whenever the job fails, at submit or at wait
+    size_t n_results = 0;
+    hipError_t copy_err = hipSuccess;  // what issuing the deferred copies out returned (zkp_ctx_job_poll may be the one that issues them; zkp_ctx_job_wait reports it)
     hipEvent_t tev[4] = {};            // profiling: job start | inputs on the device | flow done | outputs on the host
     bool timed = false;
     float ms[3] = {};                  // host -> device copies, kernels, device -> host copies of the last job (zkp_ctx_job_timing)
@@ -1377,7 +1407,7 @@ inline bool terms_batched_encode(const zkp_ctx* c, uint32_t n_terms, uint32_t n_
   return n_terms >= 1024 && (uint64_t)n_msm >= ((throughput && !c->batch_encode_user) ? kThroughputEncodeMin : c->batch_encode_min);
 }
 
-template <bool CT, int TEETH, bool SCAN = false>
+template <bool CT, int TEETH, int LOOKUP>
 void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
                         const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
                         const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part) {
@@ -1388,12 +1418,12 @@ void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_sca
     stride = (grid.x / 2) / lb;
     if (stride < 2) stride = 0;
   }
-  prof_note(c, ZKP_K_TERMS, std::string("k_terms_split<") + (CT ? "true" : "false") + ", " + std::to_string(TEETH) + ", " + (ladder ? "true" : "false") + ", " + (SCAN ? "true" : "false") + ">");
+  prof_note(c, ZKP_K_TERMS, std::string("k_terms_split<") + (CT ? "true" : "false") + ", " + std::to_string(TEETH) + ", " + (ladder ? "true" : "false") + ", " + std::to_string(LOOKUP) + ">");
   if (ladder)
-    hipLaunchKernelGGL((k_terms_split<CT, TEETH, true, SCAN>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
+    hipLaunchKernelGGL((k_terms_split<CT, TEETH, true, LOOKUP>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
                        c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
   else
-    hipLaunchKernelGGL((k_terms_split<CT, TEETH, false, SCAN>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
+    hipLaunchKernelGGL((k_terms_split<CT, TEETH, false, LOOKUP>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
                        c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
 }
 
@@ -1429,7 +1459,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     // (the LDS walk has fewer instructions but less independent work per lane than the masked scans: it wins once the call
     //  keeps every SIMD busy -- single kernel, 4096 CMZ proofs 590 vs 370 us, 8192: 860 vs 690, 16384: 1300 vs 1390; pipelined
     //  step: 4096 proofs -1 %, 8192 +1.6 %, 16384 +7 %, 524,288 +4.7 %)
-    const bool group_on = c->ct_masked_scans ? false : c->grouped_comb < 0 ? n_terms >= (k.throughput ? zkp_ctx::kWideCallTerms : zkp_ctx::kGroupedCombTerms) : c->grouped_comb != 0;
+    const bool group_on = (HOT_LDS_ROWS && c->ct_lookup == LOOKUP_SCAN) ? false : c->grouped_comb < 0 ? n_terms >= (k.throughput ? zkp_ctx::kWideCallTerms : zkp_ctx::kGroupedCombTerms) : c->grouped_comb != 0;
     const uint32_t group_min = (flags == ZKP_CT && k.teeth == 16 && group_on && k.max_tables) ? GROUP_MIN_USES : 0xffffffffu;
     uint32_t* gstart = reinterpret_cast<uint32_t*>(base + o.gstart);
     uint32_t* gfill = reinterpret_cast<uint32_t*>(base + o.gfill);
@@ -1490,16 +1520,22 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
       }
     }
     if (phase & PH_SCALARS) {
-      if (flags == ZKP_CT && c->ct_masked_scans) {
-        if (k.teeth == 16) launch_terms_split<true, 16, true>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
-        else launch_terms_split<true, 4, true>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
-      } else if (flags == ZKP_CT) {
-        if (k.teeth == 16) launch_terms_split<true, 16>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
-        else launch_terms_split<true, 4>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
-      } else {
-        if (k.teeth == 16) launch_terms_split<false, 16>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
-        else launch_terms_split<false, 4>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part);
+      // (vartime calls have nothing to hide: they never scan)
+      const int lookup = (!HOT_LDS_ROWS || c->ct_lookup == LOOKUP_XBAR) ? LOOKUP_XBAR : (flags == ZKP_CT ? c->ct_lookup : LOOKUP_LDS);
+#define ZKP_LAUNCH_TERMS(CT_, TEETH_, LK_) launch_terms_split<CT_, TEETH_, LK_>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part)
+      if (lookup == LOOKUP_XBAR) {
+        if (flags == ZKP_CT) { if (k.teeth == 16) ZKP_LAUNCH_TERMS(true, 16, LOOKUP_XBAR); else ZKP_LAUNCH_TERMS(true, 4, LOOKUP_XBAR); }
+        else { if (k.teeth == 16) ZKP_LAUNCH_TERMS(false, 16, LOOKUP_XBAR); else ZKP_LAUNCH_TERMS(false, 4, LOOKUP_XBAR); }
       }
+#if ZKP_HOT_W <= 6
+      else if (lookup == LOOKUP_SCAN) {
+        if (k.teeth == 16) ZKP_LAUNCH_TERMS(true, 16, LOOKUP_SCAN); else ZKP_LAUNCH_TERMS(true, 4, LOOKUP_SCAN);
+      } else {
+        if (flags == ZKP_CT) { if (k.teeth == 16) ZKP_LAUNCH_TERMS(true, 16, LOOKUP_LDS); else ZKP_LAUNCH_TERMS(true, 4, LOOKUP_LDS); }
+        else { if (k.teeth == 16) ZKP_LAUNCH_TERMS(false, 16, LOOKUP_LDS); else ZKP_LAUNCH_TERMS(false, 4, LOOKUP_LDS); }
+      }
+#endif
+#undef ZKP_LAUNCH_TERMS
     }
   } else {
     if (n_points && (phase & PH_POINTS)) hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, (const uint32_t*)nullptr);
@@ -1694,9 +1730,13 @@ extern "C" {
 
 const char* zkp_last_error(void) { return g_last_error.c_str(); }
 #ifdef ZKP_BUILD_TEST_HOOKS
-const char* zkp_version(void) { return "zkp-mi355x 0.3 gfx950 (9x29-bit limbs, v_mad_u64_u32) +test-hooks"; }
+#define ZKP_VERSION_TEXT_(w) "zkp-mi355x 0.5 gfx950 (9x29-bit limbs, v_mad_u64_u32; " #w "-bit fixed-base windows)"
+#define ZKP_VERSION_TEXT(w) ZKP_VERSION_TEXT_(w)
+const char* zkp_version(void) { return ZKP_VERSION_TEXT(ZKP_HOT_W) " +test-hooks"; }
 #else
-const char* zkp_version(void) { return "zkp-mi355x 0.3 gfx950 (9x29-bit limbs, v_mad_u64_u32)"; }
+#define ZKP_VERSION_TEXT_(w) "zkp-mi355x 0.5 gfx950 (9x29-bit limbs, v_mad_u64_u32; " #w "-bit fixed-base windows)"
+#define ZKP_VERSION_TEXT(w) ZKP_VERSION_TEXT_(w)
+const char* zkp_version(void) { return ZKP_VERSION_TEXT(ZKP_HOT_W); }
 #endif
 
 int zkp_ctx_create(zkp_ctx** out, int device_id) {
@@ -1782,7 +1822,10 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
-    case ZKP_OPT_CT_MASKED_SCANS: c->ct_masked_scans = value != 0 && value != ~0ull; return ZKP_OK;
+    case ZKP_OPT_CT_LOOKUP:
+      if (value == ~0ull) value = 0;
+      if (value > 2 || (value && !HOT_LDS_ROWS)) return fail(ZKP_ERR_ARG, "ZKP_OPT_CT_LOOKUP: 0 (lane crossbar), 1 (masked scans), 2 (LDS rows); 1 and 2 exist for 6-bit fixed-base windows only");
+      c->ct_lookup = (int)value; return ZKP_OK;
     case ZKP_OPT_LADDER_INTERLEAVE: c->ladder_interleave = value == ~0ull ? -1 : value != 0; return ZKP_OK;
     case ZKP_OPT_JOB_DEFER_D2H: c->defer_d2h = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_SYNC_SCHEDULE: c->sync_throughput = value != 0 && value != ~0ull; return ZKP_OK;

@@ -15,7 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkp_mi355x.so")
 TESTHOOKS_LIB_PATH = os.path.join(_HERE, "libzkp_mi355x_testhooks.so")     # -DZKP_BUILD_TEST_HOOKS build (tests / A-B tools)
 ZKP_TESTOPT_DUMMY_LAUNCHES, ZKP_TESTOPT_GENERIC_CLASSIFIER, ZKP_TESTOPT_WAVE_CYCLES = 1001, 1002, 1003
-ZKP_OPT_CT_MASKED_SCANS, ZKP_OPT_EACH_STRAUS, ZKP_OPT_LADDER_INTERLEAVE = 9, 10, 11
+ZKP_OPT_CT_LOOKUP, ZKP_OPT_EACH_STRAUS, ZKP_OPT_LADDER_INTERLEAVE = 9, 10, 11
+ZKP_OPT_CT_MASKED_SCANS = ZKP_OPT_CT_LOOKUP           # the round-3 name (value 1 = masked scans)
+ZKP_CT_LOOKUP_XBAR, ZKP_CT_LOOKUP_SCAN, ZKP_CT_LOOKUP_LDS = 0, 1, 2
 ZKP_OPT_WS_LIMIT_BYTES, ZKP_OPT_JOB_DEFER_D2H, ZKP_OPT_SYNC_SCHEDULE = 12, 13, 14
 
 ZKP_VARTIME = 0
@@ -31,7 +33,7 @@ EXPORTS = (
     "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_verify_batchable_dev", "zkp_fused_batch_verify_dev",
     "zkp_fused_verify_batchable_coeffs", "zkp_fused_batch_verify_many", "zkp_fused_batch_verify_many_dev", "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_ctx_capture_abort", "zkp_graph_launch", "zkp_graph_destroy",
     "zkp_fused_prove_submit", "zkp_fused_verify_compact_submit", "zkp_fused_batch_verify_many_submit", "zkp_fused_verify_batchable_submit",
-    "zkp_ctx_job_wait", "zkp_ctx_job_poll", "zkp_ctx_job_pending", "zkp_ctx_job_timing", "zkp_ctx_last_kernels", "zkp_host_alloc", "zkp_host_free", "zkp_host_register", "zkp_host_unregister",
+    "zkp_ctx_job_wait", "zkp_ctx_job_poll", "zkp_ctx_job_pending", "zkp_ctx_job_discard", "zkp_ctx_job_timing", "zkp_ctx_last_kernels", "zkp_host_alloc", "zkp_host_alloc_on", "zkp_host_numa_node", "zkp_host_node_of", "zkp_host_free", "zkp_host_register", "zkp_host_unregister",
     "zkp_host_is_pinned", "zkp_chacha20_fill_dev",
 )
 TEST_HOOK_EXPORTS = ("zkp_debug_quad_selftest", "zkp_debug_wave_cycles")      # only in libzkp_mi355x_testhooks.so
@@ -277,6 +279,12 @@ class Engine:
                                                            ptr(arrs[3]), ptr(arrs[4]), ptr(arrs[5]), ptr(res), ptr(co)), "zkp_fused_verify_batchable_coeffs")
         transcripts[...] = arrs[0]
         return res, co
+
+    @property
+    def ct_lookups(self):
+        """the values of ZKP_OPT_CT_LOOKUP this build of the library has: (0,) = lane crossbar only (7-bit fixed-base windows, the shipped shape);
+        (0, 1, 2) in a -DZKP_HOT_W=6 build (masked scans and the LDS rows of rounds 2 - 4 exist for the 6-bit window only)"""
+        return (0, 1, 2) if "6-bit" in self.version else (0,)
 
     def set_option(self, option: int, value: int) -> None:
         """Tuning knobs of include/zkp_mi355x.h (ZKP_OPT_*); results never depend on them."""

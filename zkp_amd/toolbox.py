@@ -18,6 +18,7 @@ marshals buffers.  Points are 32-byte ristretto255 encodings, scalars 32-byte li
 from __future__ import annotations
 
 import ctypes
+import weakref
 import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -41,7 +42,7 @@ EXPORTS = (
     "zkp_proof_compact_size", "zkp_proof_batchable_size", "zkp_proof_compact_encode", "zkp_proof_compact_decode",
     "zkp_proof_batchable_encode", "zkp_proof_batchable_decode", "zkp_batch_verify_locate", "zkp_batch_verify_many",
     "zkp_pipe_create", "zkp_pipe_destroy", "zkp_pipe_num_contexts", "zkp_pipe_num_devices", "zkp_pipe_context", "zkp_pipe_context_device",
-    "zkp_pipe_jobs_in_flight", "zkp_pipe_last_error", "zkp_prove_batch_submit", "zkp_verify_compact_batch_submit",
+    "zkp_pipe_jobs_in_flight", "zkp_pipe_set_submit_threads", "zkp_pipe_last_error", "zkp_prove_batch_submit", "zkp_verify_compact_batch_submit",
     "zkp_verify_batchable_each_submit", "zkp_batch_verify_many_submit", "zkp_job_done", "zkp_job_wait", "zkp_job_context_index", "zkp_pipe_prove_batch",
     "zkp_pipe_verify_compact_batch", "zkp_pipe_verify_batchable_each", "zkp_pipe_batch_verify", "zkp_pipe_batch_verify_many",
     "zkp_pipe_batch_verify_locate", "zkp_toolbox_set_host_max_terms", "zkp_toolbox_get_host_max_terms",
@@ -100,6 +101,7 @@ def lib() -> ctypes.CDLL:
         _lib.zkp_pipe_context.argtypes = [vp, i32]
         _lib.zkp_pipe_context.restype = vp
         _lib.zkp_pipe_context_device.argtypes = [vp, i32]
+        _lib.zkp_pipe_set_submit_threads.argtypes = [vp, i32]
         _lib.zkp_pipe_last_error.argtypes = [vp]
         _lib.zkp_pipe_last_error.restype = ctypes.c_char_p
         pj = ctypes.POINTER(vp)
@@ -493,11 +495,15 @@ def pinned_copy(a) -> np.ndarray:
 
 class Job:
     """A submitted call of a Pipe.  wait() returns what the synchronous call returns; the arrays handed to submit (kept alive
-    here) hold the outputs afterwards."""
+    here) hold the outputs afterwards.  The C side holds pointers into those arrays until the job has been waited for, so a Job
+    that is dropped un-waited waits in __del__, and Pipe.close() waits for every job it still has in flight first."""
 
-    def __init__(self, handle, keep, outputs, kind):
+    def __init__(self, handle, keep, outputs, kind, pipe=None):
         self._h, self._keep, self.outputs, self.kind = handle, keep, outputs, kind
         self.context = int(lib().zkp_job_context_index(handle))
+        self._pipe = pipe                                   # (keeps the pipe alive as long as the job is)
+        if pipe is not None:
+            pipe._jobs.add(self)
 
     def done(self) -> bool:
         return self._h is None or bool(lib().zkp_job_done(self._h))
@@ -512,6 +518,19 @@ class Job:
             _raise(rc, "zkp_job_wait")
         return self.outputs
 
+    def _retire(self) -> None:
+        """wait without raising (drop / pipe shutdown): afterwards nothing on the C side names this job's arrays"""
+        if self._h is not None:
+            h, self._h = self._h, None
+            self.rc = lib().zkp_job_wait(h)
+
+    def __del__(self):
+        try:
+            if self._pipe is None or getattr(self._pipe, "_h", None):
+                self._retire()
+        except Exception:
+            pass
+
 
 class Pipe:
     """zkp_pipe: `contexts_per_device` engine contexts on each listed GPU; asynchronous jobs (submit_* -> Job) and synchronous
@@ -524,9 +543,12 @@ class Pipe:
         if rc != 0:
             _raise(rc, "zkp_pipe_create")
         self._h = h
+        self._jobs = weakref.WeakSet()                      # submitted and not yet waited for
 
     def close(self):
         if getattr(self, "_h", None):
+            for j in list(self._jobs):                      # their arrays are still named by the contexts' pending copies
+                j._retire()
             lib().zkp_pipe_destroy(self._h)
             self._h = None
 
@@ -553,6 +575,13 @@ class Pipe:
 
     def last_error(self) -> str:
         return lib().zkp_pipe_last_error(self._h).decode()
+
+    def set_submit_threads(self, on: int) -> None:
+        """zkp_pipe_set_submit_threads: 1 = asynchronous submits are carried out by one host thread per entry of the device list (the default of a
+        pipe over several entries), 0 = by the caller's thread, -1 = default.  Only while no job is in flight."""
+        rc = lib().zkp_pipe_set_submit_threads(self._h, int(on))
+        if rc != 0:
+            _raise(rc, "zkp_pipe_set_submit_threads")
 
     def set_profiling(self, on: bool) -> None:
         hip = load_library()
@@ -610,7 +639,7 @@ class Pipe:
         rc = lib().zkp_prove_batch_submit(self._h, st._h, n, flags, _p(keep[0]), _p(keep[1]), _p(keep[2]), inst_stride or n, _p(keep[3]), _p(keep[4]),
                                           _p(ts_out), _p(chal), _p(resp), _p(coms), ctypes.byref(h))
         self._submit(rc, h, "zkp_prove_batch_submit")
-        return Job(h, keep, (chal, resp, coms) + ((ts_out,) if want_transcripts else ()), "prove")
+        return Job(h, keep + [st], (chal, resp, coms) + ((ts_out,) if want_transcripts else ()), "prove", self)
 
     def submit_batch_verify_many(self, st: Statement, n_batches: int, n_each: int, transcripts, inst, common, commitments, responses, weights16=None,
                                  want_transcripts=False, inst_stride: Optional[int] = None, weights_stride: Optional[int] = None) -> Job:
@@ -625,7 +654,7 @@ class Pipe:
         rc = lib().zkp_batch_verify_many_submit(self._h, st._h, n_batches, n_each, flags, _p(keep[0]), _p(keep[1]), inst_stride or n, _p(keep[2]), _p(keep[3]),
                                                 _p(keep[4]), _p(keep[5]), weights_stride or n, _p(ts_out), _p(verdicts), ctypes.byref(h))
         self._submit(rc, h, "zkp_batch_verify_many_submit")
-        return Job(h, keep, (verdicts,) + ((ts_out,) if want_transcripts else ()), "batch_verify_many")
+        return Job(h, keep + [st], (verdicts,) + ((ts_out,) if want_transcripts else ()), "batch_verify_many", self)
 
     def submit_verify_compact(self, st: Statement, n: int, transcripts, inst, common, challenges, responses, want_transcripts=False,
                               inst_stride: Optional[int] = None) -> Job:
@@ -638,7 +667,7 @@ class Pipe:
         rc = lib().zkp_verify_compact_batch_submit(self._h, st._h, n, flags, _p(keep[0]), _p(keep[1]), inst_stride or n, _p(keep[2]), _p(keep[3]), _p(keep[4]),
                                                    _p(ts_out), _p(res), ctypes.byref(h))
         self._submit(rc, h, "zkp_verify_compact_batch_submit")
-        return Job(h, keep, (res,) + ((ts_out,) if want_transcripts else ()), "verify_compact")
+        return Job(h, keep + [st], (res,) + ((ts_out,) if want_transcripts else ()), "verify_compact", self)
 
     def submit_verify_batchable_each(self, st: Statement, n: int, transcripts, inst, common, commitments, responses, weights16=None,
                                      want_transcripts=False, inst_stride: Optional[int] = None) -> Job:
@@ -651,7 +680,7 @@ class Pipe:
         rc = lib().zkp_verify_batchable_each_submit(self._h, st._h, n, flags, _p(keep[0]), _p(keep[1]), inst_stride or n, _p(keep[2]), _p(keep[3]), _p(keep[4]),
                                                     _p(keep[5]), _p(ts_out), _p(res), ctypes.byref(h))
         self._submit(rc, h, "zkp_verify_batchable_each_submit")
-        return Job(h, keep, (res,) + ((ts_out,) if want_transcripts else ()), "verify_batchable_each")
+        return Job(h, keep + [st], (res,) + ((ts_out,) if want_transcripts else ()), "verify_batchable_each", self)
 
     # -- synchronous calls sharded over every context (one host thread per listed device) ------------------------------
     def prove_batch(self, st: Statement, transcripts: np.ndarray, secrets, inst, common, entropy=None):

@@ -59,8 +59,8 @@ METRIC = "proofs/sec + batch-verifies/sec, CMZ13 10-attr credential, 1/2/4/8 MI3
 # (v_and / v_add_u32 / v_mov ...) -- SQ_ACTIVE_INST_VALU2 counts those second instructions; an isolated 2-cycle instruction between v_mad_u64_u32 costs a
 # whole slot (profiles/r04_valu_mix_microbench.txt).  valu_busy = 4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) per kernel
 # (one PMC pass, the chip's own clock), and issue cycles / (1024 x 2.4 GHz nameplate x ms_per_step) for the timed step -- <= 1 by construction.
-# profiles/r04_opcode_mix.json (tools/opcode_mix.py) is the static opcode mix of every kernel, keyed to the kernel sources: information, not the weights.
-OPCODE_MIX = os.path.join("profiles", "r04_opcode_mix.json")
+# profiles/r05_opcode_mix.json (tools/opcode_mix.py) is the static opcode mix of every kernel, keyed to the kernel sources: information, not the weights.
+OPCODE_MIX = os.path.join("profiles", "r05_opcode_mix.json")
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
 # how the constant-time prover MSMs (prover.rs:94) pick the table entry a secret digit names: ZKP_OPT_CT_LOOKUP (include/zkp_mi355x.h)
 CT_SCHEDULES = {0: "lane crossbar: rows in registers, entries by ds_bpermute_b32 from one half of the wavefront, 8-entry private rows scanned with v_cndmask -- constant time BY CONSTRUCTION "
@@ -833,7 +833,7 @@ def main():
     ap.add_argument("--no-multi-configs", action="store_true", help="--gpus > 1: skip the strong-scaling sub-records of BASELINE configs[3] / configs[4]")
     ap.add_argument("--multi-total4", type=int, default=1 << 22, help="--gpus > 1: total proofs of the configs[3] sub-record (2^22 CMZ proofs over the GPUs)")
     ap.add_argument("--multi-total5", type=int, default=1 << 18, help="--gpus > 1: total proofs of the configs[4] sub-record (2^18 W64 proofs over the GPUs)")
-    ap.add_argument("--pmc-json", default=None, help="rocprofv3 --pmc summary (tools/pmc_summary.py); default profiles/r03_pmc_counters_cfg<config>_k<batches per call>.json; "
+    ap.add_argument("--pmc-json", default=None, help="rocprofv3 --pmc summary (tools/pmc_summary.py); default profiles/r05_pmc_counters_cfg<config>_k<batches per call>.json; "
                                                      "used only if its source hash and workload shape match")
     ap.add_argument("--in-process", action="store_true", help="--gpus N > 1 WITHOUT torchrun / gloo / RCCL: this one process drives the N GPUs, one host "
                                                              "thread and one set of engine contexts per GPU, the verdict AND is taken on the host "
@@ -1071,8 +1071,8 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
             "algorithmic_bytes_per_launch": achieved * 1e9 * dom["avg_launch_ms"] * 1e-3, "launch_ms": dom["avg_launch_ms"],
             "launch_ms_note": "HIP events on the engine's stream around the launch, one call chain in flight (the kernel alone on the chip), the repetition with the median call time; "
                               "launch_ms_rocprof_one_stream (when pmc_source is set) = rocprofv3's average for the same kernel and shape on ONE stream "
-                              "(profiles/r04_kernel_stats_cfg<config>_k<K>_one_stream.txt), a few per cent longer -- the profiler's own dispatch overhead; in the timed loop "
-                              "several chains share the chip and a launch takes correspondingly longer (profiles/r04_kernel_stats_cfg<config>_k<K>.txt)",
+                              "(profiles/r05_kernel_stats_cfg<config>_k<K>_one_stream.txt), a few per cent longer -- the profiler's own dispatch overhead; in the timed loop "
+                              "several chains share the chip and a launch takes correspondingly longer (profiles/r05_kernel_stats_cfg<config>_k<K>.txt)",
             "note": "integer-VALU bound by construction (SURVEY.md 8(d)): algorithmic bytes = 64 B per (scalar, point) term + 32 B per output, "
                     "so the HBM fraction of ANY kernel of this path is ~1e-3; the binding roofline is step_valu / *_valu_busy (PMC, VALU issue slots)",
             "by_kernel": by_kernel}

@@ -380,9 +380,10 @@ int zkp_ctx_job_timing(zkp_ctx* ctx, float ms[3]);
  * points into such memory.  Registering costs ~12 us per MiB (profiles/r04_pcie_copy_rates.txt): register long-lived buffers once. */
 int zkp_host_alloc(void** out, size_t bytes);
 /* The same on the NUMA node of GPU `device` (round 5): on a two-socket host a staging buffer on the far socket sends every copied byte over the
- * socket interconnect first.  zkp_host_numa_node: the node the device's PCIe root hangs off (sysfs), -1 = unknown; zkp_host_node_of: the node the
- * page at p lives on, -1 = unknown.  Where the node is unknown or the kernel refuses the memory policy (a container's seccomp filter),
- * zkp_host_alloc_on is zkp_host_alloc.  zkp_pipe's staging rings are allocated this way (zkp_toolbox.h). */
+ * socket interconnect first.  The runtime places pinned memory next to the calling thread's CURRENT device; zkp_host_alloc_on makes `device` current
+ * for the allocation and restores the thread's device.  zkp_host_numa_node: the node the device hangs off (hipDeviceAttributeHostNumaId, else sysfs),
+ * -1 = unknown; zkp_host_node_of: the node the page at p lives on (get_mempolicy), -1 = unknown / not permitted.  zkp_pipe's staging rings are
+ * allocated this way (zkp_toolbox.h). */
 int zkp_host_alloc_on(void** out, size_t bytes, int device);
 int zkp_host_numa_node(int device);
 int zkp_host_node_of(const void* p);
@@ -425,7 +426,7 @@ enum {
 int zkp_ctx_last_timing(zkp_ctx* ctx, float* kernel_ms /*[ZKP_K_COUNT]*/, float* total_ms);
 /* With profiling on: which VARIANT of a kind's kernel the last call launched, by the name rocprofv3 prints -- the kernels whose template
  * arguments depend on the call's size, flags or options (ZKP_K_TERMS: "k_terms_split<true, 16, true, false>", ZKP_K_TABLES:
- * "zkp::k_comb_tables_lane<16>" / "zkp::k_tables_transcript<16>", ZKP_K_TRANSCRIPT: "zkp::k_transcript_run" / "...run1", ZKP_K_DECODE of the
+ * "zkp::k_comb_tables_lane<16>" / "zkp::k_tables_transcript_pc<16>", ZKP_K_TRANSCRIPT: "zkp::k_transcript_run" / "...run1", ZKP_K_DECODE of the
  * large-MSM path: "k_pip_prepare<11>"); several names are joined with ';', kinds whose kernels never vary give "".  Writes a NUL-terminated
  * string of at most cap - 1 characters and returns the untruncated length.  Profiles and benchmarks label kernels from THIS, not from a
  * copy of the dispatch thresholds. */

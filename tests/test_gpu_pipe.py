@@ -412,8 +412,9 @@ def test_submitter_threads_give_the_bytes_of_the_callers_thread(cmz, pinned):
     itself arrive from wait(); a corrupted proof fails exactly its batch; dropping the pipe with jobs in flight is safe."""
     mod, secrets, inst, common, entropy, w = cmz
     st = mod.statement
-    n, K = 128, 4
+    n, K = 96, 5
     nn = n * K
+    assert len(secrets) >= nn
     mk = T.pinned_copy if pinned else np.ascontiguousarray
     a_sec, a_inst, a_com, a_ent = mk(secrets[:nn]), mk(inst[:, :nn]), mk(common), mk(entropy[:nn])
     ref = T.Pipe((0,), 2)
@@ -436,7 +437,7 @@ def test_submitter_threads_give_the_bytes_of_the_callers_thread(cmz, pinned):
         ej = pipe.submit_verify_batchable_each(st, nn, _t0(), a_inst, a_com, coms0, resp0)
         while not all(j.done() for j in vj):                                         # done() never blocks and never touches a context
             pass
-        assert [j.wait()[0].tolist() for j in vj] == [[0] * K, [0, 0, 1, 0], [0] * K]
+        assert [j.wait()[0].tolist() for j in vj] == [[0] * K, [0, 0, 1, 0, 0], [0] * K]
         res = cj.wait()[0]
         assert res[2 * n + 5] == 1 and res.sum() == 1 and not ej.wait()[0].any()
         # an error the submit itself finds (a stride smaller than the proof count) arrives from wait(), the context is free again afterwards

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static VALU opcode mix of every kernel in the shipped code object -> profiles/r04_opcode_mix.json (keyed to the kernel sources).  INFORMATION
+"""Static VALU opcode mix of every kernel in the shipped code object -> profiles/r05_opcode_mix.json (keyed to the kernel sources).  INFORMATION
 about the code (share of 2-cycle-class opcodes, of 64-bit integer opcodes, the top opcodes), not the weights of the VALU ceiling any more.
 
 History: rounds 1 - 3 divided raw SQ_INSTS_VALU counts by ONE peak, 34.5e12 lane-instructions/s -- 4 issue cycles per instruction at
@@ -97,7 +97,7 @@ def kernel_mixes(asm):
 def main():
     from zkp_amd import engine
     import bench
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_opcode_mix.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_opcode_mix.json")
     rates = measured_rates()
     res = {"_source_sha256": bench.source_sha256(), "_rates_file": os.path.relpath(RATES_FILE, ROOT), "_default_rate": DEFAULT_RATE,
            "_note": "per kernel: static VALU mix of the shipped code object priced in SIMD issue cycles (2 or 4 per opcode); "

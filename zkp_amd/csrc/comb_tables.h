@@ -185,6 +185,72 @@ k_comb_tables_lane(const uint32_t* __restrict__ n_slots, uint32_t max_tables, co
   comb_table_lane<TEETH>(blockIdx.x * blockDim.x + threadIdx.x, n_slots, max_tables, slot_pt, pts, comb);
 }
 
+// The one-lane builder as a PRODUCER wavefront and a CONSUMER wavefront (round 5): a lone wavefront already issues a point operation's ~1,000 dependent
+// instructions at 4.6 cycles each, so a table's 368 sequential point operations ARE the 0.9 ms of the launch -- no schedule inside the lane shortens them.  Two
+// wavefronts on two SIMDs do: wavefront 0 runs the 256-doubling chain of 64 tables and hands the base of every tooth over through LDS, wavefront 1 computes
+// the eight multiples of that tooth (7 operations + 8 conversions) while the producer doubles on: same instructions in total, chain 256 instead of 368
+// operations long.  One barrier per tooth; the hand-over is double buffered (the producer writes buffer j & 1 after barrier j - 1, which the consumer only
+// passes once it has read buffer (j - 2) & 1).  `hand` = LDS [2][36][64] words.
+template <int TEETH>
+__device__ __forceinline__ void comb_table_pc(uint32_t slot0, const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
+                                              const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb, uint32_t* hand) {
+  using cfg = comb_cfg<TEETH>;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t ns = min(*n_slots, max_tables);
+  const uint32_t slot = slot0 + lane;
+  const bool have = slot < ns;
+  dev_ext* tbl = comb + (size_t)(have ? slot : 0u) * cfg::ENTRIES;
+  if (wave == 0) {
+    ge_p3 base;
+    ge_identity(base);
+    if (have) load_affine(base, pts + slot_pt[slot]);
+#pragma unroll 1
+    for (int j = 0; j < TEETH; ++j) {
+      uint32_t* h = hand + (j & 1) * 36 * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { h[64 * i] = base.X.v[i]; h[64 * (9 + i)] = base.Y.v[i]; h[64 * (18 + i)] = base.Z.v[i]; h[64 * (27 + i)] = base.T.v[i]; }
+      __syncthreads();                                                       // tooth j's base is there (and the consumer is done with tooth j - 1)
+#pragma unroll 1
+      for (int d = 0; d < cfg::BITS - 1; ++d) ge_double<false>(base, base);
+      ge_double<true>(base, base);                                           // 2^BITS x base
+    }
+    if (have) {
+      ge_cached c;
+      ge_to_cached(c, base);                                                 // 2^256 * P
+      store_comb_entry(tbl + 8 * TEETH, c);
+    }
+  } else {
+#pragma unroll 1
+    for (int j = 0; j < TEETH; ++j) {
+      __syncthreads();
+      const uint32_t* h = hand + (j & 1) * 36 * 64 + lane;
+      ge_p3 base, m2, m3, m4, m;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { base.X.v[i] = h[64 * i]; base.Y.v[i] = h[64 * (9 + i)]; base.Z.v[i] = h[64 * (18 + i)]; base.T.v[i] = h[64 * (27 + i)]; }
+      FE_TRACK(fe_set_ub_tight(base.X); fe_set_ub_tight(base.Y); fe_set_ub_tight(base.Z); fe_set_ub_tight(base.T));
+      ge_cached c1, c;
+      ge_to_cached(c1, base);
+      ge_double<true>(m2, base);
+      ge_add_cached(m3, m2, c1);
+      ge_double<true>(m4, m2);
+      if (have) {
+        store_comb_entry(tbl + 8 * j + 0, c1);
+        ge_to_cached(c, m2); store_comb_entry(tbl + 8 * j + 1, c);
+        ge_to_cached(c, m3); store_comb_entry(tbl + 8 * j + 2, c);
+        ge_to_cached(c, m4); store_comb_entry(tbl + 8 * j + 3, c);
+      }
+      ge_add_cached(m, m4, c1);                                              // 5
+      if (have) { ge_to_cached(c, m); store_comb_entry(tbl + 8 * j + 4, c); }
+      ge_double<true>(m, m3);                                                // 6
+      if (have) { ge_to_cached(c, m); store_comb_entry(tbl + 8 * j + 5, c); }
+      ge_add_cached(m, m, c1);                                               // 7
+      if (have) { ge_to_cached(c, m); store_comb_entry(tbl + 8 * j + 6, c); }
+      ge_double<true>(m, m4);                                                // 8
+      if (have) { ge_to_cached(c, m); store_comb_entry(tbl + 8 * j + 7, c); }
+    }
+  }
+}
+
 __device__ __forceinline__ void load_comb_entry(ge_cached& c, const dev_ext* src) {
   uint32_t w[36];
   load_vec<9>(w, src);

@@ -440,10 +440,9 @@ int zkp_host_numa_node(int device) {
   return node;
 }
 // Pinned memory on the NUMA node of `device`: on a two-socket host a staging ring on the far socket sends every byte of every copy over
-// the socket interconnect first.  The pages of a hipHostMalloc are placed when they are pinned, under the calling thread's memory policy:
-// the policy is set to "prefer the GPU's node" around the allocation (hipHostMallocNumaUser: the runtime keeps its hands off the policy) and
-// restored afterwards.  Raw syscalls, no libnuma.  Wherever the node is unknown or the kernel refuses the policy (seccomp in a container)
-// this is zkp_host_alloc: same memory, wherever the first touch lands it.
+// the socket interconnect first.  The HIP runtime places a hipHostMalloc on the node closest to the CALLING THREAD'S CURRENT DEVICE (unless
+// hipHostMallocNumaUser hands the policy to the user), so the allocation is made with `device` current and the thread's device restored
+// afterwards -- no memory-policy system calls, nothing a container's seccomp filter can refuse.  zkp_host_node_of says where a page landed.
 int zkp_host_alloc_on(void** out, size_t bytes, int device) {
   if (!out) return fail(ZKP_ERR_ARG, "NULL pointer");
   *out = nullptr;
@@ -451,26 +450,12 @@ int zkp_host_alloc_on(void** out, size_t bytes, int device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(ZKP_ERR_NO_DEVICE, "no HIP device visible");
   if (device < 0 || device >= count) return fail(ZKP_ERR_ARG, "zkp_host_alloc_on: no such device");
-  const int node = zkp_host_numa_node(device);
-#if defined(__linux__) && defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
-  if (node >= 0 && node < 1024) {
-    constexpr unsigned long MAXNODE = 1024;
-    unsigned long old_mask[MAXNODE / (8 * sizeof(unsigned long))] = {0}, want[MAXNODE / (8 * sizeof(unsigned long))] = {0};
-    int old_mode = 0;
-    const bool saved = syscall(SYS_get_mempolicy, &old_mode, old_mask, MAXNODE, nullptr, 0ul) == 0;
-    want[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
-    if (saved && syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, want, MAXNODE) == 0) {
-      const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable | hipHostMallocNumaUser);
-      (void)syscall(SYS_set_mempolicy, old_mode, old_mask, MAXNODE);
-      if (e == hipSuccess) return ZKP_OK;
-      (void)hipGetLastError();
-      *out = nullptr;                                                // (an older runtime without the flag: fall through to the plain allocation)
-    }
-  }
-#else
-  (void)node;
-#endif
-  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+  int before = -1;
+  if (hipGetDevice(&before) != hipSuccess) { (void)hipGetLastError(); before = -1; }
+  HIP_TRY(hipSetDevice(device));
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+  if (before >= 0 && before != device) (void)hipSetDevice(before);
+  if (e != hipSuccess) { *out = nullptr; return fail(ZKP_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
   return ZKP_OK;
 }
 // the NUMA node the page at p lives on (-1: unknown / not permitted): get_mempolicy(MPOL_F_NODE | MPOL_F_ADDR)

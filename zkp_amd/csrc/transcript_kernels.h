@@ -66,7 +66,7 @@ constexpr int TR_BLOCK = 64;       // lanes per workgroup (one wavefront) = 32 p
 __device__ __forceinline__ void transcript_pair_block(uint32_t bid, uint32_t* S /*LDS [25 * TR_BLOCK]*/, const tr_op* __restrict__ prog, uint32_t n_ops,
                                                       const uint64_t* __restrict__ tables, uint32_t N, const tr_bufs& bufs, uint8_t* __restrict__ ts,
                                                       uint32_t* __restrict__ saved /*[25][2N]*/, uint32_t* __restrict__ failed, uint32_t tail) {
-  const uint32_t lane = threadIdx.x, h = lane & 1;
+  const uint32_t lane = threadIdx.x & (TR_BLOCK - 1), h = lane & 1;     // (one wavefront per transcript block; k_tables_transcript_pc runs two in a workgroup)
   const uint32_t j_raw = bid * (TR_BLOCK / 2) + (lane >> 1);
   const bool live = j_raw < N;                          // lanes past the end shadow the last proof (they must stay in the
   const uint32_t j = live ? j_raw : N - 1;              // wavefront: they carry operations for v_readlane) and store nothing
@@ -156,16 +156,26 @@ k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t*
 // Transcript program + comb-table construction in ONE launch (asynchronous _dev flows): both are a few dozen wavefronts of long
 // dependent chains (Keccak-f rounds; 256 doublings per table) that do not depend on each other, and the _dev flows keep
 // everything on one stream (a second stream per context costs the pipelined caller more than the overlap returns:
-// ZKP_OPT_DEV_OVERLAP).  Blocks [0, tr_blocks) interpret the program, the others build one table per lane.
+// ZKP_OPT_DEV_OVERLAP).  Rounds 3 - 4 ran one wavefront per workgroup -- a transcript block, or 64 tables built by one lane each
+// (comb_table_lane: 368 sequential point operations, the 0.9 ms pole of the launch).  Round 5:
+// the table builder is split into a producer and a consumer wavefront (comb_table_pc): workgroups of two wavefronts -- two transcript blocks of 32
+// proofs, or 64 tables.  The launch's pole drops from the 368-operation table chain to the transcript program: a lone call of 4096 proofs 1.75 -> 1.88 M
+// proofs/s, four such calls in flight 3.67 -> 4.03 M, wide pipelined calls unchanged (profiles/r05_ab_experiments.txt, block c).
 template <int TEETH>
-__global__ void __launch_bounds__(TR_BLOCK, 2)
-k_tables_transcript(uint32_t tr_blocks, const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t* __restrict__ tables, uint32_t N, const tr_bufs bufs,
-                    uint8_t* __restrict__ ts, uint32_t* __restrict__ saved, uint32_t* __restrict__ failed, uint32_t tail,
-                    const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
-                    const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
-  __shared__ uint32_t S[25 * TR_BLOCK];
-  if (blockIdx.x < tr_blocks) transcript_pair_block(blockIdx.x, S, prog, n_ops, tables, N, bufs, ts, saved, failed, tail);
-  else comb_table_lane<TEETH>((blockIdx.x - tr_blocks) * TR_BLOCK + threadIdx.x, n_slots, max_tables, slot_pt, pts, comb);
+__global__ void __launch_bounds__(2 * TR_BLOCK, 2)
+k_tables_transcript_pc(uint32_t tr_blocks, const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t* __restrict__ tables, uint32_t N, const tr_bufs bufs,
+                       uint8_t* __restrict__ ts, uint32_t* __restrict__ saved, uint32_t* __restrict__ failed, uint32_t tail,
+                       const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
+                       const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
+  __shared__ uint32_t S[2 * 36 * 64];                      // two transcript states (2 x 25 x 64 words), or the producer's double-buffered hand-over
+  static_assert(2 * 36 * 64 >= 2 * 25 * TR_BLOCK, "LDS of k_tables_transcript_pc");
+  const uint32_t wave = threadIdx.x >> 6, trb = (tr_blocks + 1) / 2;
+  if (blockIdx.x < trb) {
+    const uint32_t bid = 2 * blockIdx.x + wave;
+    if (bid < tr_blocks) transcript_pair_block(bid, S + wave * 25 * TR_BLOCK, prog, n_ops, tables, N, bufs, ts, saved, failed, tail);
+  } else {
+    comb_table_pc<TEETH>((blockIdx.x - trb) * 64u, n_slots, max_tables, slot_pt, pts, comb, S);
+  }
 }
 
 // The same interpreter with ONE lane per proof (64-bit words, tr_exec_op): 208 instead of 2 x 135 VALU operations per Keccak

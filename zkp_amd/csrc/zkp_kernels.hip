@@ -1496,10 +1496,11 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
         if (k.teeth == 16 && c->pending_tr.active) {               // the flow's transcript program shares the launch
           const auto& t = c->pending_tr;
           const uint32_t tr_blocks = (t.N + TR_BLOCK / 2 - 1) / (TR_BLOCK / 2);
-          hipLaunchKernelGGL(k_tables_transcript<16>, dim3(tr_blocks + (k.max_tables + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, c->stream, tr_blocks, t.ops, t.n_ops,
+          // tables as producer / consumer wavefronts (comb_table_pc): workgroups of two wavefronts = two transcript blocks, or 64 tables
+          hipLaunchKernelGGL(k_tables_transcript_pc<16>, dim3((tr_blocks + 1) / 2 + (k.max_tables + 63) / 64), dim3(2 * TR_BLOCK), 0, c->stream, tr_blocks, t.ops, t.n_ops,
                              t.tables, t.N, t.bufs, t.ts, t.saved, t.failed, t.tail, n_slots, k.max_tables, slot_pt, pts, comb);
           c->pending_tr.active = false;
-          prof_note(c, ZKP_K_TABLES, "zkp::k_tables_transcript<16>");
+          prof_note(c, ZKP_K_TABLES, "zkp::k_tables_transcript_pc<16>");
         } else if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables_lane<16>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
         else hipLaunchKernelGGL(k_comb_tables_lane<4>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       } else {

@@ -616,6 +616,12 @@ class Pipe:
             raise ValueError("transcripts must be one blob [208] or [%d][208]" % n)
         return t, 0
 
+    @staticmethod
+    def _need(what, a, n_elems):
+        """the C side reads n_elems elements: a shorter array would be an out-of-bounds read, not an error code"""
+        if a is not None and np.asarray(a).size < n_elems:
+            raise ValueError("%s has %d elements, the call reads %d" % (what, np.asarray(a).size, n_elems))
+
     def _submit(self, rc, h, what):
         if rc == ZKP_TB_PIPE_FULL:
             raise BlockingIOError("every context of the pipe has a job in flight")
@@ -628,6 +634,10 @@ class Pipe:
         """zkp_prove_batch_submit.  transcripts: one blob [208] (every proof starts from it) or [n][208].  out = optional dict of
         preallocated (e.g. pinned) arrays chal / resp / coms / ts.  -> Job whose outputs are (chal, resp, coms[, ts])."""
         ts, flags = self._ts(transcripts, n)
+        self._need("secrets", secrets, n * st.m * 32)
+        if not inst_stride:                       # (with a stride the caller passes a window into a larger array: its extent is the caller's business)
+            self._need("inst", inst, st.ni * n * 32)
+        self._need("common", common, st.ns * 32); self._need("entropy", entropy, n * 32)
         out = out or {}
         chal = out.get("chal") if out.get("chal") is not None else np.zeros((n, 32), np.uint8)
         resp = out.get("resp") if out.get("resp") is not None else np.zeros((n, st.m, 32), np.uint8)
@@ -646,6 +656,11 @@ class Pipe:
         """zkp_batch_verify_many_submit -> Job whose outputs are (verdicts[n_batches] (0 = Ok, 1 = VerificationFailure)[, ts])."""
         n = n_batches * n_each
         ts, flags = self._ts(transcripts, n)
+        if not inst_stride:
+            self._need("inst", inst, st.ni * n * 32)
+        self._need("common", common, st.ns * 32); self._need("commitments", commitments, n * st.nc * 32); self._need("responses", responses, n * st.m * 32)
+        if not weights_stride:
+            self._need("weights16", weights16, st.nc * n * 16)
         verdicts = np.ones(n_batches, np.int32)
         ts_out = np.zeros((n, TRANSCRIPT_BYTES), np.uint8) if want_transcripts else None
         keep = [ts, inst if inst_stride else np.ascontiguousarray(inst), np.ascontiguousarray(common), np.ascontiguousarray(commitments),
@@ -659,6 +674,9 @@ class Pipe:
     def submit_verify_compact(self, st: Statement, n: int, transcripts, inst, common, challenges, responses, want_transcripts=False,
                               inst_stride: Optional[int] = None) -> Job:
         ts, flags = self._ts(transcripts, n)
+        if not inst_stride:
+            self._need("inst", inst, st.ni * n * 32)
+        self._need("common", common, st.ns * 32); self._need("challenges", challenges, n * 32); self._need("responses", responses, n * st.m * 32)
         res = np.ones(n, np.uint8)
         ts_out = np.zeros((n, TRANSCRIPT_BYTES), np.uint8) if want_transcripts else None
         keep = [ts, inst if inst_stride else np.ascontiguousarray(inst), np.ascontiguousarray(common), np.ascontiguousarray(challenges),
@@ -672,6 +690,10 @@ class Pipe:
     def submit_verify_batchable_each(self, st: Statement, n: int, transcripts, inst, common, commitments, responses, weights16=None,
                                      want_transcripts=False, inst_stride: Optional[int] = None) -> Job:
         ts, flags = self._ts(transcripts, n)
+        if not inst_stride:
+            self._need("inst", inst, st.ni * n * 32)
+        self._need("common", common, st.ns * 32); self._need("commitments", commitments, n * st.nc * 32); self._need("responses", responses, n * st.m * 32)
+        self._need("weights16", weights16, n * st.nc * 16)
         res = np.ones(n, np.uint8)
         ts_out = np.zeros((n, TRANSCRIPT_BYTES), np.uint8) if want_transcripts else None
         keep = [ts, inst if inst_stride else np.ascontiguousarray(inst), np.ascontiguousarray(common), np.ascontiguousarray(commitments),

@@ -1252,7 +1252,8 @@ def cpu_baseline(ps, label, sample):
     # north_star names and which cannot be built here): a MEASURED number instead of a recalled factor -- on the best instruction set the host CPU has
     # (AVX-512 IFMA, else AVX2); where IFMA exists, AVX2 is timed too, on a sub-sample
     ISA_TEXT = {"avx512ifma": "AVX-512 IFMA (vpmadd52, radix 2^51, 4 x 64-bit lanes = the four coordinates of a point)",
-                "avx2": "AVX2 (vpmuludq, radix 2^25.5 with one limb per vector, 4 x 64-bit lanes = the four coordinates of a point)"}
+                "avx2": "AVX2 (vpmuludq, radix 2^25.5 with one limb per vector, 4 x 64-bit lanes = the four coordinates of a point)",
+                "avx2p": "AVX2 (vpmuludq, radix 2^25.5 in dalek's packed FieldElement2625x4 layout: five vectors of eight 32-bit limbs hold the four coordinates of a point)"}
     simd = {"value": None, "isa": None, "note": "this host CPU (or the oracle's build) has neither AVX-512 IFMA nor AVX2: not measured"}
 
     def simd_run(isa, m):
@@ -1279,11 +1280,13 @@ def cpu_baseline(ps, label, sample):
         simd = simd_run(isas[0], m)
         simd["note"] = ("MSM inner loops (point addition / doubling in the 4-way parallel formulas, constant-time and NAF Straus, Pippenger) vectorised as in "
                         "curve25519-dalek's simd_backend; decompression, compression, Merlin and scalar arithmetic stay scalar, as there")
-        if len(isas) > 1:
-            simd["avx2"] = simd_run("avx2", min(m, 512))
-            simd["avx2"]["note"] = ("the same backend on AVX2 for hosts without IFMA, timed on the first %d proofs of the sample.  One limb per vector (ten vectors per four field "
-                                    "elements), not dalek's packed 2625x4 layout: on a core with a fast 64-bit multiplier it does not beat the scalar port -- reported, never the baseline"
+        if "avx2p" in isas and isas[0] != "avx2p":
+            simd["avx2"] = simd_run("avx2p", min(m, 512))
+            simd["avx2"]["note"] = ("the same backend on AVX2 for hosts without IFMA, in curve25519-dalek's packed layout (FieldElement2625x4: four field elements in five vectors of "
+                                    "eight 32-bit limbs, vpmuludq on operands unpacked per product -- backend/vector/avx2/field.rs), timed on the first %d proofs of the sample.  "
+                                    "On a core with two 64-bit multipliers per cycle (Zen 5) a 32 x 32 -> 64 vector multiplier does not beat the scalar port -- reported, never the baseline"
                                     % min(m, 512))
+            simd["avx2"]["one_limb_per_vector"] = simd_run("avx2", min(m, 256))["value"]      # round 4's form (ten vectors per four elements): what the packing buys
     outd = {"value": n_done / (t_prove + t_bv), "unit": "proofs/s", "cores": 1, "kind": "port", "simd": simd,
             "sample": "; ".join(notes) + "; Merlin + radix-16 constant-time Straus + responses / Merlin + coefficients + Pippenger; gcc -O3 -march=native, 5x51-bit limbs",
             "batch_verifies_per_s": n_done / t_bv,

@@ -78,8 +78,8 @@ const char* zkp_version(void);
  *     always do: a shorter call, more cross-stream dependencies.  Default 0.  (Measured again in round 4 on a LONE call chain: 2.87 -> 3.17 ms per
  *     prove call of 20,480 proofs -- no gain there either.)  In a process that owns one hardware queue (GPU_MAX_HW_QUEUES=1) a capture records the
  *     flow without the fork: ROCm 7.2.0 crashes in hipGraphLaunch on a forked graph under that setting.
- *   ZKP_OPT_GROUPED_COMB: 1 = constant-time calls list the terms of every point with 11 or more uses next to each other; a wavefront
- *     then holds the rows of the (at most 8) 16-teeth comb tables its 64 terms need and every lane takes the entry its digit names over
+ *   ZKP_OPT_GROUPED_COMB: 1 = constant-time calls list the terms of every point with 10 or more uses next to each other; a wavefront
+ *     then holds the rows of the (at most 8) 16-teeth comb tables its 62 terms need and every lane takes the entry its digit names over
  *     the lane crossbar (ZKP_OPT_CT_LOOKUP: no masked scan, 20 % fewer instructions per addition, a row fetched once per wavefront instead
  *     of once per lane); 0 = every comb term scans its rows with masks; UINT64_MAX = default: 1 for calls of 400,000 terms or more
  *     (asynchronous _dev calls: 250,000).

@@ -97,6 +97,7 @@ void orc_msm_straus_ct(ge_ext* r, size_t n, const uint8_t* scalars, const ge_ext
 #endif
 #if ORC_HAVE_AVX2
   if (g_orc_simd == 2) { simd_straus_ct_avx2(r, n, scalars, points); return; }
+  if (g_orc_simd == 3) { simd_straus_ct_avx2p(r, n, scalars, points); return; }
 #endif
   ge_pniels* tables = (ge_pniels*)malloc(sizeof(ge_pniels) * 8 * (n ? n : 1));
   int8_t* digits = (int8_t*)malloc(64 * (n ? n : 1));
@@ -133,6 +134,7 @@ void orc_msm_straus_vartime(ge_ext* r, size_t n, const uint8_t* scalars, const g
 #endif
 #if ORC_HAVE_AVX2
   if (g_orc_simd == 2) { simd_straus_vartime_avx2(r, n, scalars, points); return; }
+  if (g_orc_simd == 3) { simd_straus_vartime_avx2p(r, n, scalars, points); return; }
 #endif
   ge_pniels* tables = (ge_pniels*)malloc(sizeof(ge_pniels) * 8 * (n ? n : 1));
   int8_t* nafs = (int8_t*)malloc(256 * (n ? n : 1));
@@ -168,6 +170,7 @@ void orc_msm_pippenger(ge_ext* r, size_t n, const uint8_t* scalars, const ge_ext
 #endif
 #if ORC_HAVE_AVX2
   if (g_orc_simd == 2) { simd_pippenger_avx2(r, n, scalars, points); return; }
+  if (g_orc_simd == 3) { simd_pippenger_avx2p(r, n, scalars, points); return; }
 #endif
   const int w = n < 500 ? 6 : (n < 800 ? 7 : 8);
   const int buckets_count = (1 << w) / 2;

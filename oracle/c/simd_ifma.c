@@ -200,11 +200,108 @@ static inline void f4_unpack_avx2(fe51 out[4], const f4_avx2* a) {
 #include "simd_x4.inc"
 #undef X4
 #undef F4N
+
+/* ---- AVX2, PACKED: curve25519-dalek's FieldElement2625x4 layout (backend/vector/avx2/field.rs) ----------------------------------------------
+ * Five vectors of eight 32-bit lanes hold four field elements A, B, C, D:  vector i = (A_2i, B_2i, A_2i+1, B_2i+1 | C_2i, D_2i, C_2i+1, D_2i+1),
+ * limbs of 26 / 25 bits.  A product unpacks both operands into the ten one-limb-per-vector operands of the section above (vpunpckl/hdq against zero),
+ * runs the same 100 vpmuludq and repacks -- exactly what dalek's Mul does -- so the multiplications cost what they cost above; what the packing
+ * halves is everything around them: additions, subtractions and their carry passes (5 vectors instead of 10), the lane shuffles and blends of the
+ * 4-way point formulas (vpermd on 5 vectors), table entries (160 instead of 320 bytes) and the register pressure between two products. */
+#define F4N 5
+#define X4(n) n##_avx2p
+#define X4_OWN_LANES 1
+typedef struct { __m256i v[5]; } f4_avx2p;
+/* position of (element e, limb parity p) inside a packed vector */
+#define PL(e, p) (((e) & 1) + 2 * (p) + 4 * ((e) >> 1))
+static inline __m256i pk_idx(int l0, int l1, int l2, int l3) {         /* vpermd index: output element k takes input element l_k, both limb parities */
+  int ix[8];
+  const int l[4] = {l0, l1, l2, l3};
+  for (int k = 0; k < 4; ++k) for (int p = 0; p < 2; ++p) ix[PL(k, p)] = PL(l[k], p);
+  return _mm256_setr_epi32(ix[0], ix[1], ix[2], ix[3], ix[4], ix[5], ix[6], ix[7]);
+}
+static inline f4_avx2p shuf_avx2p(const f4_avx2p* a, const int imm) {
+  const __m256i ix = pk_idx(imm & 3, (imm >> 2) & 3, (imm >> 4) & 3, (imm >> 6) & 3);
+  f4_avx2p r;
+  for (int i = 0; i < 5; ++i) r.v[i] = _mm256_permutevar8x32_epi32(a->v[i], ix);
+  return r;
+}
+static inline f4_avx2p blend_avx2p(const f4_avx2p* a, const f4_avx2p* b, const int lanes) {
+  int m[8];
+  for (int k = 0; k < 4; ++k) for (int p = 0; p < 2; ++p) m[PL(k, p)] = (lanes >> k) & 1 ? -1 : 0;
+  const __m256i mv = _mm256_setr_epi32(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+  f4_avx2p r;
+  for (int i = 0; i < 5; ++i) r.v[i] = _mm256_blendv_epi8(a->v[i], b->v[i], mv);
+  return r;
+}
+static inline f4_avx2p f4_addraw_avx2p(const f4_avx2p* a, const f4_avx2p* b) { f4_avx2p r; for (int i = 0; i < 5; ++i) r.v[i] = _mm256_add_epi32(a->v[i], b->v[i]); return r; }
+/* one carry pass over the packed form: the even limbs of a vector (lanes 0, 1, 4, 5) carry into its odd limbs (lanes 2, 3, 6, 7), the odd limbs into
+ * the even limbs of the NEXT vector, limb 9 wraps to limb 0 with weight 19.  Inputs < 2^31 per lane. */
+static inline void f4_reduce_avx2p(f4_avx2p* a) {
+  const __m256i sh = _mm256_setr_epi32(26, 26, 25, 25, 26, 26, 25, 25);
+  const __m256i mk = _mm256_setr_epi32((1 << 26) - 1, (1 << 26) - 1, (1 << 25) - 1, (1 << 25) - 1, (1 << 26) - 1, (1 << 26) - 1, (1 << 25) - 1, (1 << 25) - 1);
+  __m256i rot[5];
+  for (int i = 0; i < 5; ++i) rot[i] = _mm256_shuffle_epi32(_mm256_srlv_epi32(a->v[i], sh), _MM_SHUFFLE(1, 0, 3, 2));      /* (odd carries | even carries) per half */
+  const __m256i w = rot[4];
+  const __m256i w19 = _mm256_add_epi32(_mm256_slli_epi32(w, 4), _mm256_add_epi32(_mm256_slli_epi32(w, 1), w));
+  for (int i = 0; i < 5; ++i) {
+    const __m256i from_prev = i ? rot[i - 1] : w19;                      /* lanes 0, 1, 4, 5: the odd-limb carries of the vector before */
+    a->v[i] = _mm256_add_epi32(_mm256_and_si256(a->v[i], mk), _mm256_blend_epi32(from_prev, rot[i], 0xCC));
+  }
+}
+static inline f4_avx2p f4_add_avx2p(const f4_avx2p* a, const f4_avx2p* b) {
+  f4_avx2p r = f4_addraw_avx2p(a, b);
+  f4_reduce_avx2p(&r);
+  return r;
+}
+/* a - b + 4 p, reduced (same bias as the unpacked section) */
+static inline f4_avx2p f4_sub_avx2p(const f4_avx2p* a, const f4_avx2p* b) {
+  const int E = (1 << 28) - 4, O = (1 << 27) - 4;
+  const __m256i bias = _mm256_setr_epi32(E, E, O, O, E, E, O, O), bias0 = _mm256_setr_epi32(E - 72, E - 72, O, O, E - 72, E - 72, O, O);
+  f4_avx2p r;
+  for (int i = 0; i < 5; ++i) r.v[i] = _mm256_sub_epi32(_mm256_add_epi32(a->v[i], i ? bias : bias0), b->v[i]);
+  f4_reduce_avx2p(&r);
+  return r;
+}
+static inline f4_avx2 pk_unpack(const f4_avx2p* a) {                     /* -> one limb per vector, 64-bit lanes (A, B | C, D) */
+  const __m256i z = _mm256_setzero_si256();
+  f4_avx2 r;
+  for (int i = 0; i < 5; ++i) { r.v[2 * i] = _mm256_unpacklo_epi32(a->v[i], z); r.v[2 * i + 1] = _mm256_unpackhi_epi32(a->v[i], z); }
+  return r;
+}
+static inline f4_avx2p pk_pack(const f4_avx2* a) {                       /* limbs < 2^32 */
+  f4_avx2p r;
+  for (int i = 0; i < 5; ++i)
+    r.v[i] = _mm256_or_si256(_mm256_shuffle_epi32(a->v[2 * i], _MM_SHUFFLE(3, 1, 2, 0)), _mm256_shuffle_epi32(a->v[2 * i + 1], _MM_SHUFFLE(2, 0, 3, 1)));
+  return r;
+}
+static inline f4_avx2p f4_mul_avx2p(const f4_avx2p* a, const f4_avx2p* b) {
+  const f4_avx2 x = pk_unpack(a), y = pk_unpack(b);
+  const f4_avx2 h = f4_mul_avx2(&x, &y);
+  return pk_pack(&h);
+}
+static inline f4_avx2p f4_sq_avx2p(const f4_avx2p* a) {
+  const f4_avx2 x = pk_unpack(a);
+  const f4_avx2 h = f4_sq_avx2(&x);
+  return pk_pack(&h);
+}
+static inline f4_avx2p f4_pack_avx2p(const fe51* a, const fe51* b, const fe51* c, const fe51* d) {
+  const f4_avx2 u = f4_pack_avx2(a, b, c, d);
+  return pk_pack(&u);
+}
+static inline void f4_unpack_avx2p(fe51 out[4], const f4_avx2p* a) {
+  const f4_avx2 u = pk_unpack(a);
+  f4_unpack_avx2(out, &u);
+}
+#include "simd_x4.inc"
+#undef PL
+#undef X4_OWN_LANES
+#undef X4
+#undef F4N
 #else
 #define ORC_HAVE_AVX2 0
 #endif
 
-/* 0 = scalar port, 1 = AVX-512 IFMA, 2 = AVX2 */
+/* 0 = scalar port, 1 = AVX-512 IFMA, 2 = AVX2 (one limb per vector), 3 = AVX2 packed (dalek's FieldElement2625x4 layout) */
 static int g_orc_simd = 0;
 /* best vector instruction set the build AND this CPU have: 1 = AVX-512 IFMA + VL, 2 = AVX2, 0 = none */
 int orc_simd_available(void) {
@@ -223,7 +320,7 @@ int orc_set_simd(int mode) {
   g_orc_simd = 0;
   if (mode == 1) g_orc_simd = best;
 #if ORC_HAVE_AVX2
-  if (mode == 2 && best) g_orc_simd = 2;               /* (IFMA implies AVX2) */
+  if ((mode == 2 || mode == 3) && best) g_orc_simd = mode;      /* (IFMA implies AVX2) */
 #endif
   return g_orc_simd;
 }

@@ -50,7 +50,7 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
-SIMD_ISA = {0: None, 1: "avx512ifma", 2: "avx2"}
+SIMD_ISA = {0: None, 1: "avx512ifma", 2: "avx2", 3: "avx2p"}
 
 
 def simd_available() -> bool:
@@ -61,7 +61,7 @@ def simd_available() -> bool:
 def simd_isas():
     """the instruction sets set_simd() accepts here, best first"""
     best = int(lib().orc_simd_available())
-    return {0: [], 1: ["avx512ifma", "avx2"], 2: ["avx2"]}[best]
+    return {0: [], 1: ["avx512ifma", "avx2p", "avx2"], 2: ["avx2p", "avx2"]}[best]
 
 
 def set_simd(on) -> bool:
@@ -72,6 +72,8 @@ def set_simd(on) -> bool:
         return False
     if on == "avx2":
         return int(lib().orc_set_simd(2)) == 2
+    if on == "avx2p":                                      # AVX2 in curve25519-dalek's packed layout (FieldElement2625x4: five vectors of eight 32-bit lanes)
+        return int(lib().orc_set_simd(3)) == 3
     got = int(lib().orc_set_simd(1))
     if on == "avx512ifma" and got != 1:
         lib().orc_set_simd(0)

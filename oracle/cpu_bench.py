@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--workers", type=int, default=usable_cpus())
     ap.add_argument("--per", type=int, default=96)
     ap.add_argument("--simd", action="store_true", help="MSM inner loops on the vector backend (oracle/c/simd_ifma.c): AVX-512 IFMA where the CPU has it, else AVX2")
-    ap.add_argument("--simd-isa", choices=["avx512ifma", "avx2"], default=None, help="the vector backend on this instruction set (implies --simd)")
+    ap.add_argument("--simd-isa", choices=["avx512ifma", "avx2p", "avx2"], default=None, help="the vector backend on this instruction set (implies --simd)")
     a = ap.parse_args()
     C.build()
     data = cmz_instance(a.per, 7)            # every worker handles an identical range: same work, no data skew

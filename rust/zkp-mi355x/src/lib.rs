@@ -348,6 +348,14 @@ impl Pipe {
         Ok(Pipe(p))
     }
     pub fn jobs_in_flight(&self) -> usize { unsafe { sys::zkp_pipe_jobs_in_flight(self.0) as usize } }
+    /// Asynchronous submits on one host thread per entry of the device list (`Some(true)`), on the caller's thread (`Some(false)`), or the
+    /// default (`None`: threads when the pipe spans more than one entry).  Only while no job is in flight.  With threads, errors the submit
+    /// itself would return arrive from `Job::wait`; the `Statement` is borrowed by the job for that reason.
+    pub fn set_submit_threads(&self, on: Option<bool>) -> Result<(), Error> {
+        let rc = unsafe { sys::zkp_pipe_set_submit_threads(self.0, match on { None => -1, Some(false) => 0, Some(true) => 1 }) };
+        if rc != 0 { return Err(self.err(rc)); }
+        Ok(())
+    }
     fn err(&self, rc: c_int) -> Error {
         match rc {
             sys::ZKP_TB_VERIFICATION_FAILURE => Error::VerificationFailure,

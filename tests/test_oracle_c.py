@@ -384,10 +384,10 @@ print("sanitizer run complete")
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("isa", ["avx512ifma", "avx2"])
+@pytest.mark.parametrize("isa", ["avx512ifma", "avx2", "avx2p"])
 def test_simd_msm_equals_scalar_port(isa):
     """oracle/c/simd_ifma.c + simd_x4.inc (the four coordinates of a point in four lanes -- the design of curve25519-dalek's simd_backend -- on
-    AVX-512 IFMA in radix 2^51 and on AVX2 in radix 2^25.5): the three MSM algorithms, whole proofs and a batch verification must give the bytes
+    AVX-512 IFMA in radix 2^51, on AVX2 in radix 2^25.5 with one limb per vector, and on AVX2 in dalek's packed FieldElement2625x4 layout): the three MSM algorithms, whole proofs and a batch verification must give the bytes
     of the scalar 5 x 51 port.  Skipped where the build or the CPU lacks the instruction set (the vector code is then not even compiled /
     refused at run time)."""
     if isa not in C.simd_isas():

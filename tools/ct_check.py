@@ -174,10 +174,12 @@ def cycles():
         a = np.array(activity[c])
         print("#   %-13s one random scalar for all lanes (broadcast look-ups, random operands): %+.2f %%     random scalars per lane: %+.2f %%" % (names.get(c, str(c)), a[:, 0].mean(), a[:, 1].mean()))
     print("# Instruction, memory-instruction and LDS bank-conflict counters are identical for all patterns (r05_constant_time_counters.txt): no branch, address or bank depends on")
-    print("# a scalar.  What remains follows the OPERANDS, not the look-ups: random digits cost a block class up to ~1 % more s_memtime ticks than structured ones whether the lanes")
-    print("# fetch different entries or all the same one (the control column).  The likeliest reading is switching activity under a power-managed clock -- these kernels already run")
-    print("# 10 - 17 % below the nameplate clock -- i.e. the frequency channel every constant-time implementation has on a power-managed processor; no instruction-level discipline")
-    print("# removes it.  (The prover's scalars are fresh uniform blindings, prover.rs:82-86: always the 'random' column.)")
+    print("# a scalar.  What is left inside the band: in the schedules that run comb SCANS next to the fixed-base blocks (grouped walk = 0) random digits cost the fixed-base class up to")
+    print("# 1 - 2 % more s_memtime ticks than structured ones -- also when every lane walks the SAME random scalar (the control column: every look-up a broadcast), so it follows the")
+    print("# operands, not the look-ups; in the schedule of wide calls (grouped walk = 1: what the benchmark and every call of 8,192 proofs or more runs) no class shows anything.")
+    print("# The likeliest reading is switching activity under a power-managed clock (the scans' selects move every table byte through v_cndmask; these kernels run 10 - 17 % below")
+    print("# the nameplate clock): the frequency channel that constant-time code has on every power-managed processor, which no instruction-level discipline removes.")
+    print("# (The prover's scalars are fresh uniform blindings, prover.rs:82-86: always the 'random' columns.)")
     eng.close()
 
 

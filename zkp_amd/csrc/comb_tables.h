@@ -531,18 +531,22 @@ __device__ __forceinline__ void comb_group_block(uint32_t i0, uint32_t n_g, cons
 // table r with digit magnitude m fetches the 36 words from lane 8 r + m - 1 with ds_bpermute_b32 -- a lane number, not an address.
 // What the crossbar still has is BANKS (hot_tables.h, tools/microbench/bpermute_rate.hip): an instruction is served in two groups of 32
 // lanes and two lanes of a group whose sources are 32 apart cost an extra cycle.  Lanes of one group read from lanes 8 r .. 8 r + 7 of
-// THEIR runs r, and sources 32 apart are entries of runs r and r + 4: with GROUP_MIN_USES >= 11, 32 consecutive list entries span at most
-// 2 + floor(30 / 11) = 4 runs (and 64 at most 2 + floor(62 / 11) = 7 <= XBAR_RUNS), so the runs of a group are four CONSECUTIVE numbers,
-// their source lanes 8 (r mod 4) + k are 32 distinct banks whatever the digits are, and SQ_LDS_BANK_CONFLICT of the walk is zero for every
-// scalar (tools/ct_check.py).  A zero digit fetches entry 1 and is masked to the identity.  No block barrier is left: a wavefront waits only
-// for its own DMA (vmcnt), so the four wavefronts of a block drift apart freely.  Per addition and wavefront: 4.5 LDS-DMA loads + 4.5
-// ds_read_b128 + 36 crossbar moves (comb_group_block: 7.5 + 9, two barriers per two additions); a table row is fetched once per WAVEFRONT
-// that holds terms of its point and pass -- 2 x 1.16 times for CMZ's P (11 terms) against 2 x 1.7 times per 16-lane column before.
+// THEIR runs r, and sources 32 apart are entries of runs r and r + 4 -- so a service group must never hold terms of five tables.  Hence
+// the shape: a half of the wavefront takes XBAR_HALF_TERMS = 31 consecutive list entries (lanes 31 and 63 carry no term; they are holders
+// like every lane), and with GROUP_MIN_USES >= 10 (CMZ's P has exactly 10 terms per proof) 31 consecutive entries span at most
+// 2 + floor(29 / 10) = 4 runs -- four CONSECUTIVE numbers, whose source lanes 8 (r mod 4) + k are 32 distinct banks whatever the digits are --
+// and the wavefront's 62 entries at most 2 + floor(60 / 10) = 8 = XBAR_RUNS (two static_asserts).  SQ_LDS_BANK_CONFLICT of the walk is zero
+// for every scalar (tools/ct_check.py).  A zero digit fetches entry 1 and is masked to the identity.  No block barrier is left: a wavefront
+// waits only for its own DMA (vmcnt), so the four wavefronts of a block drift apart freely.  Per addition and wavefront: 4.5 LDS-DMA loads +
+// 4.5 ds_read_b128 + 36 crossbar moves (comb_group_block: 7.5 + 9, two barriers per two additions); a table row is fetched once per WAVEFRONT
+// that holds terms of its point and pass -- 2 x 1.15 times for CMZ's P against 2 x 1.7 times per 16-lane column before.
 constexpr uint32_t XBAR_RUNS = 8;
+constexpr uint32_t XBAR_HALF_TERMS = 31, XBAR_WAVE_TERMS = 2 * XBAR_HALF_TERMS, XBAR_BLOCK_TERMS = 4 * XBAR_WAVE_TERMS;      // list entries per half / wavefront / 256-lane block
 constexpr int XBAR_WAVE_UINT4 = 9 * 64;                         // a wavefront's staged pairs: chunk q of lane l at q * 64 + l
 constexpr int XBAR_LDS_UINT4 = 4 * XBAR_WAVE_UINT4;             // 36 KB per 256-lane block
-static_assert(2 + (64 - 2) / GROUP_MIN_USES <= XBAR_RUNS, "64 consecutive grouped terms must span at most XBAR_RUNS points");
-static_assert(2 + (32 - 2) / GROUP_MIN_USES <= 4, "32 consecutive grouped terms (one crossbar service group) must span at most 4 points: sources 32 lanes apart never meet");
+static_assert(2 + (XBAR_WAVE_TERMS - 2) / GROUP_MIN_USES <= XBAR_RUNS, "a wavefront's consecutive grouped terms must span at most XBAR_RUNS points");
+static_assert(2 + (XBAR_HALF_TERMS - 2) / GROUP_MIN_USES <= 4 && XBAR_HALF_TERMS <= 32,
+              "the terms of one crossbar service group (a half of the wavefront) must span at most 4 points: sources 32 lanes apart never meet");
 
 __device__ __forceinline__ void comb_group_xbar(uint32_t i0, uint32_t n_g, const uint32_t* __restrict__ list_g, const uint8_t* __restrict__ scalars,
                                                 const uint32_t* __restrict__ pidx, const uint32_t* __restrict__ slot_of,
@@ -551,13 +555,19 @@ __device__ __forceinline__ void comb_group_xbar(uint32_t i0, uint32_t n_g, const
   constexpr uint32_t NONE = 0xffffffffu;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  if (i0 + wave * 64u >= n_g) return;                              // (a whole wavefront past the end of the list: nothing waits for it)
-  const uint32_t i = i0 + tid;
-  const bool listed = i < n_g;
+  if (i0 + wave * XBAR_WAVE_TERMS >= n_g) return;                  // (a whole wavefront past the end of the list: nothing waits for it)
+  // lane l < 31 takes entry l of the wavefront's 62, lane 32 + l entry 31 + l; lanes 31 and 63 take none
+  const uint32_t hl = lane & 31u;
+  const uint32_t i = i0 + wave * XBAR_WAVE_TERMS + (lane >> 5) * XBAR_HALF_TERMS + hl;
+  const bool listed = hl < XBAR_HALF_TERMS && i < n_g;
   uint32_t t = 0, slot = NONE;
   if (listed) { t = list_g[i]; slot = slot_of[pidx[t]]; }           // (a grouped term's point index is in range by construction)
-  // runs of equal table slots in the wavefront (lanes past the end of the list join the last run)
-  const uint32_t before = (uint32_t)__shfl_up((int)slot, 1);
+  // runs of equal table slots in the wavefront: lanes without a term (31, 63, past the end of the list) join the run before them -- lanes 31 and
+  // 63 pass the slot of their left neighbour on, so that a table whose terms sit on both sides of them stays ONE run
+  uint32_t cur = slot;
+  const uint32_t left = (uint32_t)__shfl_up((int)cur, 1);
+  if (hl == 31u) cur = left;
+  const uint32_t before = (uint32_t)__shfl_up((int)cur, 1);
   const bool change = lane == 0u || (listed && slot != before);
   const uint64_t cm = __ballot(change);
   const uint32_t run = (uint32_t)__popcll(cm & ((2ull << lane) - 1ull)) - 1u;

@@ -36,7 +36,7 @@ constexpr int HOT_ROW = HOT_HALF + 1;                            // entries per 
 constexpr int HOT_SLOTS = 64;
 constexpr int HOT_CLASSES = HOT_SLOTS + 3;                       // class 64 = "cold" terms through a comb table, 65 = cold terms on a ladder,
 constexpr int CLASS_COMB = HOT_SLOTS, CLASS_LADDER = HOT_SLOTS + 1, CLASS_GROUP = HOT_SLOTS + 2;   // 66 = comb terms listed point by point
-constexpr uint32_t GROUP_MIN_USES = 11;                          // a point's terms form a group from this many cold uses on (comb_tables.h: 32 consecutive grouped terms then span <= 4 points, 64 <= 7)
+constexpr uint32_t GROUP_MIN_USES = 10;                          // a point's terms form a group from this many cold uses on (CMZ's P has 10; comb_tables.h: 31 consecutive grouped terms then span <= 4 points, 62 <= 8)
 constexpr size_t HOT_SLOT_NIELS = (size_t)HOT_WINDOWS * HOT_ROW;
 constexpr int HOT_ROW_CHUNKS = HOT_ROW * (int)(sizeof(dev_niels) / 16);   // 16-byte chunks per row
 constexpr int HOT_COPIES = 16;

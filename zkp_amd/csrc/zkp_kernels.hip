@@ -184,7 +184,8 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   const uint32_t n_group = (CT && TEETH == 16) ? class_start[HOT_CLASSES] - class_start[CLASS_GROUP] : 0u;
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
   const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
-  const uint32_t group_blocks = (n_group + blockDim.x - 1) / blockDim.x;
+  const uint32_t group_terms = LOOKUP == LOOKUP_XBAR ? XBAR_BLOCK_TERMS : 256u;       // list entries a grouped block takes (crossbar: 31 per half of a wavefront)
+  const uint32_t group_blocks = (n_group + group_terms - 1) / group_terms;
   // Logical block number (ladder blocks, comb blocks, grouped blocks, fixed-base blocks -- longest first).  ladder_stride > 1 spreads the
   // ladder blocks over the front of the grid (ladder block i sits at position i * stride) instead of starting them all at once: a ladder
   // lane scans its own 1.1 KB table 65 times, and only as many of those tables as are in flight together have to fit the L2s
@@ -220,7 +221,7 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   } else if (vb < ladder_blocks + comb_blocks + group_blocks) {
     if constexpr (CT && TEETH == 16) {                            // terms of points with many uses, listed point by point
       if constexpr (LOOKUP == LOOKUP_XBAR)
-        comb_group_xbar((vb - ladder_blocks - comb_blocks) * 256u, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
+        comb_group_xbar((vb - ladder_blocks - comb_blocks) * XBAR_BLOCK_TERMS, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
       else
         comb_group_block((vb - ladder_blocks - comb_blocks) * 256u, n_group, list + class_start[CLASS_GROUP], scalars, pidx, slot_of, comb, partial, hot_lds);
     }
@@ -1416,6 +1417,10 @@ void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_sca
   const uint32_t lb = (max_ladder + 255) / 256;
   if (ladder && lb && (c->ladder_interleave < 0 ? lb >= zkp_ctx::kInterleaveLadderBlocks : c->ladder_interleave != 0)) {
     stride = (grid.x / 2) / lb;
+    // ODD: workgroups go to the 8 XCDs round robin by their index, so an even stride puts every ladder block -- the long ones, 1.65 M cycles each -- on half, a
+    // stride of 16 on ONE of the XCDs, and the launch ends in a tail on 32 CUs (round 5: 524,288 CMZ proofs 34 -> 87 ms when a 3 % larger grid moved the stride
+    // from 15 to 16; profiles/r05_ab_experiments.txt block e)
+    if (stride % 2 == 0 && stride) --stride;
     if (stride < 2) stride = 0;
   }
   prof_note(c, ZKP_K_TERMS, std::string("k_terms_split<") + (CT ? "true" : "false") + ", " + std::to_string(TEETH) + ", " + (ladder ? "true" : "false") + ", " + std::to_string(LOOKUP) + ">");
@@ -1511,7 +1516,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     if ((phase & PH_POINTS) && k.max_tables && c->kernel_names[ZKP_K_TABLES].find("k_tables_transcript") == std::string::npos)
       prof_note(c, ZKP_K_TABLES, std::string((c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) ? "zkp::k_comb_tables_lane<" : "zkp::k_comb_tables<") + (k.teeth == 16 ? "16>" : "4>"));
     if (phase & PH_POINTS) prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
-    const dim3 grid((unsigned)((n_terms + 255) / 256 + 4 + HOT_SLOTS));     // every class starts a new block
+    const dim3 grid((unsigned)((n_terms + XBAR_BLOCK_TERMS - 1) / XBAR_BLOCK_TERMS + 4 + HOT_SLOTS));     // every class starts a new block (grouped blocks take 248 terms)
     // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l
     if (batched_encode) {
       uint8_t* d_half = reinterpret_cast<uint8_t*>(base + o.half);

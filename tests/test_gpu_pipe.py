@@ -459,3 +459,34 @@ def test_submitter_threads_give_the_bytes_of_the_callers_thread(cmz, pinned):
         pipe.set_submit_threads(0)
         chal, resp, coms = pipe.submit_prove(st, nn, _t0(), a_sec, a_inst, a_com, a_ent).wait()
         assert (chal == chal0).all() and (resp == resp0).all() and (coms == coms0).all()
+
+
+@pytest.mark.parametrize("threads", [0, 1])
+def test_destroying_a_pipe_discards_abandoned_jobs(cmz, threads):
+    """zkp_pipe_destroy under jobs nobody waited for (a forgotten handle in Rust, a crashed caller): kernels are waited for, queued submits dropped, no copy out is
+    issued -- the outputs are either untouched (discarded) or, with submitter threads, complete (the device's thread had retired the job already); never half written,
+    and nothing is written after destroy returns."""
+    mod, secrets, inst, common, entropy, w = cmz
+    st = mod.statement
+    n = 480
+    inst_n = np.ascontiguousarray(inst[:, :n])
+    ref = T.Pipe((0,), 1)
+    want = ref.submit_prove(st, n, _t0(), secrets[:n], inst_n, common, entropy[:n]).wait()
+    ref.close()
+    pipe = T.Pipe((0, 0), 2)
+    pipe.set_submit_threads(threads)
+    jobs = [pipe.submit_prove(st, n, _t0(), secrets[:n], inst_n, common, entropy[:n]) for _ in range(4)]
+    handles = [(j._h, j.outputs, j._keep) for j in jobs]                 # keep every array alive ourselves ...
+    for j in jobs:
+        j._h = None                                                      # ... and abandon the handles: nobody will wait
+    pipe._jobs.clear()
+    T.lib().zkp_pipe_destroy(pipe._h)
+    pipe._h = None
+    snap = [[a.copy() for a in outs] for _, outs, _ in handles]
+    for (h, outs, keep), before in zip(handles, snap):
+        untouched = all(not a.any() for a in outs)
+        complete = all((a == b).all() for a, b in zip(outs, want))
+        assert untouched or complete
+        assert all((a == b).all() for a, b in zip(outs, before))
+    if not threads:
+        assert all(not a.any() for _, outs, _ in handles for a in outs)  # the caller's thread never issued a copy out

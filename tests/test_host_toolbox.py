@@ -517,3 +517,44 @@ def test_option_numbers_agree_between_header_python_and_rust():
     assert rs == enum
     for k in enum:                                   # every option is documented in the header's comment block
         assert (" *   %s:" % k) in header, k
+
+
+def test_crossbar_layout_is_bank_conflict_free_for_every_run_structure():
+    """The constant-time argument of the grouped comb walk (comb_tables.h: comb_group_xbar), checked as arithmetic: ds_bpermute_b32 is served in two groups of 32
+    lanes and two lanes of a group conflict iff their source lanes differ by 32 (profiles/r05_bpermute_microbench.txt).  A half of a wavefront takes XBAR_HALF_TERMS
+    consecutive entries of a list in which every table's terms form a run of >= GROUP_MIN_USES entries; a lane of run r (counted from the wavefront's first entry)
+    reads lanes 8 r .. 8 r + 7.  For every run structure the constants admit: at most 8 runs per wavefront, and within a half no two POSSIBLE sources 32 apart --
+    whatever the secret digits are.  The constants are read from the headers, so the test fails if somebody relaxes one of them."""
+    import re
+    from hypothesis import given, settings, strategies as st_
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hot = open(os.path.join(root, "zkp_amd", "csrc", "hot_tables.h")).read()
+    comb = open(os.path.join(root, "zkp_amd", "csrc", "comb_tables.h")).read()
+    gmin = int(re.search(r"constexpr uint32_t GROUP_MIN_USES = (\d+);", hot).group(1))
+    half = int(re.search(r"XBAR_HALF_TERMS = (\d+)", comb).group(1))
+    runs_max = int(re.search(r"constexpr uint32_t XBAR_RUNS = (\d+);", comb).group(1))
+    assert half <= 32 and runs_max == 8
+
+    def check(run_lengths, start):
+        # entry e of the list belongs to table owner[e]; the wavefront takes entries [start, start + 2 * half)
+        owner = [t for t, n in enumerate(run_lengths) for _ in range(n)]
+        for w0 in range(start, len(owner) - 2 * half + 1, 2 * half):
+            entries = owner[w0:w0 + 2 * half]
+            tables = sorted(set(entries), key=entries.index)
+            assert len(tables) <= runs_max, (run_lengths, w0)
+            for h in range(2):
+                runs = sorted({tables.index(t) for t in entries[h * half:(h + 1) * half]})
+                sources = {8 * r + k for r in runs for k in range(8)}                      # every lane a lane of this half MAY read, over all digits
+                assert len({s % 32 for s in sources}) == len(sources), (run_lengths, w0, h, runs)      # distinct banks: no two sources 32 apart
+
+    @settings(max_examples=400, deadline=None)
+    @given(st_.lists(st_.integers(min_value=gmin, max_value=3 * gmin + 5), min_size=8, max_size=40), st_.integers(min_value=0, max_value=61))
+    def prop(run_lengths, start):
+        check(run_lengths, start)
+    prop()
+    check([gmin] * 64, 0)                                   # the CMZ shape: ten terms of P per proof, proof after proof
+    check([gmin] * 64, 7)
+    # and the bound is tight: one use fewer per table admits a half with five tables
+    with pytest.raises(AssertionError):
+        for s in range(2 * half):
+            check([gmin - 1] * 64, s)

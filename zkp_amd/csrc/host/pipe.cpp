@@ -62,8 +62,9 @@ struct Worker {
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<std::function<void()>> q;
-  bool stop = false;
+  struct Item { std::function<void()> run; struct zkp_job* outer; };
+  std::deque<Item> q;
+  bool stop = false;                 // zkp_pipe_destroy: whatever is still queued or on a stream is DISCARDED -- nothing is submitted any more, no output is copied
 };
 
 struct OutCopy { uint8_t* user; const uint8_t* staged; size_t bytes; };
@@ -227,7 +228,7 @@ int zkp_pipe_create(zkp_pipe** out, const int* device_ids, int n_devices, int co
 
 void zkp_pipe_destroy(zkp_pipe* p) {
   if (!p) return;
-  for (auto& w : p->workers) {                           // queued submits are carried out (their callers may be about to wait), then the threads end
+  for (auto& w : p->workers) {                           // what is still queued is dropped, what is on a stream discarded; then the threads end
     { std::lock_guard<std::mutex> lk(w->mu); w->stop = true; }
     w->cv.notify_all();
     if (w->th.joinable()) w->th.join();
@@ -278,14 +279,24 @@ void finish_outer(zkp_job* o, int state, int rc) {
 }
 // the device's thread: jobs of this device whose kernels are done get their copies out issued (poll), finished ones are retired completely --
 // staged outputs copied to the caller's buffers, verdict words written -- so that the caller's zkp_job_wait only picks up the result
-void retire_group(zkp_pipe* p, int group) {
+void retire_group(zkp_pipe* p, int group, bool discard) {
   for (auto& sp : p->slots) {
     Slot* s = sp.get();
     if (s->group != group || !s->cur || !s->busy.load(std::memory_order_acquire)) continue;
+    zkp_job* o = s->cur;
+    if (discard) {
+      // the pipe is going away under a job nobody waited for: its owner, buffers and verdict words may be gone.  Kernels are waited for, no copy out is
+      // issued, nothing is written to caller memory (zkp_ctx_job_discard); whoever still holds the handle gets an error
+      { std::lock_guard<std::mutex> lk(s->ctx_mu); (void)zkp_ctx_job_discard(s->ctx); s->busy.store(false, std::memory_order_release); }
+      s->cur = nullptr;
+      delete o->inner;
+      o->inner = nullptr;
+      finish_outer(o, 3, ZKP_TB_BAD_STATEMENT);
+      continue;
+    }
     bool done;
     { std::lock_guard<std::mutex> lk(s->ctx_mu); done = zkp_ctx_job_poll(s->ctx) != 0; }
     if (!done) continue;
-    zkp_job* o = s->cur;
     s->cur = nullptr;
     finish_outer(o, 3, wait_inner(o->inner));
   }
@@ -293,24 +304,24 @@ void retire_group(zkp_pipe* p, int group) {
 
 void worker_loop(zkp_pipe* p, int group, Worker* w) {
   for (;;) {
-    std::function<void()> fn;
+    Worker::Item it{nullptr, nullptr};
+    bool stopping;
     {
       std::unique_lock<std::mutex> lk(w->mu);
       // wake for work, or every 200 us to move this device's finished jobs along (their copies out are issued by the first poll after the kernels)
       w->cv.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || !w->q.empty(); });
-      if (w->q.empty()) {
-        if (w->stop) {
-          bool pending = false;                           // (jobs still on a stream: retired before the thread ends, their callers may be waiting)
-          for (auto& sp : p->slots) pending = pending || (sp->group == group && sp->cur);
-          if (!pending) return;
-        }
-      } else {
-        fn = std::move(w->q.front());
+      stopping = w->stop;
+      if (!w->q.empty()) {
+        it = std::move(w->q.front());
         w->q.pop_front();
       }
     }
-    if (fn) fn();
-    retire_group(p, group);
+    if (it.outer) {
+      if (stopping) finish_outer(it.outer, 2, ZKP_TB_BAD_STATEMENT);       // never submitted: the buffers it names may be gone
+      else it.run();
+    }
+    retire_group(p, group, stopping);
+    if (stopping && !it.outer) return;                       // (queue drained, every job of this device discarded)
   }
 }
 Worker* worker_of(zkp_pipe* p, int group) {
@@ -544,7 +555,7 @@ int submit_threaded(zkp_pipe* p, const zkp_statement* st, zkp_job** job, F&& do_
   Worker* w = worker_of(p, s->group);
   {
     std::lock_guard<std::mutex> lk(w->mu);
-    w->q.emplace_back([s, o, k, fn = std::forward<F>(do_submit)]() mutable {
+    w->q.push_back(Worker::Item{[s, o, k, fn = std::forward<F>(do_submit)]() mutable {
       zkp_job* in = nullptr;
       const int rc = fn(k, &in);
       if (rc) { finish_outer(o, 2, rc); return; }
@@ -552,7 +563,7 @@ int submit_threaded(zkp_pipe* p, const zkp_statement* st, zkp_job** job, F&& do_
       if (in->immediate) { finish_outer(o, 3, wait_inner(in)); return; }      // (small or ragged batch: it ran inside the submit)
       s->cur = o;
       { std::lock_guard<std::mutex> lk2(o->mu); o->state = 1; }
-    });
+    }, o});
   }
   w->cv.notify_one();
   *job = o;

@@ -308,8 +308,12 @@ void worker_loop(zkp_pipe* p, int group, Worker* w) {
     bool stopping;
     {
       std::unique_lock<std::mutex> lk(w->mu);
-      // wake for work, or every 200 us to move this device's finished jobs along (their copies out are issued by the first poll after the kernels)
-      w->cv.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || !w->q.empty(); });
+      // wake for work -- or, while jobs of this device are on their streams, every 200 us to move them along (a finished job's copies out are issued by the
+      // first poll after its kernels); with nothing in flight the thread sleeps until somebody queues work
+      bool in_flight = false;
+      for (auto& sp : p->slots) in_flight = in_flight || (sp->group == group && sp->cur);
+      if (in_flight) w->cv.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || !w->q.empty(); });
+      else w->cv.wait(lk, [&] { return w->stop || !w->q.empty(); });
       stopping = w->stop;
       if (!w->q.empty()) {
         it = std::move(w->q.front());

@@ -189,19 +189,20 @@ ZKP_HD void ge_neg(ge_p3& r, const ge_p3& p) {
 }
 
 // conditional negation of cached / niels forms: swap (Y+X, Y-X), negate the T term.  flag in {0,1}.
+// The negated term is NOT carried (round 5): 2p - x has limbs <= 2^30, and the one place it goes is the product with the accumulator's tight T
+// (c = T * T2d / T * xy2d), whose columns stay below 2^64 with a 2p-class operand -- the interval tracker checks exactly these compositions
+// (tests/host/fe_host_lib.cpp: t_point_op 6 and 7).  27 instructions per table addition less than with the carry rounds 1 - 4 paid.
 ZKP_HD void ge_cached_cneg(ge_cached& q, uint32_t flag) {
   fe_cswap(q.YpX, q.YmX, flag);
-  fe n, c;
+  fe n;
   fe_neg(n, q.T2d);
-  fe_carry(c, n);
-  fe_cmov(q.T2d, c, flag);
+  fe_cmov(q.T2d, n, flag);
 }
 ZKP_HD void ge_niels_cneg(ge_niels& q, uint32_t flag) {
   fe_cswap(q.ypx, q.ymx, flag);
-  fe n, c;
+  fe n;
   fe_neg(n, q.xy2d);
-  fe_carry(c, n);
-  fe_cmov(q.xy2d, c, flag);
+  fe_cmov(q.xy2d, n, flag);
 }
 ZKP_HD void ge_cached_cmov(ge_cached& r, const ge_cached& q, uint32_t flag) {
   fe_cmov(r.YpX, q.YpX, flag);

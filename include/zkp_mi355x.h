@@ -436,10 +436,12 @@ int zkp_ctx_set_profiling(zkp_ctx* ctx, int enabled);
 
 #ifdef ZKP_BUILD_TEST_HOOKS
 /* ---- test-hook builds only (zkp_amd/libzkp_mi355x_testhooks.so, compiled with -DZKP_BUILD_TEST_HOOKS; the shipped library
- *      has none of this: no extra options, no k_noop / k_debug_quad kernels, no scratch in its code object) ----------------
+ *      has none of this: no extra options, no k_noop / k_debug_quad / k_debug_row kernels, no scratch in its code object) ----------------
  * zkp_debug_quad_selftest: exercises the 4-lane cooperative point arithmetic used by the latency-bound kernels.  pairs =
  *   [n][2][32] encodings (P, Q); out = [n][4][32] = enc(2P), enc(P+Q), enc(P+Q) through Q's niels form, enc(P-Q) through the
  *   negated niels form.
+ * zkp_debug_row_selftest: the same for the one-limb-per-lane arithmetic of the Horner tail (zkp_amd/csrc/rowfe.h): out = [n][3][32] = enc(2P),
+ *   enc(P+Q), enc(2^11 P + Q).
  * zkp_ctx_set_option extras (measurement, profiles/r02_ab_experiments.txt blocks o and p):
  *   ZKP_TESTOPT_DUMMY_LAUNCHES = n empty kernels added to every zkp_fused_prove_dev call (what a launch costs a pipelined caller);
  *   ZKP_TESTOPT_GENERIC_CLASSIFIER = 1 sends the fused flows through the generic six-kernel term classifier instead of
@@ -448,6 +450,7 @@ int zkp_ctx_set_profiling(zkp_ctx* ctx, int enabled);
  * zkp_debug_wave_cycles copies out (and clears) up to cap records, [block][wavefront 0..3] = block class << 56 | cycles (class 1 =
  *   ladder, 2 = comb scan, 3 = grouped comb walk, 4 = fixed-base; 0 = no record): the timing side of the constant-time evidence. */
 int zkp_debug_quad_selftest(zkp_ctx* ctx, uint32_t n, const uint8_t* pairs /*[n][64]*/, uint8_t* out /*[n][128]*/);
+int zkp_debug_row_selftest(zkp_ctx* ctx, uint32_t n, const uint8_t* pairs /*[n][64]*/, uint8_t* out /*[n][96]*/);
 int zkp_debug_wave_cycles(zkp_ctx* ctx, uint64_t* out, uint32_t cap);     /* returns the number of records copied */
 enum { ZKP_TESTOPT_DUMMY_LAUNCHES = 1001, ZKP_TESTOPT_GENERIC_CLASSIFIER = 1002, ZKP_TESTOPT_WAVE_CYCLES = 1003 };
 #endif

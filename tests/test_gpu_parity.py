@@ -271,6 +271,30 @@ def test_quad_cooperative_point_ops(base_points):
             assert out[i, k].tobytes() == M.ristretto_encode(exp[k]), (i, k)
 
 
+def test_row_cooperative_point_ops(base_points):
+    """one-limb-per-lane doubling / cached addition (rowfe.h: the Horner tail of every Pippenger run) against the oracle: 2P, P + Q and the
+    chain 2^11 P + Q, incl. identity operands, P = Q and P = -Q.  Test-hook build only, like the quad self-test."""
+    from zkp_amd.engine import Engine
+    eng = Engine(0, test_hooks=True)
+    rng = random.Random(4242)
+    _, encs = base_points
+    ident = bytes(32)
+    negs = [M.ristretto_encode(M.pt_neg(M.ristretto_decode(e))) for e in encs[:4]]
+    pairs = [(ident, ident), (encs[0], ident), (ident, encs[1]), (encs[2], encs[2]), (encs[3], negs[3])]
+    pairs += [(encs[rng.randrange(64)], encs[rng.randrange(64)]) for _ in range(200)]
+    arr = np.frombuffer(b"".join(p + q for p, q in pairs), np.uint8).reshape(-1, 64)
+    out = eng.debug_row_selftest(arr)
+    eng.close()
+    for i, (pe, qe) in enumerate(pairs):
+        P, Q = M.ristretto_decode(pe), M.ristretto_decode(qe)
+        chain = P
+        for _ in range(11):
+            chain = M.pt_double(chain)
+        exp = [M.pt_double(P), M.pt_add(P, Q), M.pt_add(chain, Q)]
+        for k in range(3):
+            assert out[i, k].tobytes() == M.ristretto_encode(exp[k]), (i, k)
+
+
 @pytest.mark.parametrize("flags", [0, 1])
 def test_batched_encoder_equals_per_output_encoder(base_points, flags):
     """ZKP_OPT_BATCH_ENCODE_MIN: outputs encoded as 2 * sum (s/2) P with one shared inversion (ristretto_dc_*, the identity

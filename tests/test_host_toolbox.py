@@ -91,8 +91,8 @@ def test_shipped_code_object_has_no_scratch_no_spills_and_no_hook_kernels(tmp_pa
     assert len(shipped) > 40
     bad = {k: v for k, v in shipped.items() if v.get("private_segment_fixed_size") or v.get("vgpr_spill_count") or v.get("sgpr_spill_count")}
     assert not bad, bad
-    assert not any("k_debug_quad" in k or "k_noop" in k for k in shipped)
-    assert any("k_debug_quad" in k for k in hooks) and any("k_noop" in k for k in hooks)
+    assert not any("k_debug_quad" in k or "k_debug_row" in k or "k_noop" in k for k in shipped)
+    assert any("k_debug_quad" in k for k in hooks) and any("k_debug_row" in k for k in hooks) and any("k_noop" in k for k in hooks)
     shutil.rmtree(str(tmp_path), ignore_errors=True)
 
 

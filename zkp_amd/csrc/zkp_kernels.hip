@@ -65,6 +65,7 @@ __device__ __forceinline__ uint32_t sel8(const uint32_t w[8], int j) {
 
 #include "hot_tables.h"
 #include "quad.h"
+#include "rowfe.h"
 #include "comb_tables.h"
 #include "sc25519.h"
 #include "transcript_kernels.h"
@@ -918,39 +919,53 @@ k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t ou
 }
 
 // The last tree level (one output per window: W1 quads of this block), then
-// result = sum_w 2^(C w) T_w  (Horner, one quad: 256 inherently sequential doublings);  encode (generic MSM) or identity test (fused batch
-// verification: shared_flags).  One block per MSM of the run.
+// result = sum_w 2^(C w) T_w  (Horner: 253 inherently sequential doublings, W1 - 1 additions);  encode (generic MSM) or identity test (fused
+// batch verification: shared_flags).  One block per MSM of the run.  The chain runs on ONE wavefront with one limb per lane (rowfe.h): 0.42 us
+// per doubling against 1.0 us for a quad of lanes; what can be done beside the chain is done before it -- the W1 quads turn their window sums
+// into cached operands (one multiplication level each) so that an addition of the chain is two levels, not three.
 __global__ void __launch_bounds__(256)
 k_pip_combine(int W1, int C, uint32_t in_stride, int level, int m, int shift, const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,
               dev_ext* __restrict__ T_all, const uint32_t* __restrict__ invalid, uint8_t* __restrict__ out_point, uint32_t* __restrict__ status,
               uint32_t shared_flags /*1: invalid[b] also carries bit 1 = "a transcript rejected a proof" -> status[2 b + 1]*/) {
   const uint32_t b = blockIdx.x;
   dev_ext* T = T_all + (size_t)b * W1;             // this MSM's window sums
-  {
-    const uint32_t g = threadIdx.x >> 2;
-    if (g < (uint32_t)W1) pip_reduce_quad(b * (uint32_t)W1 + g, (int)(threadIdx.x & 3u), 1u, in_stride, 1u, level, m, shift, A_in, R_in, T_all, nullptr);
-  }
+  const uint32_t g = threadIdx.x >> 2;
+  const int q = (int)(threadIdx.x & 3u);
+  if (g < (uint32_t)W1) pip_reduce_quad(b * (uint32_t)W1 + g, q, 1u, in_stride, 1u, level, m, shift, A_in, R_in, T_all, nullptr);
   __syncthreads();                                 // (T is written and read by this block only)
-  // the W1 window sums go to LDS once, all lanes loading: the Horner quad then reads them at LDS latency instead of paying a round trip to L2
-  // per window inside its dependent chain (22 x ~2 us of a 0.47 ms kernel)
+  // LDS: window w's operand at 36 w + 9 (coordinate) + limb -- the top window as the point itself (the chain starts from it), the others cached
   __shared__ uint32_t Tl[64 * 36];                 // (W1 <= 64: pip_run)
-  for (uint32_t i = threadIdx.x; i < (uint32_t)W1 * 36u; i += blockDim.x) Tl[i] = reinterpret_cast<const uint32_t*>(T)[i];
-  __syncthreads();
-  if (threadIdx.x >= 4) return;                    // one quad of lanes (quad.h)
-  const int q = (int)threadIdx.x;
-  auto load_T = [&](qpt& p, int k) {
+  if (g < (uint32_t)W1) {
+    qpt t;
+    q_load_ext(t, T + g, q);
+    if (g + 1 < (uint32_t)W1) {
+      qcached cc;
+      q_to_cached(cc, t, q);
+      t.c = cc.c;
+    }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) p.c.v[i] = Tl[36 * k + 9 * q + i];
-  };
-  qpt acc, t;
-  load_T(acc, W1 - 1);
-#pragma unroll 1
-  for (int k = W1 - 2; k >= 0; --k) {
-#pragma unroll 1
-    for (int d = 0; d < C; ++d) q_double(acc, acc, q);
-    load_T(t, k);
-    q_add(acc, acc, t, q);
+    for (int i = 0; i < 9; ++i) Tl[36 * g + 9 * q + i] = t.c.v[i];
   }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    rowctx rc;
+    row_init(rc);
+    const uint32_t at = 9u * rc.r + (rc.live ? rc.k : 0u);
+    uint32_t acc = rc.live ? Tl[36 * (W1 - 1) + at] : 0u;
+#pragma unroll 1
+    for (int k = W1 - 2; k >= 0; --k) {
+#pragma unroll 1
+      for (int d = 0; d < C; ++d) acc = row_double(rc, acc);
+      const uint32_t t = rc.live ? Tl[36 * k + at] : 0u;
+      acc = row_add_cached(rc, acc, t);
+    }
+    if (rc.live) Tl[at] = acc;                     // (window 0's operand has been consumed: every lane of this wavefront is past its read)
+  }
+  __syncthreads();
+  if (threadIdx.x >= 4) return;                    // one quad of lanes: lane q now holds coordinate q
+  qpt acc;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc.c.v[i] = Tl[9 * q + i];
   ge_p3 full;
   q_gather(full, acc);
   uint32_t o[8];
@@ -1008,6 +1023,59 @@ k_debug_quad(uint32_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ 
     q_gather(R, r);
     ristretto_encode(o, R);
     if (q == 0) store_vec<2>(out + 128 * (size_t)i + 32 * op, o);
+  }
+}
+// self-test hook for the one-limb-per-lane arithmetic (rowfe.h), one wavefront per pair (P, Q): out[i] = enc(2P), enc(P+Q), enc(2^11 P + Q)
+__global__ void __launch_bounds__(64)
+k_debug_row(uint32_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x;
+  if (i >= n) return;
+  __shared__ uint32_t S[3 * 36];                   // P (X, Y, Z, T), Q cached (Y-X, Y+X, 2Z, 2dT), result
+  if (threadIdx.x == 0) {
+    uint32_t w[8];
+    ge_p3 P, Q;
+    load_vec<2>(w, enc + 64 * (size_t)i);
+    ristretto_decode(P, w);
+    load_vec<2>(w, enc + 64 * (size_t)i + 32);
+    ristretto_decode(Q, w);
+    fe c[4], d2;
+    fe_sub(c[0], Q.Y, Q.X);
+    fe_carry(c[0], c[0]);
+    fe_add(c[1], Q.Y, Q.X);
+    fe_carry(c[1], c[1]);
+    fe_add(c[2], Q.Z, Q.Z);
+    fe_carry(c[2], c[2]);
+    fe_from_const(d2, FE_D2);
+    fe_mul(c[3], Q.T, d2);
+    const fe* pc[4] = {&P.X, &P.Y, &P.Z, &P.T};
+    for (int r = 0; r < 4; ++r)
+      for (int k = 0; k < 9; ++k) { S[9 * r + k] = pc[r]->v[k]; S[36 + 9 * r + k] = c[r].v[k]; }
+  }
+  __syncthreads();
+  rowctx rc;
+  row_init(rc);
+  const uint32_t at = 9u * rc.r + (rc.live ? rc.k : 0u);
+  const uint32_t p = rc.live ? S[at] : 0u, qc = rc.live ? S[36 + at] : 0u;
+  for (int op = 0; op < 3; ++op) {
+    uint32_t r;
+    if (op == 0) r = row_double(rc, p);
+    else if (op == 1) r = row_add_cached(rc, p, qc);
+    else {
+      r = p;
+#pragma unroll 1
+      for (int d = 0; d < 11; ++d) r = row_double(rc, r);
+      r = row_add_cached(rc, r, qc);
+    }
+    __syncthreads();
+    if (rc.live) S[72 + at] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      ge_p3 R;
+      for (int k = 0; k < 9; ++k) { R.X.v[k] = S[72 + k]; R.Y.v[k] = S[81 + k]; R.Z.v[k] = S[90 + k]; R.T.v[k] = S[99 + k]; }
+      uint32_t o[8];
+      ristretto_encode(o, R);
+      store_vec<2>(out + 96 * (size_t)i + 32 * op, o);
+    }
   }
 }
 #endif  // ZKP_BUILD_TEST_HOOKS
@@ -2256,6 +2324,26 @@ int zkp_debug_quad_selftest(zkp_ctx* c, uint32_t n, const uint8_t* pairs, uint8_
   hipLaunchKernelGGL(k_debug_quad, grid1((size_t)n * 4, 256), dim3(256), 0, c->stream, n, reinterpret_cast<uint8_t*>(base + o_in), reinterpret_cast<uint8_t*>(base + o_out));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, base + o_out, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+}
+#endif  // ZKP_BUILD_TEST_HOOKS
+
+#ifdef ZKP_BUILD_TEST_HOOKS
+int zkp_debug_row_selftest(zkp_ctx* c, uint32_t n, const uint8_t* pairs, uint8_t* out) {
+  if (!c || !pairs || !out) return fail(ZKP_ERR_ARG, "NULL pointer");
+  if (n == 0) return ZKP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  carve cv;
+  const size_t o_in = cv.take((size_t)n * 64);
+  const size_t o_out = cv.take((size_t)n * 96);
+  const int rc = ensure_ws(c, cv.off);
+  if (rc) return rc;
+  char* base = static_cast<char*>(c->ws);
+  HIP_TRY(hipMemcpyAsync(base + o_in, pairs, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_debug_row, dim3(n), dim3(64), 0, c->stream, n, reinterpret_cast<uint8_t*>(base + o_in), reinterpret_cast<uint8_t*>(base + o_out));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, base + o_out, (size_t)n * 96, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ZKP_OK;
 }

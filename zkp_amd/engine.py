@@ -36,7 +36,7 @@ EXPORTS = (
     "zkp_ctx_job_wait", "zkp_ctx_job_poll", "zkp_ctx_job_pending", "zkp_ctx_job_discard", "zkp_ctx_job_timing", "zkp_ctx_last_kernels", "zkp_host_alloc", "zkp_host_alloc_on", "zkp_host_numa_node", "zkp_host_node_of", "zkp_host_free", "zkp_host_register", "zkp_host_unregister",
     "zkp_host_is_pinned", "zkp_chacha20_fill_dev",
 )
-TEST_HOOK_EXPORTS = ("zkp_debug_quad_selftest", "zkp_debug_wave_cycles")      # only in libzkp_mi355x_testhooks.so
+TEST_HOOK_EXPORTS = ("zkp_debug_quad_selftest", "zkp_debug_row_selftest", "zkp_debug_wave_cycles")      # only in libzkp_mi355x_testhooks.so
 
 
 class ZkpError(RuntimeError):
@@ -85,6 +85,7 @@ def load_library(test_hooks: bool = False) -> ctypes.CDLL:
     lib.zkp_ctx_capture_abort.argtypes = [vp]
     if test_hooks:
         lib.zkp_debug_quad_selftest.argtypes = [vp, ctypes.c_uint32, u8p, u8p]
+        lib.zkp_debug_row_selftest.argtypes = [vp, ctypes.c_uint32, u8p, u8p]
         lib.zkp_debug_wave_cycles.argtypes = [vp, ctypes.c_void_p, ctypes.c_uint32]
         _hooks_lib = lib
     else:
@@ -183,6 +184,15 @@ class Engine:
         if not self.test_hooks:
             raise ZkpError("zkp_debug_quad_selftest exists in the test-hook build only: Engine(device, test_hooks=True)")
         _check(self._lib.zkp_debug_quad_selftest(self._h, len(pairs), _ptr(pairs), _ptr(out)), "zkp_debug_quad_selftest")
+        return out
+
+    def debug_row_selftest(self, pairs) -> np.ndarray:
+        """(test-hook build) one-limb-per-lane point arithmetic (csrc/rowfe.h): [n][64] encodings (P, Q) -> [n][3][32] = enc(2P), enc(P+Q), enc(2^11 P + Q)"""
+        pairs = _u8(pairs, 64)
+        out = np.zeros((len(pairs), 3, 32), np.uint8)
+        if not self.test_hooks:
+            raise ZkpError("zkp_debug_row_selftest exists in the test-hook build only: Engine(device, test_hooks=True)")
+        _check(self._lib.zkp_debug_row_selftest(self._h, len(pairs), _ptr(pairs), _ptr(out)), "zkp_debug_row_selftest")
         return out
 
     def debug_wave_cycles(self, cap: int = 1 << 20):

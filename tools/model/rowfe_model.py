@@ -149,6 +149,38 @@ def row_add_cached(p, c):
     return row_mul(m1, m2)                 # X3 = E F, Y3 = H G, Z3 = F G, T3 = E H
 
 
+def row_sqn(a, n):
+    for _ in range(n):
+        a = row_mul(a, a)
+    return a
+
+
+def row_invert(z):
+    t0 = row_mul(z, z)
+    t1 = row_sqn(t0, 2)
+    t1 = row_mul(z, t1)
+    t0 = row_mul(t0, t1)
+    z11 = t0
+    t0 = row_mul(t0, t0)
+    t0 = row_mul(t1, t0)
+    t1 = row_sqn(t0, 5)
+    t0 = row_mul(t1, t0)
+    t1 = row_sqn(t0, 10)
+    t1 = row_mul(t1, t0)
+    t2 = row_sqn(t1, 20)
+    t1 = row_mul(t2, t1)
+    t1 = row_sqn(t1, 10)
+    t0 = row_mul(t1, t0)
+    t1 = row_sqn(t0, 50)
+    t1 = row_mul(t1, t0)
+    t2 = row_sqn(t1, 100)
+    t1 = row_mul(t2, t1)
+    t1 = row_sqn(t1, 50)
+    t0 = row_mul(t1, t0)
+    t0 = row_sqn(t0, 5)
+    return row_mul(t0, z11)
+
+
 # ---------------------------------------------------------------------------------------------- checks against integers
 def limbs_of(x, top=False):
     return [(x >> (29 * k)) & (M29 if k < 8 else M23) for k in range(9)]
@@ -243,6 +275,13 @@ def self_check(rounds=200, seed=1):
             assert got[0] * got[1] % P == got[2] * got[3] % P
             for r in range(4):
                 assert all(acc[16 * r + k] <= TIGHT[k] for k in range(9))
+    # the inversion chain (k_encode_invert): z^(p - 2), 0 -> 0, from the top of the tight class too
+    vals = [rng.randrange(1, P), 0, 1, P - 1]
+    out = row_invert(rows_of(vals))
+    for r in range(4):
+        assert value_of(out, r) == pow(vals[r], P - 2, P)
+    top = sum(x << (29 * k) for k, x in enumerate(TIGHT)) % P
+    assert value_of(row_invert(rows_of(None, [TIGHT] * 4)), 2) == pow(top, P - 2, P)
     return True
 
 

@@ -386,6 +386,7 @@ __device__ __forceinline__ void encode_invert_block(enc_tree& tree, int tid, uin
   tree_put(tree, ENC_BLOCK + tid, x);
   __syncthreads();
   tree_up(tree, tid);
+#ifdef ZKP_AB_LANE_INVERT
   if (tid == 0) {
     fe r, inv;
     tree_get(r, tree, 1);
@@ -393,6 +394,15 @@ __device__ __forceinline__ void encode_invert_block(enc_tree& tree, int tid, uin
     fe_invert(inv, r);
     tree_put(tree, 1, inv);
   }
+#else
+  if (tid < 64) {              // the block's one inversion, which everything after it waits for: a wavefront on it, one limb per lane (rowfe.h)
+    rowctx rc;
+    row_init(rc);
+    const uint32_t z = rc.live ? tree.node[1][rc.k] : 0u;
+    const uint32_t inv = row_invert(rc, z);
+    if (rc.live && rc.r == 0u) tree.node[1][rc.k] = inv;
+  }
+#endif
   __syncthreads();
   tree_down(tree, tid);
   if (b < n_blocks) {
@@ -718,7 +728,24 @@ k_pip_tile_scatter(uint32_t n, const uint32_t* __restrict__ digits, const uint32
                    uint32_t* __restrict__ sorted) {
   using cfg = pip_cfg<C>;
   __shared__ uint32_t base[cfg::B1];
-  const uint32_t w = blockIdx.y, t = blockIdx.x, tiles = gridDim.x;
+  // Every tile of a window scatters 4-byte entries all over that window's sorted list.  Workgroups go to the 8 XCDs round robin by their linear index, so
+  // with (tile, window) = (x, y) the tiles of one window sit on different XCDs and every 128-byte line of the list is written in pieces from several L2s.
+  // Windows are dealt out in groups of 8 instead: linear index i -> window 8 (i / (8 tiles)) + i % 8, i.e. window w lives on XCD w % 8 with all its tiles
+  // and its list is assembled in ONE L2 (the windows past the last full group of 8 keep the plain order).
+  const uint32_t tiles = gridDim.x, WK = gridDim.y, lin = blockIdx.x + blockIdx.y * tiles, full = (WK & ~7u) * tiles;
+  uint32_t w, t;
+#ifdef ZKP_AB_PLAIN_SCATTER
+  if (false) {
+#else
+  if (lin < full) {
+#endif
+    const uint32_t grp = lin / (8u * tiles), r = lin - grp * 8u * tiles;
+    w = grp * 8u + (r & 7u);
+    t = r >> 3;
+  } else {
+    w = blockIdx.y;
+    t = blockIdx.x;
+  }
   const uint32_t* in = tilehist + ((size_t)w * tiles + t) * cfg::B1;
   for (uint32_t b = threadIdx.x; b < cfg::B1; b += blockDim.x) base[b] = in[b];
   __syncthreads();
@@ -761,6 +788,8 @@ k_pip_bucket_part(uint32_t n, uint32_t W1, uint32_t bins, uint32_t L, uint32_t v
                   const uint32_t* __restrict__ hist, const uint32_t* __restrict__ vstart, const uint32_t* __restrict__ vmap,
                   const uint32_t* __restrict__ sorted, const dev_niels* __restrict__ niels,
                   dev_ext* __restrict__ parts) {
+  // (plain (part block, window) order: dealing the windows out in contiguous runs per XCD, so that an XCD's L2 sees at most two batches' operand arrays, lost
+  // 10 % on this kernel and 6 % on config 3 -- profiles/r05_ab_experiments.txt block i; the 0.9 GB of gathers per K = 5 launch stay)
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t w = blockIdx.y;
   const uint32_t* vs = vstart + (size_t)w * (bins + 1);
@@ -920,8 +949,8 @@ k_pip_reduce_lvl(uint32_t n_out, uint32_t total, uint32_t in_stride, uint32_t ou
 
 // The last tree level (one output per window: W1 quads of this block), then
 // result = sum_w 2^(C w) T_w  (Horner: 253 inherently sequential doublings, W1 - 1 additions);  encode (generic MSM) or identity test (fused
-// batch verification: shared_flags).  One block per MSM of the run.  The chain runs on ONE wavefront with one limb per lane (rowfe.h): 0.42 us
-// per doubling against 1.0 us for a quad of lanes; what can be done beside the chain is done before it -- the W1 quads turn their window sums
+// batch verification: shared_flags).  One block per MSM of the run.  The chain runs on ONE wavefront with one limb per lane (rowfe.h): ~0.45 us
+// per doubling against ~1.05 us for a quad of lanes (354 -> 144 us per launch, profiles/r05_ab_experiments.txt blocks h, i); what can be done beside the chain is done before it -- the W1 quads turn their window sums
 // into cached operands (one multiplication level each) so that an addition of the chain is two levels, not three.
 __global__ void __launch_bounds__(256)
 k_pip_combine(int W1, int C, uint32_t in_stride, int level, int m, int shift, const dev_ext* __restrict__ A_in, const dev_ext* __restrict__ R_in,

@@ -558,3 +558,31 @@ def test_crossbar_layout_is_bank_conflict_free_for_every_run_structure():
     with pytest.raises(AssertionError):
         for s in range(2 * half):
             check([gmin - 1] * 64, s)
+
+
+def _scatter_block_to_tile_window(lin, tiles, WK):
+    """k_pip_tile_scatter's block order (zkp_amd/csrc/zkp_kernels.hip): linear workgroup index -> (tile, window)"""
+    full = (WK & ~7) * tiles
+    if lin < full:
+        grp, r = divmod(lin, 8 * tiles)
+        return r >> 3, grp * 8 + (r & 7)
+    return lin % tiles, lin // tiles
+
+
+@pytest.mark.parametrize("tiles,WK", [(1, 1), (1, 8), (5, 120), (5, 24), (21, 24), (7, 17), (3, 7), (40, 129), (512, 17), (2, 16)])
+def test_scatter_pass_block_order_is_a_bijection_that_keeps_a_window_on_one_xcd(tiles, WK):
+    """Round 5: the counting sort's scatter pass deals whole windows to XCDs (workgroups go to the 8 XCDs round robin by linear index).  The kernel's index
+    arithmetic, restated: every (tile, window) pair is visited exactly once, and all tiles of a window inside the full groups of 8 land on XCD window % 8."""
+    seen = set()
+    xcd_of = {}
+    for lin in range(tiles * WK):
+        t, w = _scatter_block_to_tile_window(lin, tiles, WK)
+        assert 0 <= t < tiles and 0 <= w < WK
+        seen.add((t, w))
+        xcd_of.setdefault(w, set()).add(lin % 8)
+    assert len(seen) == tiles * WK
+    for w in range(WK & ~7):
+        assert xcd_of[w] == {w % 8}
+    # the source carries this formula
+    src = open(os.path.join(ROOT, "zkp_amd", "csrc", "zkp_kernels.hip")).read()
+    assert "w = grp * 8u + (r & 7u);" in src and "full = (WK & ~7u) * tiles" in src

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, last GPU call: the GPU suite and the collection of every profile and bench line on the final sources (row-limb Horner tail and inversion,
+# Round 5, the collection call: the GPU suite and the collection of every profile and bench line on the final sources (row-limb Horner tail and inversion,
 # whole windows per XCD in the scatter pass); the constant-time evidence and the host-scaling table of tools/x/r05_job13.sh stay (term kernel and pipe unchanged).
 export TMPDIR=/tmp
 R="${GRAFT_REPO_ROOT:-/root/repo}"

@@ -42,3 +42,28 @@ def test_identity_and_doubling_through_the_unified_addition():
             got = R.row_add_cached(R.rows_of(lhs), cached(rhs))
             vals = tuple(R.value_of(got, r) for r in range(4))
             assert R.same_point(vals, R.ext_add(lhs, rhs))
+
+
+def test_lane_swaps_of_the_model_are_what_the_hardware_probe_printed():
+    """profiles/r05_permlane_probe.txt is the output of tools/microbench/permlane_probe.hip on an MI355X: the model's v_permlane32_swap / v_permlane16_swap
+    must give the same source row for every output row (rowfe.h's movement between coordinates rests on exactly these six lines, plus the raw swap16)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = {}
+    for line in open(os.path.join(root, "profiles", "r05_permlane_probe.txt")):
+        m = re.match(r"(\S+)\s+rows from: (\d) (\d) (\d) (\d)\s+\(lane order inside rows kept\)", line)
+        assert m, line
+        want[m.group(1)] = [int(g) for g in m.groups()[1:]]
+    x = list(range(64))
+    rows = lambda v: [v[16 * r] >> 4 for r in range(4)]
+    h0, h1 = R.swap32(x, x)
+    got = {"swap32(x,x)[0]": rows(h0), "swap32(x,x)[1]": rows(h1)}
+    a, b = R.swap16(h0, h0)
+    got["swap16(h0,h0)[0]"], got["swap16(h0,h0)[1]"] = rows(a), rows(b)
+    a, b = R.swap16(h1, h1)
+    got["swap16(h1,h1)[0]"], got["swap16(h1,h1)[1]"] = rows(a), rows(b)
+    a, b = R.swap16(x, x)
+    got["swap16(x,x)[0]"], got["swap16(x,x)[1]"] = rows(a), rows(b)
+    assert got == want
+    for v in (h0, h1, a, b):
+        assert all(v[16 * r + k] == v[16 * r] + k for r in range(4) for k in range(16))

@@ -1,7 +1,7 @@
 """Lane-level model of zkp_amd/csrc/rowfe.h: GF(2^255-19) with ONE LIMB PER LANE (9 limbs in the low lanes of a 16-lane DPP row, one row per
 coordinate of an extended point), the arithmetic of the 253-doubling Horner tail of k_pip_combine.  Every function below is the HIP routine of
 the same name, instruction for instruction, over lists of 64 Python ints with the DPP moves modelled exactly (row_shr / row_shl with
-bound_ctrl = zero fill, row_newbcast, and the cross-row pulls that ds_bpermute_b32 does).  It checks (1) values against big-integer arithmetic
+bound_ctrl = zero fill, row_newbcast) and the gfx950 lane swaps between rows as probed on the hardware (profiles/r05_permlane_probe.txt).  It checks (1) values against big-integer arithmetic
 and (2) that no intermediate exceeds its register width for operands at the top of the limb classes the callers use.
 Run:  python tools/model/rowfe_model.py     (also imported by tests/test_rowfe_model.py)"""
 import random
@@ -50,6 +50,35 @@ def bcast(v, j):
 
 def pull(v, rowmap):
     return [v[16 * rowmap[R[l]] + K[l]] for l in range(64)]
+
+
+def swap32(v, s):
+    """v_permlane32_swap_b32 v, s: lanes 32 .. 63 of v <-> lanes 0 .. 31 of s (profiles/r05_permlane_probe.txt); returns (v', s')"""
+    return v[:32] + s[:32], v[32:] + s[32:]
+
+
+def swap16(v, s):
+    """v_permlane16_swap_b32 v, s: the odd 16-lane rows of v <-> the even rows of s; returns (v', s')"""
+    vo, so = list(v), list(s)
+    for half in (0, 32):
+        vo[half + 16:half + 32], so[half:half + 16] = s[half:half + 16], v[half + 16:half + 32]
+    return vo, so
+
+
+def row_bcast01(x):
+    """rows 0 and 1 of x, each in front of every row: three lane swaps (rowfe.h)"""
+    lo, _ = swap32(x, x)                   # rows 0 1 0 1
+    return swap16(lo, lo)                  # (0 0 0 0), (1 1 1 1)
+
+
+def row_bcast23(x):
+    _, hi = swap32(x, x)                   # rows 2 3 2 3
+    return swap16(hi, hi)
+
+
+def row_bcast_all(x):
+    lo, hi = swap32(x, x)
+    return swap16(lo, lo) + swap16(hi, hi)
 
 
 def row_mul(a, b):
@@ -115,17 +144,17 @@ def pick(rows, *vals):
 
 
 def row_double(p):
-    x, y = pull(p, [0, 0, 0, 0]), pull(p, [1, 1, 1, 1])
+    x, y = row_bcast01(p)
     w = add(x, y)
     t = pick(None, p, p, p, w)
     s = row_mul(t, t)
-    a, b = pull(s, [0, 0, 0, 0]), pull(s, [1, 1, 1, 1])
+    a, b = row_bcast01(s)
     h = add(b, a)
     g = sub2p(b, a)
     e = sub4p(s, h)
     f = sub4p(add(s, s), g)
     v = row_carry(pick(None, f, f, f, e))
-    ee, ff = pull(v, [3, 3, 3, 3]), pull(v, [2, 2, 2, 2])
+    ff, ee = row_bcast23(v)
     m1 = pick(None, ee, g, ff, ee)
     m2 = pick(None, ff, h, g, h)
     return row_mul(m1, m2)
@@ -133,19 +162,18 @@ def row_double(p):
 
 def row_add_cached(p, c):
     """c rows: Y2-X2, Y2+X2, 2 Z2, 2d T2 (tight)"""
-    o = pull(p, [1, 0, 2, 3])
-    s = sub2p(o, p)
-    a = add(p, o)
-    t = pick(None, s, a, p, p)
+    x, y = row_bcast01(p)
+    t = pick(None, sub2p(y, p), add(p, x), p, p)
     u = row_mul(t, c)                      # A, B, D, C
-    o = pull(u, [1, 0, 3, 2])
+    u0, u1, u2, u3 = row_bcast_all(u)
+    o = pick(None, u1, u0, u3, u2)
     d0 = sub2p(o, u)                       # row 0: E = B - A
     d2 = sub2p(u, o)                       # row 2: F = D - C
     sm = add(u, o)                         # row 1: H, row 3: G
     v = row_carry(pick(None, d0, sm, d2, sm))   # E, H, F, G
-    m2 = pull(v, [2, 3, 3, 1])             # F, G, G, H
-    e0 = pull(v, [0, 0, 0, 0])
-    m1 = pick(None, v, v, v, e0)           # E, H, F, E
+    v0, v1, v2, v3 = row_bcast_all(v)
+    m2 = pick(None, v2, v3, v3, v1)        # F, G, G, H
+    m1 = pick(None, v, v, v, v0)           # E, H, F, E
     return row_mul(m1, m2)                 # X3 = E F, Y3 = H G, Z3 = F G, T3 = E H
 
 

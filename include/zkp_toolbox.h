@@ -178,11 +178,17 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, u
 typedef struct zkp_pipe zkp_pipe;
 typedef struct zkp_job zkp_job;
 int zkp_pipe_create(zkp_pipe** out, const int* device_ids, int n_devices, int contexts_per_device);
-void zkp_pipe_destroy(zkp_pipe* pipe);                    /* jobs nobody waited for are DISCARDED: kernels waited for, nothing written to caller memory */
+void zkp_pipe_destroy(zkp_pipe* pipe);                    /* jobs nobody waited for are DISCARDED: kernels waited for, nothing written to caller memory.  A handle
+                                                           * that outlives its pipe: one made by a SUBMITTER THREAD may still go to zkp_job_wait (error code, the
+                                                           * handle is freed -- otherwise it leaks); any other handle must not be touched after zkp_pipe_destroy */
 int zkp_pipe_num_contexts(const zkp_pipe* pipe);
 int zkp_pipe_num_devices(const zkp_pipe* pipe);
 zkp_ctx* zkp_pipe_context(zkp_pipe* pipe, int i);        /* context i (tuning options, ZKP_OPT_WS_LIMIT_BYTES); do not destroy it */
 int zkp_pipe_context_device(const zkp_pipe* pipe, int i);
+/* The partition the synchronous calls of (b) use, as plain arithmetic (no pipe, no GPU): n_items proofs -- or whole batches of `unit` proofs each for
+ * zkp_pipe_batch_verify_many -- over at most n_contexts contexts, every range at least fused_min_batch proofs wide; writes the G <= n_contexts non-empty
+ * ranges [lo[g], hi[g]) (lo / hi: n_contexts words each) and returns G.  Range g runs on context g. */
+uint32_t zkp_pipe_shard_plan(uint32_t n_items, uint32_t unit, uint32_t n_contexts, uint32_t fused_min_batch, uint32_t* lo, uint32_t* hi);
 int zkp_pipe_jobs_in_flight(const zkp_pipe* pipe);
 int zkp_pipe_set_submit_threads(zkp_pipe* pipe, int on);  /* -1 default (threads when the device list has more than one entry), 0 off, 1 on */
 const char* zkp_pipe_last_error(const zkp_pipe* pipe);    /* text of the last failure of a pipe call (never NULL) */

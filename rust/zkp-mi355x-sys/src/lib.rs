@@ -231,6 +231,7 @@ extern "C" {
     pub fn zkp_pipe_num_devices(pipe: *const zkp_pipe) -> c_int;
     pub fn zkp_pipe_context(pipe: *mut zkp_pipe, i: c_int) -> *mut zkp_ctx;
     pub fn zkp_pipe_context_device(pipe: *const zkp_pipe, i: c_int) -> c_int;
+    pub fn zkp_pipe_shard_plan(n_items: u32, unit: u32, n_contexts: u32, fused_min_batch: u32, lo: *mut u32, hi: *mut u32) -> u32;
     pub fn zkp_pipe_jobs_in_flight(pipe: *const zkp_pipe) -> c_int;
     pub fn zkp_pipe_set_submit_threads(pipe: *mut zkp_pipe, on: c_int) -> c_int;
     pub fn zkp_pipe_last_error(pipe: *const zkp_pipe) -> *const c_char;

@@ -443,8 +443,10 @@ impl Drop for Pipe {
 
 /// A submitted call.  The C side holds pointers into the job's buffers -- the borrowed inputs and outputs, and the boxed `verdicts` --
 /// until `zkp_job_wait` has returned, so a job that is dropped without `wait()` waits in `Drop` (its result is discarded): no pointer the
-/// library holds ever outlives the memory it names.  (`mem::forget`-ing a job leaks the box and keeps its context busy; it is still not a
-/// use-after-free, because `zkp_pipe_destroy` DISCARDS whatever jobs are pending -- it waits for their kernels and writes nothing.)
+/// library holds ever outlives the memory it names.  `mem::forget`-ing a job is NOT covered by that: the box leaks, the context stays busy, and with
+/// submitter threads the device's thread may still retire the job on its own -- copy staged outputs, write verdicts -- into buffers whose borrow has
+/// ended.  `zkp_pipe_destroy` discards what is still pending (kernels waited for, nothing written), which bounds the damage to the pipe's lifetime;
+/// do not forget jobs.
 pub struct Job<'a> {
     job: *mut sys::zkp_job,
     pipe: &'a Pipe,

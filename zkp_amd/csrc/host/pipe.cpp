@@ -202,6 +202,19 @@ int fail_pipe(zkp_pipe* p, int rc, const std::string& what) {
 
 extern "C" {
 
+uint32_t zkp_pipe_shard_plan(uint32_t n_items, uint32_t unit, uint32_t n_contexts, uint32_t fused_min_batch, uint32_t* lo, uint32_t* hi) {
+  if (!n_items || !n_contexts || !lo || !hi) return 0;
+  const uint32_t u = std::max<uint32_t>(1, unit);
+  const uint64_t min_items = std::max<uint64_t>(1, ((uint64_t)std::max<uint32_t>(1, fused_min_batch) + u - 1) / u);
+  const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_contexts, n_items), n_items / min_items));
+  uint32_t k = 0;
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint32_t a = (uint32_t)((uint64_t)g * n_items / G), b = (uint32_t)((uint64_t)(g + 1) * n_items / G);
+    if (a < b) { lo[k] = a; hi[k] = b; ++k; }
+  }
+  return k;
+}
+
 int zkp_pipe_create(zkp_pipe** out, const int* device_ids, int n_devices, int contexts_per_device) {
   if (!out) return ZKP_TB_BAD_STATEMENT;
   *out = nullptr;
@@ -256,7 +269,14 @@ int zkp_pipe_set_submit_threads(zkp_pipe* p, int on) {
   p->threaded = on < 0 ? -1 : (on ? 1 : 0);
   return ZKP_TB_OK;
 }
-const char* zkp_pipe_last_error(const zkp_pipe* p) { return p ? p->last_error.c_str() : ""; }
+// (submitter threads and the per-device threads of the synchronous calls report asynchronously: the text is copied under err_mu into a buffer of the CALLING
+// thread, valid until that thread asks again)
+const char* zkp_pipe_last_error(const zkp_pipe* p) {
+  if (!p) return "";
+  static thread_local std::string text;
+  { std::lock_guard<std::mutex> lk(const_cast<zkp_pipe*>(p)->err_mu); text = p->last_error; }
+  return text.c_str();
+}
 
 }  // extern "C"
 
@@ -273,8 +293,14 @@ void kick_all(zkp_pipe* p) {
   for (auto& s : p->slots) kick_slot(s.get());
 }
 int wait_inner(zkp_job* jp);
-void finish_outer(zkp_job* o, int state, int rc) {
-  { std::lock_guard<std::mutex> lk(o->mu); o->rc = rc; o->state = state; }
+// state >= 2 hands the job back to whoever holds the handle: zkp_job_wait may return and free it the moment it sees the state, so the notification goes out
+// UNDER the job's mutex (the waiter cannot leave cv.wait -- it re-takes o->mu -- before this thread has let go of the condition variable), and nothing
+// touches `o` afterwards.  pipe_gone: the pipe is being destroyed under the job -- the handle must not reach into it any more.
+void finish_outer(zkp_job* o, int state, int rc, bool pipe_gone = false) {
+  std::lock_guard<std::mutex> lk(o->mu);
+  o->rc = rc;
+  if (pipe_gone) o->pipe = nullptr;
+  o->state = state;
   o->cv.notify_all();
 }
 // the device's thread: jobs of this device whose kernels are done get their copies out issued (poll), finished ones are retired completely --
@@ -291,7 +317,7 @@ void retire_group(zkp_pipe* p, int group, bool discard) {
       s->cur = nullptr;
       delete o->inner;
       o->inner = nullptr;
-      finish_outer(o, 3, ZKP_TB_BAD_STATEMENT);
+      finish_outer(o, 3, ZKP_TB_BAD_STATEMENT, true);
       continue;
     }
     bool done;
@@ -321,7 +347,7 @@ void worker_loop(zkp_pipe* p, int group, Worker* w) {
       }
     }
     if (it.outer) {
-      if (stopping) finish_outer(it.outer, 2, ZKP_TB_BAD_STATEMENT);       // never submitted: the buffers it names may be gone
+      if (stopping) finish_outer(it.outer, 2, ZKP_TB_BAD_STATEMENT, true); // never submitted: the buffers it names may be gone
       else it.run();
     }
     retire_group(p, group, stopping);
@@ -638,12 +664,14 @@ int zkp_job_wait(zkp_job* jp) {
   if (!jp->outer) return wait_inner(jp);
   std::unique_ptr<zkp_job> o(jp);
   int rc;
+  zkp_pipe* pipe;
   {
     std::unique_lock<std::mutex> lk(o->mu);
     o->cv.wait(lk, [&] { return o->state >= 2; });
     rc = o->rc;
+    pipe = o->pipe;                                        // NULL: zkp_pipe_destroy discarded the job -- the pipe and its slots are gone, only the handle is left to free
   }
-  o->pipe->slots[o->slot]->reserved.store(false, std::memory_order_release);
+  if (pipe) pipe->slots[o->slot]->reserved.store(false, std::memory_order_release);
   return rc;
 }
 
@@ -683,15 +711,14 @@ struct Shard { uint32_t lo, hi; int slot; };
 // ranges [g n / G, (g + 1) n / G) over the first G = min(#contexts, n) contexts (SURVEY 8(e) / DESIGN section 8); empty ones dropped
 // -- and no more contexts than keep every range on the fused device route (>= fused_min_batch proofs each): a range below it would run the
 // host-transcript route synchronously inside submit, one range after the other (N = 100 over 24 contexts: 24 ranges of 4 proofs, each a full
-// GPU call chain; one range of 100 instead).  `unit` = proofs per schedulable item (a whole batch for the K-batch call).
+// GPU call chain; one range of 100 instead).  `unit` = proofs per schedulable item (a whole batch for the K-batch call).  Range g goes to slot g:
+// zkp_pipe_create lays the slots out round robin over the device list (slot = k * n_devices + d), so G <= #contexts ranges reach the GPUs evenly
+// before any GPU gets a second one.  The arithmetic is zkp_pipe_shard_plan (exported: the CPU suite checks it without a GPU).
 std::vector<Shard> make_shards(const zkp_pipe* p, uint32_t n, uint32_t unit = 1) {
+  std::vector<uint32_t> lo(p->slots.size()), hi(p->slots.size());
+  const uint32_t G = zkp_pipe_shard_plan(n, unit, (uint32_t)p->slots.size(), zkp_toolbox_get_fused_min_batch(), lo.data(), hi.data());
   std::vector<Shard> out;
-  const uint64_t min_items = std::max<uint64_t>(1, ((uint64_t)std::max<uint32_t>(1, zkp_toolbox_get_fused_min_batch()) + unit - 1) / std::max<uint32_t>(1, unit));
-  const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(p->slots.size(), n), n / min_items));
-  for (uint32_t g = 0; g < G; ++g) {
-    const uint32_t lo = (uint32_t)((uint64_t)g * n / G), hi = (uint32_t)((uint64_t)(g + 1) * n / G);
-    if (lo < hi) out.push_back({lo, hi, (int)g});
-  }
+  for (uint32_t g = 0; g < G; ++g) out.push_back({lo[g], hi[g], (int)g});
   return out;
 }
 

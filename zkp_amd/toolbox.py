@@ -41,7 +41,7 @@ EXPORTS = (
     "zkp_prove_phase_a", "zkp_prove_phase_b", "zkp_toolbox_set_fused_min_batch", "zkp_toolbox_get_fused_min_batch", "zkp_chacha20_block",
     "zkp_proof_compact_size", "zkp_proof_batchable_size", "zkp_proof_compact_encode", "zkp_proof_compact_decode",
     "zkp_proof_batchable_encode", "zkp_proof_batchable_decode", "zkp_batch_verify_locate", "zkp_batch_verify_many",
-    "zkp_pipe_create", "zkp_pipe_destroy", "zkp_pipe_num_contexts", "zkp_pipe_num_devices", "zkp_pipe_context", "zkp_pipe_context_device",
+    "zkp_pipe_create", "zkp_pipe_destroy", "zkp_pipe_num_contexts", "zkp_pipe_num_devices", "zkp_pipe_context", "zkp_pipe_context_device", "zkp_pipe_shard_plan",
     "zkp_pipe_jobs_in_flight", "zkp_pipe_set_submit_threads", "zkp_pipe_last_error", "zkp_prove_batch_submit", "zkp_verify_compact_batch_submit",
     "zkp_verify_batchable_each_submit", "zkp_batch_verify_many_submit", "zkp_job_done", "zkp_job_wait", "zkp_job_context_index", "zkp_pipe_prove_batch",
     "zkp_pipe_verify_compact_batch", "zkp_pipe_verify_batchable_each", "zkp_pipe_batch_verify", "zkp_pipe_batch_verify_many",
@@ -101,6 +101,8 @@ def lib() -> ctypes.CDLL:
         _lib.zkp_pipe_context.argtypes = [vp, i32]
         _lib.zkp_pipe_context.restype = vp
         _lib.zkp_pipe_context_device.argtypes = [vp, i32]
+        _lib.zkp_pipe_shard_plan.argtypes = [u32, u32, u32, u32, vp, vp]
+        _lib.zkp_pipe_shard_plan.restype = u32
         _lib.zkp_pipe_set_submit_threads.argtypes = [vp, i32]
         _lib.zkp_pipe_last_error.argtypes = [vp]
         _lib.zkp_pipe_last_error.restype = ctypes.c_char_p
@@ -149,6 +151,15 @@ def get_fused_min_batch() -> int:
     f = lib().zkp_toolbox_get_fused_min_batch
     f.restype = ctypes.c_uint32
     return int(f())
+
+
+def pipe_shard_plan(n_items: int, n_contexts: int, unit: int = 1, fused_min_batch: Optional[int] = None):
+    """The contiguous ranges zkp_pipe_prove_batch / zkp_pipe_batch_verify[_many] ... cut n_items proofs (batches of `unit` proofs) into, one per
+    context: [(lo, hi)] for contexts 0 .. G - 1 (zkp_pipe_shard_plan; plain arithmetic, no GPU)."""
+    lo = np.zeros(max(1, n_contexts), np.uint32)
+    hi = np.zeros(max(1, n_contexts), np.uint32)
+    g = lib().zkp_pipe_shard_plan(n_items, unit, n_contexts, get_fused_min_batch() if fused_min_batch is None else fused_min_batch, _p(lo), _p(hi))
+    return [(int(lo[i]), int(hi[i])) for i in range(int(g))]
 
 
 def _p(a):

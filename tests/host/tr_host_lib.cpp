@@ -86,5 +86,23 @@ extern "C" int t_tr_selftest(uint32_t seed, uint32_t N, uint32_t m, uint32_t np,
   }
   if (memcmp(got_wide.data(), want_wide.data(), want_wide.size()) != 0) bad |= 8;
   if (memcmp(got_chal.data(), want_chal.data(), want_chal.size()) != 0) bad |= 16;
+  // ---- the same program in step form (round 6: assemble + chain; tr_steps_build / tr_steps_run_one) ----
+  const tr_step_prog sp = tr_steps_build(prog, c.tables());
+  std::vector<uint8_t> s_wide(64 * (size_t)N * m + 8), s_chal(64 * (size_t)N + 8);
+  bufs.dst[D_WIDE] = s_wide.data(); bufs.dst[D_CHAL] = s_chal.data();
+  size_t perms = 0;
+  for (const tr_step& st : sp.steps) perms += (st.flags & TS_PERMUTE) ? 1 : 0;
+  if (perms != c.permutations()) bad |= 32;
+  for (const tr_step& st : sp.steps) if (st.emit_n > 64) bad |= 32;                 // (the chain kernel fetches a step's emit operations with one load)
+  for (uint32_t j = 0; j < N; ++j) {
+    uint64_t S[25], saved[25];
+    memcpy(S, &blobs[208 * (size_t)j], 200);
+    uint32_t failed = 0;
+    tr_steps_run_one(sp, j, bufs, S, saved, &failed);
+    if (memcmp(S, &want_blobs[208 * (size_t)j], 200) != 0) bad |= 64;
+    if ((failed != 0) != (want_fail[j] != 0)) bad |= 128;
+  }
+  if (memcmp(s_wide.data(), want_wide.data(), want_wide.size()) != 0) bad |= 256;
+  if (memcmp(s_chal.data(), want_chal.data(), want_chal.size()) != 0) bad |= 512;
   return bad ? -bad : (int)prog.size();
 }

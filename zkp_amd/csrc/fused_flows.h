@@ -631,7 +631,9 @@ enum { SRC_TABLE = 0, SRC_SECRETS = 1, SRC_ENTROPY = 2, SRC_COMS = 3 };
 enum { DST_WIDE = 0, DST_CHAL = 1 };
 enum fused_flow : char { FLOW_PROVE = 'P', FLOW_VERIFY = 'V', FLOW_BATCH = 'B' };
 
-struct prog_dev { const tr_op* ops = nullptr; uint32_t n = 0; uint32_t tail = 0; const uint64_t* tables = nullptr; };
+// sd / steps: the same program in step form (assemble + chain, transcript_kernels.h); steps = false when the plan could not build it (a step with more
+// than 64 PRF-output operations, more image words than a grid has rows) or the call is wide enough for the one-lane interpreter
+struct prog_dev { const tr_op* ops = nullptr; uint32_t n = 0; uint32_t tail = 0; const uint64_t* tables = nullptr; tr_steps_dev sd; bool steps = false; };
 struct fused_plan {
   fused_shape s;
   uint32_t N = 0, T1 = 0;          // T1 = terms per proof of the flow's CSR job
@@ -641,6 +643,7 @@ struct fused_plan {
   const uint32_t* d_order = nullptr;  // constraints by descending number of terms (msm_map of the reduce / encode kernels)
   const uint32_t* d_inc = nullptr;
   std::vector<uint32_t> tpt;       // host copy of tpt[]: comb-table shape and table / ladder bounds of the flow's CSR job
+  size_t img_bytes = 0;            // workspace of the step programs' images: max over the plan's programs of n_img * 21 words per proof (0 = no step form)
 };
 
 // Table / ladder bounds and comb shape of a CSR job whose proofs all multiply the point ids tpt[] (ids < ns: common to the
@@ -861,7 +864,27 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
     if (!pb.empty()) dump_program(flow, "program B (commitments, challenge)", pb, N);
   }
   const std::vector<uint32_t> inc = incidence_words(s);
+  // the step form of both programs (round 6): not for calls the one-lane interpreter serves (>= kVeryWideCallProofs proofs: their images would be gigabytes)
+  const tr_step_prog spa = tr_steps_build(pa, tbl_a), spb = tr_steps_build(pb, tbl_b);
+  auto steps_ok = [&](const tr_step_prog& sp) {
+    if (sp.steps.empty() || N >= zkp_ctx::kVeryWideCallProofs || (size_t)sp.n_img * 21 + 1 > 65535) return false;
+    for (const tr_step& t : sp.steps) if (t.emit_n > (uint32_t)TR_BLOCK) return false;
+    return true;
+  };
+  const bool ok_a = steps_ok(spa), ok_b = steps_ok(spb);
   carve cv;
+  struct step_off { size_t steps, emit, src, soff, cx, keep, chk; } so_a{}, so_b{};
+  auto carve_steps = [&](const tr_step_prog& sp, step_off& o) {
+    o.steps = cv.take(sp.steps.size() * sizeof(tr_step) + 64);
+    o.emit = cv.take(sp.emit.size() * sizeof(tr_op) + 64);
+    o.src = cv.take(sp.src.size() * sizeof(tr_op) + 64);
+    o.soff = cv.take(sp.src_off.size() * 4 + 64);
+    o.cx = cv.take(sp.cx.size() * 8 + 64);
+    o.keep = cv.take(sp.keep.size() * 8 + 64);
+    o.chk = cv.take(sp.chk.size() * sizeof(tr_op) + 64);
+  };
+  if (ok_a) carve_steps(spa, so_a);
+  if (ok_b) carve_steps(spb, so_b);
   const size_t o_a = cv.take(pa.size() * sizeof(tr_op) + 64);
   const size_t o_b = cv.take(pb.size() * sizeof(tr_op) + 64);
   const size_t o_ta = cv.take(tbl_a.size() * 8 + 64);
@@ -877,11 +900,34 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   if (e == hipSuccess) e = put(o_tb, tbl_b.data(), tbl_b.size() * 8);
   if (e == hipSuccess) e = put(o_t, tarr.data(), tarr.size() * 4);
   if (e == hipSuccess) e = put(o_i, inc.data(), inc.size() * 4);
+  auto put_steps = [&](const tr_step_prog& sp, const step_off& o, tr_steps_dev& d) {
+    if (e == hipSuccess) e = put(o.steps, sp.steps.data(), sp.steps.size() * sizeof(tr_step));
+    if (e == hipSuccess) e = put(o.emit, sp.emit.data(), sp.emit.size() * sizeof(tr_op));
+    if (e == hipSuccess) e = put(o.src, sp.src.data(), sp.src.size() * sizeof(tr_op));
+    if (e == hipSuccess) e = put(o.soff, sp.src_off.data(), sp.src_off.size() * 4);
+    if (e == hipSuccess) e = put(o.cx, sp.cx.data(), sp.cx.size() * 8);
+    if (e == hipSuccess) e = put(o.keep, sp.keep.data(), sp.keep.size() * 8);
+    if (e == hipSuccess) e = put(o.chk, sp.chk.data(), sp.chk.size() * sizeof(tr_op));
+    d.steps = reinterpret_cast<const tr_step*>(pl->d_block + o.steps);
+    d.emit = reinterpret_cast<const tr_op*>(pl->d_block + o.emit);
+    d.src = reinterpret_cast<const tr_op*>(pl->d_block + o.src);
+    d.src_off = reinterpret_cast<const uint32_t*>(pl->d_block + o.soff);
+    d.cx = reinterpret_cast<const uint64_t*>(pl->d_block + o.cx);
+    d.keep32 = reinterpret_cast<const uint32_t*>(pl->d_block + o.keep);
+    d.chk = reinterpret_cast<const tr_op*>(pl->d_block + o.chk);
+    d.n_steps = (uint32_t)sp.steps.size(); d.n_img = sp.n_img; d.n_chk = (uint32_t)sp.chk.size();
+  };
+  tr_steps_dev sda, sdb;
+  if (ok_a) put_steps(spa, so_a, sda);
+  if (ok_b) put_steps(spb, so_b, sdb);
   if (e != hipSuccess) { hipFree(pl->d_block); return fail(ZKP_ERR_HIP, std::string("plan upload: ") + hipGetErrorString(e)); }
   pl->a = prog_dev{reinterpret_cast<const tr_op*>(pl->d_block + o_a), (uint32_t)pa.size(), tailA[0] | (uint32_t)tailA[1] << 8 | (uint32_t)tailA[2] << 16,
                     reinterpret_cast<const uint64_t*>(pl->d_block + o_ta)};
   pl->b = prog_dev{reinterpret_cast<const tr_op*>(pl->d_block + o_b), (uint32_t)pb.size(), tailB[0] | (uint32_t)tailB[1] << 8 | (uint32_t)tailB[2] << 16,
                     reinterpret_cast<const uint64_t*>(pl->d_block + o_tb)};
+  pl->a.sd = sda; pl->a.steps = ok_a;
+  pl->b.sd = sdb; pl->b.steps = ok_b;
+  pl->img_bytes = (size_t)std::max(ok_a ? spa.n_img : 0u, ok_b ? spb.n_img : 0u) * 21 * 8 * N;
   pl->d_tarr = reinterpret_cast<const uint32_t*>(pl->d_block + o_t);
   pl->d_order = order_at ? pl->d_tarr + order_at : nullptr;
   pl->d_inc = reinterpret_cast<const uint32_t*>(pl->d_block + o_i);
@@ -899,11 +945,30 @@ __global__ void k_noop(uint32_t* p) { if (p) *p = 0; }
 bool transcript_single_lane(const zkp_ctx* c, uint32_t N, bool throughput) {
   return c->tr_lanes < 0 ? (throughput && N >= zkp_ctx::kVeryWideCallProofs) : c->tr_lanes == 1;
 }
+// the step form (assemble + chain) serves every call the lane-pair interpreter would: ZKP_OPT_TRANSCRIPT_STEPS = 0 goes back to the interpreter
+bool transcript_steps(const zkp_ctx* c, const prog_dev& p, uint32_t N, bool throughput, const uint64_t* d_img) {
+  return c->tr_steps && p.steps && d_img && !transcript_single_lane(c, N, throughput);
+}
+// the wide half of a step program: image words + identity checks (nothing here depends on a transcript state)
+void launch_assemble(zkp_ctx* c, const tr_steps_dev& sd, uint32_t N, const tr_bufs& bufs, uint64_t* d_img, uint32_t* d_failed) {
+  const uint32_t rows = sd.n_img * 21u + ((sd.n_chk || (sd.tail >> 31)) ? 1u : 0u);
+  if (rows) hipLaunchKernelGGL(k_transcript_assemble, dim3((N + 255) / 256, rows), dim3(256), 0, c->stream, sd, N, bufs, d_img, d_failed);
+}
 void run_program(zkp_ctx* c, const prog_dev& p_in, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput,
-                 bool owns_failed = false) {
+                 uint64_t* d_img, bool owns_failed = false) {
   if (!p_in.n) return;
   prog_dev p = p_in;
   if (owns_failed) p.tail |= 0x80000000u;          // the kernel writes every proof's rejection flag, 0 included
+  if (transcript_steps(c, p, N, throughput, d_img)) {
+    prof_note(c, ZKP_K_TRANSCRIPT, "zkp::k_transcript_chain");
+    tr_steps_dev sd = p.sd;
+    sd.tail = p.tail;
+    launch_assemble(c, sd, N, bufs, d_img, d_failed);
+    constexpr uint32_t per_block = TR_BLOCK / 2;
+    hipLaunchKernelGGL(k_transcript_chain, dim3((N + per_block - 1) / per_block), dim3(TR_BLOCK), 0, c->stream, sd, reinterpret_cast<const uint32_t*>(d_img), N, bufs, d_ts,
+                       reinterpret_cast<uint32_t*>(d_saved));
+    return;
+  }
   prof_note(c, ZKP_K_TRANSCRIPT, transcript_single_lane(c, N, throughput) ? "zkp::k_transcript_run1" : "zkp::k_transcript_run");
   if (transcript_single_lane(c, N, throughput)) {
     hipLaunchKernelGGL(k_transcript_run1, dim3((N + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, c->stream, p.ops, p.n, p.tables, N, bufs, d_ts, d_saved, d_failed, p.tail);
@@ -915,16 +980,20 @@ void run_program(zkp_ctx* c, const prog_dev& p_in, uint32_t N, const tr_bufs& bu
 }
 // Offer the program to the point phase of the term path that follows (it runs with the comb-table construction if there is
 // one: k_tables_transcript); run_program_pending() afterwards runs it on its own if nobody took it.
-void offer_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput, bool overlap) {
+void offer_program(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput, bool overlap,
+                   uint64_t* d_img) {
   auto& t = c->pending_tr;
   const bool fuse = c->fuse_tables_transcript < 0 ? N < zkp_ctx::kVeryWideCallProofs : c->fuse_tables_transcript != 0;
   t.offered = t.active = fuse && p.n != 0 && throughput && !overlap && !transcript_single_lane(c, N, throughput);
   t.ops = p.ops; t.n_ops = p.n; t.tables = p.tables; t.N = N; t.bufs = bufs; t.ts = d_ts; t.saved = reinterpret_cast<uint32_t*>(d_saved); t.failed = d_failed; t.tail = p.tail;
+  t.steps = transcript_steps(c, p, N, throughput, d_img);
+  t.sd = p.sd; t.sd.tail = p.tail; t.img = d_img;
 }
-void run_program_pending(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput) {
+void run_program_pending(zkp_ctx* c, const prog_dev& p, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput,
+                         uint64_t* d_img) {
   const bool taken = c->pending_tr.offered && !c->pending_tr.active;      // the term path launched it with its tables
   c->pending_tr.offered = c->pending_tr.active = false;
-  if (!taken) run_program(c, p, N, bufs, d_ts, d_saved, d_failed, throughput);
+  if (!taken) run_program(c, p, N, bufs, d_ts, d_saved, d_failed, throughput, d_img);
 }
 
 // ---- side stream: the scalar-independent half of path A runs next to the transcripts -------------------------------------
@@ -974,7 +1043,7 @@ struct ws_view {
   uint32_t* u32(size_t o) const { return reinterpret_cast<uint32_t*>(base + o); }
 };
 
-struct prove_inter { size_t saved, failed, wide, blind, off, sc, pidx, wchal, end; };
+struct prove_inter { size_t saved, failed, wide, blind, off, sc, pidx, wchal, img, end; };
 prove_inter prove_carve(const fused_plan& pl, size_t start) {
   const size_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T = pl.T1;
   carve cv;
@@ -988,6 +1057,7 @@ prove_inter prove_carve(const fused_plan& pl, size_t start) {
   o.sc = cv.take(N * T * 32 + 32);
   o.pidx = cv.take(N * T * 4 + 4);
   o.wchal = cv.take(N * 64 + 64);
+  o.img = cv.take(pl.img_bytes);
   o.end = cv.off;
   return o;
 }
@@ -1009,7 +1079,8 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
 #ifdef ZKP_BUILD_TEST_HOOKS
   for (int q = 0; q < c->debug_dummy_launches; ++q) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, c->stream, (uint32_t*)nullptr);   // (launch-count sensitivity probe)
 #endif
-  offer_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput, overlap);
+  uint64_t* d_img = pl.img_bytes ? reinterpret_cast<uint64_t*>(w.base + o.img) : nullptr;
+  offer_program(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput, overlap, d_img);
   {   // side stream: operand indices, decode, classification, comb tables (nothing here depends on the blindings)
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
@@ -1021,7 +1092,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) { c->pending_tr.offered = c->pending_tr.active = false; return rc ? rc : rc2; }
   }
-  run_program_pending(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput);
+  run_program_pending(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput, d_img);
   prof_mark(c, ZKP_K_TRANSCRIPT);
 
   // the blindings are canonical (k_wide_reduce), so the halving the batched encoder wants is three instructions per limb here
@@ -1044,7 +1115,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
     if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_SCALARS, tk);
     if (rc) return rc;
   }
-  run_program(c, pl.b, N, hb, d_ts, d_saved, w.u32(o.failed), throughput);
+  run_program(c, pl.b, N, hb, d_ts, d_saved, w.u32(o.failed), throughput, d_img);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   if (m && m <= 256) {
     const uint32_t P = 256 / m;
@@ -1058,7 +1129,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
   return ZKP_OK;
 }
 
-struct verify_inter { size_t failed, mc, off, sc, pidx, coms, st8, wchal, chal, end; };
+struct verify_inter { size_t failed, mc, off, sc, pidx, coms, st8, wchal, chal, img, end; };
 verify_inter verify_carve(const fused_plan& pl, size_t start) {
   const size_t N = pl.N, nc = pl.s.nc, T1 = pl.T1;
   carve cv;
@@ -1073,6 +1144,7 @@ verify_inter verify_carve(const fused_plan& pl, size_t start) {
   o.st8 = cv.take(N * nc + 4);
   o.wchal = cv.take(N * 64 + 64);
   o.chal = cv.take(N * 32 + 32);
+  o.img = cv.take(pl.img_bytes);
   o.end = cv.off;
   return o;
 }
@@ -1091,7 +1163,8 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
   tk.stmt.toff = pl.d_tarr; tk.stmt.tpt = pl.d_tarr + nc + 1 + T1; tk.stmt.N = N; tk.stmt.T = T1; tk.stmt.nc = nc; tk.stmt.ns = pl.s.ns; tk.stmt.np = pl.s.np;
   tk.stmt.off = w.u32(o.off); tk.stmt.pidx = w.u32(o.pidx); tk.stmt.on = c->stmt_classify;
-  offer_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, overlap);
+  uint64_t* d_img = pl.img_bytes ? reinterpret_cast<uint64_t*>(w.base + o.img) : nullptr;
+  offer_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, overlap, d_img);
   {   // side stream: operand indices and the point phase.  With no constraints there is no MSM, but every allocated
       // point must still decode (verifier.rs:87-92)
     hipStream_t main;
@@ -1103,7 +1176,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) { c->pending_tr.offered = c->pending_tr.active = false; return rc ? rc : rc2; }
   }
-  run_program_pending(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput);
+  run_program_pending(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, d_img);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, d_claim, w.u8(o.mc));
   if (T1) hipLaunchKernelGGL(k_stmt_scalars, grid1((size_t)N * T1, 256), dim3(256), 0, c->stream, N, T1, m, pl.d_tarr + nc + 1, d_resp, w.u8(o.mc), w.u8(o.sc), 0u);
@@ -1113,7 +1186,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   if (rc) return rc;
   rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_SCALARS, tk);
   if (rc) return rc;
-  run_program(c, pl.b, N, hb, d_ts, nullptr, w.u32(o.failed), throughput);
+  run_program(c, pl.b, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, d_img);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.chal));
   // the decoded point table is the first thing msm_terms_path carves after its reserved prefix
@@ -1127,7 +1200,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
 // K batch verifications of N_each = pl.N / K proofs each in one pass (K = 1: zkp_fused_batch_verify).  The N = pl.N proofs of the
 // call lie next to each other, batch b = proofs [b N_each, (b + 1) N_each).
 // d_pts = [ns + (ni + nc) N][32] with static || instance rows filled in by the caller; the commitment rows are written here
-struct batch_inter { size_t sc, failed, flags, wchal, mc, part, end; };
+struct batch_inter { size_t sc, failed, flags, wchal, mc, part, img, end; };
 batch_inter batch_carve(const fused_plan& pl, size_t start, uint32_t K = 1) {
   const size_t N = pl.N, ns = pl.s.ns, N_each = N / (K ? K : 1), total = (size_t)K * ns + ((size_t)pl.s.ni + pl.s.nc) * N, nblk = (size_t)K * ((N_each + 255) / 256);
   carve cv;
@@ -1139,6 +1212,7 @@ batch_inter batch_carve(const fused_plan& pl, size_t start, uint32_t K = 1) {
   o.wchal = cv.take(N * 64 + 64);
   o.mc = cv.take(N * 32 + 32);
   o.part = cv.take((ns ? ns : 1) * (nblk ? nblk : 1) * 32);
+  o.img = cv.take(pl.img_bytes);
   o.end = cv.off;
   return o;
 }
@@ -1172,7 +1246,7 @@ int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* 
     tr_bufs hb{};
     hb.src[SRC_TABLE] = d_pts; hb.src[SRC_COMS] = d_coms;
     hb.dst[DST_CHAL] = w.u8(o.wchal);
-    run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, /*owns_failed=*/true);
+    run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, pl.img_bytes ? reinterpret_cast<uint64_t*>(w.base + o.img) : nullptr, /*owns_failed=*/true);
     prof_mark(c, ZKP_K_TRANSCRIPT);
     const size_t lanes = std::max<size_t>(std::max<size_t>(N, (size_t)N * nc), (size_t)N * pl.s.m);
     hipLaunchKernelGGL(k_batch_after_transcript, grid1(lanes, 256), dim3(256), 0, c->stream, N, N_each, nc, pl.s.m, w.u32(o.failed),
@@ -1194,7 +1268,7 @@ int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* 
 
 // d_tbl = [ns + ni N + N nc][32]: common || instance rows || commitments [N][nc] (the last part doubles as the
 // transcripts' commitment source)
-struct each_inter { size_t failed, wchal, mc, off, sc, pidx, out, st8, end; };
+struct each_inter { size_t failed, wchal, mc, off, sc, pidx, out, st8, img, end; };
 each_inter each_carve(const fused_plan& pl, size_t start) {
   const size_t N = pl.N, K = (size_t)pl.s.np + pl.s.nc;
   carve cv;
@@ -1208,6 +1282,7 @@ each_inter each_carve(const fused_plan& pl, size_t start) {
   o.pidx = cv.take(N * K * 4 + 4);
   o.out = cv.take(N * 32 + 32);
   o.st8 = cv.take(N + 4);
+  o.img = cv.take(pl.img_bytes);
   o.end = cv.off;
   return o;
 }
@@ -1288,7 +1363,7 @@ int each_core(zkp_ctx* c, const fused_plan& pl, const each_inter& o, uint8_t* d_
     rc = side_end(c, main, overlap);
     if (rc) return rc;
   }
-  run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), false);
+  run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), false, pl.img_bytes ? reinterpret_cast<uint64_t*>(w.base + o.img) : nullptr);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_wide_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.wchal), w.u8(o.mc));
   hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, w.u8(o.mc), w.u8(o.mc));

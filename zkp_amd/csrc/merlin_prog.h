@@ -220,6 +220,142 @@ ZKP_HD void tr_run_one(const tr_op* prog, uint32_t n_ops, const uint64_t* tables
 
 }  // namespace zkp
 
+namespace zkp {
+// ---- round 6: the same program as STEPS -- a wide "assemble" pass plus a chain of bare permutations ---------------------------------
+// Measured (tools/microbench/keccak_lat.hip, profiles/r06_keccak_microbench.txt): a lone wavefront needs 5.5 - 6.2 us per Keccak-f[1600] in the
+// lane-pair layout, but the interpreter above spends 9.4 - 14 us per permutation: every word operation is a DEPENDENT global load (address -> load ->
+// shift -> LDS read-modify-write, ~1 us each, ~480 of them per CMZ proof) in a chain whose only true dependency is the hash state.  None of those
+// loads depends on the state.  So the operation list is regrouped per flush unit ("step": everything up to and including one APPLY):
+//   image   img[step][w][proof] = CX[w] ^ (the per-proof bytes of the step's word operations, shifted into place)       -- k_transcript_assemble,
+//           one lane per (step, word, proof), every load independent, the whole chip busy for ~10 us;
+//   chain   per step: [restore] -> [emit PRF bytes of the CURRENT state] -> state[w] = (state[w] & KEEP[w]) ^ img[w] -> [permute] -> [save]
+//           with the state in 25 registers per lane, the next step's image (and keep words) prefetched under the permutation -- k_transcript_chain.
+// KEEP[w] = the table's keep word AND the keep masks of the step's overwriting operations (their bytes are disjoint from every other
+// operation's and from the table's cleared bytes, so the nested ((s & k1) ^ x1) & k2 ... collapses).  Identity checks (mod.rs:191, :215) do not
+// touch the state at all: they go to the assemble pass.  Semantics = tr_steps_run_one below, which the host tests compare with tr_run_one.
+constexpr uint32_t TS_RESTORE = 1, TS_IMG = 2, TS_KEEP = 4, TS_PERMUTE = 8, TS_SAVE = 16, TS_EMIT = 32;
+struct tr_step { uint32_t flags, img, emit_lo, emit_n; };      // img: index of the step's image / keep row; emit ops [emit_lo, emit_lo + emit_n) of tr_step_prog::emit
+static_assert(sizeof(tr_step) == 16, "tr_step layout");
+
+}  // namespace zkp
+#include <vector>
+namespace zkp {
+
+struct tr_step_prog {
+  std::vector<tr_step> steps;
+  std::vector<tr_op> emit;          // PRF-output operations (dst_buf != 0), executed by the chain from the step's incoming state
+  std::vector<tr_op> src;           // word operations with a per-proof source, grouped by (image, word)
+  std::vector<uint32_t> src_off;    // [n_img * 21 + 1]: operations src[src_off[k] .. src_off[k + 1]) feed image word k = img * 21 + w
+  std::vector<uint64_t> cx, keep;   // [n_img * 21] each
+  std::vector<tr_op> chk;           // identity checks
+  uint32_t n_img = 0;
+};
+
+inline tr_step_prog tr_steps_build(const std::vector<tr_op>& ops, const std::vector<uint64_t>& tables) {
+  tr_step_prog sp;
+  struct Cur { uint32_t flags = 0; std::vector<tr_op> emit; std::vector<tr_op> src[21]; uint64_t keep[21]; bool any = false; } cur;
+  auto reset = [&] { cur = Cur(); for (auto& k : cur.keep) k = ~0ULL; };
+  reset();
+  sp.src_off.push_back(0);
+  auto close = [&](const uint64_t* tbl, bool permute) {
+    tr_step st{cur.flags, 0, (uint32_t)sp.emit.size(), (uint32_t)cur.emit.size()};
+    if (!cur.emit.empty()) st.flags |= TS_EMIT;
+    sp.emit.insert(sp.emit.end(), cur.emit.begin(), cur.emit.end());
+    bool img = false, keep = false;
+    uint64_t kw[21], cw[21];
+    for (int w = 0; w < 21; ++w) {
+      kw[w] = cur.keep[w] & (tbl ? tbl[w] : ~0ULL);
+      cw[w] = tbl ? tbl[21 + w] : 0;
+      img = img || cw[w] != 0 || !cur.src[w].empty();
+      keep = keep || kw[w] != ~0ULL;
+    }
+    if (img || keep) {
+      st.flags |= TS_IMG | (keep ? TS_KEEP : 0);
+      st.img = sp.n_img++;
+      for (int w = 0; w < 21; ++w) {
+        sp.cx.push_back(cw[w]);
+        sp.keep.push_back(kw[w]);
+        sp.src.insert(sp.src.end(), cur.src[w].begin(), cur.src[w].end());
+        sp.src_off.push_back((uint32_t)sp.src.size());
+      }
+    } else {
+      st.img = ~0u;                                        // patched below: the shared identity image
+    }
+    if (permute) st.flags |= TS_PERMUTE;
+    sp.steps.push_back(st);
+    reset();
+  };
+  for (const tr_op& o : ops) {
+    const tr_fields f = tr_unpack(o.ctl, o.stride, o.off);
+    if (f.flags & TR_RESTORE) {
+      if (cur.any) close(nullptr, false);
+      cur.flags |= TS_RESTORE;
+      cur.any = true;
+    }
+    if (f.flags & TR_CHECK_NONZERO) { sp.chk.push_back(o); continue; }
+    if (f.dst_buf) { cur.emit.push_back(o); cur.any = true; }
+    if (f.src_buf) { cur.src[f.w].push_back(o); cur.keep[f.w] &= f.keep; cur.any = true; }
+    if (f.flags & TR_APPLY) close(tables.data() + (size_t)TR_TABLE_WORDS * f.off, (f.flags & TR_PERMUTE) != 0);
+    if (f.flags & TR_SAVE) {
+      if (cur.any) close(nullptr, false);                  // (a restore or word operations without their APPLY: does not happen, handled all the same)
+      if (sp.steps.empty()) close(nullptr, false);
+      sp.steps.back().flags |= TS_SAVE;
+    }
+  }
+  if (cur.any) close(nullptr, false);
+  // EVERY step gets an image, so that the chain applies and prefetches unconditionally: steps that change no rate word share one identity image
+  // (cx = 0, keep = all ones); one sentinel step behind the last is what the last step's look-ahead reads
+  uint32_t ident = ~0u;
+  for (tr_step& t : sp.steps)
+    if (t.img == ~0u) {
+      if (ident == ~0u) {
+        ident = sp.n_img++;
+        for (int w = 0; w < 21; ++w) { sp.cx.push_back(0); sp.keep.push_back(~0ULL); sp.src_off.push_back((uint32_t)sp.src.size()); }
+      }
+      t.img = ident;
+    }
+  if (!sp.steps.empty()) sp.steps.push_back(tr_step{0, sp.steps.back().img, 0, 0});
+  return sp;
+}
+
+// the 64-bit value a source operation contributes for proof j
+ZKP_HD uint64_t tr_src_word(const tr_fields& op, const tr_bufs& bufs, uint64_t j) {
+  const uint64_t addr = j * op.stride + op.off;
+  const uint32_t sh = (uint32_t)(addr & 7);
+  const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, op.src_buf - 1u) + (addr - sh));
+  uint64_t x = p[0] >> (8 * sh);
+  if (sh + op.nb > 8) x |= p[1] << (64 - 8 * sh);
+  return (x & tr_bytemask(op.nb)) << (8 * op.lb);
+}
+// reference semantics of the step form for one proof (host tests; the kernels split it into assemble + chain)
+inline void tr_steps_run_one(const tr_step_prog& sp, uint64_t j, const tr_bufs& bufs, uint64_t S[25], uint64_t saved[25], uint32_t* failed) {
+  for (const tr_op& o : sp.chk) {
+    const tr_fields f = tr_unpack(o.ctl, o.stride, o.off);
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(tr_src_ptr(bufs, f.src_buf - 1u) + j * f.stride + f.off);
+    if ((p[0] | p[1] | p[2] | p[3]) == 0) *failed = 1;
+  }
+  const uint64_t ident[TR_TABLE_WORDS] = {~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL};
+  for (const tr_step& st : sp.steps) {
+    if (st.flags & TS_RESTORE) for (int i = 0; i < 25; ++i) S[i] = saved[i];
+    for (uint32_t q = 0; q < st.emit_n; ++q) {
+      const tr_op& o = sp.emit[st.emit_lo + q];
+      tr_exec_op(tr_unpack(o.ctl, o.stride, o.off), nullptr, j, bufs, S, 1, saved, 1, failed, true);     // (a pure dst operation)
+    }
+    if (st.flags & TS_IMG) {
+      for (int w = 0; w < 21; ++w) {
+        const size_t k = (size_t)st.img * 21 + w;
+        uint64_t x = sp.cx[k];
+        for (uint32_t q = sp.src_off[k]; q < sp.src_off[k + 1]; ++q) x ^= tr_src_word(tr_unpack(sp.src[q].ctl, sp.src[q].stride, sp.src[q].off), bufs, j);
+        S[w] = (S[w] & sp.keep[k]) ^ x;
+      }
+    }
+    if (st.flags & TS_PERMUTE) tr_apply_block(S, 1, ident, true);
+    if (st.flags & TS_SAVE) for (int i = 0; i < 25; ++i) saved[i] = S[i];
+  }
+}
+
+}  // namespace zkp
+
 // ---- host side: the compiler (plain C++, also parsed by the device pass of hipcc, never emitted there) ----
 #include <string>
 #include <vector>

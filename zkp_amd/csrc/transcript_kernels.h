@@ -24,16 +24,16 @@ __device__ __forceinline__ uint32_t rotl_half(uint32_t mine, uint32_t partner, i
 }
 __device__ __forceinline__ uint32_t half_of(uint64_t v, uint32_t h) { return h ? (uint32_t)(v >> 32) : (uint32_t)v; }
 
+template <bool UNROLL = false>
 __device__ __forceinline__ void keccak_f1600_split(uint32_t a[25], uint32_t h) {
-  static const uint64_t RC[24] = {
+  constexpr uint64_t RC[24] = {
       0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
       0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
       0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
       0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
       0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
   constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};   // [x + 5 y]
-#pragma unroll 1
-  for (int round = 0; round < 24; ++round) {
+  auto one_round = [&](const uint64_t rc) {
     uint32_t c[5], b[25];
 #pragma unroll
     for (int x = 0; x < 5; ++x) c[x] = tr_xor5_32(a[x], a[x + 5], a[x + 10], a[x + 15], a[x + 20]);
@@ -55,7 +55,20 @@ __device__ __forceinline__ void keccak_f1600_split(uint32_t a[25], uint32_t h) {
     for (int y = 0; y < 5; ++y)                         // chi
 #pragma unroll
       for (int x = 0; x < 5; ++x) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-    a[0] ^= half_of(RC[round], h);                      // iota
+    a[0] ^= half_of(rc, h);                             // iota
+  };
+  if constexpr (UNROLL) {                               // the chain kernel: round constants as literals, no loop (5.5 instead of 6.2 us per permutation on a lone
+#pragma unroll                                          // wavefront, profiles/r06_keccak_microbench.txt)
+    for (int round = 0; round < 24; ++round) one_round(RC[round]);
+  } else {
+    static const uint64_t RCT[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+        0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+        0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+        0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+#pragma unroll 1
+    for (int round = 0; round < 24; ++round) one_round(RCT[round]);
   }
 }
 
@@ -153,6 +166,136 @@ k_transcript_run(const tr_op* __restrict__ prog, uint32_t n_ops, const uint64_t*
   transcript_pair_block(blockIdx.x, S, prog, n_ops, tables, N, bufs, ts, saved, failed, tail);
 }
 
+// ---- round 6: assemble + chain (the step form of a program, merlin_prog.h) ------------------------------------------------
+struct tr_steps_dev {
+  const tr_step* steps = nullptr;          // [n_steps]: the last one is a sentinel (never executed: the last real step's look-ahead)
+  const tr_op* emit = nullptr;
+  const tr_op* src = nullptr;
+  const uint32_t* src_off = nullptr;       // [n_img * 21 + 1]
+  const uint64_t* cx = nullptr;            // [n_img * 21]
+  const uint32_t* keep32 = nullptr;        // [n_img * 21][2]: the halves of the 64-bit keep words
+  const tr_op* chk = nullptr;
+  uint32_t n_steps = 0, n_img = 0, n_chk = 0, tail = 0;
+};
+
+// One workgroup row (blockIdx.y) per image word k = img * 21 + w: lane j builds proof j's 64-bit word (every load independent of every other);
+// the last row checks the encodings the verifiers must reject as identity (mod.rs:191, :215) and owns the rejection flags.
+// img = [n_img * 21][N] uint64 (the chain reads it as [..][2 N] uint32: proof j's halves next to each other): coalesced on both sides.  (A proof-major
+// layout -- 168 contiguous bytes per proof and image, one pointer + immediate offsets in the chain -- was measured: assemble 15 -> 31 us, chain no faster.)
+__global__ void __launch_bounds__(256)
+k_transcript_assemble(const tr_steps_dev p, uint32_t N, const tr_bufs bufs, uint64_t* __restrict__ img, uint32_t* __restrict__ failed) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x, k = blockIdx.y;
+  if (j >= N) return;
+  if (k < p.n_img * 21u) {
+    uint64_t x = p.cx[k];
+    for (uint32_t q = p.src_off[k]; q < p.src_off[k + 1]; ++q) {
+      const tr_op o = p.src[q];
+      x ^= tr_src_word(tr_unpack(o.ctl, o.stride, o.off), bufs, j);
+    }
+    img[(size_t)k * N + j] = x;
+  } else {
+    uint32_t bad = 0;
+    for (uint32_t q = 0; q < p.n_chk; ++q) {
+      const tr_op o = p.chk[q];
+      const tr_fields f = tr_unpack(o.ctl, o.stride, o.off);
+      const uint4* s = reinterpret_cast<const uint4*>(tr_src_ptr(bufs, f.src_buf - 1u) + (size_t)j * f.stride + f.off);
+      const uint4 lo = s[0], hi = s[1];
+      if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) bad = 1;
+    }
+    // bit 31 of the tail: this program owns the rejection flags (it writes 0 too, so that nobody has to clear them first)
+    if (bad || (p.tail >> 31)) failed[j] = bad;
+    if ((p.tail >> 31) && j == 0) failed[N] = 0;        // the spare word behind the flags: the flow's shared status bits
+  }
+}
+
+// The chain: a lane pair per proof, the state in 25 registers per lane, per step 21 + 21 loads that were issued one permutation earlier.
+// PRF output (rare: 21 blinding strings, one challenge) goes through an LDS column like in the interpreter above.
+__device__ __forceinline__ void transcript_chain_block(uint32_t bid, uint32_t* S /*LDS [25 * TR_BLOCK]*/, const tr_steps_dev& p, const uint32_t* __restrict__ img32, uint32_t N,
+                                                       const tr_bufs& bufs, uint8_t* __restrict__ ts, uint32_t* __restrict__ saved /*[25][2N]*/) {
+  const uint32_t lane = threadIdx.x & (TR_BLOCK - 1), h = lane & 1;
+  const uint32_t j_raw = bid * (TR_BLOCK / 2) + (lane >> 1);
+  const bool live = j_raw < N;                          // lanes past the end shadow the last proof and store nothing
+  const uint32_t j = live ? j_raw : N - 1;
+  uint32_t* col = S + lane;
+  uint32_t* blob = reinterpret_cast<uint32_t*>(ts + 208 * (size_t)j);
+  uint32_t a[25], ni[21], nk[21];
+#pragma unroll
+  for (int i = 0; i < 25; ++i) a[i] = blob[2 * i + h];
+  const size_t wstride = 2 * (size_t)N;
+  const uint32_t* mycol = img32 + 2 * (size_t)j + h;
+  uint32_t* sv = saved + 2 * (size_t)j + h;
+  // Every step has an image row (steps that change nothing share an identity row) and the list ends in a sentinel, so the loop below has ONE place where
+  // the look-ahead image is loaded and one where it is consumed -- nothing merges in front of the permutation, and the loads' s_waitcnt lands behind it.
+  // (The first version loaded "if the next step has an image" and fell back to loading on demand: the compiler resolved that merge with register copies
+  // in front of the permutation, i.e. a full vmcnt(0) wait per step -- 8.2 us per step instead of 7.3.)
+  const uint32_t n_real = p.n_steps - 1;                // the sentinel is not executed
+  {
+    const uint32_t im0 = p.steps[0].img;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) { ni[k] = mycol[((size_t)im0 * 21 + k) * wstride]; nk[k] = p.keep32[(size_t)im0 * 42 + 2 * k + h]; }
+  }
+  constexpr uint32_t CH = TR_BLOCK - 1;                  // steps per descriptor fetch: lane CH holds the look-ahead of the chunk's last step
+  for (uint32_t base = 0; base < n_real; base += CH) {
+    const uint32_t cnt = n_real - base < CH ? n_real - base : CH;
+    uint4 mine = make_uint4(0, 0, 0, 0);
+    if (lane <= cnt) mine = reinterpret_cast<const uint4*>(p.steps)[base + lane];
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)i);
+      const uint32_t nim = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)(i + 1));
+      if (fl & TS_RESTORE) {
+#pragma unroll
+        for (int k = 0; k < 25; ++k) a[k] = sv[k * wstride];
+      }
+      if (fl & TS_EMIT) {
+        const uint32_t elo = (uint32_t)__builtin_amdgcn_readlane((int)mine.z, (int)i), en = (uint32_t)__builtin_amdgcn_readlane((int)mine.w, (int)i);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) col[TR_BLOCK * k] = a[k];
+        uint4 eo = make_uint4(0, 0, 0, 0);
+        if (lane < en) eo = reinterpret_cast<const uint4*>(p.emit)[elo + lane];
+        for (uint32_t q = 0; q < en; ++q) {
+          const uint32_t o_ctl = (uint32_t)__builtin_amdgcn_readlane((int)eo.x, (int)q), o_stride = (uint32_t)__builtin_amdgcn_readlane((int)eo.y, (int)q);
+          const uint64_t o_off = (uint32_t)__builtin_amdgcn_readlane((int)eo.z, (int)q) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)eo.w, (int)q) << 32;
+          const tr_fields op = tr_unpack(o_ctl, o_stride, o_off);
+          uint8_t* d = tr_dst_ptr(bufs, op.dst_buf - 1u) + (size_t)j * op.stride + op.off;
+          // this half holds bytes [4h, 4h + 4) of the word; its share of [dlb, dlb + dnb) is one run
+          const uint32_t lo = op.dlb > 4 * h ? op.dlb : 4 * h;
+          const uint32_t hi = op.dlb + op.dnb < 4 * h + 4 ? op.dlb + op.dnb : 4 * h + 4;
+          if (hi > lo && live) {
+            const uint32_t v = col[TR_BLOCK * op.w] >> (8 * (lo - 4 * h));
+            uint8_t* dp = d + (lo - op.dlb);
+            if (hi - lo == 4) {
+              __builtin_memcpy(dp, &v, 4);
+            } else {
+              for (uint32_t k = 0; k < hi - lo; ++k) dp[k] = (uint8_t)(v >> (8 * k));
+            }
+          }
+        }
+      }
+      // state[w] = (state[w] & KEEP[w]) ^ image[w]: one v_bitop3_b32 per word (truth table (a & b) ^ c = 0x6A)
+#pragma unroll
+      for (int k = 0; k < 21; ++k) a[k] = (uint32_t)__builtin_amdgcn_bitop3_b32((int)a[k], (int)nk[k], (int)ni[k], 0x6A);
+      // the next step's image and keep words travel under this step's permutation
+#pragma unroll
+      for (int k = 0; k < 21; ++k) { ni[k] = mycol[((size_t)nim * 21 + k) * wstride]; nk[k] = p.keep32[(size_t)nim * 42 + 2 * k + h]; }
+      if (fl & TS_PERMUTE) keccak_f1600_split<true>(a, h);
+      if ((fl & TS_SAVE) && live) {
+#pragma unroll
+        for (int k = 0; k < 25; ++k) sv[k * wstride] = a[k];
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < 25; ++i) blob[2 * i + h] = a[i];
+  if (h == 0) { blob[50] = p.tail & 0xffffffu; blob[51] = 0; }
+}
+
+__global__ void __launch_bounds__(TR_BLOCK)
+k_transcript_chain(const tr_steps_dev p, const uint32_t* __restrict__ img32, uint32_t N, const tr_bufs bufs, uint8_t* __restrict__ ts, uint32_t* __restrict__ saved) {
+  __shared__ uint32_t S[25 * TR_BLOCK];
+  transcript_chain_block(blockIdx.x, S, p, img32, N, bufs, ts, saved);
+}
+
 // Transcript program + comb-table construction in ONE launch (asynchronous _dev flows): both are a few dozen wavefronts of long
 // dependent chains (Keccak-f rounds; 256 doublings per table) that do not depend on each other, and the _dev flows keep
 // everything on one stream (a second stream per context costs the pipelined caller more than the overlap returns:
@@ -173,6 +316,22 @@ k_tables_transcript_pc(uint32_t tr_blocks, const tr_op* __restrict__ prog, uint3
   if (blockIdx.x < trb) {
     const uint32_t bid = 2 * blockIdx.x + wave;
     if (bid < tr_blocks) transcript_pair_block(bid, S + wave * 25 * TR_BLOCK, prog, n_ops, tables, N, bufs, ts, saved, failed, tail);
+  } else {
+    comb_table_pc<TEETH>((blockIdx.x - trb) * 64u, n_slots, max_tables, slot_pt, pts, comb, S);
+  }
+}
+
+// the shared launch with the chain of a step program in place of the interpreter (its assemble pass has run before)
+template <int TEETH>
+__global__ void __launch_bounds__(2 * TR_BLOCK, 2)
+k_tables_chain_pc(uint32_t tr_blocks, const tr_steps_dev p, const uint32_t* __restrict__ img32, uint32_t N, const tr_bufs bufs, uint8_t* __restrict__ ts,
+                  uint32_t* __restrict__ saved, const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
+                  const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
+  __shared__ uint32_t S[2 * 36 * 64];
+  const uint32_t wave = threadIdx.x >> 6, trb = (tr_blocks + 1) / 2;
+  if (blockIdx.x < trb) {
+    const uint32_t bid = 2 * blockIdx.x + wave;
+    if (bid < tr_blocks) transcript_chain_block(bid, S + wave * 25 * TR_BLOCK, p, img32, N, bufs, ts, saved);
   } else {
     comb_table_pc<TEETH>((blockIdx.x - trb) * 64u, n_slots, max_tables, slot_pt, pts, comb, S);
   }

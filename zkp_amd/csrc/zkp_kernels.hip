@@ -1292,7 +1292,8 @@ struct zkp_ctx {
   // a transcript program the flow wants run next to the comb-table construction of the term path's point phase (one launch:
   // k_tables_transcript); consumed by msm_terms_path if it builds tables with one lane per point, else run by the flow itself
   struct { bool offered = false, active = false; const tr_op* ops = nullptr; uint32_t n_ops = 0; const uint64_t* tables = nullptr; uint32_t N = 0; tr_bufs bufs{};
-           uint8_t* ts = nullptr; uint32_t* saved = nullptr; uint32_t* failed = nullptr; uint32_t tail = 0; } pending_tr;
+           uint8_t* ts = nullptr; uint32_t* saved = nullptr; uint32_t* failed = nullptr; uint32_t tail = 0;
+           bool steps = false; tr_steps_dev sd; uint64_t* img = nullptr; } pending_tr;       // steps: the program in step form (assemble + chain)
   int debug_dummy_launches = 0;      // ZKP_TESTOPT_DUMMY_LAUNCHES (test-hook builds only): empty kernels added to every prove call
   bool stmt_classify = true;         // the fused flows' one-launch term classifier (ZKP_TESTOPT_GENERIC_CLASSIFIER of test-hook builds turns it off)
   int fuse_tables_transcript = -1;       // ZKP_OPT_FUSE_TABLES_TRANSCRIPT: -1 = asynchronous _dev calls below kVeryWideCallProofs proofs, 0 = never, 1 = always
@@ -1311,6 +1312,7 @@ struct zkp_ctx {
 #endif
   static constexpr size_t kGroupedCombTerms = 400000;
   bool dev_overlap = false;          // ZKP_OPT_DEV_OVERLAP: the _dev flows fork their scalar-independent half onto the side stream too
+  bool tr_steps = true;              // ZKP_OPT_TRANSCRIPT_STEPS: lane-pair transcripts as assemble + chain (1, default) or by the word-operation interpreter (0)
   int tr_lanes = -1;                 // ZKP_OPT_TRANSCRIPT_LANES: -1 = by entry point, 1 = one lane per proof, 2 = a lane pair per proof
   // The instruction-saving variants of the asynchronous entry points (ladder for single-use points, one transcript lane per
   // proof) lengthen a call's narrow kernels; they pay once a single call fills the chip.  Measured on CMZ batches
@@ -1599,10 +1601,16 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
           const auto& t = c->pending_tr;
           const uint32_t tr_blocks = (t.N + TR_BLOCK / 2 - 1) / (TR_BLOCK / 2);
           // tables as producer / consumer wavefronts (comb_table_pc): workgroups of two wavefronts = two transcript blocks, or 64 tables
-          hipLaunchKernelGGL(k_tables_transcript_pc<16>, dim3((tr_blocks + 1) / 2 + (k.max_tables + 63) / 64), dim3(2 * TR_BLOCK), 0, c->stream, tr_blocks, t.ops, t.n_ops,
-                             t.tables, t.N, t.bufs, t.ts, t.saved, t.failed, t.tail, n_slots, k.max_tables, slot_pt, pts, comb);
+          if (t.steps) {
+            const uint32_t rows = t.sd.n_img * 21u + ((t.sd.n_chk || (t.sd.tail >> 31)) ? 1u : 0u);
+            if (rows) hipLaunchKernelGGL(k_transcript_assemble, dim3((t.N + 255) / 256, rows), dim3(256), 0, c->stream, t.sd, t.N, t.bufs, t.img, t.failed);
+            hipLaunchKernelGGL(k_tables_chain_pc<16>, dim3((tr_blocks + 1) / 2 + (k.max_tables + 63) / 64), dim3(2 * TR_BLOCK), 0, c->stream, tr_blocks, t.sd,
+                               reinterpret_cast<const uint32_t*>(t.img), t.N, t.bufs, t.ts, t.saved, n_slots, k.max_tables, slot_pt, pts, comb);
+          } else
+            hipLaunchKernelGGL(k_tables_transcript_pc<16>, dim3((tr_blocks + 1) / 2 + (k.max_tables + 63) / 64), dim3(2 * TR_BLOCK), 0, c->stream, tr_blocks, t.ops, t.n_ops,
+                               t.tables, t.N, t.bufs, t.ts, t.saved, t.failed, t.tail, n_slots, k.max_tables, slot_pt, pts, comb);
           c->pending_tr.active = false;
-          prof_note(c, ZKP_K_TABLES, "zkp::k_tables_transcript_pc<16>");
+          prof_note(c, ZKP_K_TABLES, t.steps ? "zkp::k_tables_chain_pc<16>" : "zkp::k_tables_transcript_pc<16>");
         } else if (k.teeth == 16) hipLaunchKernelGGL(k_comb_tables_lane<16>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
         else hipLaunchKernelGGL(k_comb_tables_lane<4>, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       } else {
@@ -1610,7 +1618,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
         else hipLaunchKernelGGL(k_comb_tables<4>, grid1((size_t)k.max_tables * 4, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       }
     }
-    if ((phase & PH_POINTS) && k.max_tables && c->kernel_names[ZKP_K_TABLES].find("k_tables_transcript") == std::string::npos)
+    if ((phase & PH_POINTS) && k.max_tables && c->kernel_names[ZKP_K_TABLES].find("k_tables_transcript") == std::string::npos && c->kernel_names[ZKP_K_TABLES].find("k_tables_chain") == std::string::npos)
       prof_note(c, ZKP_K_TABLES, std::string((c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) ? "zkp::k_comb_tables_lane<" : "zkp::k_comb_tables<") + (k.teeth == 16 ? "16>" : "4>"));
     if (phase & PH_POINTS) prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
     const dim3 grid((unsigned)((n_terms + XBAR_BLOCK_TERMS - 1) / XBAR_BLOCK_TERMS + 4 + HOT_SLOTS));     // every class starts a new block (grouped blocks take 248 terms)
@@ -1943,6 +1951,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
       c->each_straus_wins = wins ? (uint32_t)(value - 0x200) : 0u;
       return ZKP_OK;
     }
+    case ZKP_OPT_TRANSCRIPT_STEPS: c->tr_steps = value != 0; return ZKP_OK;
     case ZKP_OPT_TRANSCRIPT_LANES:
       if (value != ~0ull && value != 1 && value != 2) return fail(ZKP_ERR_ARG, "ZKP_OPT_TRANSCRIPT_LANES: 1, 2 or UINT64_MAX");
       c->tr_lanes = value == ~0ull ? -1 : (int)value;

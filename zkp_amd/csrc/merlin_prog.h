@@ -252,38 +252,17 @@ struct tr_step_prog {
 };
 
 inline tr_step_prog tr_steps_build(const std::vector<tr_op>& ops, const std::vector<uint64_t>& tables) {
-  tr_step_prog sp;
-  struct Cur { uint32_t flags = 0; std::vector<tr_op> emit; std::vector<tr_op> src[21]; uint64_t keep[21]; bool any = false; } cur;
-  auto reset = [&] { cur = Cur(); for (auto& k : cur.keep) k = ~0ULL; };
-  reset();
-  sp.src_off.push_back(0);
+  // 1. logical steps: everything up to and including one APPLY (or a lone marker)
+  struct L { uint32_t flags = 0; std::vector<tr_op> emit; std::vector<tr_op> src[21]; uint64_t keep[21], cx[21]; bool any = false;
+             L() { for (int w = 0; w < 21; ++w) { keep[w] = ~0ULL; cx[w] = 0; } } };
+  std::vector<L> ls;
+  std::vector<tr_op> chk;
+  L cur;
   auto close = [&](const uint64_t* tbl, bool permute) {
-    tr_step st{cur.flags, 0, (uint32_t)sp.emit.size(), (uint32_t)cur.emit.size()};
-    if (!cur.emit.empty()) st.flags |= TS_EMIT;
-    sp.emit.insert(sp.emit.end(), cur.emit.begin(), cur.emit.end());
-    bool img = false, keep = false;
-    uint64_t kw[21], cw[21];
-    for (int w = 0; w < 21; ++w) {
-      kw[w] = cur.keep[w] & (tbl ? tbl[w] : ~0ULL);
-      cw[w] = tbl ? tbl[21 + w] : 0;
-      img = img || cw[w] != 0 || !cur.src[w].empty();
-      keep = keep || kw[w] != ~0ULL;
-    }
-    if (img || keep) {
-      st.flags |= TS_IMG | (keep ? TS_KEEP : 0);
-      st.img = sp.n_img++;
-      for (int w = 0; w < 21; ++w) {
-        sp.cx.push_back(cw[w]);
-        sp.keep.push_back(kw[w]);
-        sp.src.insert(sp.src.end(), cur.src[w].begin(), cur.src[w].end());
-        sp.src_off.push_back((uint32_t)sp.src.size());
-      }
-    } else {
-      st.img = ~0u;                                        // patched below: the shared identity image
-    }
-    if (permute) st.flags |= TS_PERMUTE;
-    sp.steps.push_back(st);
-    reset();
+    for (int w = 0; w < 21 && tbl; ++w) { cur.keep[w] &= tbl[w]; cur.cx[w] = tbl[21 + w]; }
+    if (permute) cur.flags |= TS_PERMUTE;
+    ls.push_back(cur);
+    cur = L();
   };
   for (const tr_op& o : ops) {
     const tr_fields f = tr_unpack(o.ctl, o.stride, o.off);
@@ -292,28 +271,74 @@ inline tr_step_prog tr_steps_build(const std::vector<tr_op>& ops, const std::vec
       cur.flags |= TS_RESTORE;
       cur.any = true;
     }
-    if (f.flags & TR_CHECK_NONZERO) { sp.chk.push_back(o); continue; }
+    if (f.flags & TR_CHECK_NONZERO) { chk.push_back(o); continue; }
     if (f.dst_buf) { cur.emit.push_back(o); cur.any = true; }
     if (f.src_buf) { cur.src[f.w].push_back(o); cur.keep[f.w] &= f.keep; cur.any = true; }
     if (f.flags & TR_APPLY) close(tables.data() + (size_t)TR_TABLE_WORDS * f.off, (f.flags & TR_PERMUTE) != 0);
     if (f.flags & TR_SAVE) {
       if (cur.any) close(nullptr, false);                  // (a restore or word operations without their APPLY: does not happen, handled all the same)
-      if (sp.steps.empty()) close(nullptr, false);
-      sp.steps.back().flags |= TS_SAVE;
+      if (ls.empty()) close(nullptr, false);
+      ls.back().flags |= TS_SAVE;
     }
   }
   if (cur.any) close(nullptr, false);
-  // EVERY step gets an image, so that the chain applies and prefetches unconditionally: steps that change no rate word share one identity image
-  // (cx = 0, keep = all ones); one sentinel step behind the last is what the last step's look-ahead reads
-  uint32_t ident = ~0u;
-  for (tr_step& t : sp.steps)
-    if (t.img == ~0u) {
-      if (ident == ~0u) {
-        ident = sp.n_img++;
-        for (int w = 0; w < 21; ++w) { sp.cx.push_back(0); sp.keep.push_back(~0ULL); sp.src_off.push_back((uint32_t)sp.src.size()); }
+  // 2. a step WITHOUT a permutation has nothing to hide its successor's image loads behind (the verifiers' validating appends flush before every identity
+  // check: 36 such steps per CMZ batch-verification program, ~0.8 us of exposed load latency each).  It folds into the next step when that one reads
+  // nothing in between (no restore, no PRF output) and nothing of the first is cleared by the second's keep words:
+  //     ((s & k1) ^ x1) & k2) ^ x2  =  (s & k1 & k2) ^ x1 ^ x2      iff  x1 & ~k2 = 0  (bytes only ever advance inside a block, so it holds; checked all the same)
+  auto mask_of = [](const tr_op& o) { const tr_fields f = tr_unpack(o.ctl, o.stride, o.off); return tr_bytemask(f.nb) << (8 * f.lb); };
+  std::vector<L> ms;
+  for (L& l : ls) {
+    bool merged = false;
+    if (!ms.empty()) {
+      L& a = ms.back();
+      bool ok = !(a.flags & (TS_PERMUTE | TS_SAVE)) && !(l.flags & TS_RESTORE) && l.emit.empty();
+      for (int w = 0; w < 21 && ok; ++w) {
+        if (a.cx[w] & ~l.keep[w]) ok = false;
+        for (const tr_op& o : a.src[w]) if (mask_of(o) & ~l.keep[w]) ok = false;
       }
-      t.img = ident;
+      if (ok) {
+        for (int w = 0; w < 21; ++w) {
+          a.keep[w] &= l.keep[w];
+          a.cx[w] ^= l.cx[w];
+          a.src[w].insert(a.src[w].end(), l.src[w].begin(), l.src[w].end());
+        }
+        a.flags |= l.flags;
+        merged = true;
+      }
     }
+    if (!merged) ms.push_back(l);
+  }
+  // 3. the arrays.  EVERY step gets an image, so that the chain applies and prefetches unconditionally: steps that change no rate word share one identity
+  // image (cx = 0, keep = all ones); one sentinel step behind the last is what the last step's look-ahead reads
+  tr_step_prog sp;
+  sp.chk = chk;
+  sp.src_off.push_back(0);
+  uint32_t ident = ~0u;
+  auto add_image = [&](const L* l) {
+    for (int w = 0; w < 21; ++w) {
+      sp.cx.push_back(l ? l->cx[w] : 0);
+      sp.keep.push_back(l ? l->keep[w] : ~0ULL);
+      if (l) sp.src.insert(sp.src.end(), l->src[w].begin(), l->src[w].end());
+      sp.src_off.push_back((uint32_t)sp.src.size());
+    }
+    return sp.n_img++;
+  };
+  for (const L& l : ms) {
+    tr_step st{l.flags, 0, (uint32_t)sp.emit.size(), (uint32_t)l.emit.size()};
+    if (!l.emit.empty()) st.flags |= TS_EMIT;
+    sp.emit.insert(sp.emit.end(), l.emit.begin(), l.emit.end());
+    bool img = false, keep = false;
+    for (int w = 0; w < 21; ++w) { img = img || l.cx[w] != 0 || !l.src[w].empty(); keep = keep || l.keep[w] != ~0ULL; }
+    if (img || keep) {
+      st.flags |= TS_IMG | (keep ? TS_KEEP : 0);
+      st.img = add_image(&l);
+    } else {
+      if (ident == ~0u) ident = add_image(nullptr);
+      st.img = ident;
+    }
+    sp.steps.push_back(st);
+  }
   if (!sp.steps.empty()) sp.steps.push_back(tr_step{0, sp.steps.back().img, 0, 0});
   return sp;
 }

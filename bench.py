@@ -843,6 +843,7 @@ def main():
     ap.add_argument("--pipe-contexts", type=int, default=6, help="e2e_host_buffers.pipelined: contexts (= jobs in flight) of the zkp_pipe")
     ap.add_argument("--w64-form", default="terms", choices=sorted(W64_FORMS), help="--config 5share: the reading of BASELINE configs[4] -- `terms` = ONE constraint of 64 terms "
                     "(SURVEY section 8), `constraints` = 64 constraints of one term, `constraints2` = 64 constraints of two terms (a per-constraint generator + one shared)")
+    ap.add_argument("--no-lone-call", action="store_true", help="--config 2: skip the `lone_call` sub-record (one batch per call, one call chain in flight, on both schedules)")
     ap.add_argument("--no-sustained", action="store_true", help="--config 2: skip the `sustained` sub-record (4000 more steps at 50 batches per call after 0.6 s under load: "
                     "the steady-state rate next to the short timed region) and the `ct` sub-record (the same steps on the other look-ups of ZKP_OPT_CT_LOOKUP)")
     ap.add_argument("--sustained-steps", type=int, default=4000, help="steps of the `sustained` sub-record (a multiple of 50: >= 2 s of GPU time at the default)")
@@ -972,6 +973,23 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
         e2e = e2e_host_buffers(eng)
     for e_ in r["engines"]:
         e_.close()
+    # ---- the reference-shaped call: ONE batch of n proofs per call, one call chain in flight, inputs resident -- prove, then batch-verify ----
+    lone = None
+    if args.config == "2" and not args.no_flow_lines and not args.no_lone_call:
+        import copy
+        torch.cuda.empty_cache()
+        lone = {"proofs_per_call": n, "calls_timed": 40, "unit": "proofs/s",
+                "note": "K = 1: one prove call of %d proofs, then one batch verification of them, on ONE stream, replayed as a HIP graph, inputs resident in HBM (`value` packs 5 batches "
+                        "per call on 4 streams).  throughput_schedule = the library's default for the asynchronous _dev entry points (everything on one stream, one-lane comb tables, "
+                        "transcript program A inside the tables' launch); latency_schedule = ZKP_OPT_DEV_OVERLAP = 2: what the synchronous host-pointer calls run -- the point halves "
+                        "(decode, comb tables; the batch MSM's decompressions) on a second stream next to the transcript chains, four lanes per comb table" % n}
+        for name, opt in (("throughput_schedule", None), ("latency_schedule", "5=2")):
+            a2 = copy.copy(args)
+            a2.engine_opt = list(args.engine_opt) + ([opt] if opt else [])
+            rl = run_workload(cx, a2, "2", n, 40, 3, 1, 1, primary=False)
+            lone[name] = {"proofs_per_s": rl["value"], "ms_per_call": rl["ms_per_step"]}
+        lone["proofs_per_s"] = max(lone["throughput_schedule"]["proofs_per_s"], lone["latency_schedule"]["proofs_per_s"])
+        torch.cuda.empty_cache()
     # ---- what the short timed region cannot show, under the same clock: the steady-state rate, and the same steps on the other look-ups ----
     sustained, ct = None, None
     user_lookup = next((int(kv.split("=")[1]) for kv in args.engine_opt if int(kv.split("=")[0]) == 9), 0)
@@ -1160,6 +1178,8 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
         out["config"]["rccl_error"] = dinfo["rccl_error"]
     if step_valu:
         out["step_valu"] = step_valu
+    if lone is not None:
+        out["lone_call"] = lone
     if sustained is not None:
         try:                                       # its own VALU busy fraction, from the counter file of ITS call shape (K = 50), same rule: only at this source sha
             pj50 = json.load(open(os.path.join(ROOT, PMC_PATTERN % ("2", 50))))

@@ -538,7 +538,7 @@ k_batch_after_transcript(uint32_t N, uint32_t N_each, uint32_t nc, uint32_t m, c
     sc_neg(r, r);
     store_vec<2>(minus_c + 32 * g, r.v);
   }
-  if (g < (size_t)N * nc) {
+  if (coms && g < (size_t)N * nc) {                       // (coms == NULL: the latency schedule has transposed them before the transcripts, k_transpose_commitments)
     const size_t j = g / nc, k = g % nc;
     uint32_t w[8];
     load_vec<2>(w, coms + 32 * g);
@@ -954,8 +954,9 @@ void launch_assemble(zkp_ctx* c, const tr_steps_dev& sd, uint32_t N, const tr_bu
   const uint32_t rows = sd.n_img * 21u + ((sd.n_chk || (sd.tail >> 31)) ? 1u : 0u);
   if (rows) hipLaunchKernelGGL(k_transcript_assemble, dim3((N + 255) / 256, rows), dim3(256), 0, c->stream, sd, N, bufs, d_img, d_failed);
 }
+// phase (step programs only): 1 = the assemble pass, 2 = the chain, 3 = both
 void run_program(zkp_ctx* c, const prog_dev& p_in, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput,
-                 uint64_t* d_img, bool owns_failed = false) {
+                 uint64_t* d_img, bool owns_failed = false, int phase = 3) {
   if (!p_in.n) return;
   prog_dev p = p_in;
   if (owns_failed) p.tail |= 0x80000000u;          // the kernel writes every proof's rejection flag, 0 included
@@ -963,10 +964,16 @@ void run_program(zkp_ctx* c, const prog_dev& p_in, uint32_t N, const tr_bufs& bu
     prof_note(c, ZKP_K_TRANSCRIPT, "zkp::k_transcript_chain");
     tr_steps_dev sd = p.sd;
     sd.tail = p.tail;
-    launch_assemble(c, sd, N, bufs, d_img, d_failed);
+    if (phase & 1) launch_assemble(c, sd, N, bufs, d_img, d_failed);
     constexpr uint32_t per_block = TR_BLOCK / 2;
-    hipLaunchKernelGGL(k_transcript_chain, dim3((N + per_block - 1) / per_block), dim3(TR_BLOCK), 0, c->stream, sd, reinterpret_cast<const uint32_t*>(d_img), N, bufs, d_ts,
-                       reinterpret_cast<uint32_t*>(d_saved));
+    if (phase & 2) {
+      if (throughput)
+        hipLaunchKernelGGL(k_transcript_chain<false>, dim3((N + per_block - 1) / per_block), dim3(TR_BLOCK), 0, c->stream, sd, reinterpret_cast<const uint32_t*>(d_img), N, bufs, d_ts,
+                           reinterpret_cast<uint32_t*>(d_saved));
+      else
+        hipLaunchKernelGGL(k_transcript_chain<true>, dim3((N + per_block - 1) / per_block), dim3(TR_BLOCK), 0, c->stream, sd, reinterpret_cast<const uint32_t*>(d_img), N, bufs, d_ts,
+                           reinterpret_cast<uint32_t*>(d_saved));
+    }
     return;
   }
   prof_note(c, ZKP_K_TRANSCRIPT, transcript_single_lane(c, N, throughput) ? "zkp::k_transcript_run1" : "zkp::k_transcript_run");
@@ -1062,7 +1069,8 @@ prove_inter prove_carve(const fused_plan& pl, size_t start) {
   return o;
 }
 int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* d_ts, const uint8_t* d_sec, const uint8_t* d_tbl,
-               const uint8_t* d_ent, uint8_t* d_chal, uint8_t* d_resp, uint8_t* d_coms, uint8_t* d_st8, bool overlap, bool throughput) {
+               const uint8_t* d_ent, uint8_t* d_chal, uint8_t* d_resp, uint8_t* d_coms, uint8_t* d_st8, bool overlap, bool throughput,
+               const std::function<int()>* late_inputs = nullptr, const std::function<int()>* early_outputs = nullptr) {
   const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
   const ws_view w{static_cast<char*>(c->ws)};
   tr_bufs hb{};
@@ -1092,6 +1100,9 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) { c->pending_tr.offered = c->pending_tr.active = false; return rc ? rc : rc2; }
   }
+  // (host-buffer calls on the latency schedule: the inputs only the transcripts read -- states, witnesses, entropy -- cross the link now, while the side
+  // stream already decodes and builds tables from the points that went first)
+  if (late_inputs) { const int rc = (*late_inputs)(); if (rc) return rc; }
   run_program_pending(c, pl.a, N, hb, d_ts, d_saved, w.u32(o.failed), throughput, d_img);
   prof_mark(c, ZKP_K_TRANSCRIPT);
 
@@ -1114,6 +1125,7 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
     if (rc) return rc;
     if (nc) rc = msm_terms_path(c, N * nc, w.u32(o.off), w.u8(o.sc), w.u32(o.pidx), d_tbl, n_points, N * T, ZKP_CT, d_coms, d_st8, nullptr, o.end, false, PH_SCALARS, tk);
     if (rc) return rc;
+    if (early_outputs) { rc = (*early_outputs)(); if (rc) return rc; }      // (the commitments are final: their copy out starts under program B and the responses)
   }
   run_program(c, pl.b, N, hb, d_ts, d_saved, w.u32(o.failed), throughput, d_img);
   prof_mark(c, ZKP_K_TRANSCRIPT);
@@ -1149,7 +1161,7 @@ verify_inter verify_carve(const fused_plan& pl, size_t start) {
   return o;
 }
 int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_claim,
-                const uint8_t* d_resp, uint8_t* d_results, bool overlap, bool throughput) {
+                const uint8_t* d_resp, uint8_t* d_results, bool overlap, bool throughput, const std::function<int()>* late_inputs = nullptr) {
   const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T1 = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
   const ws_view w{static_cast<char*>(c->ws)};
   tr_bufs hb{};
@@ -1176,6 +1188,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
     const int rc2 = side_end(c, main, overlap);
     if (rc || rc2) { c->pending_tr.offered = c->pending_tr.active = false; return rc ? rc : rc2; }
   }
+  if (late_inputs) { const int rc = (*late_inputs)(); if (rc) return rc; }
   run_program_pending(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, d_img);
   prof_mark(c, ZKP_K_TRANSCRIPT);
   hipLaunchKernelGGL(k_neg_reduce, grid1(N, 256), dim3(256), 0, c->stream, N, d_claim, w.u8(o.mc));
@@ -1226,7 +1239,8 @@ size_t optional_many_ws(uint64_t n_each, uint32_t K) {
 }
 int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* d_ts, uint8_t* d_pts, const uint8_t* d_coms,
                const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_out /*[K][32]*/,
-               uint32_t* d_status /*[K][2]: MSM decode failure | transcript rejection or non-canonical response*/, bool throughput, uint32_t K = 1) {
+               uint32_t* d_status /*[K][2]: MSM decode failure | transcript rejection or non-canonical response*/, bool throughput, uint32_t K = 1,
+               bool overlap = false, const std::function<int()>* late_ts = nullptr, const std::function<int()>* late_scalars = nullptr) {
   const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni, N_each = N / K;
   const size_t n_each = (size_t)ns + ((size_t)ni + nc) * N_each;          // terms of one batch's MSM (batch_verifier.rs:219-228)
   const ws_view w{static_cast<char*>(c->ws)};
@@ -1242,19 +1256,45 @@ int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* 
   }
   if (!shared) HIP_TRY(hipMemsetAsync(d_status, 0, 8, c->stream));
   prof_begin(c);
+  uint64_t* d_img = pl.img_bytes ? reinterpret_cast<uint64_t*>(w.base + o.img) : nullptr;
+  // Latency schedule (one call in flight: the synchronous entry points, ZKP_OPT_DEV_OVERLAP = 2): the point half of the MSM's prepare step -- 24 N + 12
+  // decompressions, batch_verifier.rs:226, which no scalar enters -- runs on the side stream next to the transcript chain (0.13 of a lone call's 0.85 ms
+  // at 4096 proofs).  Needs the step form: its assemble pass clears the shared flag word BEFORE the fork, so the decoder's atomicOr cannot meet it.
+  const bool split = overlap && K == 1 && N && shared && transcript_steps(c, pl.a, N, throughput, d_img);
   if (N) {
     tr_bufs hb{};
     hb.src[SRC_TABLE] = d_pts; hb.src[SRC_COMS] = d_coms;
     hb.dst[DST_CHAL] = w.u8(o.wchal);
-    run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, pl.img_bytes ? reinterpret_cast<uint64_t*>(w.base + o.img) : nullptr, /*owns_failed=*/true);
+    if (split) {
+      run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, d_img, /*owns_failed=*/true, /*phase=*/1);
+      hipStream_t main;
+      int rc = side_begin(c, &main, true);
+      if (rc) return rc;
+      if (nc) hipLaunchKernelGGL(k_transpose_commitments, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, N, nc, d_coms, d_pts + 32 * ((size_t)ns + (size_t)ni * N));
+      rc = msm_optional_impl(c, n_each, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared, /*phases=*/1);
+      const int rc2 = side_end(c, main, true);
+      if (rc || rc2) return rc ? rc : rc2;
+      if (late_ts) { rc = (*late_ts)(); if (rc) return rc; }             // (host-buffer calls: the transcript states cross the link while the side stream decodes)
+      run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, d_img, /*owns_failed=*/true, /*phase=*/2);
+    } else {
+      if (late_ts) { const int rc = (*late_ts)(); if (rc) return rc; }
+      run_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, d_img, /*owns_failed=*/true);
+    }
     prof_mark(c, ZKP_K_TRANSCRIPT);
+    if (late_scalars) { const int rc = (*late_scalars)(); if (rc) return rc; }   // (responses and weights: nobody reads them before the chain is on its stream)
     const size_t lanes = std::max<size_t>(std::max<size_t>(N, (size_t)N * nc), (size_t)N * pl.s.m);
     hipLaunchKernelGGL(k_batch_after_transcript, grid1(lanes, 256), dim3(256), 0, c->stream, N, N_each, nc, pl.s.m, w.u32(o.failed),
-                       shared ? shared : d_status + 1, 1u, shared ? 2u : 1u, w.u8(o.wchal), w.u8(o.mc), d_coms, d_pts + 32 * ((size_t)ns + (size_t)ni * N), d_resp);
+                       shared ? shared : d_status + 1, 1u, shared ? 2u : 1u, w.u8(o.wchal), w.u8(o.mc), split ? (const uint8_t*)nullptr : d_coms,
+                       d_pts + 32 * ((size_t)ns + (size_t)ni * N), d_resp);
   }
   launch_coeff_build(c, pl.s, N_each, pl.d_inc, w.u8(o.mc), d_resp, d_w, w.u8(o.sc), w.u32(o.part), K);
   prof_mark(c, ZKP_K_SCALARS);
   HIP_TRY(hipGetLastError());
+  if (split) {
+    const int rc = side_join(c, true);
+    if (rc) return rc;
+    return msm_optional_impl(c, n_each, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared, /*phases=*/2);
+  }
   if (K == 1) return msm_optional_impl(c, n_each, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared);
   pip_seg seg;
   seg.K = K; seg.ns = ns; seg.N_each = N_each;
@@ -1496,9 +1536,9 @@ int zkp_fused_prove_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, u
     return fail(ZKP_ERR_ARG, "NULL device pointer");
   if ((uint64_t)N * s.T > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const prove_inter o = prove_carve(*pl, 0);
-  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min(true, (size_t)N * s.T))));
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * s.T, N * s.nc, cfg_from_terms(pl->tpt.data(), s.T, s.ns, s.np, N, c->ct_comb_min(!c->dev_latency, (size_t)N * s.T))));
   if (rc) return rc;
-  return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status, /*overlap=*/c->dev_overlap, /*throughput=*/true);
+  return prove_core(c, *pl, o, d_transcripts, d_secrets, d_table, d_entropy, d_challenges, d_responses, d_commitments, d_status, /*overlap=*/c->dev_overlap, /*throughput=*/!c->dev_latency);
 }
 
 // ---- verify_compact --------------------------------------------------------------------------------------------------
@@ -1516,7 +1556,7 @@ int zkp_fused_verify_compact_dev(zkp_ctx* c, const zkp_fused_statement* st, uint
   const verify_inter o = verify_carve(*pl, 0);
   rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1, N * s.nc, cfg_from_terms(pl->tpt.data(), pl->T1, s.ns, s.np, N, 2)));
   if (rc) return rc;
-  return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results, /*overlap=*/c->dev_overlap, /*throughput=*/true);
+  return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results, /*overlap=*/c->dev_overlap, /*throughput=*/!c->dev_latency);
 }
 
 // ---- batch verification ----------------------------------------------------------------------------------------------
@@ -1539,7 +1579,7 @@ int zkp_fused_batch_verify_dev(zkp_ctx* c, const zkp_fused_statement* st, uint32
   const batch_inter o = batch_carve(*pl, 0);
   rc = ensure_ws(c, o.end + optional_ws(total));
   if (rc) return rc;
-  return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_point, d_status, /*throughput=*/true);
+  return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_point, d_status, /*throughput=*/!c->dev_latency, 1, /*overlap=*/c->dev_latency);
 }
 
 // ---- K batch verifications in one pass ------------------------------------------------------------------------------
@@ -1580,7 +1620,7 @@ int zkp_fused_batch_verify_many_dev(zkp_ctx* c, const zkp_fused_statement* st, u
   const batch_inter o = batch_carve(*pl, 0, K);
   rc = ensure_ws(c, o.end + optional_many_ws(n_each, K));
   if (rc) return rc;
-  return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_points, d_status, /*throughput=*/true, K);
+  return batch_core(c, *pl, o, d_transcripts, d_points, d_commitments, d_responses, d_weights16, d_out_points, d_status, /*throughput=*/!c->dev_latency, K, /*overlap=*/c->dev_latency);
 }
 
 // ---- verify_batchable, one verdict per proof -----------------------------------------------------------------------------

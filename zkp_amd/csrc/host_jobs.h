@@ -70,7 +70,9 @@ k_any_nonzero_bytes(size_t n, const uint8_t* __restrict__ flags, uint32_t* __res
 namespace {
 
 // ---- pinned scratch and the pending-job record of a context -------------------------------------------------------------
-inline bool job_defers(const zkp_ctx* c) { return c->defer_d2h != 0; }
+// (a SYNCHRONOUS call is the only job of its context and its caller waits right behind it: its copies out are queued with the kernels -- deferring them would
+// only add a host round trip between the last kernel and the first copy)
+inline bool job_defers(const zkp_ctx* c) { return c->defer_d2h != 0 && !c->job.inline_out; }
 int job_begin(zkp_ctx* c, size_t pin_bytes) {
   if (c->job.kind) return fail(ZKP_ERR_ARG, "a submitted job is pending on this context: zkp_ctx_job_wait first");
   if (c->capturing) return fail(ZKP_ERR_ARG, "graph capture: host-buffer jobs cannot be recorded (their copies name the caller's buffers)");
@@ -85,6 +87,7 @@ int job_begin(zkp_ctx* c, size_t pin_bytes) {
     c->job.pin_bytes = pin_bytes + 256;
   }
   c->job.outs.clear();
+  c->job.inline_out = false;
   c->job.copies_issued = false;
   c->job.copy_err = hipSuccess;
   c->job.results = nullptr;
@@ -217,21 +220,34 @@ int prove_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t fl
   rc = job_begin(c, 16);
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
-  ZKP_JOB_TRY(put_transcripts(c, N, shared, transcripts, w.u8(o_ts), w.u8(o_blob)));
-  if (m) ZKP_JOB_TRY(h2d(c, w.base + o_sec, secrets, (size_t)N * m * 32));
+  c->job.inline_out = sync_variant;
+  // The points go first: decode, classification and comb tables (side stream of the latency schedule) need nothing else.  What only the transcripts read --
+  // states, witnesses, entropy, two thirds of the bytes -- follows once that work is queued (a copy from pageable memory holds the host thread until it is
+  // staged), so it crosses the link under those kernels.  The asynchronous jobs keep everything in front: their copies ride under OTHER jobs' kernels.
   if (s.ns) ZKP_JOB_TRY(h2d(c, w.base + o_tbl, common, (size_t)s.ns * 32));
   ZKP_JOB_TRY(h2d_rows(c, w.base + o_tbl + 32 * (size_t)s.ns, inst, s.ni, (size_t)N * 32, (size_t)inst_stride * 32));
-  if (entropy) ZKP_JOB_TRY(h2d(c, w.base + o_ent, entropy, (size_t)N * 32));
-  else ZKP_JOB_TRY(chacha_fill(c, rng_seed, 0, w.base + o_ent, (size_t)N * 32));
+  const std::function<int()> rest = [&]() -> int {
+    int r = put_transcripts(c, N, shared, transcripts, w.u8(o_ts), w.u8(o_blob));
+    if (!r && m) r = h2d(c, w.base + o_sec, secrets, (size_t)N * m * 32);
+    if (!r) r = entropy ? h2d(c, w.base + o_ent, entropy, (size_t)N * 32) : chacha_fill(c, rng_seed, 0, w.base + o_ent, (size_t)N * 32);
+    return r;
+  };
+  bool coms_out = false;
+  const std::function<int()> early = [&]() -> int {          // (pageable destinations hold the host until the copy is done: only pinned ones may leave early)
+    if (!nc || !zkp_host_is_pinned(commitments)) return ZKP_OK;
+    coms_out = true;
+    return d2h(c, commitments, w.base + o_coms, (size_t)N * nc * 32);
+  };
+  if (!sync_variant) ZKP_JOB_TRY(rest());
   job_mark(c, 1);
   ZKP_JOB_TRY(prove_core(c, *pl, o, w.u8(o_ts), w.u8(o_sec), w.u8(o_tbl), w.u8(o_ent), w.u8(o_chal), w.u8(o_resp), w.u8(o_coms), w.u8(o_st), /*overlap=*/sync_variant,
-                         /*throughput=*/!sync_variant));
+                         /*throughput=*/!sync_variant, sync_variant ? &rest : nullptr, sync_variant ? &early : nullptr));
   job_mark(c, 2);
   if (hipMemsetAsync(w.base + o_flag, 0, 4, c->stream) != hipSuccess) return job_abort(c, fail(ZKP_ERR_HIP, "hipMemsetAsync failed"));
   if (nc) hipLaunchKernelGGL(k_any_nonzero_bytes, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, (size_t)N * nc, w.u8(o_st), w.u32(o_flag));
   ZKP_JOB_TRY(d2h(c, challenges, w.base + o_chal, (size_t)N * 32));
   if (m) ZKP_JOB_TRY(d2h(c, responses, w.base + o_resp, (size_t)N * m * 32));
-  if (nc) ZKP_JOB_TRY(d2h(c, commitments, w.base + o_coms, (size_t)N * nc * 32));
+  if (nc && !coms_out) ZKP_JOB_TRY(d2h(c, commitments, w.base + o_coms, (size_t)N * nc * 32));
   if (transcripts_out) ZKP_JOB_TRY(d2h(c, transcripts_out, w.base + o_ts, (size_t)N * 208));
   ZKP_JOB_TRY(d2h(c, c->job.pin, w.base + o_flag, 4));
   ZKP_JOB_TRY(job_commit(c, 'P', 0, nullptr, invalid_point));
@@ -272,13 +288,19 @@ int verify_compact_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, ui
   if (rc) return rc;
   job_results(c, results, N);
   const ws_view w{static_cast<char*>(c->ws)};
-  ZKP_JOB_TRY(put_transcripts(c, N, shared, transcripts, w.u8(o_ts), w.u8(o_blob)));
+  c->job.inline_out = sync_variant;
   if (s.ns) ZKP_JOB_TRY(h2d(c, w.base + o_tbl, common, (size_t)s.ns * 32));
   ZKP_JOB_TRY(h2d_rows(c, w.base + o_tbl + 32 * (size_t)s.ns, inst, s.ni, (size_t)N * 32, (size_t)inst_stride * 32));
-  ZKP_JOB_TRY(h2d(c, w.base + o_claim, challenges, (size_t)N * 32));
-  if (m) ZKP_JOB_TRY(h2d(c, w.base + o_resp, responses, (size_t)N * m * 32));
+  const std::function<int()> rest = [&]() -> int {            // (see prove_job: the points first, the rest under the side stream's kernels)
+    int r = put_transcripts(c, N, shared, transcripts, w.u8(o_ts), w.u8(o_blob));
+    if (!r) r = h2d(c, w.base + o_claim, challenges, (size_t)N * 32);
+    if (!r && m) r = h2d(c, w.base + o_resp, responses, (size_t)N * m * 32);
+    return r;
+  };
+  if (!sync_variant) ZKP_JOB_TRY(rest());
   job_mark(c, 1);
-  ZKP_JOB_TRY(verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res), /*overlap=*/sync_variant, /*throughput=*/!sync_variant));
+  ZKP_JOB_TRY(verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res), /*overlap=*/sync_variant, /*throughput=*/!sync_variant,
+                          sync_variant ? &rest : nullptr));
   job_mark(c, 2);
   ZKP_JOB_TRY(d2h(c, results, w.base + o_res, (size_t)N));
   if (transcripts_out) ZKP_JOB_TRY(d2h(c, transcripts_out, w.base + o_ts, (size_t)N * 208));
@@ -329,19 +351,25 @@ int batch_verify_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t K, uint
   rc = job_begin(c, (size_t)K * 40);
   if (rc) return rc;
   const ws_view w{static_cast<char*>(c->ws)};
+  c->job.inline_out = sync_variant;
+  // points and commitments first (the assemble pass and the decoder on the side stream read them); transcript states once that work is queued; responses and
+  // weights (nobody reads them before the coefficient build) once the chain is on its stream -- see prove_job
   if (ns) ZKP_JOB_TRY(h2d(c, w.base + o_pts, common, (size_t)ns * 32));
   if (N) {
     ZKP_JOB_TRY(h2d_rows(c, w.base + o_pts + 32 * (size_t)ns, inst, ni, (size_t)N * 32, (size_t)inst_stride * 32));
-    ZKP_JOB_TRY(put_transcripts(c, N, shared, transcripts, w.u8(o_ts), w.u8(o_blob)));
-    if (nc) {
-      ZKP_JOB_TRY(h2d(c, w.base + o_coms, commitments, (size_t)N * nc * 32));
-      if (weights16) ZKP_JOB_TRY(h2d_rows(c, w.base + o_w, weights16, nc, (size_t)N * 16, (size_t)w_stride * 16));
-      else ZKP_JOB_TRY(chacha_fill(c, rng_seed, 0, w.base + o_w, (size_t)nc * N * 16));
-    }
-    if (m) ZKP_JOB_TRY(h2d(c, w.base + o_resp, responses, (size_t)N * m * 32));
+    if (nc) ZKP_JOB_TRY(h2d(c, w.base + o_coms, commitments, (size_t)N * nc * 32));
   }
+  const std::function<int()> late_ts = [&]() -> int { return put_transcripts(c, N, shared, transcripts, w.u8(o_ts), w.u8(o_blob)); };
+  const std::function<int()> late_sc = [&]() -> int {
+    int r = ZKP_OK;
+    if (nc) r = weights16 ? h2d_rows(c, w.base + o_w, weights16, nc, (size_t)N * 16, (size_t)w_stride * 16) : chacha_fill(c, rng_seed, 0, w.base + o_w, (size_t)nc * N * 16);
+    if (!r && m) r = h2d(c, w.base + o_resp, responses, (size_t)N * m * 32);
+    return r;
+  };
+  if (N && !sync_variant) { ZKP_JOB_TRY(late_ts()); ZKP_JOB_TRY(late_sc()); }
   job_mark(c, 1);
-  ZKP_JOB_TRY(batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st), /*throughput=*/!sync_variant, K));
+  ZKP_JOB_TRY(batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st), /*throughput=*/!sync_variant, K, /*overlap=*/sync_variant,
+                         sync_variant ? &late_ts : nullptr, sync_variant ? &late_sc : nullptr));
   job_mark(c, 2);
   if (debug_scalars) ZKP_JOB_TRY(d2h(c, debug_scalars, w.base + o.sc, n_sc * 32));
   ZKP_JOB_TRY(d2h(c, c->job.pin, w.base + o_out, (size_t)K * 32));

@@ -290,9 +290,16 @@ __device__ __forceinline__ void transcript_chain_block(uint32_t bid, uint32_t* S
   if (h == 0) { blob[50] = p.tail & 0xffffffu; blob[51] = 0; }
 }
 
+// ALONE = the latency schedule's instantiation: the wavefront claims (almost) a whole SIMD's register file -- 192 VGPRs + 240 accumulation registers nobody
+// uses -- so that no wavefront of the point phase that runs on the side stream at the same time (comb tables: 86 registers, decode: 186) can be placed on ITS SIMD.
+// A chain wavefront that shares its SIMD issues every other slot: next to k_comb_tables the chain of program A took 549 us instead of 345 (rocprofv3
+// timeline of a synchronous call, profiles/r06_ab_experiments.txt block c), which is the whole gain of running the two side by side.  128 wavefronts on a chip
+// of 1024 SIMDs: the registers cost nothing.  Pipelined callers (throughput schedule) take ALONE = false: their other streams' kernels should fill those SIMDs.
+template <bool ALONE>
 __global__ void __launch_bounds__(TR_BLOCK)
 k_transcript_chain(const tr_steps_dev p, const uint32_t* __restrict__ img32, uint32_t N, const tr_bufs bufs, uint8_t* __restrict__ ts, uint32_t* __restrict__ saved) {
   __shared__ uint32_t S[25 * TR_BLOCK];
+  if constexpr (ALONE) asm volatile("" ::: "a239");
   transcript_chain_block(blockIdx.x, S, p, img32, N, bufs, ts, saved);
 }
 

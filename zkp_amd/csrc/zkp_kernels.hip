@@ -28,6 +28,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -551,7 +552,9 @@ __device__ __forceinline__ void pip_seg_src(const pip_seg& seg, uint32_t b, uint
   }
 }
 
-template <int C>
+// PHASE: 3 = both halves; 1 = the points only (decode -> niels: nothing here depends on a scalar, so the latency schedule of the batch verifier runs it on the
+// side stream next to the transcripts); 2 = the digits only
+template <int C, int PHASE = 3>
 __global__ void __launch_bounds__(256, 2)
 k_pip_prepare(uint32_t n, const pip_seg seg, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points,
               dev_niels* __restrict__ niels, uint32_t* __restrict__ digits, uint32_t* __restrict__ invalid) {
@@ -562,7 +565,7 @@ k_pip_prepare(uint32_t n, const pip_seg seg, const uint8_t* __restrict__ scalars
   pip_seg_src(seg, b, i, si, pi);
   niels += (size_t)b * n;
   digits += (size_t)b * cfg::W1 * n;
-  {
+  if constexpr (PHASE & 1) {
     uint32_t w[8];
     load_vec<2>(w, points + 32 * pi);
     ge_p3 p;
@@ -572,6 +575,7 @@ k_pip_prepare(uint32_t n, const pip_seg seg, const uint8_t* __restrict__ scalars
     store_niels(niels + i, q, ok);
     if (!ok) atomicOr(invalid + b, 1u);
   }
+  if constexpr (!(PHASE & 2)) return;
   uint32_t s[8], e[10];
   load_vec<2>(s, scalars + 32 * si);
   const uint32_t flip = sc_fold_sign(s);      // s * P = (l - s) * (-P): the point's sign moves into the digits
@@ -1312,6 +1316,7 @@ struct zkp_ctx {
 #endif
   static constexpr size_t kGroupedCombTerms = 400000;
   bool dev_overlap = false;          // ZKP_OPT_DEV_OVERLAP: the _dev flows fork their scalar-independent half onto the side stream too
+  bool dev_latency = false;          // ZKP_OPT_DEV_OVERLAP = 2: the _dev flows run the whole latency schedule of the synchronous entry points (a lone caller's choice)
   bool tr_steps = true;              // ZKP_OPT_TRANSCRIPT_STEPS: lane-pair transcripts as assemble + chain (1, default) or by the word-operation interpreter (0)
   int tr_lanes = -1;                 // ZKP_OPT_TRANSCRIPT_LANES: -1 = by entry point, 1 = one lane per proof, 2 = a lane pair per proof
   // The instruction-saving variants of the asynchronous entry points (ladder for single-use points, one transcript lane per
@@ -1372,6 +1377,7 @@ struct zkp_ctx {
     std::vector<out_copy> outs;
     hipEvent_t copied = nullptr;       // recorded behind the deferred copies once they are issued
     bool copies_issued = false;
+    bool inline_out = false;           // a synchronous call: its copies out are queued with its kernels (job_defers)
   } job;
   int defer_d2h = -1;                  // ZKP_OPT_JOB_DEFER_D2H: -1 = default (1), 0 = queue the copies out at submit
   bool sync_throughput = false;        // ZKP_OPT_SYNC_SCHEDULE: the synchronous host-pointer entry points run the jobs' throughput schedule (callers with a thread per context)
@@ -1710,7 +1716,7 @@ size_t pip_ws(uint64_t n, uint32_t K = 1) {
 // d_out [K][32]; d_status [K] words, or [K][2] with shared_flags (the caller's K zeroed flag words: bit 0 ours, bit 1 the caller's)
 template <int C>
 int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_points, uint8_t* d_out,
-            uint32_t* d_status, size_t ws_reserved, uint32_t* shared_flags, const pip_seg seg = pip_seg()) {
+            uint32_t* d_status, size_t ws_reserved, uint32_t* shared_flags, const pip_seg seg = pip_seg(), int phases = 3) {
   using cfg = pip_cfg<C>;
   const uint32_t K = seg.K;
   const size_t WK = (size_t)cfg::W1 * K;
@@ -1741,9 +1747,17 @@ int pip_run(zkp_ctx* c, uint32_t n, const uint8_t* d_scalars, const uint8_t* d_p
   dev_ext* lvlR = lvlA + lvl_cap;
   if (cv.off > c->ws_bytes) return fail(ZKP_ERR_ARG, "internal: workspace too small");
 
+  // phases: 1 = the point half of the prepare step only (the caller runs it on a side stream; needs shared_flags, zeroed before), 2 = everything after it
+  if (phases == 1) {
+    if (!shared_flags) return fail(ZKP_ERR_ARG, "internal: split prepare without the caller's flag words");
+    hipLaunchKernelGGL((k_pip_prepare<C, 1>), dim3((n + 255) / 256, K), dim3(256), 0, c->stream, n, seg, d_scalars, d_points, niels, digits, invalid);
+    HIP_TRY(hipGetLastError());
+    return ZKP_OK;
+  }
   if (!shared_flags) HIP_TRY(hipMemsetAsync(invalid, 0, (size_t)K * 4, c->stream));
   prof_note(c, ZKP_K_DECODE, "k_pip_prepare<" + std::to_string(C) + ">");
-  hipLaunchKernelGGL(k_pip_prepare<C>, dim3((n + 255) / 256, K), dim3(256), 0, c->stream, n, seg, d_scalars, d_points, niels, digits, invalid);
+  if (phases == 2) hipLaunchKernelGGL((k_pip_prepare<C, 2>), dim3((n + 255) / 256, K), dim3(256), 0, c->stream, n, seg, d_scalars, d_points, niels, digits, invalid);
+  else hipLaunchKernelGGL((k_pip_prepare<C, 3>), dim3((n + 255) / 256, K), dim3(256), 0, c->stream, n, seg, d_scalars, d_points, niels, digits, invalid);
   prof_mark(c, ZKP_K_DECODE);
   hipLaunchKernelGGL(k_pip_tile_hist<C>, dim3(tiles, (unsigned)WK), dim3(sort_cfg<C>::THREADS), 0, c->stream, n, digits, tilehist);
   hipLaunchKernelGGL(k_pip_tile_total, grid1(nb, 256), dim3(256), 0, c->stream, cfg::B1, tiles, (uint32_t)nb, tilehist, hist);
@@ -1910,7 +1924,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
   switch (option) {
     case ZKP_OPT_BATCH_ENCODE_MIN: c->batch_encode_min = value; c->batch_encode_user = true; return ZKP_OK;
     case ZKP_OPT_CT_SINGLE_USE_TABLES: c->ct_single_use_tables = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
-    case ZKP_OPT_DEV_OVERLAP: c->dev_overlap = value != 0; return ZKP_OK;
+    case ZKP_OPT_DEV_OVERLAP: c->dev_overlap = value != 0 && value != ~0ull; c->dev_latency = value == 2; return ZKP_OK;
 #ifdef ZKP_BUILD_TEST_HOOKS
     case ZKP_TESTOPT_GENERIC_CLASSIFIER: c->stmt_classify = value == 0; return ZKP_OK;
     case ZKP_TESTOPT_DUMMY_LAUNCHES: c->debug_dummy_launches = (int)std::min<uint64_t>(value, 1000); return ZKP_OK;
@@ -2234,7 +2248,7 @@ int zkp_msm_many(zkp_ctx* c, uint32_t n_msm, const uint32_t* off, const uint8_t*
 // shared_flags (optional, Pippenger sizes only): a zeroed device word that replaces the path's own decode-failure flag (bit 0) and
 // whose bit 1 the caller may have set; the last kernel then writes status[0] = bit 0 and status[1] = bit 1 (no memsets)
 static int msm_optional_impl(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, const uint8_t* d_points,
-                             uint8_t* d_out, uint32_t* d_status, size_t reserved, uint32_t* shared_flags = nullptr) {
+                             uint8_t* d_out, uint32_t* d_status, size_t reserved, uint32_t* shared_flags = nullptr, int phases = 3) {
   if (n <= kSmallOptional) {
     if (shared_flags) return fail(ZKP_ERR_ARG, "internal: shared flags with a small MSM");
     carve cv;
@@ -2262,10 +2276,10 @@ static int msm_optional_impl(zkp_ctx* c, uint64_t n, const uint8_t* d_scalars, c
   int rc = ensure_ws(c, reserved + need);
   if (rc) return rc;
   switch (cbits) {
-    case 7: return pip_run<7>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags);
-    case 10: return pip_run<10>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags);
-    case 11: return pip_run<11>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags);
-    default: return pip_run<16>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags);
+    case 7: return pip_run<7>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags, pip_seg(), phases);
+    case 10: return pip_run<10>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags, pip_seg(), phases);
+    case 11: return pip_run<11>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags, pip_seg(), phases);
+    default: return pip_run<16>(c, (uint32_t)n, d_scalars, d_points, d_out, d_status, reserved, shared_flags, pip_seg(), phases);
   }
 }
 

@@ -60,7 +60,7 @@ METRIC = "proofs/sec + batch-verifies/sec, CMZ13 10-attr credential, 1/2/4/8 MI3
 # whole slot (profiles/r04_valu_mix_microbench.txt).  valu_busy = 4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) per kernel
 # (one PMC pass, the chip's own clock), and issue cycles / (1024 x 2.4 GHz nameplate x ms_per_step) for the timed step -- <= 1 by construction.
 # profiles/r05_opcode_mix.json (tools/opcode_mix.py) is the static opcode mix of every kernel, keyed to the kernel sources: information, not the weights.
-OPCODE_MIX = os.path.join("profiles", "r05_opcode_mix.json")
+OPCODE_MIX = os.path.join("profiles", "r06_opcode_mix.json")
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md
 # how the constant-time prover MSMs (prover.rs:94) pick the table entry a secret digit names: ZKP_OPT_CT_LOOKUP (include/zkp_mi355x.h)
 CT_SCHEDULES = {0: "lane crossbar: rows in registers, entries by ds_bpermute_b32 from one half of the wavefront, 8-entry private rows scanned with v_cndmask -- constant time BY CONSTRUCTION "
@@ -70,7 +70,7 @@ CT_SCHEDULES = {0: "lane crossbar: rows in registers, entries by ds_bpermute_b32
                    "NOT by construction (ZKP_OPT_CT_LOOKUP = 2, the default of rounds 2 - 4)"}
 LABEL = b"Benchmark"
 BASE = bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76")
-PMC_PATTERN = os.path.join("profiles", "r05_pmc_counters_cfg%s_k%d.json")   # one counter file per workload and batches-per-call (tools/collect_profiles.sh)
+PMC_PATTERN = os.path.join("profiles", "r06_pmc_counters_cfg%s_k%d.json")   # one counter file per workload and batches-per-call (tools/collect_profiles.sh)
 # what the HIP-event timing kinds of zkp_ctx_last_timing are, per flow: (kernel names as rocprofv3 prints them, launches per call).
 # roofline.kernel is chosen among the GROUPS below by kernel name, summed across flows (k_transcript_run* = 3 launches per step).
 KERNELS = {
@@ -226,6 +226,38 @@ def make_instance(eng, st, n, rng):
 def cmz_instance(eng, n, rng):
     """n consistent CMZ presentations: witnesses, instance points [13][n][32] (C_1..C_10, P, Q, V), common [12][32]."""
     return make_instance(eng, cmz_statement(), n, rng)
+
+
+# ---- SURVEY 8(d): "1 point decode per distinct point + 1 scalar-mult-equivalent per term; report field-mults actually executed alongside" ----------------------
+MADS_PER_FE_MUL, MADS_PER_FE_SQ = 98, 62          # v_mad_u64_u32 of one 9 x 29-bit multiplication (81 + 17 for the fold) / squaring (45 + 17): zkp_amd/csrc/fe25519.h
+
+
+def cmz_field_mult_model(n, K=5):
+    """Field multiplications per CMZ proof of one bench step (prove + batch verify), three ways.  Unit: one multiplication = 98 v_mad_u64_u32; a squaring
+    counts 62 / 98 of one (what fe_sq executes).
+      floor      the algorithm-independent reference count SURVEY 8(d) defines: per distinct point one decode (254 S + 11 M), per (scalar, point) term one
+                 scalar-multiplication equivalent = signed radix-16 double-and-add on extended coordinates, 252 doublings (4 S + 4 M) + 64 additions (8 M).
+                 It is a unit, not a bound: fixed-base tables and Pippenger do fewer operations per term than one scalar multiplication.
+      algorithm  what THIS library's algorithms ask for at the call shape of `value` (point operations of DESIGN.md section 5, counted, not measured).
+      (executed = v_mad_u64_u32 the hardware counted / 98 comes from the PMC file.)"""
+    S = MADS_PER_FE_SQ / MADS_PER_FE_MUL
+    dbl, add8, add7, dec = 4 * S + 4, 8.0, 7.0, 254 * S + 11
+    smul = 252 * dbl + 64 * add8
+    terms_p, terms_v = 31, 24 + 12.0 / n
+    floor = {"prove": terms_p * smul + (2 + 11.0 / n) * dec, "batch_verify": terms_v * (smul + dec)}
+    # prove (throughput schedule, calls of K x n proofs): P and Q decoded; a 16-teeth comb table each (256 + 4 x 16 doublings, 3 x 16 additions, 129 conversions
+    # to the cached form, 1 M each); 20 fixed-base terms of 37 mixed additions; P's 10 terms on the grouped walk (16 doublings + 65 additions each) and Q's on
+    # the scan (same counts); 20 additions of partial sums; the batched encoder (~25 M per commitment).  Common points: 11 fixed-base tables per CONTEXT, not per call.
+    table = (256 + 64) * dbl + 48 * add8 + 129
+    wide = K * n * terms_p >= 250000              # zkp_ctx::kWideCallTerms: Q (one use per proof) walks a radix-16 ladder of its own instead of getting a table
+    prove = {"decode": 2 * dec, "comb_tables": (1 if wide else 2) * table, "fixed_base_terms": 20 * 37 * add7,
+             "comb_terms": 10 * (16 * dbl + 65 * add8) + ((7 * add8 + 256 * dbl + 65 * add8) if wide else (16 * dbl + 65 * add8)), "sum_and_encode": 20 * add8 + 11 * 25.0}
+    # batch verify: 24 decodes; Pippenger with 11-bit windows: 23 populated windows x one mixed addition per term, the bucket tree (2^10 buckets x 24 windows, two
+    # additions each, shared by the batch's n proofs) and the 253-doubling Horner tail (shared likewise)
+    verify = {"decode": terms_v * dec, "bucket_additions": terms_v * 23 * add7, "bucket_tree_and_horner": (24 * 1024 * 2 * add8 + 253 * dbl) / n}
+    algo = {"prove": sum(prove.values()), "batch_verify": sum(verify.values())}
+    return {"floor": floor, "algorithm": algo, "algorithm_by_phase": {"prove": prove, "batch_verify": verify},
+            "floor_per_proof": sum(floor.values()), "algorithm_per_proof": sum(algo.values())}
 
 
 def pick_streams(steps):
@@ -1096,7 +1128,7 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
             "by_kernel": by_kernel}
     # ---- PMC-derived fields: only from a counter file collected from exactly these sources and this call shape ---------------------------
     sha = source_sha256()
-    pmc_source, step_valu = None, None
+    pmc_source, step_valu, roof_valu = None, None, None
     pmc_rel = args.pmc_json or (PMC_PATTERN % (args.config, K))
     pmc_path = pmc_rel if os.path.isabs(pmc_rel) else os.path.join(ROOT, pmc_rel)
     if os.path.exists(pmc_path):
@@ -1156,6 +1188,24 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
                                          "issue cycles that were really there -- an estimate: the clock of the four-stream run is not observable from HIP.  "
                                          "Rounds 1-3 charged 4 cycles to every instruction at one assumed clock; this round first charged 2 to every 2-cycle-class opcode "
                                          "(too few: isolated ones cost 4, profiles/r04_valu_mix_microbench.txt)."}
+                    mads = st_tot.get("mad_u64_wave_instructions_per_step")
+                    if args.config == "2" and mads:
+                        # executed field multiplications next to the reference count and to what the library's own algorithms ask for
+                        md = cmz_field_mult_model(n, K)
+                        ex = mads * 64.0 / MADS_PER_FE_MUL / n
+                        cyc = st_tot.get("valu_issue_cycles_per_step")
+                        roof_valu = {"bound": "integer VALU issue slots (v_mad_u64_u32 class, 4 cycles per wave64 instruction per SIMD)",
+                                     "field_mults_executed_per_proof": ex, "field_mults_floor_per_proof": md["floor_per_proof"], "field_mults_algorithm_per_proof": md["algorithm_per_proof"],
+                                     "executed_over_floor": ex / md["floor_per_proof"], "efficiency": md["algorithm_per_proof"] / ex,
+                                     "mad_share_of_issue_slots": 4.0 * mads / cyc if cyc else None, "issue_slot_frac": floor / ms_per_step if floor else None,
+                                     "achieved_field_mults_per_s": ex * value, "peak_field_mults_per_s": 1024 * 2.4e9 / 4.0 * 64.0 / MADS_PER_FE_MUL,
+                                     "algorithm_by_phase": md["algorithm_by_phase"], "floor_by_flow": md["floor"],
+                                     "note": "one field multiplication = 98 v_mad_u64_u32 (a squaring executes 62 and counts 0.63).  executed = the step's v_mad_u64_u32 wave-instructions "
+                                             "(SQ_INSTS_VALU_INT64 per kernel x the static share of mads in that counter's class, pmc_source + profiles/r06_opcode_mix.json) x 64 lanes / 98 / proofs; "
+                                             "floor = SURVEY 8(d)'s reference count (a decode per distinct point + one radix-16 double-and-add per term) -- a unit, not a bound: executed_over_floor "
+                                             "< 1 is what fixed-base tables and Pippenger save; algorithm = the point operations this library's algorithms ask for (bench.py: cmz_field_mult_model); "
+                                             "efficiency = algorithm / executed: what is NOT lost to idle lanes, masked scans, recomputation; mad_share_of_issue_slots x issue_slot_frac = the share of "
+                                             "the chip's VALU issue slots in the timed region that executed a multiplication's product; peak = every SIMD issuing a mad every slot at 2.4 GHz"}
         except Exception:                       # noqa: BLE001 -- a reported extra, never the measurement
             pmc_source = None
     out = {
@@ -1178,6 +1228,9 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
         out["config"]["rccl_error"] = dinfo["rccl_error"]
     if step_valu:
         out["step_valu"] = step_valu
+    if roof_valu:
+        out["roofline_valu"] = roof_valu
+        out["roofline"]["bound"] = "valu"                     # (what binds; achieved / peak / frac stay the HBM figures the contract asks for, roofline_valu has the VALU ones)
     if lone is not None:
         out["lone_call"] = lone
     if sustained is not None:

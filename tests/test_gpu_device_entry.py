@@ -66,15 +66,22 @@ def test_msm_many_dev_equals_host_entry_and_oracle(eng, flags):
     assert (want == exp).all()
 
 
-@pytest.mark.parametrize("n,wide", [(40, False), (1500, False), (40, True), (1500, True), (40, "fuse"), (1500, "fuse")])
+@pytest.mark.parametrize("n,wide", [(40, False), (1500, False), (40, True), (1500, True), (40, "fuse"), (1500, "fuse"), (40, "interp"), (1500, "interp"),
+                                    (1500, "fuse+interp"), (40, "latency"), (1500, "latency"), (4096, "latency")])
 def test_fused_dev_flows_equal_host_pointer_flows(eng, n, wide):
     """zkp_fused_prove_dev / _verify_compact_dev / _batch_verify_dev / _verify_batchable_dev against zkp_fused_prove / ... (through the toolbox).
     wide: with the variants the _dev entry points pick for calls that fill the chip on their own (one transcript lane per
     proof, constant-time ladder for single-use points), forced here at a small batch size; "fuse": with
-    ZKP_OPT_FUSE_TABLES_TRANSCRIPT."""
-    if wide == "fuse":
+    ZKP_OPT_FUSE_TABLES_TRANSCRIPT; "interp": ZKP_OPT_TRANSCRIPT_STEPS = 0, the word-operation interpreter of rounds 2 - 5 instead of assemble + chain
+    (the default, which every other case runs); "latency": ZKP_OPT_DEV_OVERLAP = 2, the synchronous calls' schedule on device buffers (side stream for the
+    point phases incl. the batch MSM's decompressions, chain wavefronts that own their SIMD)."""
+    if "fuse" in str(wide):
         eng.set_option(8, 1)            # ZKP_OPT_FUSE_TABLES_TRANSCRIPT: program A in the comb tables' launch
-    elif wide:
+    if "interp" in str(wide):
+        eng.set_option(15, 0)           # ZKP_OPT_TRANSCRIPT_STEPS
+    if wide == "latency":
+        eng.set_option(5, 2)            # ZKP_OPT_DEV_OVERLAP
+    elif wide is True:
         eng.set_option(4, 1)            # ZKP_OPT_TRANSCRIPT_LANES
         eng.set_option(3, 0)            # ZKP_OPT_CT_SINGLE_USE_TABLES
     try:
@@ -83,6 +90,8 @@ def test_fused_dev_flows_equal_host_pointer_flows(eng, n, wide):
         eng.set_option(4, 2**64 - 1)
         eng.set_option(3, 2**64 - 1)
         eng.set_option(8, 2**64 - 1)
+        eng.set_option(15, 1)
+        eng.set_option(5, 0)
 
 
 def _fused_dev_flows(eng, n):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static VALU opcode mix of every kernel in the shipped code object -> profiles/r05_opcode_mix.json (keyed to the kernel sources).  INFORMATION
+"""Static VALU opcode mix of every kernel in the shipped code object -> profiles/r06_opcode_mix.json (keyed to the kernel sources).  INFORMATION
 about the code (share of 2-cycle-class opcodes, of 64-bit integer opcodes, the top opcodes), not the weights of the VALU ceiling any more.
 
 History: rounds 1 - 3 divided raw SQ_INSTS_VALU counts by ONE peak, 34.5e12 lane-instructions/s -- 4 issue cycles per instruction at
@@ -119,6 +119,7 @@ def main():
         int64 = sum(c for op, c in valu.items() if op in ("v_mad_u64_u32", "v_lshl_add_u64", "v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64", "v_mov_b64")) / n
         res[kernel] = {"valu_instructions_static": n, "all_instructions_static": sum(h.values()), "seconds_per_wave_instruction": spw, "issue_cycles_per_wave_instruction": cyc,
                        "equivalent_peak_lane_instr_per_s": 64.0 / spw, "share_2cycle_class": two_cycle, "share_unmeasured": unmeasured, "share_int64_static": int64,
+                       "share_mad_u64_static": valu.get("v_mad_u64_u32", 0) / n,
                        "top": [[op, round(c / n, 4)] for op, c in valu.most_common(8)]}
     json.dump(res, open(out_path, "w"), indent=1)
     print("%-62s %8s %10s %8s %8s" % ("kernel", "valu", "peak T/s", "2-cycle", "unmeas."))

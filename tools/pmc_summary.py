@@ -75,6 +75,7 @@ def main():
         m = mix.get(k)
         if m:
             row["share_int64_static"] = m["share_int64_static"]
+            row["share_mad_u64_static"] = m.get("share_mad_u64_static")
             row["share_2cycle_static"] = m["share_2cycle_class"]
         if "SQ_INSTS_VALU" in row and "SQ_ACTIVE_INST_VALU2" in row:
             # issue slots: one per instruction, minus the instructions that shared a slot with another 2-cycle-class instruction
@@ -87,6 +88,10 @@ def main():
                     row["sclk_ghz"] = row["GRBM_GUI_ACTIVE"] / XCDS / (row["us_in_pmc_pass"] * 1e3)
         if "SQ_INSTS_VALU_INT64" in row and row.get("SQ_INSTS_VALU"):
             row["share_int64_dynamic"] = row["SQ_INSTS_VALU_INT64"] / row["SQ_INSTS_VALU"]
+            # executed v_mad_u64_u32 (wave-instructions): the hardware counts the 64-bit integer class (mads, v_lshl_add_u64, 64-bit shifts); the class's static
+            # composition splits it -- mads are 84 - 100 % of the class in every kernel of the path (profiles/r06_opcode_mix.json)
+            if row.get("share_mad_u64_static") is not None and row.get("share_int64_static"):
+                row["mad_u64_wave_instructions"] = row["SQ_INSTS_VALU_INT64"] * row["share_mad_u64_static"] / row["share_int64_static"]
         res[k] = row
         print("%-34s %s" % (k[-34:], "  ".join("%s=%.4g" % (c, v) for c, v in sorted(row.items()))))
     # whole-step totals: every kernel's per-launch average x its launches, divided by the number of bench steps the trace holds
@@ -107,7 +112,10 @@ def main():
         # the clock these kernels really ran at: issue-cycle-weighted over the kernels long enough for GRBM_GUI_ACTIVE / duration to be a clock
         long_k = [(v["valu_issue_cycles"] * v["launches"], v["sclk_ghz"]) for k, v in step_kernels if v.get("us_in_pmc_pass", 0) >= 200.0 and "valu_issue_cycles" in v]
         sclk = sum(w * f for w, f in long_k) / sum(w for w, _ in long_k) if long_k else None
+        mads = sum(v.get("mad_u64_wave_instructions", 0.0) * v["launches"] for k, v in step_kernels) / steps
+        mads_by_kernel = {k: v["mad_u64_wave_instructions"] * v["launches"] / steps for k, v in step_kernels if v.get("mad_u64_wave_instructions")}
         res["_step_totals"] = {"steps": steps, "valu_wave_instructions_per_step": tot,
+                               "mad_u64_wave_instructions_per_step": mads or None, "mad_u64_wave_instructions_per_step_by_kernel": mads_by_kernel,
                                "valu_issue_cycles_per_step": cyc if ok else None,
                                "valu_floor_ms_per_step_nameplate_clock": cyc / SIMDS / (NAMEPLATE_GHZ * 1e6) if ok else None,
                                "sclk_ghz_observed": sclk,

@@ -867,7 +867,7 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   // the step form of both programs (round 6): not for calls the one-lane interpreter serves (>= kVeryWideCallProofs proofs: their images would be gigabytes)
   const tr_step_prog spa = tr_steps_build(pa, tbl_a), spb = tr_steps_build(pb, tbl_b);
   auto steps_ok = [&](const tr_step_prog& sp) {
-    if (sp.steps.empty() || N >= zkp_ctx::kVeryWideCallProofs || (size_t)sp.n_img * 21 + 1 > 65535) return false;
+    if (sp.steps.empty() || N >= zkp_ctx::kVeryWideCallProofs || (size_t)sp.n_img * 3 + 1 > 65535) return false;
     for (const tr_step& t : sp.steps) if (t.emit_n > (uint32_t)TR_BLOCK) return false;
     return true;
   };
@@ -951,8 +951,8 @@ bool transcript_steps(const zkp_ctx* c, const prog_dev& p, uint32_t N, bool thro
 }
 // the wide half of a step program: image words + identity checks (nothing here depends on a transcript state)
 void launch_assemble(zkp_ctx* c, const tr_steps_dev& sd, uint32_t N, const tr_bufs& bufs, uint64_t* d_img, uint32_t* d_failed) {
-  const uint32_t rows = sd.n_img * 21u + ((sd.n_chk || (sd.tail >> 31)) ? 1u : 0u);
-  if (rows) hipLaunchKernelGGL(k_transcript_assemble, dim3((N + 255) / 256, rows), dim3(256), 0, c->stream, sd, N, bufs, d_img, d_failed);
+  const uint32_t rows = sd.n_img * 3u + ((sd.n_chk || (sd.tail >> 31)) ? 1u : 0u);
+  if (rows) hipLaunchKernelGGL(k_transcript_assemble, dim3((N + TA_BLOCK - 1) / TA_BLOCK, rows), dim3(TA_BLOCK), 0, c->stream, sd, N, bufs, d_img, d_failed);
 }
 // phase (step programs only): 1 = the assemble pass, 2 = the chain, 3 = both
 void run_program(zkp_ctx* c, const prog_dev& p_in, uint32_t N, const tr_bufs& bufs, uint8_t* d_ts, uint64_t* d_saved, uint32_t* d_failed, bool throughput,

@@ -178,21 +178,28 @@ struct tr_steps_dev {
   uint32_t n_steps = 0, n_img = 0, n_chk = 0, tail = 0;
 };
 
-// One workgroup row (blockIdx.y) per image word k = img * 21 + w: lane j builds proof j's 64-bit word (every load independent of every other);
+// Lane j builds proof j's 64-bit image words (every load independent of every other), seven words per lane;
 // the last row checks the encodings the verifiers must reject as identity (mod.rs:191, :215) and owns the rejection flags.
 // img = [n_img * 21][N] uint64 (the chain reads it as [..][2 N] uint32: proof j's halves next to each other): coalesced on both sides.  (A proof-major
 // layout -- 168 contiguous bytes per proof and image, one pointer + immediate offsets in the chain -- was measured: assemble 15 -> 31 us, chain no faster.)
-__global__ void __launch_bounds__(256)
+constexpr uint32_t TA_WORDS = 7, TA_BLOCK = 64;     // image words per lane / lanes per workgroup of k_transcript_assemble
+__global__ void __launch_bounds__(TA_BLOCK)
 k_transcript_assemble(const tr_steps_dev p, uint32_t N, const tr_bufs bufs, uint64_t* __restrict__ img, uint32_t* __restrict__ failed) {
-  const uint32_t j = blockIdx.x * 256u + threadIdx.x, k = blockIdx.y;
+  // blockIdx.y = a third of an image (7 of its 21 words), or the check row: one launch of (N / 64) x (3 n_img + 1) wavefronts.  (One word per lane and
+  // 256-lane workgroups, the first version, was 188 k workgroups of ~20 instructions per wide call: bound by the dispatcher, 1.6 ms per 40,960 proofs.)
+  const uint32_t j = blockIdx.x * TA_BLOCK + threadIdx.x, y = blockIdx.y;
   if (j >= N) return;
-  if (k < p.n_img * 21u) {
-    uint64_t x = p.cx[k];
-    for (uint32_t q = p.src_off[k]; q < p.src_off[k + 1]; ++q) {
-      const tr_op o = p.src[q];
-      x ^= tr_src_word(tr_unpack(o.ctl, o.stride, o.off), bufs, j);
+  if (y < p.n_img * 3u) {
+    const uint32_t k0 = (y / 3u) * 21u + (y % 3u) * TA_WORDS;
+#pragma unroll 1
+    for (uint32_t k = k0; k < k0 + TA_WORDS; ++k) {
+      uint64_t x = p.cx[k];
+      for (uint32_t q = p.src_off[k]; q < p.src_off[k + 1]; ++q) {
+        const tr_op o = p.src[q];
+        x ^= tr_src_word(tr_unpack(o.ctl, o.stride, o.off), bufs, j);
+      }
+      img[(size_t)k * N + j] = x;
     }
-    img[(size_t)k * N + j] = x;
   } else {
     uint32_t bad = 0;
     for (uint32_t q = 0; q < p.n_chk; ++q) {

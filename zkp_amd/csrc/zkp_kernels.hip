@@ -1608,8 +1608,8 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
           const uint32_t tr_blocks = (t.N + TR_BLOCK / 2 - 1) / (TR_BLOCK / 2);
           // tables as producer / consumer wavefronts (comb_table_pc): workgroups of two wavefronts = two transcript blocks, or 64 tables
           if (t.steps) {
-            const uint32_t rows = t.sd.n_img * 21u + ((t.sd.n_chk || (t.sd.tail >> 31)) ? 1u : 0u);
-            if (rows) hipLaunchKernelGGL(k_transcript_assemble, dim3((t.N + 255) / 256, rows), dim3(256), 0, c->stream, t.sd, t.N, t.bufs, t.img, t.failed);
+            const uint32_t rows = t.sd.n_img * 3u + ((t.sd.n_chk || (t.sd.tail >> 31)) ? 1u : 0u);
+            if (rows) hipLaunchKernelGGL(k_transcript_assemble, dim3((t.N + TA_BLOCK - 1) / TA_BLOCK, rows), dim3(TA_BLOCK), 0, c->stream, t.sd, t.N, t.bufs, t.img, t.failed);
             hipLaunchKernelGGL(k_tables_chain_pc<16>, dim3((tr_blocks + 1) / 2 + (k.max_tables + 63) / 64), dim3(2 * TR_BLOCK), 0, c->stream, tr_blocks, t.sd,
                                reinterpret_cast<const uint32_t*>(t.img), t.N, t.bufs, t.ts, t.saved, n_slots, k.max_tables, slot_pt, pts, comb);
           } else

@@ -78,6 +78,11 @@ const char* zkp_version(void);
  *     always do: a shorter call, more cross-stream dependencies.  Default 0.  (Measured again in round 4 on a LONE call chain: 2.87 -> 3.17 ms per
  *     prove call of 20,480 proofs -- no gain there either.)  In a process that owns one hardware queue (GPU_MAX_HW_QUEUES=1) a capture records the
  *     flow without the fork: ROCm 7.2.0 crashes in hipGraphLaunch on a forked graph under that setting.
+ *     2 (round 6) = the whole LATENCY SCHEDULE of the synchronous entry points on device buffers, for a caller that keeps ONE call in flight: the second
+ *     stream as above -- for zkp_fused_batch_verify[_many]_dev too: the decompressions of the batch MSM (batch_verifier.rs:226) run next to the transcript
+ *     chain --, comb tables built by four lanes per point, tables for single-use points, and transcript-chain wavefronts that own their SIMD
+ *     (k_transcript_chain<true>).  One batch of 4096 CMZ proofs proven and batch-verified per call: 2.53 M proofs/s against 2.30 M on the default schedule
+ *     and 2.05 M in round 5 (bench.py: lone_call).
  *   ZKP_OPT_GROUPED_COMB: 1 = constant-time calls list the terms of every point with 10 or more uses next to each other; a wavefront
  *     then holds the rows of the (at most 8) 16-teeth comb tables its 62 terms need and every lane takes the entry its digit names over
  *     the lane crossbar (ZKP_OPT_CT_LOOKUP: no masked scan, 20 % fewer instructions per addition, a row fetched once per wavefront instead

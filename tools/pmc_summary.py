@@ -86,6 +86,12 @@ def main():
                 if gui_ns.get(k):
                     row["us_in_pmc_pass"] = sum(gui_ns[k]) / len(gui_ns[k]) / 1e3
                     row["sclk_ghz"] = row["GRBM_GUI_ACTIVE"] / XCDS / (row["us_in_pmc_pass"] * 1e3)
+        if row.get("SQ_WAIT_ANY") is not None and row.get("SQ_WAVE_CYCLES"):
+            # wavefront-cycles parked at s_waitcnt / barriers (memory, LDS-DMA, barrier) as a share of all wavefront-cycles -- per WAVEFRONT: with two
+            # wavefronts per SIMD one's wait is the other's issue slot, so the SIMD idles for less than this (1 - valu_busy is the bound on that)
+            row["wave_parked_frac"] = row["SQ_WAIT_ANY"] / row["SQ_WAVE_CYCLES"]
+        if row.get("TCC_HIT_sum") is not None and (row.get("TCC_HIT_sum", 0) + row.get("TCC_MISS_sum", 0)) > 0:
+            row["l2_hit_rate"] = row["TCC_HIT_sum"] / (row["TCC_HIT_sum"] + row["TCC_MISS_sum"])
         if "SQ_INSTS_VALU_INT64" in row and row.get("SQ_INSTS_VALU"):
             row["share_int64_dynamic"] = row["SQ_INSTS_VALU_INT64"] / row["SQ_INSTS_VALU"]
             # executed v_mad_u64_u32 (wave-instructions): the hardware counts the 64-bit integer class (mads, v_lshl_add_u64, 64-bit shifts); the class's static

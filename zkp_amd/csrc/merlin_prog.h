@@ -227,7 +227,7 @@ namespace zkp {
 // shift -> LDS read-modify-write, ~1 us each, ~480 of them per CMZ proof) in a chain whose only true dependency is the hash state.  None of those
 // loads depends on the state.  So the operation list is regrouped per flush unit ("step": everything up to and including one APPLY):
 //   image   img[step][w][proof] = CX[w] ^ (the per-proof bytes of the step's word operations, shifted into place)       -- k_transcript_assemble,
-//           one lane per (step, word, proof), every load independent, the whole chip busy for ~10 us;
+//           a lane per proof and seven words, every load independent, the whole chip busy for ~15 us per 4096 CMZ proofs;
 //   chain   per step: [restore] -> [emit PRF bytes of the CURRENT state] -> state[w] = (state[w] & KEEP[w]) ^ img[w] -> [permute] -> [save]
 //           with the state in 25 registers per lane, the next step's image (and keep words) prefetched under the permutation -- k_transcript_chain.
 // KEEP[w] = the table's keep word AND the keep masks of the step's overwriting operations (their bytes are disjoint from every other

@@ -97,7 +97,7 @@ def kernel_mixes(asm):
 def main():
     from zkp_amd import engine
     import bench
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_opcode_mix.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_opcode_mix.json")
     rates = measured_rates()
     res = {"_source_sha256": bench.source_sha256(), "_rates_file": os.path.relpath(RATES_FILE, ROOT), "_default_rate": DEFAULT_RATE,
            "_note": "per kernel: static VALU mix of the shipped code object priced in SIMD issue cycles (2 or 4 per opcode); "

@@ -241,20 +241,25 @@ def cmz_field_mult_model(n, K=5):
       algorithm  what THIS library's algorithms ask for at the call shape of `value` (point operations of DESIGN.md section 5, counted, not measured).
       (executed = v_mad_u64_u32 the hardware counted / 98 comes from the PMC file.)"""
     S = MADS_PER_FE_SQ / MADS_PER_FE_MUL
-    dbl, add8, add7, dec = 4 * S + 4, 8.0, 7.0, 254 * S + 11
+    dbl, dblf, add8, add7, dec = 4 * S + 4, 4 * S + 3, 8.0, 7.0, 254 * S + 11     # dblf: a doubling whose result is doubled again needs no T coordinate (ge_double<false>)
     smul = 252 * dbl + 64 * add8
     terms_p, terms_v = 31, 24 + 12.0 / n
     floor = {"prove": terms_p * smul + (2 + 11.0 / n) * dec, "batch_verify": terms_v * (smul + dec)}
-    # prove (throughput schedule, calls of K x n proofs): P and Q decoded; a 16-teeth comb table each (256 + 4 x 16 doublings, 3 x 16 additions, 129 conversions
-    # to the cached form, 1 M each); 20 fixed-base terms of 37 mixed additions; P's 10 terms on the grouped walk (16 doublings + 65 additions each) and Q's on
-    # the scan (same counts); 20 additions of partial sums; the batched encoder (~25 M per commitment).  Common points: 11 fixed-base tables per CONTEXT, not per call.
-    table = (256 + 64) * dbl + 48 * add8 + 129
-    wide = K * n * terms_p >= 250000              # zkp_ctx::kWideCallTerms: Q (one use per proof) walks a radix-16 ladder of its own instead of getting a table
+    # prove (throughput schedule, calls of K x n proofs): P and Q decoded; a 16-teeth comb table (per tooth a run of 16 doublings to the next tooth's base, four
+    # doublings and three additions for the eight multiples; 129 conversions to the cached form, 1 M each); 20 fixed-base terms of 37 mixed additions; P's 10 terms
+    # on the grouped walk (4 windows x (4 doublings + 16 additions) + the carry window's addition); Q on a table like P's, or in wide calls on a signed radix-16 ladder
+    # of its own (7 operations for its eight multiples, 64 x 4 doublings, 65 additions); 20 additions of partial sums; the batched encoder (~25 M per commitment).
+    # Common points: 11 fixed-base tables per CONTEXT, not per call.
+    run4 = 3 * dblf + dbl
+    table = 16 * (15 * dblf + dbl) + 64 * dbl + 48 * add8 + 129
+    walk = 4 * run4 + 65 * add8
+    wide = K * n * terms_p >= 250000              # zkp_ctx::kWideCallTerms
     prove = {"decode": 2 * dec, "comb_tables": (1 if wide else 2) * table, "fixed_base_terms": 20 * 37 * add7,
-             "comb_terms": 10 * (16 * dbl + 65 * add8) + ((7 * add8 + 256 * dbl + 65 * add8) if wide else (16 * dbl + 65 * add8)), "sum_and_encode": 20 * add8 + 11 * 25.0}
-    # batch verify: 24 decodes; Pippenger with 11-bit windows: 23 populated windows x one mixed addition per term, the bucket tree (2^10 buckets x 24 windows, two
-    # additions each, shared by the batch's n proofs) and the 253-doubling Horner tail (shared likewise)
-    verify = {"decode": terms_v * dec, "bucket_additions": terms_v * 23 * add7, "bucket_tree_and_horner": (24 * 1024 * 2 * add8 + 253 * dbl) / n}
+             "comb_terms": 10 * walk + ((4 * dbl + 3 * add8 + 64 * run4 + 65 * add8) if wide else walk), "sum_and_encode": 20 * add8 + 11 * 25.0}
+    # batch verify: 24 decodes; Pippenger with 11-bit windows: one mixed addition per term and populated window -- 23 windows for the 13 instance rows, 12 for the 11
+    # commitment rows, whose coefficients -r are 128 bits wide after sign folding (batch_verifier.rs:183) --, the bucket tree (2^10 buckets x 24 windows, two additions
+    # each, shared by the batch's n proofs) and the 253-doubling Horner tail (shared likewise)
+    verify = {"decode": terms_v * dec, "bucket_additions": (13 * 23 + 11 * 12 + 12.0 * 23 / n) * add7, "bucket_tree_and_horner": (24 * 1024 * 2 * add8 + 253 * dbl) / n}
     algo = {"prove": sum(prove.values()), "batch_verify": sum(verify.values())}
     return {"floor": floor, "algorithm": algo, "algorithm_by_phase": {"prove": prove, "batch_verify": verify},
             "floor_per_proof": sum(floor.values()), "algorithm_per_proof": sum(algo.values())}

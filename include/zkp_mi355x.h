@@ -258,6 +258,12 @@ typedef struct {
 int zkp_fused_prove(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
                     const uint8_t* inst, const uint8_t* common, const uint8_t* entropy, uint8_t* challenges,
                     uint8_t* responses, uint8_t* commitments, int* invalid_point);
+/* The same with the prover's entropy drawn ON THE DEVICE (round 6): seed = 40 bytes the caller took from the operating system; proof j's 32 bytes of
+ * `thread_rng()` (prover.rs:82) are bytes [32 j, 32 j + 32) of the ChaCha20 stream keyed with seed[0..32), nonce seed[32..40) -- what the asynchronous jobs of
+ * section 2d do.  Drawing 32 N bytes on the host costs a synchronous call of 4096 proofs ~0.1 ms, the batch verifier's 16 N n_constraints bytes ~0.2 ms. */
+int zkp_fused_prove_seeded(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets,
+                           const uint8_t* inst, const uint8_t* common, const uint8_t seed[40], uint8_t* challenges,
+                           uint8_t* responses, uint8_t* commitments, int* invalid_point);
 /* N x { build_verifier (macros.rs:280-311) ; Verifier::verify_compact (verifier.rs:80-120) }.  results[j]: 0 = accepted. */
 int zkp_fused_verify_compact(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts,
                              const uint8_t* inst, const uint8_t* common, const uint8_t* challenges,
@@ -282,6 +288,11 @@ int zkp_fused_batch_verify(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t
 int zkp_fused_batch_verify_many(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t n_batches, uint32_t N_each, uint8_t* transcripts,
                                 const uint8_t* inst, const uint8_t* common, const uint8_t* commitments, const uint8_t* responses,
                                 const uint8_t* weights16, int* verdicts, uint8_t* debug_scalars);
+/* The same with the weights of batch_verifier.rs:179 drawn on the device from the ChaCha20 stream of a 40-byte seed (see zkp_fused_prove_seeded): weight
+ * (constraint k, proof j) = bytes [16 (k N + j), + 16) of the stream. */
+int zkp_fused_batch_verify_many_seeded(zkp_ctx* ctx, const zkp_fused_statement* st, uint32_t n_batches, uint32_t N_each, uint8_t* transcripts,
+                                       const uint8_t* inst, const uint8_t* common, const uint8_t* commitments, const uint8_t* responses,
+                                       const uint8_t seed[40], int* verdicts);
 
 /* N x { build_verifier ; Verifier::verify_batchable (verifier.rs:123-173) }: one MSM of (points + commitments) terms per
  * proof, folded with the 128-bit weights16 [N][n_constraints][16] (verifier.rs:153).  results[j]: 0 = accepted.  This is

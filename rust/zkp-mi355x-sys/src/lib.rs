@@ -119,6 +119,10 @@ extern "C" {
     pub fn zkp_fused_prove(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, transcripts: *mut u8, secrets: *const u8,
                            inst: *const u8, common: *const u8, entropy: *const u8, challenges: *mut u8, responses: *mut u8,
                            commitments: *mut u8, invalid_point: *mut c_int) -> c_int;
+    pub fn zkp_fused_prove_seeded(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, transcripts: *mut u8, secrets: *const u8, inst: *const u8,
+                                  common: *const u8, seed: *const u8, challenges: *mut u8, responses: *mut u8, commitments: *mut u8, invalid_point: *mut c_int) -> c_int;
+    pub fn zkp_fused_batch_verify_many_seeded(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n_batches: u32, n_each: u32, transcripts: *mut u8, inst: *const u8,
+                                              common: *const u8, commitments: *const u8, responses: *const u8, seed: *const u8, verdicts: *mut c_int) -> c_int;
     pub fn zkp_fused_verify_compact(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, transcripts: *mut u8, inst: *const u8,
                                     common: *const u8, challenges: *const u8, responses: *const u8, results: *mut u8) -> c_int;
     pub fn zkp_fused_batch_verify(ctx: *mut zkp_ctx, st: *const zkp_fused_statement, n: u32, transcripts: *mut u8, inst: *const u8,

@@ -1070,7 +1070,7 @@ prove_inter prove_carve(const fused_plan& pl, size_t start) {
 }
 int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* d_ts, const uint8_t* d_sec, const uint8_t* d_tbl,
                const uint8_t* d_ent, uint8_t* d_chal, uint8_t* d_resp, uint8_t* d_coms, uint8_t* d_st8, bool overlap, bool throughput,
-               const std::function<int()>* late_inputs = nullptr, const std::function<int()>* early_outputs = nullptr) {
+               const std::function<int()>* late_inputs = nullptr, const std::function<int()>* early_outputs = nullptr, bool late_early = false) {
   const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
   const ws_view w{static_cast<char*>(c->ws)};
   tr_bufs hb{};
@@ -1093,6 +1093,16 @@ int prove_core(zkp_ctx* c, const fused_plan& pl, const prove_inter& o, uint8_t* 
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
     if (rc) { c->pending_tr.offered = c->pending_tr.active = false; return rc; }
+    // (late_early: those inputs sit in PINNED memory -- their copies are DMA that returns at once, so they are queued on the main stream now, behind the fork
+    // event the side stream waits for and in front of the point phase's launches, instead of after them)
+    if (late_inputs && late_early) {
+      hipStream_t cur = c->stream;
+      c->stream = main;
+      rc = (*late_inputs)();
+      c->stream = cur;
+      late_inputs = nullptr;
+      if (rc) { (void)side_end(c, main, overlap); c->pending_tr.offered = c->pending_tr.active = false; return rc; }
+    }
     // (with constraints the term path's classifier writes the CSR offsets and point indices too: k_stmt_classify)
     if (!(nc && stmt_classify_applies(tk, N * T)))
       hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T, w.u32(o.off), w.u32(o.pidx));
@@ -1161,7 +1171,7 @@ verify_inter verify_carve(const fused_plan& pl, size_t start) {
   return o;
 }
 int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_claim,
-                const uint8_t* d_resp, uint8_t* d_results, bool overlap, bool throughput, const std::function<int()>* late_inputs = nullptr) {
+                const uint8_t* d_resp, uint8_t* d_results, bool overlap, bool throughput, const std::function<int()>* late_inputs = nullptr, bool late_early = false) {
   const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T1 = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
   const ws_view w{static_cast<char*>(c->ws)};
   tr_bufs hb{};
@@ -1182,6 +1192,14 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
     hipStream_t main;
     int rc = side_begin(c, &main, overlap);
     if (rc) { c->pending_tr.offered = c->pending_tr.active = false; return rc; }
+    if (late_inputs && late_early) {                     // (pinned inputs: see prove_core)
+      hipStream_t cur = c->stream;
+      c->stream = main;
+      rc = (*late_inputs)();
+      c->stream = cur;
+      late_inputs = nullptr;
+      if (rc) { (void)side_end(c, main, overlap); c->pending_tr.offered = c->pending_tr.active = false; return rc; }
+    }
     if (!stmt_classify_applies(tk, N * T1))
       hipLaunchKernelGGL(k_stmt_index, grid1(lanes, 256), dim3(256), 0, c->stream, N, T1, nc, pl.s.ns, pl.d_tarr, pl.d_tarr + nc + 1 + T1, w.u32(o.off), w.u32(o.pidx));
     rc = msm_terms_path(c, N * nc, w.u32(o.off), nullptr, w.u32(o.pidx), d_tbl, n_points, N * T1, ZKP_VARTIME, w.u8(o.coms), w.u8(o.st8), nullptr, o.end, /*decode_all=*/true, PH_POINTS, tk);
@@ -1240,7 +1258,7 @@ size_t optional_many_ws(uint64_t n_each, uint32_t K) {
 int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* d_ts, uint8_t* d_pts, const uint8_t* d_coms,
                const uint8_t* d_resp, const uint8_t* d_w, uint8_t* d_out /*[K][32]*/,
                uint32_t* d_status /*[K][2]: MSM decode failure | transcript rejection or non-canonical response*/, bool throughput, uint32_t K = 1,
-               bool overlap = false, const std::function<int()>* late_ts = nullptr, const std::function<int()>* late_scalars = nullptr) {
+               bool overlap = false, const std::function<int()>* late_ts = nullptr, const std::function<int()>* late_scalars = nullptr, bool late_early = false) {
   const uint32_t N = pl.N, nc = pl.s.nc, ns = pl.s.ns, ni = pl.s.ni, N_each = N / K;
   const size_t n_each = (size_t)ns + ((size_t)ni + nc) * N_each;          // terms of one batch's MSM (batch_verifier.rs:219-228)
   const ws_view w{static_cast<char*>(c->ws)};
@@ -1270,6 +1288,15 @@ int batch_core(zkp_ctx* c, const fused_plan& pl, const batch_inter& o, uint8_t* 
       hipStream_t main;
       int rc = side_begin(c, &main, true);
       if (rc) return rc;
+      if (late_early) {                                  // (pinned inputs: see prove_core)
+        hipStream_t cur = c->stream;
+        c->stream = main;
+        if (late_ts) rc = (*late_ts)();
+        if (!rc && late_scalars) rc = (*late_scalars)();
+        c->stream = cur;
+        late_ts = late_scalars = nullptr;
+        if (rc) { (void)side_end(c, main, true); return rc; }
+      }
       if (nc) hipLaunchKernelGGL(k_transpose_commitments, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, N, nc, d_coms, d_pts + 32 * ((size_t)ns + (size_t)ni * N));
       rc = msm_optional_impl(c, n_each, w.u8(o.sc), d_pts, d_out, d_status, o.end, shared, /*phases=*/1);
       const int rc2 = side_end(c, main, true);

@@ -428,12 +428,14 @@ int zkp_prove_batch(zkp_ctx* ctx, const zkp_statement* st, uint32_t N, uint8_t* 
   if (!st) return ZKP_TB_BAD_STATEMENT;                                  // (ctx == NULL: the host backend, host_backend.cpp)
   if (N == 0) return ZKP_TB_OK;
   if (ctx && ts && use_fused(ts, N)) {
-    std::vector<uint8_t> own_entropy;
-    if (!entropy) { own_entropy.resize(32 * (size_t)N); if (!os_random(own_entropy.data(), own_entropy.size())) return ZKP_TB_NO_ENTROPY; entropy = own_entropy.data(); }
+    // no entropy from the caller: 40 bytes of getrandom() key a ChaCha20 stream that is expanded on the device (what thread_rng() is to prover.rs:82)
+    uint8_t seed[40];
+    if (!entropy && !os_entropy(seed, sizeof(seed))) return ZKP_TB_NO_ENTROPY;
     if (st->ns && N >= 32) { const int rc = zkp_ctx_prepare_fixed_points(ctx, st->ns, common); if (rc) return rc; }
     FusedView fv(*st);
     int invalid = 0;
-    const int rc = zkp_fused_prove(ctx, &fv.fs, N, ts, secrets, inst, common, entropy, challenges, responses, commitments, &invalid);
+    const int rc = entropy ? zkp_fused_prove(ctx, &fv.fs, N, ts, secrets, inst, common, entropy, challenges, responses, commitments, &invalid)
+                           : zkp_fused_prove_seeded(ctx, &fv.fs, N, ts, secrets, inst, common, seed, challenges, responses, commitments, &invalid);
     if (rc) return rc;
     return invalid ? ZKP_TB_INVALID_POINT : ZKP_TB_OK;
   }
@@ -700,10 +702,18 @@ int zkp_batch_verify_coeffs(zkp_ctx* ctx, const zkp_statement* stp, uint32_t N, 
     return (!status && std::memcmp(out, zero32, 32) == 0) ? ZKP_TB_OK : ZKP_TB_VERIFICATION_FAILURE;      // :230-234
   }
   if (ts && use_fused(ts, N)) {
-    std::vector<uint8_t> own_w;
-    if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
     FusedView fv(st);
     int verdict = 1;
+    if (!weights16 && !coeffs && nc) {
+      // no weights from the caller: 40 bytes of getrandom() key a ChaCha20 stream that is expanded on the device (batch_verifier.rs:179's thread_rng())
+      uint8_t seed[40];
+      if (!os_entropy(seed, sizeof(seed))) return ZKP_TB_NO_ENTROPY;
+      const int rc = zkp_fused_batch_verify_many_seeded(ctx, &fv.fs, 1, N, ts, inst, common, commitments, responses, seed, &verdict);
+      if (rc) return rc;
+      return verdict ? ZKP_TB_VERIFICATION_FAILURE : ZKP_TB_OK;
+    }
+    std::vector<uint8_t> own_w;
+    if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
     const int rc = zkp_fused_batch_verify(ctx, &fv.fs, N, ts, inst, common, commitments, responses, weights16, &verdict, coeffs);
     if (rc) return rc;
     return verdict ? ZKP_TB_VERIFICATION_FAILURE : ZKP_TB_OK;
@@ -764,6 +774,15 @@ int zkp_batch_verify_many(zkp_ctx* ctx, const zkp_statement* stp, uint32_t K, ui
   const zkp_statement& st = *stp;
   const uint32_t m = (uint32_t)st.secrets.size(), nc = (uint32_t)st.cons.size(), ni = st.ni;
   std::vector<uint8_t> own_w;
+  if (!weights16 && ctx && nc && use_fused(ts, N)) {                   // weights drawn on the device from 40 bytes of getrandom() (see zkp_batch_verify)
+    uint8_t seed[40];
+    if (!os_entropy(seed, sizeof(seed))) return ZKP_TB_NO_ENTROPY;
+    FusedView fv(st);
+    const int rc = zkp_fused_batch_verify_many_seeded(ctx, &fv.fs, K, N_each, ts, inst, common, commitments, responses, seed, verdicts);
+    if (rc) return rc;
+    for (uint32_t b = 0; b < K; ++b) verdicts[b] = verdicts[b] ? ZKP_TB_VERIFICATION_FAILURE : ZKP_TB_OK;
+    return ZKP_TB_OK;
+  }
   if (!weights16) { own_w.resize(16 * (size_t)N * nc); if (!os_random(own_w.data(), own_w.size())) return ZKP_TB_NO_ENTROPY; weights16 = own_w.data(); }
   if (ctx && use_fused(ts, N)) {
     FusedView fv(st);

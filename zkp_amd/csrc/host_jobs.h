@@ -241,7 +241,8 @@ int prove_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint32_t fl
   if (!sync_variant) ZKP_JOB_TRY(rest());
   job_mark(c, 1);
   ZKP_JOB_TRY(prove_core(c, *pl, o, w.u8(o_ts), w.u8(o_sec), w.u8(o_tbl), w.u8(o_ent), w.u8(o_chal), w.u8(o_resp), w.u8(o_coms), w.u8(o_st), /*overlap=*/sync_variant,
-                         /*throughput=*/!sync_variant, sync_variant ? &rest : nullptr, sync_variant ? &early : nullptr));
+                         /*throughput=*/!sync_variant, sync_variant ? &rest : nullptr, sync_variant ? &early : nullptr,
+                         /*late_early=*/zkp_host_is_pinned(transcripts) && (!m || zkp_host_is_pinned(secrets)) && (!entropy || zkp_host_is_pinned(entropy))));
   job_mark(c, 2);
   if (hipMemsetAsync(w.base + o_flag, 0, 4, c->stream) != hipSuccess) return job_abort(c, fail(ZKP_ERR_HIP, "hipMemsetAsync failed"));
   if (nc) hipLaunchKernelGGL(k_any_nonzero_bytes, grid1((size_t)N * nc, 256), dim3(256), 0, c->stream, (size_t)N * nc, w.u8(o_st), w.u32(o_flag));
@@ -300,7 +301,7 @@ int verify_compact_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, ui
   if (!sync_variant) ZKP_JOB_TRY(rest());
   job_mark(c, 1);
   ZKP_JOB_TRY(verify_core(c, *pl, o, w.u8(o_ts), w.u8(o_tbl), w.u8(o_claim), w.u8(o_resp), w.u8(o_res), /*overlap=*/sync_variant, /*throughput=*/!sync_variant,
-                          sync_variant ? &rest : nullptr));
+                          sync_variant ? &rest : nullptr, /*late_early=*/zkp_host_is_pinned(transcripts) && zkp_host_is_pinned(challenges) && (!m || zkp_host_is_pinned(responses))));
   job_mark(c, 2);
   ZKP_JOB_TRY(d2h(c, results, w.base + o_res, (size_t)N));
   if (transcripts_out) ZKP_JOB_TRY(d2h(c, transcripts_out, w.base + o_ts, (size_t)N * 208));
@@ -369,7 +370,8 @@ int batch_verify_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t K, uint
   if (N && !sync_variant) { ZKP_JOB_TRY(late_ts()); ZKP_JOB_TRY(late_sc()); }
   job_mark(c, 1);
   ZKP_JOB_TRY(batch_core(c, *pl, o, w.u8(o_ts), w.u8(o_pts), w.u8(o_coms), w.u8(o_resp), w.u8(o_w), w.u8(o_out), w.u32(o_st), /*throughput=*/!sync_variant, K, /*overlap=*/sync_variant,
-                         sync_variant ? &late_ts : nullptr, sync_variant ? &late_sc : nullptr));
+                         sync_variant ? &late_ts : nullptr, sync_variant ? &late_sc : nullptr,
+                         /*late_early=*/N && zkp_host_is_pinned(transcripts) && (!m || zkp_host_is_pinned(responses)) && (!nc || !weights16 || zkp_host_is_pinned(weights16))));
   job_mark(c, 2);
   if (debug_scalars) ZKP_JOB_TRY(d2h(c, debug_scalars, w.base + o.sc, n_sc * 32));
   ZKP_JOB_TRY(d2h(c, c->job.pin, w.base + o_out, (size_t)K * 32));
@@ -556,6 +558,11 @@ int zkp_fused_prove(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8
   if (c && N && !entropy) return fail(ZKP_ERR_ARG, "NULL pointer");
   return job_finish(c, prove_job(c, st, N, 0, transcripts, secrets, inst, N, common, entropy, nullptr, transcripts, challenges, responses, commitments, invalid_point, sync_latency(c)));
 }
+int zkp_fused_prove_seeded(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* secrets, const uint8_t* inst, const uint8_t* common,
+                           const uint8_t seed[40], uint8_t* challenges, uint8_t* responses, uint8_t* commitments, int* invalid_point) {
+  if (c && N && !seed) return fail(ZKP_ERR_ARG, "NULL pointer");
+  return job_finish(c, prove_job(c, st, N, 0, transcripts, secrets, inst, N, common, nullptr, seed, transcripts, challenges, responses, commitments, invalid_point, sync_latency(c)));
+}
 int zkp_fused_verify_compact(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst, const uint8_t* common,
                              const uint8_t* challenges, const uint8_t* responses, uint8_t* results) {
   return job_finish(c, verify_compact_job(c, st, N, 0, transcripts, inst, N, common, challenges, responses, transcripts, results, sync_latency(c)));
@@ -566,6 +573,13 @@ int zkp_fused_batch_verify_many(zkp_ctx* c, const zkp_fused_statement* st, uint3
   if (c && K * N_each && st && st->shape.n_constraints && !weights16) return fail(ZKP_ERR_ARG, "NULL pointer");
   return job_finish(c, batch_verify_job(c, st, K, N_each, 0, transcripts, inst, K * N_each, common, commitments, responses, weights16, K * N_each, nullptr, transcripts, verdicts,
                                         debug_scalars, sync_latency(c)));
+}
+int zkp_fused_batch_verify_many_seeded(zkp_ctx* c, const zkp_fused_statement* st, uint32_t K, uint32_t N_each, uint8_t* transcripts, const uint8_t* inst, const uint8_t* common,
+                                       const uint8_t* commitments, const uint8_t* responses, const uint8_t seed[40], int* verdicts) {
+  if (c && (K == 0 || N_each == 0)) return fail(ZKP_ERR_ARG, "n_batches and N_each must be positive");
+  if (c && !seed) return fail(ZKP_ERR_ARG, "NULL pointer");
+  return job_finish(c, batch_verify_job(c, st, K, N_each, 0, transcripts, inst, K * N_each, common, commitments, responses, nullptr, K * N_each, seed, transcripts, verdicts,
+                                        nullptr, sync_latency(c)));
 }
 int zkp_fused_batch_verify(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, uint8_t* transcripts, const uint8_t* inst, const uint8_t* common,
                            const uint8_t* commitments, const uint8_t* responses, const uint8_t* weights16, int* verdict, uint8_t* debug_scalars) {

@@ -33,7 +33,7 @@ EXPORTS = (
     "zkp_fused_verify_batchable", "zkp_fused_prove_dev", "zkp_fused_verify_compact_dev", "zkp_fused_verify_batchable_dev", "zkp_fused_batch_verify_dev",
     "zkp_fused_verify_batchable_coeffs", "zkp_fused_batch_verify_many", "zkp_fused_batch_verify_many_dev", "zkp_ctx_capture_begin", "zkp_ctx_capture_end", "zkp_ctx_capture_abort", "zkp_graph_launch", "zkp_graph_destroy",
     "zkp_fused_prove_submit", "zkp_fused_verify_compact_submit", "zkp_fused_batch_verify_many_submit", "zkp_fused_verify_batchable_submit",
-    "zkp_ctx_job_wait", "zkp_ctx_job_poll", "zkp_ctx_job_pending", "zkp_ctx_job_discard", "zkp_ctx_job_timing", "zkp_ctx_last_kernels", "zkp_host_alloc", "zkp_host_alloc_on", "zkp_host_numa_node", "zkp_host_node_of", "zkp_host_free", "zkp_host_register", "zkp_host_unregister",
+    "zkp_fused_prove_seeded", "zkp_fused_batch_verify_many_seeded", "zkp_ctx_job_wait", "zkp_ctx_job_poll", "zkp_ctx_job_pending", "zkp_ctx_job_discard", "zkp_ctx_job_timing", "zkp_ctx_last_kernels", "zkp_host_alloc", "zkp_host_alloc_on", "zkp_host_numa_node", "zkp_host_node_of", "zkp_host_free", "zkp_host_register", "zkp_host_unregister",
     "zkp_host_is_pinned", "zkp_chacha20_fill_dev",
 )
 TEST_HOOK_EXPORTS = ("zkp_debug_quad_selftest", "zkp_debug_row_selftest", "zkp_debug_wave_cycles")      # only in libzkp_mi355x_testhooks.so

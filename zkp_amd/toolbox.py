@@ -339,15 +339,23 @@ def _store_transcripts(transcripts: Sequence[Transcript], arr: np.ndarray) -> No
 
 # ---- batched entry points (numpy arrays in the layouts of include/zkp_toolbox.h) -------------------
 def prove_batch(eng: Engine, st: Statement, transcripts: np.ndarray, secrets: np.ndarray, inst: np.ndarray,
-                common: np.ndarray, entropy: Optional[np.ndarray] = None, threads: int = 0):
-    """-> (challenges[N][32], responses[N][m][32], commitments[N][nc][32]); transcripts advanced in place."""
+                common: np.ndarray, entropy: Optional[np.ndarray] = None, threads: int = 0, out=None):
+    """-> (challenges[N][32], responses[N][m][32], commitments[N][nc][32]); transcripts advanced in place.
+    out = (challenges, responses, commitments) to fill (C-contiguous uint8 arrays of those shapes, e.g. from pinned_empty: the engine's copies
+    out are then true DMA that leaves under the call's last kernels); default: fresh arrays."""
     n = len(transcripts)
     _check_batch_shapes(st, n, inst, common, None, secrets)
     if entropy is not None and tuple(np.shape(entropy)) != (n, 32):
         raise ValueError("entropy must have shape (%d, 32)" % n)
-    chal = np.zeros((n, 32), np.uint8)
-    resp = np.zeros((n, st.m, 32), np.uint8)
-    coms = np.zeros((n, st.nc, 32), np.uint8)
+    if out is None:
+        chal = np.zeros((n, 32), np.uint8)
+        resp = np.zeros((n, st.m, 32), np.uint8)
+        coms = np.zeros((n, st.nc, 32), np.uint8)
+    else:
+        chal, resp, coms = out
+        for name, a, shape in (("challenges", chal, (n, 32)), ("responses", resp, (n, st.m, 32)), ("commitments", coms, (n, st.nc, 32))):
+            if tuple(np.shape(a)) != shape or a.dtype != np.uint8 or not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("out: %s must be a C-contiguous uint8 array of shape %r" % (name, shape))
     rc = lib().zkp_prove_batch(eng._h, st._h, ctypes.c_uint32(n), _p(transcripts), _p(np.ascontiguousarray(secrets)),
                                _p(np.ascontiguousarray(inst)), _p(np.ascontiguousarray(common)),
                                _p(None if entropy is None else np.ascontiguousarray(entropy)), threads, _p(chal), _p(resp), _p(coms))

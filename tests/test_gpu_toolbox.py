@@ -639,3 +639,50 @@ def test_c_example_on_the_gpu(tmp_path, n):
     assert out.returncode == 0 and "all checks passed (GPU 0, N = %d)" % n in out.stdout, (out.stdout, out.stderr)
     host = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert host.returncode == 0 and host.stdout.splitlines()[:3] == out.stdout.splitlines()[:3]       # proof 0: the bytes of the host backend
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [False, True])
+def test_seeded_synchronous_calls_draw_the_pinned_chacha_stream(eng, pinned):
+    """zkp_fused_prove_seeded / zkp_fused_batch_verify_many_seeded (round 6: what zkp_prove_batch / zkp_batch_verify call when the caller gives no entropy /
+    no weights): proof j is the proof zkp_fused_prove makes from bytes [32 j, 32 j + 32) of the ChaCha20 stream of the seed, byte for byte -- on ordinary and
+    on pinned buffers (pinned inputs are queued right behind the fork, the commitments leave early) -- and the seeded batch verification accepts the batch and
+    rejects it after a flipped response bit."""
+    import ctypes
+    from zkp_amd.engine import load_library
+    from tests.test_gpu_device_entry import _cmz_fused_statement
+    hip = load_library()
+    n = 700
+    mod, secrets, inst, common = _cmz_batch(n, 41)
+    fst = _cmz_fused_statement()
+    seed = bytes(range(7, 47))
+    T.lib().zkp_chacha20_block.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p]
+    out, stream = ctypes.create_string_buffer(64), b""
+    for b in range((32 * n + 63) // 64):
+        T.lib().zkp_chacha20_block(seed[:32], b, int.from_bytes(seed[32:], "little"), out)
+        stream += out.raw
+    entropy = np.frombuffer(stream[: 32 * n], np.uint8).reshape(n, 32)
+    t0 = np.stack([T.Transcript(b"seeded").state] * n)
+    T.set_fused_min_batch(0)
+    try:
+        chal, resp, coms = T.prove_batch(eng, mod.statement, t0.copy(), secrets, inst, common, entropy)       # zkp_fused_prove with the stream as entropy
+    finally:
+        T.set_fused_min_batch(32)
+    mk = T.pinned_copy if pinned else (lambda a: np.array(a, copy=True))      # (the calls advance the transcripts in place)
+    ts, sec, ins, com = mk(t0), mk(secrets), mk(inst), mk(common)
+    alloc = T.pinned_empty if pinned else (lambda shape: np.zeros(shape, np.uint8))
+    c2, r2, k2 = alloc((n, 32)), alloc((n, 21, 32)), alloc((n, 11, 32))
+    invalid = ctypes.c_int(1)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    eng.prepare_fixed_points(common)
+    rc = hip.zkp_fused_prove_seeded(eng._h, ctypes.byref(fst.c), ctypes.c_uint32(n), p(ts), p(sec), p(ins), p(com), seed, p(c2), p(r2), p(k2), ctypes.byref(invalid))
+    assert rc == 0 and invalid.value == 0
+    assert (c2 == chal).all() and (r2 == resp).all() and (k2 == coms).all()
+    for flip in (False, True):
+        rr = r2.copy() if not pinned else T.pinned_copy(np.asarray(r2))
+        if flip:
+            rr[n // 2, 3, 0] ^= 1
+        ts2 = mk(t0)
+        verdicts = (ctypes.c_int * 1)(7)
+        rc = hip.zkp_fused_batch_verify_many_seeded(eng._h, ctypes.byref(fst.c), ctypes.c_uint32(1), ctypes.c_uint32(n), p(ts2), p(ins), p(com), p(k2), p(rr), seed, verdicts)
+        assert rc == 0 and verdicts[0] == (1 if flip else 0)

@@ -134,8 +134,8 @@ const char* zkp_version(void);
  *     stream for the point phase, comb tables built by four lanes per point, single-use points on tables): one call at a time per process, the caller sees
  *     the call's duration.  1 = the throughput schedule of the asynchronous jobs (section 2d): for callers that issue synchronous calls from several host
  *     threads at once, one context per thread -- every call is a little longer, the chip does less work per proof (profiles/r04_ab_experiments.txt, block r).
- *   ZKP_OPT_WS_LIMIT_BYTES: the largest device workspace this context may allocate (it grows with the largest call it has served: ~75 KB per CMZ
- *     proof of a prove call).  A call that would need more returns ZKP_ERR_OOM instead of allocating -- the way to keep several contexts of a
+ *   ZKP_OPT_WS_LIMIT_BYTES: the largest device workspace this context may allocate (it grows with the largest call it has served: ~85 KB per CMZ
+ *     proof of a prove call, 9 KB of it the transcript images).  A call that would need more returns ZKP_ERR_OOM instead of allocating -- the way to keep several contexts of a
  *     zkp_pipe (zkp_toolbox.h) inside one GPU's memory.  0 / UINT64_MAX = no cap (default).
  *   ZKP_OPT_TRANSCRIPT_STEPS: how the lane-pair Merlin transcripts of the fused flows run (round 6).  1 (default) = assemble + chain: one wide kernel builds every
  *     proof's per-block absorb image (all loads independent; identity checks too), then a chain kernel does nothing but state = (state & KEEP) ^ image and

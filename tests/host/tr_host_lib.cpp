@@ -106,3 +106,51 @@ extern "C" int t_tr_selftest(uint32_t seed, uint32_t N, uint32_t m, uint32_t np,
   if (memcmp(s_chal.data(), want_chal.data(), want_chal.size()) != 0) bad |= 512;
   return bad ? -bad : (int)prog.size();
 }
+
+// tr_steps_build folds a step without a permutation into its successor only when nothing of the first is cleared by the second's keep words.  The compiler never
+// emits such a pair (bytes only advance inside a block), so it is built by hand here: step 1 absorbs 8 bytes into word 3, step 2 OVERWRITES 4 bytes of word 3
+// (a KEY operation on bytes 2..5) and permutes.  The step form must give what the operation list gives (tr_run_one), merged or not, and must NOT have merged.
+extern "C" int t_tr_merge_selftest() {
+  std::vector<uint8_t> a(64), b(64);
+  for (size_t i = 0; i < 64; ++i) { a[i] = (uint8_t)(17 * i + 3); b[i] = (uint8_t)(29 * i + 5); }
+  auto word_op = [](uint8_t w, uint8_t nb, uint8_t lb, uint8_t buf, uint64_t off, bool overwrite) {
+    tr_op_wide o{};
+    const uint64_t mask = (nb >= 8 ? ~0ULL : ((1ULL << (8 * nb)) - 1)) << (8 * lb);
+    o.keep = overwrite ? ~mask : ~0ULL;
+    if (overwrite) o.flags |= TR_OVERWRITE;
+    o.w = w; o.nb = nb; o.lb = lb; o.src_buf = (uint8_t)(buf + 1); o.src_stride = 32; o.src_off = off;
+    return tr_pack(o);
+  };
+  auto apply_op = [](uint64_t table, bool permute) {
+    tr_op_wide o{};
+    o.keep = ~0ULL;
+    o.flags = (uint8_t)(TR_APPLY | (permute ? TR_PERMUTE : 0));
+    o.src_off = table;
+    return tr_pack(o);
+  };
+  std::vector<uint64_t> tables(2 * TR_TABLE_WORDS, 0);
+  for (int t = 0; t < 2; ++t) for (int w = 0; w < 21; ++w) { tables[t * TR_TABLE_WORDS + w] = ~0ULL; tables[t * TR_TABLE_WORDS + 21 + w] = 0x0101010101010101ULL * (uint64_t)(t + 1) * (w == 5); }
+  int bad = 0;
+  for (int variant = 0; variant < 2; ++variant) {           // 0: the second step overwrites bytes the first absorbed (no merge); 1: it touches another word (merge)
+    std::vector<tr_op> ops;
+    ops.push_back(word_op(3, 8, 0, 0, 0, false));
+    ops.push_back(apply_op(0, false));
+    ops.push_back(word_op(variant == 0 ? 3 : 4, 4, 2, 1, 8, true));
+    ops.push_back(apply_op(1, true));
+    const tr_step_prog sp = tr_steps_build(ops, tables);
+    size_t real = sp.steps.size() ? sp.steps.size() - 1 : 0;     // (the sentinel)
+    if (variant == 0 && real != 2) bad |= 1;
+    if (variant == 1 && real != 1) bad |= 2;
+    tr_bufs bufs{};
+    bufs.src[0] = a.data(); bufs.src[1] = b.data();
+    for (uint64_t j = 0; j < 2; ++j) {
+      uint64_t S1[25], S2[25], sv[25];
+      for (int i = 0; i < 25; ++i) S1[i] = S2[i] = 0x9e3779b97f4a7c15ULL * (uint64_t)(i + 1 + 31 * j);
+      uint32_t f1 = 0, f2 = 0;
+      tr_run_one(ops.data(), (uint32_t)ops.size(), tables.data(), j, bufs, S1, 1, sv, 1, &f1);
+      tr_steps_run_one(sp, j, bufs, S2, sv, &f2);
+      if (memcmp(S1, S2, 200) != 0) bad |= 4 << variant;
+    }
+  }
+  return bad ? -bad : 1;
+}

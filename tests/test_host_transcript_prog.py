@@ -34,3 +34,9 @@ def lib():
 def test_compiled_program_equals_host_merlin(lib, args):
     rc = lib.t_tr_selftest(*args)
     assert rc > 0, f"mismatch bits {-rc}"
+
+
+def test_step_form_merges_only_what_commutes(lib):
+    """merlin_prog.h: tr_steps_build folds a step without a permutation into its successor unless the successor clears bytes the first one wrote --
+    a hand-built pair of each kind through the operation list and through the step form."""
+    assert lib.t_tr_merge_selftest() == 1

@@ -67,7 +67,7 @@ def test_msm_many_dev_equals_host_entry_and_oracle(eng, flags):
 
 
 @pytest.mark.parametrize("n,wide", [(40, False), (1500, False), (40, True), (1500, True), (40, "fuse"), (1500, "fuse"), (40, "interp"), (1500, "interp"),
-                                    (1500, "fuse+interp"), (40, "latency"), (1500, "latency"), (4096, "latency")])
+                                    (1500, "fuse+interp"), (40, "latency"), (1500, "latency"), (4096, "latency"), (1500, "fuse+wide"), (40, "wide+interp")])
 def test_fused_dev_flows_equal_host_pointer_flows(eng, n, wide):
     """zkp_fused_prove_dev / _verify_compact_dev / _batch_verify_dev / _verify_batchable_dev against zkp_fused_prove / ... (through the toolbox).
     wide: with the variants the _dev entry points pick for calls that fill the chip on their own (one transcript lane per
@@ -81,7 +81,7 @@ def test_fused_dev_flows_equal_host_pointer_flows(eng, n, wide):
         eng.set_option(15, 0)           # ZKP_OPT_TRANSCRIPT_STEPS
     if wide == "latency":
         eng.set_option(5, 2)            # ZKP_OPT_DEV_OVERLAP
-    elif wide is True:
+    elif wide is True or "wide" in str(wide):      # ("fuse+wide": the one-lane chain inside the comb tables' launch; "wide+interp": the one-lane interpreter)
         eng.set_option(4, 1)            # ZKP_OPT_TRANSCRIPT_LANES
         eng.set_option(3, 0)            # ZKP_OPT_CT_SINGLE_USE_TABLES
     try:

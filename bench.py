@@ -1194,6 +1194,14 @@ def rank_main(args, desc, n, K, n_streams, rank_, local_rank_, world_, thread_gr
                         roof["terms_kernel_launch_ms"] = {"hip_events_this_run": kms["prove"]["terms"], "rocprof_one_stream": tv["avg_us_one_stream"] / 1e3,
                                                           "rocprof_pmc_pass": tv.get("us_in_pmc_pass", 0.0) / 1e3 or None}
                     roof["terms_kernel_traffic"] = tv.get("hbm_bytes_per_launch")
+                    # does that traffic cost the kernel anything?  wavefront-cycles parked at s_waitcnt / barriers, the L2's hit rate, TCP stall cycles
+                    roof["terms_kernel_memory_wait"] = {
+                        "wave_parked_frac": tv.get("wave_parked_frac"), "l2_hit_rate": tv.get("l2_hit_rate"),
+                        "tcp_pending_stall_cycles_per_launch": tv.get("TCP_PENDING_STALL_CYCLES_sum"), "sq_busy_cycles_per_launch": tv.get("SQ_BUSY_CYCLES"),
+                        "issue_stall_frac": (tv["SQ_WAIT_INST_ANY"] / tv["SQ_WAVE_CYCLES"]) if tv.get("SQ_WAIT_INST_ANY") and tv.get("SQ_WAVE_CYCLES") else None,
+                        "note": "wave_parked_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (a wavefront parked at s_waitcnt or a barrier; with two wavefronts per SIMD one's wait is the other's issue "
+                                "slot); issue_stall_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (dependency / pipe stalls).  The traffic is 40 x the algorithmic bytes and is NOT free: it "
+                                "is bounded by the 1 - terms_kernel_valu_busy of issue slots the kernel leaves empty, all other stalls included"}
                     roof["terms_kernel_algorithmic_bytes"] = algo["prove"]
                     roof["terms_kernel_share_int64"] = {"static": tv.get("share_int64_static"), "dynamic_pmc": tv.get("share_int64_dynamic")}
                 st_tot = pj.get("_step_totals", {})

@@ -39,6 +39,11 @@ rm -rf $O/r06_gap_pipe $O/r06_gap_res
 # Keccak-f[1600] on a lone wavefront: the shipped lane-pair layout, unrolled, and one word per lane over the crossbar
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench/keccak_lat.hip -o tools/microbench/keccak_lat 2>/dev/null
 tools/microbench/keccak_lat > $O/r06_keccak_microbench.txt 2>&1
+# constant-time evidence for the whole prover flow (secrets = witnesses and entropy)
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/r06_ctf -o flow -- python tools/ct_check_flow.py > $O/r06_ctf1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_FLAT --output-format csv -d $O/r06_ctf -o flow2 -- python tools/ct_check_flow.py > $O/r06_ctf2.log 2>&1
+python tools/ct_check_flow.py --summarise $(ls $O/r06_ctf/*flow_counter_collection.csv $O/r06_ctf/*flow2_counter_collection.csv 2>/dev/null) > $O/r06_constant_time_flow_counters.txt
+rm -rf $O/r06_ctf
 python tools/e2e_toolbox_bench.py 4096 16384 > $O/r06_e2e_toolbox_host_included.txt 2>&1
 python bench.py --steps 20 --warmup 5 > $O/r06_bench_1gpu_steps20.json 2> $O/err1.log
 python bench.py > $O/r06_bench_1gpu.json 2> $O/err2.log

@@ -282,7 +282,7 @@ def test_hip_graph_replay_equals_direct_calls(eng):
     stale.close()
 
 
-@pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1), (0, "masked"), (1, "masked"), (0, "lds"), (1, "lds"), (0, "interleave")])
+@pytest.mark.parametrize("single_use_tables,grouped", [(0, 0), (1, 0), (0, 1), (1, 1), (0, "masked"), (1, "masked"), (0, "lds"), (1, "lds"), (0, "interleave"), (0, "split"), (1, "split")])
 def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_tables, grouped):
     """ZKP_OPT_CT_SINGLE_USE_TABLES: a constant-time call serves a point that only one term multiplies either through a comb
     table (default when the call has shared points) or through the masked radix-16 ladder; both must give the oracle's bytes.
@@ -307,6 +307,10 @@ def test_constant_time_single_use_schedules_agree_with_oracle(eng, single_use_ta
         # ZKP_OPT_CT_LOOKUP = 2: the look-up of rounds 2 - 4 (rows replicated in LDS, read at the digit's index), grouped walk through LDS
         e.set_option(9, 2)
         e.set_option(6, 1)
+    elif grouped == "split":
+        # ZKP_OPT_COMB_SPLIT: a quad of lanes per masked comb scan, one 64-bit window each, joined over DPP, next to the grouped walk (round 6: the default of
+        # constant-time calls of 8,192 .. 400,000 terms on the latency schedule); calls with a ladder class keep one lane per scan
+        e.set_option(16, 1)
     elif grouped == "interleave":
         # ZKP_OPT_LADDER_INTERLEAVE: the ladder blocks spread over the front of the term kernel's grid (the default of launches with
         # 65,536 single-use points or more), forced here on grids of a few blocks: strides 0 (too few blocks), 2 and more

@@ -359,6 +359,96 @@ __device__ __forceinline__ void term_comb(uint32_t t, const uint8_t* __restrict_
   store_ext(partial + t, acc);
 }
 
+// The constant-time comb scan of ONE term spread over a QUAD of lanes, lane q walking window q (round 6; narrow calls on the latency schedule).  A point with
+// fewer than GROUP_MIN_USES terms cannot join the grouped walk (its crossbar needs <= 4 tables per half wavefront), so each of its terms scans its own rows:
+// 64 scanned additions + 12 doublings in one lane, 745 k cycles -- the pole of the term kernel of a 4096-proof call, whose grouped and fixed-base blocks take
+// 485 k and 470 k (profiles/r06_constant_time_wave_cycles.txt).  Here lane q adds the 16 teeth of window q (16 scanned additions, no doubling in between), then
+//     lanes 3, 1:  x 16          lane 2 += lane 3's, lane 0 += lane 1's          lane 2: x 256          lane 0 += lane 2's
+// = 16 scanned additions + 12 doublings + 2 additions per lane: a third of the chain for 1.45 x the instructions.  Same table, same digits, same entries scanned
+// completely (no address or branch depends on the scalar); the sum is the same group element, hence the same bytes.
+__device__ __forceinline__ void ge_p3_dpp_from(ge_p3& r, const ge_p3& a, int ctrl_sel) {     // ctrl_sel: 0 = lanes take their odd neighbour's (1,1,3,3), 1 = lane 2's (2,2,2,2)
+  if (ctrl_sel == 0) { fe_dpp<ZKP_QP(1, 1, 3, 3)>(r.X, a.X); fe_dpp<ZKP_QP(1, 1, 3, 3)>(r.Y, a.Y); fe_dpp<ZKP_QP(1, 1, 3, 3)>(r.Z, a.Z); fe_dpp<ZKP_QP(1, 1, 3, 3)>(r.T, a.T); }
+  else { fe_dpp<ZKP_QP(2, 2, 2, 2)>(r.X, a.X); fe_dpp<ZKP_QP(2, 2, 2, 2)>(r.Y, a.Y); fe_dpp<ZKP_QP(2, 2, 2, 2)>(r.Z, a.Z); fe_dpp<ZKP_QP(2, 2, 2, 2)>(r.T, a.T); }
+}
+template <int TEETH>
+__device__ __forceinline__ void term_comb_split4(uint32_t t, uint32_t q, const uint8_t* __restrict__ scalars, const dev_ext* __restrict__ comb, uint32_t slot,
+                                                 dev_ext* __restrict__ partial, uint32_t* ecol) {
+  using cfg = comb_cfg<TEETH>;
+  static_assert(cfg::WINDOWS == 4, "one lane of the quad per window");
+  // (the term and slot numbers wait in the lane's LDS column for the last step instead of in registers: the additions below need all of them)
+  typedef __attribute__((address_space(3))) volatile uint32_t lds_word;
+  lds_word* stash = (lds_word*)(ecol + 256 * 8);
+  stash[0] = slot;
+  stash[256] = t;
+  const dev_ext* __restrict__ tbl = comb + (size_t)slot * cfg::ENTRIES;
+  uint32_t s[8], e[8], top;
+  load_vec<2>(s, scalars + 32 * (size_t)t);
+  sc_add_pattern(e, top, s, 0x88888888u);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ecol[256 * j] = e[j];
+  stash[512] = top;
+  ge_p3 acc;
+  ge_identity(acc);
+  {
+    ge_cached n0, n1;
+    load_comb_entry(n0, tbl + 0);
+    load_comb_entry(n1, tbl + 1);
+#pragma unroll 1
+    for (int j = 0; j < TEETH; ++j) {
+      const uint32_t nidx = (uint32_t)j * cfg::WINDOWS + q;      // nibble number of tooth j, this lane's window
+      const uint32_t nib = (ecol[256 * (nidx >> 3)] >> (4 * (nidx & 7))) & 15u;
+      const uint32_t neg = (uint32_t)(nib < 8u);
+      const uint32_t mag = neg ? 8u - nib : nib - 8u;
+      const dev_ext* row = tbl + 8 * j;
+      ge_cached sel;
+      ge_cached_identity(sel);
+      ge_cached_cmov(sel, n0, (uint32_t)(mag == 1));
+      ge_cached_cmov(sel, n1, (uint32_t)(mag == 2));
+#pragma unroll 1
+      for (uint32_t h = 1; h < 4; ++h) {
+        ge_cached c0, c1;
+        load_comb_entry(c0, row + 2 * h + 0);
+        load_comb_entry(c1, row + 2 * h + 1);
+        ge_cached_cmov(sel, c0, (uint32_t)(mag == 2 * h + 1));
+        ge_cached_cmov(sel, c1, (uint32_t)(mag == 2 * h + 2));
+      }
+      const dev_ext* next = (j + 1 < TEETH) ? row + 8 : tbl;
+      load_comb_entry(n0, next + 0);
+      load_comb_entry(n1, next + 1);
+      ge_cached_cneg(sel, neg);
+      ge_add_cached(acc, acc, sel);
+    }
+  }
+  // the quad's Horner: every lane runs every step (DPP sources must be active lanes); a lane keeps a step's result only where the schedule above says so
+  {
+    ge_p3 d = acc;
+    ge_double4(d);                                                // 16 x (window 3's, window 1's sum)
+    fe_pick(acc.X, d.X, (q & 1u) != 0); fe_pick(acc.Y, d.Y, (q & 1u) != 0); fe_pick(acc.Z, d.Z, (q & 1u) != 0); fe_pick(acc.T, d.T, (q & 1u) != 0);
+    ge_p3 o;
+    ge_p3_dpp_from(o, acc, 0);                                    // lanes 0 / 2 see lanes 1 / 3
+    ge_cached c;
+    ge_to_cached(c, o);
+    ge_add_cached(d, acc, c);
+    fe_pick(acc.X, d.X, (q & 1u) == 0); fe_pick(acc.Y, d.Y, (q & 1u) == 0); fe_pick(acc.Z, d.Z, (q & 1u) == 0); fe_pick(acc.T, d.T, (q & 1u) == 0);
+    d = acc;
+    ge_double4(d);
+    ge_double4(d);                                                // 256 x (windows 3 and 2)
+    fe_pick(acc.X, d.X, q == 2u); fe_pick(acc.Y, d.Y, q == 2u); fe_pick(acc.Z, d.Z, q == 2u); fe_pick(acc.T, d.T, q == 2u);
+    ge_p3_dpp_from(o, acc, 1);                                    // every lane sees lane 2
+    ge_to_cached(c, o);
+    ge_add_cached(d, acc, c);
+    fe_pick(acc.X, d.X, q == 0u); fe_pick(acc.Y, d.Y, q == 0u); fe_pick(acc.Z, d.Z, q == 0u); fe_pick(acc.T, d.T, q == 0u);
+  }
+  {
+    ge_cached sel, c;
+    ge_cached_identity(sel);
+    load_comb_entry(c, comb + (size_t)stash[0] * cfg::ENTRIES + 8 * TEETH);      // carry out of bit 255: 2^256 * P
+    ge_cached_cmov(sel, c, stash[512]);
+    ge_add_cached(acc, acc, sel);
+  }
+  if (q == 0u) store_ext(partial + stash[256], acc);
+}
+
 // ---- grouped comb terms: the table rows pass through LDS, every lane reads the entry its digit names --------------------
 // The constant-time walk above pays 72 loads + 288 v_cndmask per addition to hide WHICH of a row's 8 entries a lane wants.
 // LDS can hide it for free (hot_tables.h): a ds_read_b128 is serviced in four groups of 16 lanes with distinct lane mod 16, so

@@ -168,7 +168,7 @@ constexpr int terms_lds_uint4() {
   if (LOOKUP == LOOKUP_XBAR) return XBAR_LDS_UINT4 > 512 ? XBAR_LDS_UINT4 : 512;          // (512: the comb / ladder blocks' scalar columns, 8 words x 256 lanes)
   return HOT_ROW_CHUNKS * HOT_COPIES > GROUP_LDS_UINT4 ? HOT_ROW_CHUNKS * HOT_COPIES : GROUP_LDS_UINT4;
 }
-template <bool CT, int TEETH, bool LADDER, int LOOKUP = LOOKUP_XBAR>
+template <bool CT, int TEETH, bool LADDER, int LOOKUP = LOOKUP_XBAR, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2)
 k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ pidx, uint32_t n_points,
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
@@ -185,7 +185,9 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
   const uint32_t n_ladder = LADDER ? class_start[CLASS_GROUP] - class_start[CLASS_LADDER] : 0u;
   const uint32_t n_group = (CT && TEETH == 16) ? class_start[HOT_CLASSES] - class_start[CLASS_GROUP] : 0u;
   const uint32_t ladder_blocks = (n_ladder + blockDim.x - 1) / blockDim.x;
-  const uint32_t comb_blocks = (n_comb + blockDim.x - 1) / blockDim.x;
+  // comb_split (constant-time narrow calls on the latency schedule): a QUAD of lanes per comb-scan term, one window each (term_comb_split4)
+  const uint32_t comb_lanes = SPLIT ? 4u * n_comb : n_comb;
+  const uint32_t comb_blocks = (comb_lanes + blockDim.x - 1) / blockDim.x;
   const uint32_t group_terms = LOOKUP == LOOKUP_XBAR ? XBAR_BLOCK_TERMS : 256u;       // list entries a grouped block takes (crossbar: 31 per half of a wavefront)
   const uint32_t group_blocks = (n_group + group_terms - 1) / group_terms;
   // Logical block number (ladder blocks, comb blocks, grouped blocks, fixed-base blocks -- longest first).  ladder_stride > 1 spreads the
@@ -211,6 +213,21 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
     ZKP_WAVE_T1(1);
   } else if (vb < ladder_blocks + comb_blocks) {
     const uint32_t i = (vb - ladder_blocks) * blockDim.x + threadIdx.x;
+    if constexpr (SPLIT) {
+      {
+        const uint32_t ti = i >> 2;                                 // (a quad shares its term: the branches below are uniform inside it)
+        if (ti < n_comb) {
+          const uint32_t t = list[n_hot + ti];
+          const uint32_t pi = pidx[t];
+          if (pi < n_points) {
+            const uint32_t slot = slot_of[pi];
+            if (slot != 0xffffffffu) term_comb_split4<TEETH>(t, i & 3u, scalars, comb, slot, partial, ecol);
+          }
+        }
+        ZKP_WAVE_T1(2);
+        return;
+      }
+    }
     if (i < n_comb) {
       const uint32_t t = list[n_hot + i];
       const uint32_t pi = pidx[t];
@@ -1302,6 +1319,7 @@ struct zkp_ctx {
   bool stmt_classify = true;         // the fused flows' one-launch term classifier (ZKP_TESTOPT_GENERIC_CLASSIFIER of test-hook builds turns it off)
   int fuse_tables_transcript = -1;       // ZKP_OPT_FUSE_TABLES_TRANSCRIPT: -1 = asynchronous _dev calls below kVeryWideCallProofs proofs, 0 = never, 1 = always
   int tables_lane = -1;              // ZKP_OPT_TABLES_LANE: comb tables built by one lane per point (1) or by a quad (0); -1 = by entry point
+  int comb_split = -1;               // ZKP_OPT_COMB_SPLIT: -1 = narrow constant-time calls on the latency schedule, 0 = never, 1 = always (with the grouped walk's own rule)
   int grouped_comb = -1;             // ZKP_OPT_GROUPED_COMB: -1 = calls of kGroupedCombTerms terms or more, 0 = never, 1 = always
   int ladder_interleave = -1;        // ZKP_OPT_LADDER_INTERLEAVE: the term kernel's ladder blocks spread over the front of its grid instead of all first
                                      // (-1 = by size: from kInterleaveLadderBlocks ladder blocks up, where the later start of the last one no longer shows)
@@ -1315,6 +1333,7 @@ struct zkp_ctx {
   static constexpr uint32_t kWaveCyclesCap = 1u << 20;
 #endif
   static constexpr size_t kGroupedCombTerms = 400000;
+  static constexpr size_t kSplitCombTerms = 8192;   // narrow constant-time calls on the latency schedule from this many terms on: grouped walk + quad-split scans (ZKP_OPT_COMB_SPLIT)
   bool dev_overlap = false;          // ZKP_OPT_DEV_OVERLAP: the _dev flows fork their scalar-independent half onto the side stream too
   bool dev_latency = false;          // ZKP_OPT_DEV_OVERLAP = 2: the _dev flows run the whole latency schedule of the synchronous entry points (a lone caller's choice)
   bool tr_steps = true;              // ZKP_OPT_TRANSCRIPT_STEPS: lane-pair transcripts as assemble + chain (1, default) or by the word-operation interpreter (0)
@@ -1516,7 +1535,7 @@ inline bool terms_batched_encode(const zkp_ctx* c, uint32_t n_terms, uint32_t n_
 template <bool CT, int TEETH, int LOOKUP>
 void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
                         const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
-                        const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part) {
+                        const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part, uint32_t comb_split) {
   // ladder blocks spread over the first half of the grid (ZKP_OPT_LADDER_INTERLEAVE), or all at the front
   uint32_t stride = 0;
   const uint32_t lb = (max_ladder + 255) / 256;
@@ -1529,6 +1548,13 @@ void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_sca
     if (stride < 2) stride = 0;
   }
   prof_note(c, ZKP_K_TERMS, std::string("k_terms_split<") + (CT ? "true" : "false") + ", " + std::to_string(TEETH) + ", " + (ladder ? "true" : "false") + ", " + std::to_string(LOOKUP) + ">");
+  if constexpr (CT && TEETH == 16 && LOOKUP == LOOKUP_XBAR) {
+    if (comb_split && !ladder) {                                   // (the caller asks for it on narrow calls only: they have no ladder class)
+      hipLaunchKernelGGL((k_terms_split<CT, TEETH, false, LOOKUP, true>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
+                         c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
+      return;
+    }
+  }
   if (ladder)
     hipLaunchKernelGGL((k_terms_split<CT, TEETH, true, LOOKUP>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
                        c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
@@ -1569,7 +1595,13 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     // (the LDS walk has fewer instructions but less independent work per lane than the masked scans: it wins once the call
     //  keeps every SIMD busy -- single kernel, 4096 CMZ proofs 590 vs 370 us, 8192: 860 vs 690, 16384: 1300 vs 1390; pipelined
     //  step: 4096 proofs -1 %, 8192 +1.6 %, 16384 +7 %, 524,288 +4.7 %)
-    const bool group_on = (HOT_LDS_ROWS && c->ct_lookup == LOOKUP_SCAN) ? false : c->grouped_comb < 0 ? n_terms >= (k.throughput ? zkp_ctx::kWideCallTerms : zkp_ctx::kGroupedCombTerms) : c->grouped_comb != 0;
+    // Round 6, narrow calls on the latency schedule (one call in flight): the scans of a point that cannot join the grouped walk are split over a quad of lanes
+    // (term_comb_split4: a third of the chain), which removes what kept the grouped walk away from such calls -- CMZ's single-use Q alone in the scan class was the
+    // pole of the kernel (4096 proofs: 580 against 380 us).  With both: P on the grouped walk, Q on quads, the fixed-base blocks are the longest class (280 us).
+    const bool lat_split = c->comb_split < 0 ? (!k.throughput && flags == ZKP_CT && k.teeth == 16 && n_terms >= zkp_ctx::kSplitCombTerms && n_terms < zkp_ctx::kGroupedCombTerms) : c->comb_split != 0;
+    const bool group_on = (HOT_LDS_ROWS && c->ct_lookup == LOOKUP_SCAN) ? false
+                          : c->grouped_comb < 0 ? (n_terms >= (k.throughput ? zkp_ctx::kWideCallTerms : zkp_ctx::kGroupedCombTerms) || lat_split) : c->grouped_comb != 0;
+    const bool comb_split = lat_split && flags == ZKP_CT && k.teeth == 16 && !(HOT_LDS_ROWS && c->ct_lookup != LOOKUP_XBAR);
     const uint32_t group_min = (flags == ZKP_CT && k.teeth == 16 && group_on && k.max_tables) ? GROUP_MIN_USES : 0xffffffffu;
     uint32_t* gstart = reinterpret_cast<uint32_t*>(base + o.gstart);
     uint32_t* gfill = reinterpret_cast<uint32_t*>(base + o.gfill);
@@ -1627,7 +1659,8 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     if ((phase & PH_POINTS) && k.max_tables && c->kernel_names[ZKP_K_TABLES].find("k_tables_transcript") == std::string::npos && c->kernel_names[ZKP_K_TABLES].find("k_tables_chain") == std::string::npos)
       prof_note(c, ZKP_K_TABLES, std::string((c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) ? "zkp::k_comb_tables_lane<" : "zkp::k_comb_tables<") + (k.teeth == 16 ? "16>" : "4>"));
     if (phase & PH_POINTS) prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
-    const dim3 grid((unsigned)((n_terms + XBAR_BLOCK_TERMS - 1) / XBAR_BLOCK_TERMS + 4 + HOT_SLOTS));     // every class starts a new block (grouped blocks take 248 terms)
+    // every class starts a new block (grouped blocks take 248 terms); with comb_split the scan class has four lanes per term
+    const dim3 grid((unsigned)((n_terms + XBAR_BLOCK_TERMS - 1) / XBAR_BLOCK_TERMS + 4 + HOT_SLOTS + (comb_split ? 3 * ((n_terms + 255) / 256) + 1 : 0)));
     // the outputs are encoded as 2 * H (batched encoder below): the term kernels work on s / 2 mod l
     if (batched_encode) {
       uint8_t* d_half = reinterpret_cast<uint8_t*>(base + o.half);
@@ -1639,7 +1672,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     if (phase & PH_SCALARS) {
       // (vartime calls have nothing to hide: they never scan)
       const int lookup = (!HOT_LDS_ROWS || c->ct_lookup == LOOKUP_XBAR) ? LOOKUP_XBAR : (flags == ZKP_CT ? c->ct_lookup : LOOKUP_LDS);
-#define ZKP_LAUNCH_TERMS(CT_, TEETH_, LK_) launch_terms_split<CT_, TEETH_, LK_>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part)
+#define ZKP_LAUNCH_TERMS(CT_, TEETH_, LK_) launch_terms_split<CT_, TEETH_, LK_>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part, comb_split ? 1u : 0u)
       if (lookup == LOOKUP_XBAR) {
         if (flags == ZKP_CT) { if (k.teeth == 16) ZKP_LAUNCH_TERMS(true, 16, LOOKUP_XBAR); else ZKP_LAUNCH_TERMS(true, 4, LOOKUP_XBAR); }
         else { if (k.teeth == 16) ZKP_LAUNCH_TERMS(false, 16, LOOKUP_XBAR); else ZKP_LAUNCH_TERMS(false, 4, LOOKUP_XBAR); }
@@ -1947,6 +1980,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
+    case ZKP_OPT_COMB_SPLIT: c->comb_split = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_CT_LOOKUP:
       if (value == ~0ull) value = 0;
       if (value > 2 || (value && !HOT_LDS_ROWS)) return fail(ZKP_ERR_ARG, "ZKP_OPT_CT_LOOKUP: 0 (lane crossbar), 1 (masked scans), 2 (LDS rows); 1 and 2 exist for 6-bit fixed-base windows only");

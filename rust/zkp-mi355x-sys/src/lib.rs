@@ -53,6 +53,7 @@ pub const ZKP_OPT_JOB_DEFER_D2H: c_int = 13;
 pub const ZKP_OPT_SYNC_SCHEDULE: c_int = 14;
 pub const ZKP_OPT_TRANSCRIPT_STEPS: c_int = 15;
 pub const ZKP_OPT_COMB_SPLIT: c_int = 16;
+pub const ZKP_OPT_JOINT_LADDER: c_int = 17;
 pub const ZKP_JOB_SHARED_TRANSCRIPT: u32 = 1;
 
 pub const ZKP_TB_OK: c_int = 0;

@@ -657,3 +657,60 @@ def test_verify_batchable_straus_more_lanes_than_operands_dleq():
             assert (got == want).all(), (opt, np.nonzero(got != want)[0][:8])
     finally:
         T.set_fused_min_batch(32)
+
+
+@pytest.mark.gpu
+def test_verify_compact_joint_ladder_equals_separate_terms():
+    """ZKP_OPT_JOINT_LADDER (round 6): in the verifier's constraints  commitment = sum s_i P_i - c LHS  (verifier.rs:95-106) the left-hand side's doubling chain
+    also carries one other per-proof term of the constraint (CMZ: P in the ten C_i constraints -- which then needs no comb table --, Q next to V; DLEQ with a
+    per-proof H: H next to B).  Both settings must accept exactly the proofs the oracle's verifier accepts: all of a valid batch (every recomputed commitment
+    bit-exact, or the challenge would differ), and none of the proofs with a tampered response of a PAIRED term, a tampered challenge, a tampered left-hand
+    side, an undecodable partner point.  Sizes: the statement classifier (what pairs the terms) runs from 1,024 terms on; 20 proofs stay below it."""
+    from zkp_amd.engine import Engine
+    rng = np.random.default_rng(77)
+    cases = []
+    for n in (20, 333, 1500):
+        mod, secrets, inst, common = _cmz_batch(n, 91 + n)
+        cases.append((b"joint-cmz", mod.statement, C.Statement.from_model(M.cmz_statement(10)), secrets, inst, common, n))
+    n = 700
+    mod, x, A, B, H = _dleq_batch(n, 23)
+    cases.append((b"joint-dleq", mod.statement, C.Statement.from_model(M.dleq_statement()), x, np.stack([A, B, H]), np.frombuffer(BASEPOINT, np.uint8).reshape(1, 32), n))
+    T.set_fused_min_batch(0)
+    try:
+        for label, st, cst, secrets, inst, common, n in cases:
+            e0 = Engine(0)
+            chal, resp, coms = T.prove_batch(e0, st, _fresh(label, n), secrets, inst, common, rng.integers(0, 256, size=(n, 32), dtype=np.uint8))
+            e0.close()
+            ni = inst.shape[0]
+            bad_resp, bad_chal, bad_inst = resp.copy(), chal.copy(), inst.copy()
+            want = np.zeros(n, np.uint8)
+            for i in range(resp.shape[1]):                               # one proof per secret: its response off by one bit
+                bad_resp[(3 + i) % n, i, (5 * i) % 31] ^= 1 << (i % 8)
+                want[(3 + i) % n] = 1
+            results = {}
+            for opt in (1, 0):
+                e = Engine(0)
+                e.set_option(17, opt)
+                ok = T.verify_compact_batch(e, st, _fresh(label, n), inst, common, chal, resp)
+                r1 = T.verify_compact_batch(e, st, _fresh(label, n), inst, common, chal, bad_resp)
+                bc = chal.copy(); bc[n - 1, 0] ^= 1
+                r2 = T.verify_compact_batch(e, st, _fresh(label, n), inst, common, bc, resp)
+                r3 = []
+                for p in range(ni):                                      # every instance point in turn: another proof's point / not a point at all
+                    bi = inst.copy()
+                    bi[p, 1] = inst[p, 0]
+                    bi[p, n - 2] = np.frombuffer(bytes([1] + [0] * 31), np.uint8)
+                    r3.append(T.verify_compact_batch(e, st, _fresh(label, n), bi, common, chal, resp))
+                e.close()
+                assert not ok.any(), (label, n, opt, np.nonzero(ok)[0][:8])
+                assert (r1 == want).all(), (label, n, opt, np.nonzero(r1 != want)[0][:8])
+                assert r2[n - 1] == 1 and r2.sum() == 1
+                for p, r in enumerate(r3):
+                    assert r[1] == 1 and r[n - 2] == 1 and r.sum() == 2, (label, n, opt, p, np.nonzero(r)[0][:8])
+                results[opt] = (ok, r1, r2, r3)
+            for j in (0, 3, 4, n - 1):                                   # the oracle's verifier on the same bytes (define_proof!'s order: instance, then common)
+                pts = np.concatenate([inst[:, j], common])
+                assert C.verify_compact(cst, label, pts, chal[j], resp[j]) == 0
+                assert C.verify_compact(cst, label, pts, chal[j], bad_resp[j]) == want[j]
+    finally:
+        T.set_fused_min_batch(32)

@@ -44,6 +44,11 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_I
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_FLAT --output-format csv -d $O/r06_ctf -o flow2 -- python tools/ct_check_flow.py > $O/r06_ctf2.log 2>&1
 python tools/ct_check_flow.py --summarise $(ls $O/r06_ctf/*flow_counter_collection.csv $O/r06_ctf/*flow2_counter_collection.csv 2>/dev/null) > $O/r06_constant_time_flow_counters.txt
 rm -rf $O/r06_ctf
+# verify_compact alone: where its time goes, kernel by kernel, in issue slots
+rocprofv3 --kernel-trace --output-format csv -d $O/r06_vc -o vc -- python tools/verify_compact_profile.py > $O/r06_vc1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_VALU2 SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/r06_vc -o vcp -- python tools/verify_compact_profile.py > $O/r06_vc2.log 2>&1
+python tools/verify_compact_profile.py --summarise $(ls $O/r06_vc/*vc_kernel_trace.csv | head -1) $(ls $O/r06_vc/*vcp_counter_collection.csv | head -1) > $O/r06_verify_compact_accounting.txt 2>&1
+rm -rf $O/r06_vc
 python tools/e2e_toolbox_bench.py 4096 16384 > $O/r06_e2e_toolbox_host_included.txt 2>&1
 python bench.py --steps 20 --warmup 5 > $O/r06_bench_1gpu_steps20.json 2> $O/err1.log
 python bench.py > $O/r06_bench_1gpu.json 2> $O/err2.log

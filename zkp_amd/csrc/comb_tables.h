@@ -867,4 +867,81 @@ __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restr
   store_ext(partial + t, acc);
 }
 
+// Two terms of one MSM on ONE chain of doublings (variable time; round 6): acc = s1 * P1 + s2 * P2 by interleaving (Straus) -- the second term costs its eight
+// multiples and its 64 additions, no doublings, no comb table.  The verifier's constraints  commitment = sum s_i P_i - c * LHS  (verifier.rs:95-106) pair the
+// left-hand side (one use per proof: a ladder anyway) with the constraint's per-proof point (CMZ: P, ten uses -- until round 6 a 16-teeth comb table per proof
+// and a 64-addition, 16-doubling walk per term), and V with Q.  partial[t2] becomes the identity: the sum of the MSM is unchanged.
+__device__ __forceinline__ void ladder_build8(uint4* __restrict__ tbl, ge_cached& c1, const dev_affine* __restrict__ pt) {
+  ge_p3 P, m2, m3, m4, m;
+  ge_cached c;
+  load_affine(P, pt);
+  ge_to_cached(c1, P);
+  ladder_store_entry(tbl, 0, c1);
+  ge_double<true>(m2, P);
+  ge_to_cached(c, m2); ladder_store_entry(tbl, 1, c);
+  ge_add_cached(m3, m2, c1);
+  ge_to_cached(c, m3); ladder_store_entry(tbl, 2, c);
+  ge_double<true>(m4, m2);
+  ge_to_cached(c, m4); ladder_store_entry(tbl, 3, c);
+  ge_add_cached(m, m4, c1);
+  ge_to_cached(c, m); ladder_store_entry(tbl, 4, c);
+  ge_double<true>(m, m3);
+  ge_to_cached(c, m); ladder_store_entry(tbl, 5, c);
+  ge_add_cached(m, m, c1);
+  ge_to_cached(c, m); ladder_store_entry(tbl, 6, c);
+  ge_double<true>(m, m4);
+  ge_to_cached(c, m); ladder_store_entry(tbl, 7, c);
+}
+__device__ __forceinline__ void term_ladder16_joint(uint32_t t, uint32_t t2, const uint8_t* __restrict__ scalars, const dev_affine* __restrict__ pt,
+                                                    const dev_affine* __restrict__ pt2, uint4* __restrict__ tbl, uint4* __restrict__ tbl2,
+                                                    dev_ext* __restrict__ partial, uint32_t* ecol) {
+  uint32_t top, top2;
+  {
+    uint32_t s[8], e[8];
+    load_vec<2>(s, scalars + 32 * (size_t)t);
+    sc_add_pattern(e, top, s, 0x88888888u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ecol[256 * j] = e[j];
+    load_vec<2>(s, scalars + 32 * (size_t)t2);
+    sc_add_pattern(e, top2, s, 0x88888888u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ecol[256 * (8 + j)] = e[j];
+  }
+  ge_p3 acc;
+  ge_identity(acc);
+  {
+    ge_cached c1;
+    ladder_build8(tbl, c1, pt);
+    if (top) ge_add_cached(acc, acc, c1);                       // carry out of bit 255: one more P at the top
+    ladder_build8(tbl2, c1, pt2);
+    if (top2) ge_add_cached(acc, acc, c1);
+  }
+#pragma unroll 1
+  for (int j = 7; j >= 0; --j) {
+    uint32_t cur = ecol[256 * j], cur2 = ecol[256 * (8 + j)];
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+      ge_double4(acc);
+      uint32_t nib = cur >> 28;
+      cur <<= 4;
+      uint32_t neg = (uint32_t)(nib < 8u);
+      uint32_t mag = neg ? 8u - nib : nib - 8u;                 // 0..8
+      ge_cached sel;
+      ladder_select<false>(sel, tbl, mag);
+      ge_cached_cneg(sel, neg);
+      ge_add_cached(acc, acc, sel);
+      nib = cur2 >> 28;
+      cur2 <<= 4;
+      neg = (uint32_t)(nib < 8u);
+      mag = neg ? 8u - nib : nib - 8u;
+      ladder_select<false>(sel, tbl2, mag);
+      ge_cached_cneg(sel, neg);
+      ge_add_cached(acc, acc, sel);
+    }
+  }
+  store_ext(partial + t, acc);
+  ge_identity(acc);
+  store_ext(partial + t2, acc);
+}
+
 }  // namespace zkp

@@ -643,15 +643,42 @@ struct fused_plan {
   const uint32_t* d_order = nullptr;  // constraints by descending number of terms (msm_map of the reduce / encode kernels)
   const uint32_t* d_inc = nullptr;
   std::vector<uint32_t> tpt;       // host copy of tpt[]: comb-table shape and table / ladder bounds of the flow's CSR job
+  std::vector<uint32_t> pair;      // FLOW_VERIFY: stmt_job::pair (empty: nothing pairs), d_pair = its device copy
+  const uint32_t* d_pair = nullptr;
   size_t img_bytes = 0;            // workspace of the step programs' images: max over the plan's programs of n_img * 21 words per proof (0 = no step form)
 };
+
+// Variable-time statement jobs: which terms share a chain of doublings (stmt_job::pair, term_ladder16_joint).  Per constraint, every term on a per-proof point
+// with ONE use in the statement (a ladder of its own) takes along one other per-proof term of the same constraint: first a term of a point with several uses
+// (which then may need no comb table at all), else another single-use term.  Empty when nothing pairs.
+std::vector<uint32_t> pair_terms(const uint32_t* toff, const uint32_t* tpt, uint32_t T1, uint32_t nc, uint32_t ns, uint32_t np) {
+  std::vector<uint32_t> u(np, 0), pair(T1, STMT_UNPAIRED);
+  for (uint32_t i = 0; i < T1; ++i) ++u[tpt[i]];
+  bool any = false;
+  for (uint32_t k = 0; k < nc; ++k) {
+    for (uint32_t h = toff[k]; h < toff[k + 1]; ++h) {
+      if (tpt[h] < ns || u[tpt[h]] != 1 || pair[h] != STMT_UNPAIRED) continue;
+      uint32_t partner = STMT_UNPAIRED;
+      for (uint32_t q = toff[k]; q < toff[k + 1] && partner == STMT_UNPAIRED; ++q)
+        if (q != h && tpt[q] >= ns && u[tpt[q]] >= 2 && pair[q] == STMT_UNPAIRED) partner = q;
+      for (uint32_t q = toff[k]; q < toff[k + 1] && partner == STMT_UNPAIRED; ++q)
+        if (q != h && tpt[q] >= ns && u[tpt[q]] == 1 && pair[q] == STMT_UNPAIRED) partner = q;
+      if (partner == STMT_UNPAIRED) continue;
+      pair[h] = partner;
+      pair[partner] = STMT_ABSORBED | h;
+      any = true;
+    }
+  }
+  if (!any) pair.clear();
+  return pair;
+}
 
 // Table / ladder bounds and comb shape of a CSR job whose proofs all multiply the point ids tpt[] (ids < ns: common to the
 // batch; the others: one point per proof).  A common point that is registered for a fixed-base table leaves the cold
 // classes at run time, which only lowers the counts.
-terms_cfg cfg_from_terms(const uint32_t* tpt, uint32_t T1, uint32_t ns, uint32_t np, uint32_t N, uint32_t comb_min) {
+terms_cfg cfg_from_terms(const uint32_t* tpt, uint32_t T1, uint32_t ns, uint32_t np, uint32_t N, uint32_t comb_min, const uint32_t* pair = nullptr) {
   std::vector<uint64_t> u(np, 0);
-  for (uint32_t i = 0; i < T1; ++i) ++u[tpt[i]];
+  for (uint32_t i = 0; i < T1; ++i) if (!stmt_absorbed(pair, i)) ++u[tpt[i]];      // (a term that rides on another's doubling chain is no use of its point)
   if (comb_min == 1) {
     // constant-time calls give single-use points a table only so that their 256 doublings run next to the table chains of
     // the shared points instead of inside the term kernel; a statement without shared points (DLEQ: B = x * H) has no
@@ -843,6 +870,7 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
     tarr.insert(tarr.end(), vsc.begin(), vsc.end());
     tarr.insert(tarr.end(), vpt.begin(), vpt.end());
     tarr.insert(tarr.end(), s.unref.begin(), s.unref.end());
+    pl->pair = pair_terms(tarr.data(), vpt.data(), pl->T1, nc, s.ns, s.np);
   } else {
     compile_allocations(ta, st, s, N, true);                            // batch_verifier.rs:92-94, :105-107, :125-128
     for (uint32_t k = 0; k < nc; ++k)                                    // :152-160 validating
@@ -851,7 +879,8 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
     pa = ta.finish(tailA);
     tbl_a = ta.tables();
   }
-  size_t order_at = 0;
+  size_t order_at = 0, pair_at = 0;
+  if (!pl->pair.empty()) { pair_at = tarr.size(); tarr.insert(tarr.end(), pl->pair.begin(), pl->pair.end()); }
   if (flow != FLOW_BATCH && nc) {       // tarr[0 .. nc] = term offsets of the flow's MSMs
     std::vector<uint32_t> order(nc);
     for (uint32_t k = 0; k < nc; ++k) order[k] = k;
@@ -930,6 +959,7 @@ int get_plan(zkp_ctx* c, char flow, const zkp_fused_statement* st, uint32_t N, u
   pl->img_bytes = (size_t)std::max(ok_a ? spa.n_img : 0u, ok_b ? spb.n_img : 0u) * 21 * 8 * N;
   pl->d_tarr = reinterpret_cast<const uint32_t*>(pl->d_block + o_t);
   pl->d_order = order_at ? pl->d_tarr + order_at : nullptr;
+  pl->d_pair = pair_at ? pl->d_tarr + pair_at : nullptr;
   pl->d_inc = reinterpret_cast<const uint32_t*>(pl->d_block + o_i);
   if (c->fused_plans.size() >= 64) free_fused_plans(c);        // a bound on what a long-lived context keeps
   *out = pl.get();
@@ -1170,6 +1200,19 @@ verify_inter verify_carve(const fused_plan& pl, size_t start) {
   o.end = cv.off;
   return o;
 }
+// the verifier's CSR job: bounds, statement structure and -- where the statement classifier runs -- the pairs of terms that share a doubling chain
+terms_cfg verify_terms_cfg(const zkp_ctx* c, const fused_plan& pl) {
+  const uint32_t N = pl.N, nc = pl.s.nc, T1 = pl.T1;
+  terms_cfg tk = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2);
+  tk.stmt.toff = pl.d_tarr; tk.stmt.tpt = pl.d_tarr + nc + 1 + T1; tk.stmt.N = N; tk.stmt.T = T1; tk.stmt.nc = nc; tk.stmt.ns = pl.s.ns; tk.stmt.np = pl.s.np;
+  tk.stmt.on = c->stmt_classify;
+  if (c->joint_ladder && pl.d_pair && stmt_classify_applies(tk, N * T1)) {
+    const terms_cfg paired = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2, pl.pair.data());
+    tk.max_tables = paired.max_tables; tk.max_ladder = paired.max_ladder; tk.teeth = paired.teeth;
+    tk.stmt.pair = pl.d_pair;
+  }
+  return tk;
+}
 int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t* d_ts, const uint8_t* d_tbl, const uint8_t* d_claim,
                 const uint8_t* d_resp, uint8_t* d_results, bool overlap, bool throughput, const std::function<int()>* late_inputs = nullptr, bool late_early = false) {
   const uint32_t N = pl.N, m = pl.s.m, nc = pl.s.nc, T1 = pl.T1, n_points = pl.s.ns + pl.s.ni * N;
@@ -1180,11 +1223,10 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
   prof_begin(c);
   const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
-  terms_cfg tk = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2);
+  terms_cfg tk = verify_terms_cfg(c, pl);
   tk.throughput = throughput;
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
-  tk.stmt.toff = pl.d_tarr; tk.stmt.tpt = pl.d_tarr + nc + 1 + T1; tk.stmt.N = N; tk.stmt.T = T1; tk.stmt.nc = nc; tk.stmt.ns = pl.s.ns; tk.stmt.np = pl.s.np;
-  tk.stmt.off = w.u32(o.off); tk.stmt.pidx = w.u32(o.pidx); tk.stmt.on = c->stmt_classify;
+  tk.stmt.off = w.u32(o.off); tk.stmt.pidx = w.u32(o.pidx);
   uint64_t* d_img = pl.img_bytes ? reinterpret_cast<uint64_t*>(w.base + o.img) : nullptr;
   offer_program(c, pl.a, N, hb, d_ts, nullptr, w.u32(o.failed), throughput, overlap, d_img);
   {   // side stream: operand indices and the point phase.  With no constraints there is no MSM, but every allocated
@@ -1581,7 +1623,7 @@ int zkp_fused_verify_compact_dev(zkp_ctx* c, const zkp_fused_statement* st, uint
   if (!d_transcripts || !d_challenges || !d_results || (s.m && !d_responses) || (s.np && !d_table)) return fail(ZKP_ERR_ARG, "NULL device pointer");
   if ((uint64_t)N * pl->T1 > 0x7fffffffull || (uint64_t)s.ns + (uint64_t)s.ni * N > 0x7fffffffull) return fail(ZKP_ERR_ARG, "batch too large");
   const verify_inter o = verify_carve(*pl, 0);
-  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1, N * s.nc, cfg_from_terms(pl->tpt.data(), pl->T1, s.ns, s.np, N, 2)));
+  rc = ensure_ws(c, o.end + terms_path_ws(s.ns + s.ni * N, N * pl->T1, N * s.nc, verify_terms_cfg(c, *pl)));
   if (rc) return rc;
   return verify_core(c, *pl, o, d_transcripts, d_table, d_challenges, d_responses, d_results, /*overlap=*/c->dev_overlap, /*throughput=*/!c->dev_latency);
 }

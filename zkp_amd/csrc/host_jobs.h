@@ -283,7 +283,7 @@ int verify_compact_job(zkp_ctx* c, const zkp_fused_statement* st, uint32_t N, ui
   const size_t o_res = cv.take((size_t)N);
   const size_t o_blob = cv.take(256);
   const verify_inter o = verify_carve(*pl, cv.off);
-  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * pl->T1, N * s.nc, cfg_from_terms(pl->tpt.data(), pl->T1, s.ns, s.np, N, 2)));
+  rc = ensure_ws(c, o.end + terms_path_ws(n_points, N * pl->T1, N * s.nc, verify_terms_cfg(c, *pl)));
   if (rc) return rc;
   rc = job_begin(c, 16);
   if (rc) return rc;

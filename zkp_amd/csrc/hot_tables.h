@@ -288,7 +288,13 @@ struct stmt_job {                      // device arrays of the plan + the shape
   uint32_t* off = nullptr;             // out: [N nc + 1]
   uint32_t* pidx = nullptr;            // out: [N T]
   bool on = false;
+  // variable-time jobs (round 6): pair[k] = k' < T -- statement term k (a point with one use: a 252-doubling ladder of its own) also carries term k' of its
+  // constraint through its doublings (term_ladder16_joint); pair[k'] = STMT_ABSORBED | k -- term k' is on no class list and counts as no use of its point;
+  // STMT_UNPAIRED otherwise.  nullptr: no pairs.
+  const uint32_t* pair = nullptr;
 };
+constexpr uint32_t STMT_UNPAIRED = 0xffffffffu, STMT_ABSORBED = 0x80000000u;
+__host__ __device__ inline bool stmt_absorbed(const uint32_t* pair, uint32_t k) { return pair && pair[k] != STMT_UNPAIRED && (pair[k] & STMT_ABSORBED); }
 __global__ void __launch_bounds__(256)
 k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t nreg, const uint32_t* __restrict__ reg_words, const int32_t* __restrict__ reg_slot,
                 uint32_t comb_min, uint32_t group_min, uint32_t max_tables, uint32_t* __restrict__ uses, uint32_t* __restrict__ class_start,
@@ -308,7 +314,7 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
   for (uint32_t p = tid; p < np; p += 256) { cnt[p] = 0; seen_p[p] = 0; }
   if (tid < HOT_CLASSES) cc[tid] = 0;
   __syncthreads();
-  for (uint32_t k = tid; k < T; k += 256) atomicAdd(&cnt[sj.tpt[k]], 1u);
+  for (uint32_t k = tid; k < T; k += 256) if (!stmt_absorbed(sj.pair, k)) atomicAdd(&cnt[sj.tpt[k]], 1u);
   __syncthreads();
   for (uint32_t p = tid; p < np; p += 256) {           // class of every point id; common points: fixed-base registry first
     int32_t c = -1;
@@ -344,6 +350,7 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
     sh[0] = n_stab; sh[1] = n_itab; sh[2] = SG; sh[3] = UG;
     // per-term ranks
     for (uint32_t k = 0; k < T; ++k) {
+      if (stmt_absorbed(sj.pair, k)) continue;
       const uint32_t p = sj.tpt[k];
       const int32_t c = cls_p[p];
       if (c == CLASS_GROUP) {
@@ -392,6 +399,7 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
     const uint32_t j = (uint32_t)(g / T), k = (uint32_t)(g % T);
     const uint32_t p = sj.tpt[k];
     sj.pidx[g] = p < ns ? p : ns + (p - ns) * N + j;
+    if (stmt_absorbed(sj.pair, k)) return;
     const int32_t c = cls_p[p];
     size_t pos;
     if (c == CLASS_GROUP) {

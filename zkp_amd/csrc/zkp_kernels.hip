@@ -174,7 +174,7 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
               const dev_ext* __restrict__ comb, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ class_start,
               const uint32_t* __restrict__ blk_start, const uint32_t* __restrict__ list, const dev_niels* __restrict__ tables,
               const dev_affine* __restrict__ pts, dev_ext* __restrict__ ladder_rw, uint32_t max_ladder, dev_ext* __restrict__ partial,
-              uint32_t ladder_stride) {
+              uint32_t ladder_stride, const uint32_t* __restrict__ pair, uint32_t stmt_T) {
   // A block of fixed-base terms serves ONE table; its rows pass through LDS one window at a time, in 16 copies, so that every
   // lane reads the entry its digit names from banks of its own (hot_tables.h): no masked scan, no bank conflict, the same
   // LDS cycles for every scalar.
@@ -207,7 +207,19 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
       if (i < n_ladder && i < max_ladder) {                       // (max_ladder bounds n_ladder by construction)
         const uint32_t t = list[n_hot + n_comb + i];
         const uint32_t pi = pidx[t];                              // < n_points (out-of-range indices are classed with the comb terms)
-        term_ladder16<CT>(t, scalars, pts + pi, reinterpret_cast<uint4*>(ladder_rw) + (size_t)(i >> 6) * LADDER_GROUP_UINT4 + (i & 63u), partial, ecol);
+        uint4* tbl = reinterpret_cast<uint4*>(ladder_rw) + (size_t)(i >> 6) * LADDER_GROUP_UINT4 + (i & 63u);
+        bool joint = false;
+        if constexpr (!CT && terms_lds_uint4<LOOKUP>() >= 1024) {  // (16 words of LDS per lane for the two recoded scalars)
+          // pair (variable-time statement jobs): this term carries another term of its MSM through its doublings; the tables of the second points lie behind
+          // those of the first ones
+          const uint32_t k2 = pair ? pair[t % stmt_T] : STMT_UNPAIRED;
+          if (k2 != STMT_UNPAIRED) {
+            const uint32_t t2 = t - t % stmt_T + k2, i2 = i + ((max_ladder + 63u) & ~63u);
+            term_ladder16_joint(t, t2, scalars, pts + pi, pts + pidx[t2], tbl, reinterpret_cast<uint4*>(ladder_rw) + (size_t)(i2 >> 6) * LADDER_GROUP_UINT4 + (i2 & 63u), partial, ecol);
+            joint = true;
+          }
+        }
+        if (!joint) term_ladder16<CT>(t, scalars, pts + pi, tbl, partial, ecol);
       }
     }
     ZKP_WAVE_T1(1);
@@ -1336,6 +1348,7 @@ struct zkp_ctx {
   static constexpr size_t kSplitCombTerms = 8192;   // narrow constant-time calls on the latency schedule from this many terms on: grouped walk + quad-split scans (ZKP_OPT_COMB_SPLIT)
   bool dev_overlap = false;          // ZKP_OPT_DEV_OVERLAP: the _dev flows fork their scalar-independent half onto the side stream too
   bool dev_latency = false;          // ZKP_OPT_DEV_OVERLAP = 2: the _dev flows run the whole latency schedule of the synchronous entry points (a lone caller's choice)
+  bool joint_ladder = true;          // ZKP_OPT_JOINT_LADDER: variable-time statement flows carry a second term of a constraint on a single-use point's doubling chain (1, default) or not (0)
   bool tr_steps = true;              // ZKP_OPT_TRANSCRIPT_STEPS: lane-pair transcripts as assemble + chain (1, default) or by the word-operation interpreter (0)
   int tr_lanes = -1;                 // ZKP_OPT_TRANSCRIPT_LANES: -1 = by entry point, 1 = one lane per proof, 2 = a lane pair per proof
   // The instruction-saving variants of the asynchronous entry points (ladder for single-use points, one transcript lane per
@@ -1513,7 +1526,7 @@ terms_layout terms_carve(size_t start, uint32_t n_points, uint32_t n_terms, uint
   o.slot_pt = cv.take(split ? (size_t)k.max_tables * 4 : 0);
   o.gstart = cv.take(split ? (size_t)n_points * 4 : 0);            // grouped comb terms: list range of a point
   o.comb = cv.take(split ? (size_t)k.max_tables * comb_entries(k.teeth) * sizeof(dev_ext) : 0);
-  o.ladder = cv.take(split ? (((size_t)k.max_ladder + 63) / 64) * LADDER_GROUP_UINT4 * sizeof(uint4) : 0);   // wave-interleaved groups of 64 tables (comb_tables.h)
+  o.ladder = cv.take(split ? (((size_t)k.max_ladder + 63) / 64) * (k.stmt.pair ? 2 : 1) * LADDER_GROUP_UINT4 * sizeof(uint4) : 0);   // wave-interleaved groups of 64 tables (comb_tables.h)
   const uint32_t enc_blocks = (n_msm + ENC_BLOCK - 1) / ENC_BLOCK;
   o.half = cv.take(split ? (size_t)n_terms * 32 : 0);            // (batched encoder: reserved whenever it could be chosen)
   o.states = cv.take(split ? (size_t)n_msm * 54 * 4 : 0);
@@ -1535,7 +1548,7 @@ inline bool terms_batched_encode(const zkp_ctx* c, uint32_t n_terms, uint32_t n_
 template <bool CT, int TEETH, int LOOKUP>
 void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_scalars, const uint32_t* d_pidx, uint32_t n_points, const dev_ext* comb,
                         const uint32_t* slot_of, const uint32_t* class_start, const uint32_t* blk_start, const uint32_t* list,
-                        const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part, uint32_t comb_split) {
+                        const dev_affine* pts, dev_ext* ladder_rw, uint32_t max_ladder, dev_ext* part, uint32_t comb_split, const uint32_t* pair, uint32_t stmt_T) {
   // ladder blocks spread over the first half of the grid (ZKP_OPT_LADDER_INTERLEAVE), or all at the front
   uint32_t stride = 0;
   const uint32_t lb = (max_ladder + 255) / 256;
@@ -1551,16 +1564,16 @@ void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_sca
   if constexpr (CT && TEETH == 16 && LOOKUP == LOOKUP_XBAR) {
     if (comb_split && !ladder) {                                   // (the caller asks for it on narrow calls only: they have no ladder class)
       hipLaunchKernelGGL((k_terms_split<CT, TEETH, false, LOOKUP, true>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
-                         c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
+                         c->hot_tables, pts, ladder_rw, max_ladder, part, stride, pair, stmt_T);
       return;
     }
   }
   if (ladder)
     hipLaunchKernelGGL((k_terms_split<CT, TEETH, true, LOOKUP>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
-                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
+                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride, pair, stmt_T);
   else
     hipLaunchKernelGGL((k_terms_split<CT, TEETH, false, LOOKUP>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,
-                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride);
+                       c->hot_tables, pts, ladder_rw, max_ladder, part, stride, pair, stmt_T);
 }
 
 // phase: everything (default), or only the part that does not look at the scalars (decode, classification, comb tables:
@@ -1603,6 +1616,9 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
                           : c->grouped_comb < 0 ? (n_terms >= (k.throughput ? zkp_ctx::kWideCallTerms : zkp_ctx::kGroupedCombTerms) || lat_split) : c->grouped_comb != 0;
     const bool comb_split = lat_split && flags == ZKP_CT && k.teeth == 16 && !(HOT_LDS_ROWS && c->ct_lookup != LOOKUP_XBAR);
     const uint32_t group_min = (flags == ZKP_CT && k.teeth == 16 && group_on && k.max_tables) ? GROUP_MIN_USES : 0xffffffffu;
+    // (a caller that pairs terms sized its bounds for the pairs: it only does so where the statement classifier runs)
+    const bool pair_on = k.stmt.pair && flags == ZKP_VARTIME && stmt_classify_applies(k, n_terms);
+    if (k.stmt.pair && !pair_on) return fail(ZKP_ERR_ARG, "paired terms outside the statement classifier");
     uint32_t* gstart = reinterpret_cast<uint32_t*>(base + o.gstart);
     uint32_t* gfill = reinterpret_cast<uint32_t*>(base + o.gfill);
     if ((phase & PH_POINTS) && stmt_classify_applies(k, n_terms)) {
@@ -1672,7 +1688,7 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     if (phase & PH_SCALARS) {
       // (vartime calls have nothing to hide: they never scan)
       const int lookup = (!HOT_LDS_ROWS || c->ct_lookup == LOOKUP_XBAR) ? LOOKUP_XBAR : (flags == ZKP_CT ? c->ct_lookup : LOOKUP_LDS);
-#define ZKP_LAUNCH_TERMS(CT_, TEETH_, LK_) launch_terms_split<CT_, TEETH_, LK_>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part, comb_split ? 1u : 0u)
+#define ZKP_LAUNCH_TERMS(CT_, TEETH_, LK_) launch_terms_split<CT_, TEETH_, LK_>(c, grid, k.max_ladder != 0, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list, pts, ladder, k.max_ladder, part, comb_split ? 1u : 0u, pair_on ? k.stmt.pair : (const uint32_t*)nullptr, k.stmt.T)
       if (lookup == LOOKUP_XBAR) {
         if (flags == ZKP_CT) { if (k.teeth == 16) ZKP_LAUNCH_TERMS(true, 16, LOOKUP_XBAR); else ZKP_LAUNCH_TERMS(true, 4, LOOKUP_XBAR); }
         else { if (k.teeth == 16) ZKP_LAUNCH_TERMS(false, 16, LOOKUP_XBAR); else ZKP_LAUNCH_TERMS(false, 4, LOOKUP_XBAR); }
@@ -1980,6 +1996,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
+    case ZKP_OPT_JOINT_LADDER: c->joint_ladder = value != 0; return ZKP_OK;
     case ZKP_OPT_COMB_SPLIT: c->comb_split = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_CT_LOOKUP:
       if (value == ~0ull) value = 0;

@@ -18,7 +18,7 @@ ZKP_TESTOPT_DUMMY_LAUNCHES, ZKP_TESTOPT_GENERIC_CLASSIFIER, ZKP_TESTOPT_WAVE_CYC
 ZKP_OPT_CT_LOOKUP, ZKP_OPT_EACH_STRAUS, ZKP_OPT_LADDER_INTERLEAVE = 9, 10, 11
 ZKP_OPT_CT_MASKED_SCANS = ZKP_OPT_CT_LOOKUP           # the round-3 name (value 1 = masked scans)
 ZKP_CT_LOOKUP_XBAR, ZKP_CT_LOOKUP_SCAN, ZKP_CT_LOOKUP_LDS = 0, 1, 2
-ZKP_OPT_WS_LIMIT_BYTES, ZKP_OPT_JOB_DEFER_D2H, ZKP_OPT_SYNC_SCHEDULE, ZKP_OPT_TRANSCRIPT_STEPS, ZKP_OPT_COMB_SPLIT = 12, 13, 14, 15, 16
+ZKP_OPT_WS_LIMIT_BYTES, ZKP_OPT_JOB_DEFER_D2H, ZKP_OPT_SYNC_SCHEDULE, ZKP_OPT_TRANSCRIPT_STEPS, ZKP_OPT_COMB_SPLIT, ZKP_OPT_JOINT_LADDER = 12, 13, 14, 15, 16, 17
 
 ZKP_VARTIME = 0
 ZKP_CT = 1

@@ -24,7 +24,9 @@ PATTERNS = ["zero", "one", "l-1", "all-ones-252", "one random scalar for all", "
 # (ZKP_OPT_CT_SINGLE_USE_TABLES, ZKP_OPT_GROUPED_COMB, ZKP_OPT_CT_LOOKUP).  Look-up 0 = lane crossbar (round 5 default: fixed-base rows and grouped comb rows
 # in registers, entries over ds_bpermute_b32), 1 = masked scans everywhere, 2 = LDS rows read at the digit's index (rounds 2 - 4).  Schedules: tables + comb
 # scans; ladder for single-use points; the grouped comb walk; then the two other look-ups
-SCHEDULES = ((1, 0, 0), (0, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 2))
+# Round 6, fourth field = ZKP_OPT_COMB_SPLIT (0: one lane per masked comb scan, as in rounds 2 - 5; 1: a quad of lanes per scan, the default of this job's size on
+# the latency schedule).  The last schedule is that default as a whole: tables for single-use points, grouped walk AND quad scans.
+SCHEDULES = ((1, 0, 0, 0), (0, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 1, 2, 0), (1, 1, 0, 1))
 LOOKUP_NAMES = {0: "lane crossbar", 1: "masked scans", 2: "LDS rows at the digit's index"}
 _last_random = [None]
 
@@ -67,12 +69,13 @@ def run():
     eng.prepare_fixed_points(pts[:11])
     # a table for every cold point with masked scans; the constant-time radix-16 ladder for single-use points; the same with the
     # grouped comb walk through LDS (ZKP_OPT_GROUPED_COMB, the default of large calls)
-    for single_use_tables, grouped, masked in SCHEDULES:
+    for single_use_tables, grouped, masked, split in SCHEDULES:
         if masked not in eng.ct_lookups:
             continue                            # (look-ups 1 and 2: -DZKP_HOT_W=6 builds only)
         eng.set_option(3, single_use_tables)    # ZKP_OPT_CT_SINGLE_USE_TABLES
         eng.set_option(6, grouped)
         eng.set_option(9, masked)               # ZKP_OPT_CT_LOOKUP
+        eng.set_option(16, split)               # ZKP_OPT_COMB_SPLIT
         for kind in PATTERNS:                   # one msm_many(ZKP_CT) call per pattern, in this order
             out, st = eng.msm_many(off, scalars(kind, 31 * n, rng), pidx, pts, ZKP_CT)
             assert not st.any()
@@ -132,12 +135,13 @@ def cycles():
     print("# columns: " + " | ".join(PATTERNS))
     verdict = True
     activity = {}
-    for single_use_tables, grouped, masked in SCHEDULES:
+    for single_use_tables, grouped, masked, split in SCHEDULES:
         if masked not in eng.ct_lookups:
             continue
         eng.set_option(3, single_use_tables)
         eng.set_option(6, grouped)
         eng.set_option(9, masked)
+        eng.set_option(16, split)
         med, noise = {}, {}
         for kind in PATTERNS:
             sc = scalars(kind, 31 * n, rng)
@@ -153,7 +157,7 @@ def cycles():
             for c, v in acc.items():
                 med.setdefault(c, []).append(float(np.median(v)))
                 noise[c] = max(noise.get(c, 0.0), float(max(v) - min(v)))     # launch-to-launch spread of the SAME input
-        print("schedule: single-use tables = %d, grouped walk = %d, look-up = %s" % (single_use_tables, grouped, LOOKUP_NAMES[masked]))
+        print("schedule: single-use tables = %d, grouped walk = %d, look-up = %s, comb scans on %s" % (single_use_tables, grouped, LOOKUP_NAMES[masked], "quads of lanes" if split else "one lane"))
         for c in sorted(med):
             v = np.array(med[c])
             spread = float(v.max() - v.min())

@@ -1560,7 +1560,9 @@ void launch_terms_split(zkp_ctx* c, dim3 grid, bool ladder, const uint8_t* d_sca
     if (stride % 2 == 0 && stride) --stride;
     if (stride < 2) stride = 0;
   }
-  prof_note(c, ZKP_K_TERMS, std::string("k_terms_split<") + (CT ? "true" : "false") + ", " + std::to_string(TEETH) + ", " + (ladder ? "true" : "false") + ", " + std::to_string(LOOKUP) + ">");
+  const bool split_kernel = CT && TEETH == 16 && LOOKUP == LOOKUP_XBAR && comb_split && !ladder;
+  prof_note(c, ZKP_K_TERMS, std::string("k_terms_split<") + (CT ? "true" : "false") + ", " + std::to_string(TEETH) + ", " + (ladder ? "true" : "false") + ", " + std::to_string(LOOKUP) + ", " +
+                            (split_kernel ? "true" : "false") + ">");
   if constexpr (CT && TEETH == 16 && LOOKUP == LOOKUP_XBAR) {
     if (comb_split && !ladder) {                                   // (the caller asks for it on narrow calls only: they have no ladder class)
       hipLaunchKernelGGL((k_terms_split<CT, TEETH, false, LOOKUP, true>), grid, dim3(256), 0, c->stream, d_scalars, d_pidx, n_points, comb, slot_of, class_start, blk_start, list,

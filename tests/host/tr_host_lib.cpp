@@ -154,3 +154,14 @@ extern "C" int t_tr_merge_selftest() {
   }
   return bad ? -bad : 1;
 }
+
+// The pairing rule of variable-time statement jobs (zkp_amd/csrc/stmt_pairs.h: which verifier terms share a chain of doublings), as the plan calls it.
+#include "../../zkp_amd/csrc/stmt_pairs.h"
+extern "C" int t_pair_terms(const uint32_t* toff, const uint32_t* tpt, uint32_t T1, uint32_t nc, uint32_t ns, uint32_t np, uint32_t* out) {
+  const std::vector<uint32_t> p = zkp::pair_terms(toff, tpt, T1, nc, ns, np);
+  if (p.empty()) return 0;
+  for (uint32_t i = 0; i < T1; ++i) out[i] = p[i];
+  int absorbed = 0;
+  for (uint32_t i = 0; i < T1; ++i) absorbed += zkp::stmt_absorbed(p.data(), i) ? 1 : 0;
+  return absorbed;
+}

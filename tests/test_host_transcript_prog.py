@@ -12,14 +12,24 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "..", "zkp_amd", "csrc")
 
 
+_LIB = []
+
+
+def _lib():
+    """the host build of the headers under test (tests/host/tr_host_lib.cpp), rebuilt when a source is newer"""
+    if not _LIB:
+        out = os.path.join(HERE, "host", "tr_host_lib.so")
+        srcs = [os.path.join(HERE, "host", "tr_host_lib.cpp"), os.path.join(CSRC, "host", "merlin.cpp")]
+        deps = srcs + [os.path.join(CSRC, "merlin_prog.h"), os.path.join(CSRC, "host", "merlin.hpp"), os.path.join(CSRC, "stmt_pairs.h")]
+        if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC"] + srcs + ["-o", out])
+        _LIB.append(ctypes.CDLL(out))
+    return _LIB[0]
+
+
 @pytest.fixture(scope="module")
 def lib():
-    out = os.path.join(HERE, "host", "tr_host_lib.so")
-    srcs = [os.path.join(HERE, "host", "tr_host_lib.cpp"), os.path.join(CSRC, "host", "merlin.cpp")]
-    deps = srcs + [os.path.join(CSRC, "merlin_prog.h"), os.path.join(CSRC, "host", "merlin.hpp")]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC"] + srcs + ["-o", out])
-    return ctypes.CDLL(out)
+    return _lib()
 
 
 @pytest.mark.parametrize("args", [

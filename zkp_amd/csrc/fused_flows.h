@@ -648,31 +648,6 @@ struct fused_plan {
   size_t img_bytes = 0;            // workspace of the step programs' images: max over the plan's programs of n_img * 21 words per proof (0 = no step form)
 };
 
-// Variable-time statement jobs: which terms share a chain of doublings (stmt_job::pair, term_ladder16_joint).  Per constraint, every term on a per-proof point
-// with ONE use in the statement (a ladder of its own) takes along one other per-proof term of the same constraint: first a term of a point with several uses
-// (which then may need no comb table at all), else another single-use term.  Empty when nothing pairs.
-std::vector<uint32_t> pair_terms(const uint32_t* toff, const uint32_t* tpt, uint32_t T1, uint32_t nc, uint32_t ns, uint32_t np) {
-  std::vector<uint32_t> u(np, 0), pair(T1, STMT_UNPAIRED);
-  for (uint32_t i = 0; i < T1; ++i) ++u[tpt[i]];
-  bool any = false;
-  for (uint32_t k = 0; k < nc; ++k) {
-    for (uint32_t h = toff[k]; h < toff[k + 1]; ++h) {
-      if (tpt[h] < ns || u[tpt[h]] != 1 || pair[h] != STMT_UNPAIRED) continue;
-      uint32_t partner = STMT_UNPAIRED;
-      for (uint32_t q = toff[k]; q < toff[k + 1] && partner == STMT_UNPAIRED; ++q)
-        if (q != h && tpt[q] >= ns && u[tpt[q]] >= 2 && pair[q] == STMT_UNPAIRED) partner = q;
-      for (uint32_t q = toff[k]; q < toff[k + 1] && partner == STMT_UNPAIRED; ++q)
-        if (q != h && tpt[q] >= ns && u[tpt[q]] == 1 && pair[q] == STMT_UNPAIRED) partner = q;
-      if (partner == STMT_UNPAIRED) continue;
-      pair[h] = partner;
-      pair[partner] = STMT_ABSORBED | h;
-      any = true;
-    }
-  }
-  if (!any) pair.clear();
-  return pair;
-}
-
 // Table / ladder bounds and comb shape of a CSR job whose proofs all multiply the point ids tpt[] (ids < ns: common to the
 // batch; the others: one point per proof).  A common point that is registered for a fixed-base table leaves the cold
 // classes at run time, which only lowers the counts.

@@ -21,6 +21,7 @@
 // SQ_LDS_BANK_CONFLICT next to the instruction counters.
 #pragma once
 #include "dev_layout.h"
+#include "stmt_pairs.h"
 
 namespace zkp {
 
@@ -288,13 +289,10 @@ struct stmt_job {                      // device arrays of the plan + the shape
   uint32_t* off = nullptr;             // out: [N nc + 1]
   uint32_t* pidx = nullptr;            // out: [N T]
   bool on = false;
-  // variable-time jobs (round 6): pair[k] = k' < T -- statement term k (a point with one use: a 252-doubling ladder of its own) also carries term k' of its
-  // constraint through its doublings (term_ladder16_joint); pair[k'] = STMT_ABSORBED | k -- term k' is on no class list and counts as no use of its point;
-  // STMT_UNPAIRED otherwise.  nullptr: no pairs.
+  // variable-time jobs (round 6): which terms share a chain of doublings (stmt_pairs.h); nullptr: no pairs
   const uint32_t* pair = nullptr;
 };
-constexpr uint32_t STMT_UNPAIRED = 0xffffffffu, STMT_ABSORBED = 0x80000000u;
-__host__ __device__ inline bool stmt_absorbed(const uint32_t* pair, uint32_t k) { return pair && pair[k] != STMT_UNPAIRED && (pair[k] & STMT_ABSORBED); }
+
 __global__ void __launch_bounds__(256)
 k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t nreg, const uint32_t* __restrict__ reg_words, const int32_t* __restrict__ reg_slot,
                 uint32_t comb_min, uint32_t group_min, uint32_t max_tables, uint32_t* __restrict__ uses, uint32_t* __restrict__ class_start,

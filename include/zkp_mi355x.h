@@ -149,7 +149,9 @@ const char* zkp_version(void);
  *   ZKP_OPT_JOINT_LADDER: variable-time statement flows (zkp_fused_verify_compact*: commitment = sum s_i P_i - c LHS per constraint, verifier.rs:95-106).  The
  *     left-hand side is multiplied once per proof -- a chain of 252 doublings of its own.  1 (default): that chain also carries ONE other per-proof term of the
  *     constraint (Straus interleaving: eight multiples + 64 additions, no doublings, no comb table) -- CMZ: P joins C_i's chain in ten constraints and needs no
- *     table, Q joins V's: 11 chains instead of 12 and no 16-teeth table per proof.  0 = every term on its own (rounds 2 - 5).  Same bytes.
+ *     table, Q joins V's: 11 chains instead of 12 and no 16-teeth table per proof.  A per-proof point ALL of whose terms ride (P) gets a table of its multiples
+ *     1 .. 128 where its comb table was: its riders add one signed 8-bit digit per byte (32 additions instead of 64) and build no multiples of their own;
+ *     2 = pairs without these tables.  0 = every term on its own (rounds 2 - 5).  Same bytes.
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,
        ZKP_OPT_FUSE_TABLES_TRANSCRIPT = 8, ZKP_OPT_CT_LOOKUP = 9, ZKP_OPT_CT_MASKED_SCANS = 9 /* round-3 name: value 1 still selects the scans */, ZKP_OPT_EACH_STRAUS = 10, ZKP_OPT_LADDER_INTERLEAVE = 11, ZKP_OPT_WS_LIMIT_BYTES = 12, ZKP_OPT_JOB_DEFER_D2H = 13, ZKP_OPT_SYNC_SCHEDULE = 14, ZKP_OPT_TRANSCRIPT_STEPS = 15, ZKP_OPT_COMB_SPLIT = 16, ZKP_OPT_JOINT_LADDER = 17 };

@@ -690,7 +690,7 @@ def test_verify_compact_joint_ladder_equals_separate_terms():
                 bad_resp[(3 + i) % n, i, (5 * i) % 31] ^= 1 << (i % 8)
                 want[(3 + i) % n] = 1
             results = {}
-            for opt in (1, 0):
+            for opt in (1, 2, 0):                                        # pairs + tables of multiples for points whose terms all ride / pairs only / separate terms
                 e = Engine(0)
                 e.set_option(17, opt)
                 ok = T.verify_compact_batch(e, st, _fresh(label, n), inst, common, chal, resp)

@@ -24,6 +24,7 @@
 //     entry 8 j + (k-1) = k * 2^(BITS j) * P   (j < TEETH, k = 1..8),      entry 8 TEETH = 2^256 * P  (carry window)
 #pragma once
 #include "quad.h"
+#include "stmt_pairs.h"
 
 namespace zkp {
 
@@ -96,6 +97,7 @@ k_comb_tables(const uint32_t* __restrict__ n_slots, uint32_t max_tables, const u
   const uint32_t ns = min(*n_slots, max_tables);
   if (slot >= ns) return;                                 // uniform within the quad
   const uint32_t pi = slot_pt[slot];
+  if (pi & STMT_ABSORBED) return;                         // (a table of multiples, not a comb: k_rider_tables)
   qpt base;
   {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(pts + pi);      // x[9] y[9] t[9] valid
@@ -147,6 +149,7 @@ __device__ __forceinline__ void comb_table_lane(uint32_t slot, const uint32_t* _
   using cfg = comb_cfg<TEETH>;
   const uint32_t ns = min(*n_slots, max_tables);
   if (slot >= ns) return;
+  if (slot_pt[slot] & STMT_ABSORBED) return;              // (a table of multiples, not a comb: k_rider_tables)
   ge_p3 base;
   load_affine(base, pts + slot_pt[slot]);
   dev_ext* tbl = comb + (size_t)slot * cfg::ENTRIES;
@@ -198,7 +201,7 @@ __device__ __forceinline__ void comb_table_pc(uint32_t slot0, const uint32_t* __
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t ns = min(*n_slots, max_tables);
   const uint32_t slot = slot0 + lane;
-  const bool have = slot < ns;
+  const bool have = slot < ns && !(slot_pt[slot < ns ? slot : 0u] & STMT_ABSORBED);     // (not the tables of multiples: k_rider_tables)
   dev_ext* tbl = comb + (size_t)(have ? slot : 0u) * cfg::ENTRIES;
   if (wave == 0) {
     ge_p3 base;
@@ -867,6 +870,32 @@ __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restr
   store_ext(partial + t, acc);
 }
 
+// Tables of the multiples 1 P .. 128 P for per-proof points whose terms all ride on other terms' doubling chains (stmt_pairs.h: stmt_rider), in the place a
+// 16-teeth comb table would take (129 entries; entry k - 1 = k P in the cached form).  One lane per table: a chain of 127 additions.
+__global__ void __launch_bounds__(256, 2)
+k_rider_tables(const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt, const dev_affine* __restrict__ pts,
+               dev_ext* __restrict__ comb) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= min(*n_slots, max_tables)) return;
+  const uint32_t pi = slot_pt[slot];
+  if (!(pi & STMT_ABSORBED)) return;
+  ge_p3 P, m;
+  load_affine(P, pts + (pi & ~STMT_ABSORBED));
+  dev_ext* tbl = comb + (size_t)slot * comb_cfg<16>::ENTRIES;
+  ge_cached c1, c;
+  ge_to_cached(c1, P);
+  store_comb_entry(tbl, c1);
+  ge_double<true>(m, P);
+  ge_to_cached(c, m);
+  store_comb_entry(tbl + 1, c);
+#pragma unroll 1
+  for (int k = 2; k < 128; ++k) {
+    ge_add_cached(m, m, c1);
+    ge_to_cached(c, m);
+    store_comb_entry(tbl + k, c);
+  }
+}
+
 // Two terms of one MSM on ONE chain of doublings (variable time; round 6): acc = s1 * P1 + s2 * P2 by interleaving (Straus) -- the second term costs its eight
 // multiples and its 64 additions, no doublings, no comb table.  The verifier's constraints  commitment = sum s_i P_i - c * LHS  (verifier.rs:95-106) pair the
 // left-hand side (one use per proof: a ladder anyway) with the constraint's per-proof point (CMZ: P, ten uses -- until round 6 a 16-teeth comb table per proof
@@ -892,9 +921,11 @@ __device__ __forceinline__ void ladder_build8(uint4* __restrict__ tbl, ge_cached
   ge_double<true>(m, m4);
   ge_to_cached(c, m); ladder_store_entry(tbl, 7, c);
 }
+// rider (optional): the second point's table of multiples 1 .. 128 (k_rider_tables) -- its term then adds one signed 8-bit digit per byte (32 additions) and
+// builds nothing; nullptr: eight multiples of its own in tbl2, one signed nibble digit per nibble (64 additions).
 __device__ __forceinline__ void term_ladder16_joint(uint32_t t, uint32_t t2, const uint8_t* __restrict__ scalars, const dev_affine* __restrict__ pt,
                                                     const dev_affine* __restrict__ pt2, uint4* __restrict__ tbl, uint4* __restrict__ tbl2,
-                                                    dev_ext* __restrict__ partial, uint32_t* ecol) {
+                                                    const dev_ext* __restrict__ rider, dev_ext* __restrict__ partial, uint32_t* ecol) {
   uint32_t top, top2;
   {
     uint32_t s[8], e[8];
@@ -903,7 +934,7 @@ __device__ __forceinline__ void term_ladder16_joint(uint32_t t, uint32_t t2, con
 #pragma unroll
     for (int j = 0; j < 8; ++j) ecol[256 * j] = e[j];
     load_vec<2>(s, scalars + 32 * (size_t)t2);
-    sc_add_pattern(e, top2, s, 0x88888888u);
+    sc_add_pattern(e, top2, s, rider ? 0x80808080u : 0x88888888u);    // digits byte - 128 in [-128, 127] / nibble - 8 in [-8, 7]
 #pragma unroll
     for (int j = 0; j < 8; ++j) ecol[256 * (8 + j)] = e[j];
   }
@@ -913,7 +944,8 @@ __device__ __forceinline__ void term_ladder16_joint(uint32_t t, uint32_t t2, con
     ge_cached c1;
     ladder_build8(tbl, c1, pt);
     if (top) ge_add_cached(acc, acc, c1);                       // carry out of bit 255: one more P at the top
-    ladder_build8(tbl2, c1, pt2);
+    if (rider) load_comb_entry(c1, rider);
+    else ladder_build8(tbl2, c1, pt2);
     if (top2) ge_add_cached(acc, acc, c1);
   }
 #pragma unroll 1
@@ -930,13 +962,26 @@ __device__ __forceinline__ void term_ladder16_joint(uint32_t t, uint32_t t2, con
       ladder_select<false>(sel, tbl, mag);
       ge_cached_cneg(sel, neg);
       ge_add_cached(acc, acc, sel);
-      nib = cur2 >> 28;
-      cur2 <<= 4;
-      neg = (uint32_t)(nib < 8u);
-      mag = neg ? 8u - nib : nib - 8u;
-      ladder_select<false>(sel, tbl2, mag);
-      ge_cached_cneg(sel, neg);
-      ge_add_cached(acc, acc, sel);
+      if (rider) {
+        if (k & 1) {                                             // a byte of the second scalar is complete: 256^b = 16^(2 b)
+          const uint32_t v = cur2 >> 24;
+          cur2 <<= 8;
+          neg = (uint32_t)(v < 128u);
+          mag = neg ? 128u - v : v - 128u;                      // 0..128
+          ge_cached_identity(sel);
+          if (mag) load_comb_entry(sel, rider + (mag - 1u));
+          ge_cached_cneg(sel, neg);
+          ge_add_cached(acc, acc, sel);
+        }
+      } else {
+        nib = cur2 >> 28;
+        cur2 <<= 4;
+        neg = (uint32_t)(nib < 8u);
+        mag = neg ? 8u - nib : nib - 8u;
+        ladder_select<false>(sel, tbl2, mag);
+        ge_cached_cneg(sel, neg);
+        ge_add_cached(acc, acc, sel);
+      }
     }
   }
   store_ext(partial + t, acc);

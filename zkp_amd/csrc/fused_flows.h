@@ -651,9 +651,9 @@ struct fused_plan {
 // Table / ladder bounds and comb shape of a CSR job whose proofs all multiply the point ids tpt[] (ids < ns: common to the
 // batch; the others: one point per proof).  A common point that is registered for a fixed-base table leaves the cold
 // classes at run time, which only lowers the counts.
-terms_cfg cfg_from_terms(const uint32_t* tpt, uint32_t T1, uint32_t ns, uint32_t np, uint32_t N, uint32_t comb_min, const uint32_t* pair = nullptr) {
-  std::vector<uint64_t> u(np, 0);
-  for (uint32_t i = 0; i < T1; ++i) if (!stmt_absorbed(pair, i)) ++u[tpt[i]];      // (a term that rides on another's doubling chain is no use of its point)
+terms_cfg cfg_from_terms(const uint32_t* tpt, uint32_t T1, uint32_t ns, uint32_t np, uint32_t N, uint32_t comb_min, const uint32_t* pair = nullptr, bool riders = false) {
+  std::vector<uint64_t> u(np, 0), a(np, 0);
+  for (uint32_t i = 0; i < T1; ++i) ++(stmt_absorbed(pair, i) ? a : u)[tpt[i]];    // (a term that rides on another's doubling chain is no use of its point)
   if (comb_min == 1) {
     // constant-time calls give single-use points a table only so that their 256 doublings run next to the table chains of
     // the shared points instead of inside the term kernel; a statement without shared points (DLEQ: B = x * H) has no
@@ -666,6 +666,8 @@ terms_cfg cfg_from_terms(const uint32_t* tpt, uint32_t T1, uint32_t ns, uint32_t
   for (uint32_t p = 0; p < np; ++p) {
     const uint64_t mult = p < ns ? 1 : N, uses = p < ns ? u[p] * N : u[p];
     if (uses >= comb_min && uses) { n_tab += mult; tab_terms += uses * mult; } else if (uses == 1) n_lad += mult;
+    // a table of multiples for a per-proof point all of whose terms ride (stmt_rider): counted like a comb table, its riders like table terms
+    if (riders && stmt_rider(1u, p, ns, (uint32_t)std::min<uint64_t>(u[p], 0xffffffffu), (uint32_t)std::min<uint64_t>(a[p], 0xffffffffu))) { n_tab += mult; tab_terms += a[p] * mult; }
   }
   terms_cfg k;
   k.comb_min = comb_min;
@@ -1182,9 +1184,10 @@ terms_cfg verify_terms_cfg(const zkp_ctx* c, const fused_plan& pl) {
   tk.stmt.toff = pl.d_tarr; tk.stmt.tpt = pl.d_tarr + nc + 1 + T1; tk.stmt.N = N; tk.stmt.T = T1; tk.stmt.nc = nc; tk.stmt.ns = pl.s.ns; tk.stmt.np = pl.s.np;
   tk.stmt.on = c->stmt_classify;
   if (c->joint_ladder && pl.d_pair && stmt_classify_applies(tk, N * T1)) {
-    const terms_cfg paired = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2, pl.pair.data());
+    const terms_cfg paired = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2, pl.pair.data(), c->rider_tables);
     tk.max_tables = paired.max_tables; tk.max_ladder = paired.max_ladder; tk.teeth = paired.teeth;
     tk.stmt.pair = pl.d_pair;
+    tk.rider_tables = c->rider_tables;           // (the classifier hands them out only if the job's tables have 16 teeth: 129 entries hold 128 multiples)
   }
   return tk;
 }

@@ -297,8 +297,9 @@ __global__ void __launch_bounds__(256)
 k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t nreg, const uint32_t* __restrict__ reg_words, const int32_t* __restrict__ reg_slot,
                 uint32_t comb_min, uint32_t group_min, uint32_t max_tables, uint32_t* __restrict__ uses, uint32_t* __restrict__ class_start,
                 uint32_t* __restrict__ blk_start, uint32_t* __restrict__ n_slots, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ slot_pt,
-                uint32_t* __restrict__ list) {
+                uint32_t* __restrict__ list, uint32_t rider_ok) {
   __shared__ uint32_t cnt[STMT_MAX_POINTS];            // terms of the statement on point id p
+  __shared__ uint32_t acnt[STMT_MAX_POINTS];           // ... that ride on another term's doubling chain (stmt_pairs.h)
   __shared__ int32_t cls_p[STMT_MAX_POINTS];           // class of the terms on p
   __shared__ uint32_t rank_p[STMT_MAX_POINTS];         // table rank (static: among static table points; instance: among instance ones), or NONE
   __shared__ uint32_t goff_p[STMT_MAX_POINTS];         // grouped points: offset of p's group (static: in the static part; instance: inside a proof's part)
@@ -306,13 +307,13 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
   __shared__ uint32_t seen_p[STMT_MAX_POINTS];         // (running count of the terms of p while the ranks are handed out)
   __shared__ uint32_t cstart[HOT_CLASSES + 1];
   __shared__ uint32_t cc[HOT_CLASSES];                 // statement terms per class
-  __shared__ uint32_t sh[4];                           // n_static_tab | n_inst_tab | SG (static grouped terms per proof) | UG (instance grouped terms per proof)
+  __shared__ uint32_t sh[5];                           // n_static_tab | n_inst_tab | SG (static grouped terms per proof) | UG (instance grouped terms per proof) | ladder terms whose rider has a table
   constexpr uint32_t NONE = 0xffffffffu;
   const uint32_t tid = threadIdx.x, N = sj.N, T = sj.T, ns = sj.ns, np = sj.np;
-  for (uint32_t p = tid; p < np; p += 256) { cnt[p] = 0; seen_p[p] = 0; }
+  for (uint32_t p = tid; p < np; p += 256) { cnt[p] = 0; seen_p[p] = 0; acnt[p] = 0; }
   if (tid < HOT_CLASSES) cc[tid] = 0;
   __syncthreads();
-  for (uint32_t k = tid; k < T; k += 256) if (!stmt_absorbed(sj.pair, k)) atomicAdd(&cnt[sj.tpt[k]], 1u);
+  for (uint32_t k = tid; k < T; k += 256) atomicAdd(stmt_absorbed(sj.pair, k) ? &acnt[sj.tpt[k]] : &cnt[sj.tpt[k]], 1u);
   __syncthreads();
   for (uint32_t p = tid; p < np; p += 256) {           // class of every point id; common points: fixed-base registry first
     int32_t c = -1;
@@ -338,7 +339,9 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
     uint32_t n_stab = 0, n_itab = 0, SG = 0, UG = 0;
     for (uint32_t p = 0; p < np; ++p) {
       const int32_t c = cls_p[p];
-      const bool table = cnt[p] && (c == CLASS_GROUP || c == CLASS_COMB);
+      // a per-proof point ALL of whose terms ride (CMZ's P in the verifier) gets a table of its multiples 1 .. 128 in a comb table's place (k_rider_tables): its
+      // riders then add one signed 8-bit digit per byte instead of one nibble digit per nibble
+      const bool table = (cnt[p] && (c == CLASS_GROUP || c == CLASS_COMB)) || stmt_rider(rider_ok, p, ns, cnt[p], acnt[p]);
       rank_p[p] = table ? (p < ns ? n_stab++ : n_itab++) : NONE;
       goff_p[p] = 0;
       if (cnt[p] && c == CLASS_GROUP) {
@@ -346,18 +349,24 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
       }
     }
     sh[0] = n_stab; sh[1] = n_itab; sh[2] = SG; sh[3] = UG;
-    // per-term ranks
+    // per-term ranks.  Ladder terms that carry a rider with a table come first, proof by proof, then the others: a wavefront runs one kind of chain
+    uint32_t lad_a = 0, lad_b = 0;
     for (uint32_t k = 0; k < T; ++k) {
       if (stmt_absorbed(sj.pair, k)) continue;
       const uint32_t p = sj.tpt[k];
       const int32_t c = cls_p[p];
       if (c == CLASS_GROUP) {
         pos_k[k] = seen_p[p]++;                                      // rank among the terms of p
+      } else if (c == CLASS_LADDER) {
+        const uint32_t k2 = sj.pair ? sj.pair[k] : STMT_UNPAIRED;
+        const bool a = k2 != STMT_UNPAIRED && stmt_rider(rider_ok, sj.tpt[k2], ns, cnt[sj.tpt[k2]], acnt[sj.tpt[k2]]);
+        pos_k[k] = a ? (STMT_ABSORBED | lad_a++) : lad_b++;           // (the high bit marks the first segment)
       } else {
         pos_k[k] = cc[c];
       }
       ++cc[c];
     }
+    sh[4] = lad_a;
     uint32_t run = 0, blk = 0;
     for (int c = 0; c < HOT_CLASSES; ++c) {
       cstart[c] = run;
@@ -388,8 +397,9 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
     uint32_t slot = NONE;
     if (rank_p[p] != NONE) slot = p < ns ? rank_p[p] : sh[0] + rank_p[p] * N + j;
     if (slot != NONE && slot >= max_tables) slot = NONE;   // (cannot happen: max_tables counts every common point as cold)
-    slot_of[g] = slot;
-    if (slot != NONE) slot_pt[slot] = (uint32_t)g;
+    const bool rider = slot != NONE && stmt_rider(rider_ok, p, ns, cnt[p], acnt[p]);
+    slot_of[g] = rider ? (slot | STMT_ABSORBED) : slot;     // (the high bit: a table of multiples, not a comb table -- read by term_ladder16_joint only: no term of p is on a list)
+    if (slot != NONE) slot_pt[slot] = rider ? ((uint32_t)g | STMT_ABSORBED) : (uint32_t)g;
   }
   if (g < (size_t)N * sj.nc) sj.off[g] = (uint32_t)((g / sj.nc) * T + sj.toff[g % sj.nc]);
   if (g == 0) sj.off[(size_t)N * sj.nc] = N * T;
@@ -404,6 +414,8 @@ k_stmt_classify(const stmt_job sj, const uint8_t* __restrict__ points, uint32_t 
       // common grouped points first (all N cnt[p] terms of a point together), then proof by proof
       pos = p < ns ? (size_t)goff_p[p] * N + (size_t)j * cnt[p] + pos_k[k]
                    : (size_t)sh[2] * N + (size_t)j * sh[3] + goff_p[p] + pos_k[k];
+    } else if (c == CLASS_LADDER) {
+      pos = (pos_k[k] & STMT_ABSORBED) ? (size_t)j * sh[4] + (pos_k[k] & ~STMT_ABSORBED) : (size_t)N * sh[4] + (size_t)j * (cc[c] - sh[4]) + pos_k[k];
     } else {
       pos = (size_t)j * cc[c] + pos_k[k];
     }

@@ -17,6 +17,12 @@ namespace zkp {
 constexpr uint32_t STMT_UNPAIRED = 0xffffffffu, STMT_ABSORBED = 0x80000000u;
 ZKP_HD bool stmt_absorbed(const uint32_t* pair, uint32_t k) { return pair && pair[k] != STMT_UNPAIRED && (pair[k] & STMT_ABSORBED); }
 
+// A per-proof point ALL of whose terms ride and that has at least STMT_RIDER_MIN of them gets a table of its multiples 1 .. 128 (in the place of a 16-teeth
+// comb table: 129 entries) -- its riders then add one signed 8-bit digit per byte of the scalar, 32 additions instead of 64, and do not build multiples of
+// their own.  `uses` = terms of the point that do NOT ride, `riders` = those that do; ok = the job's tables have 16 teeth.
+constexpr uint32_t STMT_RIDER_MIN = 2;
+ZKP_HD bool stmt_rider(uint32_t ok, uint32_t p, uint32_t ns, uint32_t uses, uint32_t riders) { return ok && p >= ns && uses == 0 && riders >= STMT_RIDER_MIN; }
+
 // toff[nc + 1]: term offsets of the constraints, tpt[T1]: point id of every term; ids < ns are common to the batch (fixed-base tables or shared comb tables:
 // never paired), the others one point per proof.  Per constraint, every term on a per-proof point with one use takes along one other per-proof term of the
 // same constraint: first a term of a point with several uses, else another single-use term.  Empty when nothing pairs.

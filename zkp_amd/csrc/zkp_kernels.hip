@@ -214,8 +214,10 @@ k_terms_split(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ 
           // those of the first ones
           const uint32_t k2 = pair ? pair[t % stmt_T] : STMT_UNPAIRED;
           if (k2 != STMT_UNPAIRED) {
-            const uint32_t t2 = t - t % stmt_T + k2, i2 = i + ((max_ladder + 63u) & ~63u);
-            term_ladder16_joint(t, t2, scalars, pts + pi, pts + pidx[t2], tbl, reinterpret_cast<uint4*>(ladder_rw) + (size_t)(i2 >> 6) * LADDER_GROUP_UINT4 + (i2 & 63u), partial, ecol);
+            const uint32_t t2 = t - t % stmt_T + k2, i2 = i + ((max_ladder + 63u) & ~63u), pi2 = pidx[t2];
+            const uint32_t s2 = slot_of[pi2];                       // (high bit: the second point has a table of its multiples 1 .. 128, k_rider_tables)
+            const dev_ext* rider = (s2 != 0xffffffffu && (s2 & STMT_ABSORBED)) ? comb + (size_t)(s2 & ~STMT_ABSORBED) * comb_cfg<16>::ENTRIES : nullptr;
+            term_ladder16_joint(t, t2, scalars, pts + pi, pts + pi2, tbl, reinterpret_cast<uint4*>(ladder_rw) + (size_t)(i2 >> 6) * LADDER_GROUP_UINT4 + (i2 & 63u), rider, partial, ecol);
             joint = true;
           }
         }
@@ -1348,6 +1350,7 @@ struct zkp_ctx {
   static constexpr size_t kSplitCombTerms = 8192;   // narrow constant-time calls on the latency schedule from this many terms on: grouped walk + quad-split scans (ZKP_OPT_COMB_SPLIT)
   bool dev_overlap = false;          // ZKP_OPT_DEV_OVERLAP: the _dev flows fork their scalar-independent half onto the side stream too
   bool dev_latency = false;          // ZKP_OPT_DEV_OVERLAP = 2: the _dev flows run the whole latency schedule of the synchronous entry points (a lone caller's choice)
+  bool rider_tables = true;          // ZKP_OPT_JOINT_LADDER = 2 turns the riders' shared tables of multiples off (pairs stay)
   bool joint_ladder = true;          // ZKP_OPT_JOINT_LADDER: variable-time statement flows carry a second term of a constraint on a single-use point's doubling chain (1, default) or not (0)
   bool tr_steps = true;              // ZKP_OPT_TRANSCRIPT_STEPS: lane-pair transcripts as assemble + chain (1, default) or by the word-operation interpreter (0)
   int tr_lanes = -1;                 // ZKP_OPT_TRANSCRIPT_LANES: -1 = by entry point, 1 = one lane per proof, 2 = a lane pair per proof
@@ -1487,6 +1490,7 @@ struct terms_cfg {
   msm_map map;                     // lane -> MSM assignment of the reduce / encode kernels (fused flows: constraints by length)
   bool prehalved = false;          // the caller already wrote s / 2 mod l where the batched encoder is used (terms_batched_encode)
   stmt_job stmt;                   // fused flows: the statement's term structure (one-launch classifier, k_stmt_classify)
+  bool rider_tables = false;       // stmt.pair: max_tables counts a table of multiples for every per-proof point whose terms all ride (stmt_pairs.h: stmt_rider)
 };
 inline bool stmt_classify_applies(const terms_cfg& k, uint32_t n_terms) {
   return k.stmt.on && n_terms >= 1024 && k.stmt.T <= STMT_MAX_TERMS && k.stmt.np <= STMT_MAX_POINTS && k.stmt.T && k.stmt.N;
@@ -1621,13 +1625,15 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     // (a caller that pairs terms sized its bounds for the pairs: it only does so where the statement classifier runs)
     const bool pair_on = k.stmt.pair && flags == ZKP_VARTIME && stmt_classify_applies(k, n_terms);
     if (k.stmt.pair && !pair_on) return fail(ZKP_ERR_ARG, "paired terms outside the statement classifier");
+    // riders whose point has no other term get a table of multiples in a 16-teeth comb table's place (stmt_pairs.h: stmt_rider; the plan's bounds count them)
+    const bool rider_ok = pair_on && k.teeth == 16 && k.rider_tables;
     uint32_t* gstart = reinterpret_cast<uint32_t*>(base + o.gstart);
     uint32_t* gfill = reinterpret_cast<uint32_t*>(base + o.gfill);
     if ((phase & PH_POINTS) && stmt_classify_applies(k, n_terms)) {
       // the statement's structure gives classes, list positions and table slots arithmetically: one launch
       const size_t lanes = std::max<size_t>(std::max<size_t>(n_terms, n_points), (size_t)k.stmt.N * k.stmt.nc + 1);
       hipLaunchKernelGGL(k_stmt_classify, grid1(lanes, 256), dim3(256), 0, c->stream, k.stmt, d_points, c->hot_nreg, c->hot_reg_words, c->hot_reg_slot, comb_min, group_min,
-                         k.max_tables, needs, class_start, blk_start, n_slots, slot_of, slot_pt, list);
+                         k.max_tables, needs, class_start, blk_start, n_slots, slot_of, slot_pt, list, rider_ok ? 1u : 0u);
       prof_mark(c, ZKP_K_SORT);
       hipLaunchKernelGGL(k_decode_affine, grid1(n_points, 256), dim3(256), 0, c->stream, n_points, d_points, pts, decode_all ? (const uint32_t*)nullptr : needs);
       prof_mark(c, ZKP_K_DECODE);
@@ -1674,6 +1680,8 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
         else hipLaunchKernelGGL(k_comb_tables<4>, grid1((size_t)k.max_tables * 4, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
       }
     }
+    if ((phase & PH_POINTS) && k.max_tables && rider_ok)
+      hipLaunchKernelGGL(k_rider_tables, grid1(k.max_tables, 256), dim3(256), 0, c->stream, n_slots, k.max_tables, slot_pt, pts, comb);
     if ((phase & PH_POINTS) && k.max_tables && c->kernel_names[ZKP_K_TABLES].find("k_tables_transcript") == std::string::npos && c->kernel_names[ZKP_K_TABLES].find("k_tables_chain") == std::string::npos)
       prof_note(c, ZKP_K_TABLES, std::string((c->tables_lane < 0 ? k.throughput : c->tables_lane != 0) ? "zkp::k_comb_tables_lane<" : "zkp::k_comb_tables<") + (k.teeth == 16 ? "16>" : "4>"));
     if (phase & PH_POINTS) prof_mark(c, ZKP_K_TABLES);        // path A: comb-table construction
@@ -1998,7 +2006,7 @@ int zkp_ctx_set_option(zkp_ctx* c, int option, uint64_t value) {
     case ZKP_OPT_FUSE_TABLES_TRANSCRIPT: c->fuse_tables_transcript = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_TABLES_LANE: c->tables_lane = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_GROUPED_COMB: c->grouped_comb = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
-    case ZKP_OPT_JOINT_LADDER: c->joint_ladder = value != 0; return ZKP_OK;
+    case ZKP_OPT_JOINT_LADDER: c->joint_ladder = value != 0; c->rider_tables = value != 2; return ZKP_OK;
     case ZKP_OPT_COMB_SPLIT: c->comb_split = value == ~0ull ? -1 : (value ? 1 : 0); return ZKP_OK;
     case ZKP_OPT_CT_LOOKUP:
       if (value == ~0ull) value = 0;

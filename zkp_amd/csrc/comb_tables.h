@@ -143,6 +143,27 @@ __device__ __forceinline__ void store_comb_entry(dev_ext* dst, const ge_cached& 
   fe_get(w, c.YmX); fe_get(w + 9, c.YpX); fe_get(w + 18, c.Z2); fe_get(w + 27, c.T2d);
   store_vec<9>(dst, w);
 }
+// One entry of 64 lanes' tables through LDS (k_rider_tables): a lane's entry is 9 chunks of 16 bytes, and 64 lanes storing chunk q of 64 different
+// tables touch 64 cache lines per instruction.  Transposed, an instruction stores the 9 chunks of 7 tables' entries: 7 runs of 144 bytes.  (The comb builder
+// k_comb_tables_lane gains nothing from it -- 3.10 against 3.12 ms for 204,800 tables: its 368 dependent point operations are the time, not its stores.)
+// stage = [36][64] words, live = [64] flags of this wavefront; every lane of the wavefront calls it.
+__device__ __forceinline__ void store_entries_staged(uint32_t (*stage)[64], const uint32_t* live, uint32_t lane, dev_ext* __restrict__ tbl0 /* table of lane 0 */,
+                                                     uint32_t entries_per_table, uint32_t e, const ge_cached& c) {
+  uint32_t w[36];
+  fe_get(w, c.YmX); fe_get(w + 9, c.YpX); fe_get(w + 18, c.Z2); fe_get(w + 27, c.T2d);
+#pragma unroll
+  for (int i = 0; i < 36; ++i) stage[i][lane] = w[i];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const uint32_t ch = (uint32_t)i * 64u + lane, t = ch / 9u, q = ch - 9u * t;      // chunk q of the table of lane t
+    if (live[t]) {
+      const uint4 v = make_uint4(stage[4 * q][t], stage[4 * q + 1][t], stage[4 * q + 2][t], stage[4 * q + 3][t]);
+      reinterpret_cast<uint4*>(tbl0 + (size_t)t * entries_per_table + e)[q] = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 template <int TEETH>
 __device__ __forceinline__ void comb_table_lane(uint32_t slot, const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt,
                                                 const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
@@ -187,6 +208,7 @@ k_comb_tables_lane(const uint32_t* __restrict__ n_slots, uint32_t max_tables, co
                    const dev_affine* __restrict__ pts, dev_ext* __restrict__ comb) {
   comb_table_lane<TEETH>(blockIdx.x * blockDim.x + threadIdx.x, n_slots, max_tables, slot_pt, pts, comb);
 }
+
 
 // The one-lane builder as a PRODUCER wavefront and a CONSUMER wavefront (round 5): a lone wavefront already issues a point operation's ~1,000 dependent
 // instructions at 4.6 cycles each, so a table's 368 sequential point operations ARE the 0.9 ms of the launch -- no schedule inside the lane shortens them.  Two
@@ -875,24 +897,28 @@ __device__ __forceinline__ void term_ladder16(uint32_t t, const uint8_t* __restr
 __global__ void __launch_bounds__(256, 2)
 k_rider_tables(const uint32_t* __restrict__ n_slots, uint32_t max_tables, const uint32_t* __restrict__ slot_pt, const dev_affine* __restrict__ pts,
                dev_ext* __restrict__ comb) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= min(*n_slots, max_tables)) return;
-  const uint32_t pi = slot_pt[slot];
-  if (!(pi & STMT_ABSORBED)) return;
+  __shared__ uint32_t stage[4][36][64];                           // (stores through LDS: store_entries_staged; 204,800 tables 2.47 -> 2.02 ms)
+  __shared__ uint32_t live[4][64];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, ns = min(*n_slots, max_tables);
+  const uint32_t pi = slot < ns ? slot_pt[slot] : 0u;
+  const bool have = slot < ns && (pi & STMT_ABSORBED);
+  live[wave][lane] = have ? 1u : 0u;
+  if (!__ballot(have)) return;                                    // (wave-uniform: nothing to build here)
   ge_p3 P, m;
-  load_affine(P, pts + (pi & ~STMT_ABSORBED));
-  dev_ext* tbl = comb + (size_t)slot * comb_cfg<16>::ENTRIES;
+  ge_identity(P);
+  if (have) load_affine(P, pts + (pi & ~STMT_ABSORBED));
+  dev_ext* tbl0 = comb + (size_t)(slot - lane) * comb_cfg<16>::ENTRIES;
   ge_cached c1, c;
   ge_to_cached(c1, P);
-  store_comb_entry(tbl, c1);
-  ge_double<true>(m, P);
-  ge_to_cached(c, m);
-  store_comb_entry(tbl + 1, c);
+  c = c1;
+  m = P;
 #pragma unroll 1
-  for (int k = 2; k < 128; ++k) {
-    ge_add_cached(m, m, c1);
-    ge_to_cached(c, m);
-    store_comb_entry(tbl + k, c);
+  for (int k = 0; k < 128; ++k) {
+    if (k == 1) ge_double<true>(m, P);
+    else if (k > 1) ge_add_cached(m, m, c1);
+    if (k) ge_to_cached(c, m);
+    store_entries_staged(stage[wave], live[wave], lane, tbl0, comb_cfg<16>::ENTRIES, (uint32_t)k, c);
   }
 }
 

@@ -1625,6 +1625,8 @@ int msm_terms_path(zkp_ctx* c, uint32_t n_msm, const uint32_t* d_off, const uint
     // (a caller that pairs terms sized its bounds for the pairs: it only does so where the statement classifier runs)
     const bool pair_on = k.stmt.pair && flags == ZKP_VARTIME && stmt_classify_applies(k, n_terms);
     if (k.stmt.pair && !pair_on) return fail(ZKP_ERR_ARG, "paired terms outside the statement classifier");
+    // (a point whose terms all ride has no use the decoder would see: such jobs decode every point, as the verifiers do anyway -- verifier.rs:87-92)
+    if (pair_on && !decode_all) return fail(ZKP_ERR_ARG, "paired terms need decode_all");
     // riders whose point has no other term get a table of multiples in a 16-teeth comb table's place (stmt_pairs.h: stmt_rider; the plan's bounds count them)
     const bool rider_ok = pair_on && k.teeth == 16 && k.rider_tables;
     uint32_t* gstart = reinterpret_cast<uint32_t*>(base + o.gstart);

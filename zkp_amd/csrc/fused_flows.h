@@ -1178,16 +1178,21 @@ verify_inter verify_carve(const fused_plan& pl, size_t start) {
   return o;
 }
 // the verifier's CSR job: bounds, statement structure and -- where the statement classifier runs -- the pairs of terms that share a doubling chain
-terms_cfg verify_terms_cfg(const zkp_ctx* c, const fused_plan& pl) {
+// riders: tables of multiples for points whose terms all ride (stmt_rider).  A table is a chain of 127 additions on one lane: worth it where calls are wide or
+// overlap (throughput schedule, or >= kRiderLatencyProofs proofs) -- a lone synchronous call of 4096 CMZ proofs takes 1.89 ms with them and 1.55 ms without,
+// 16,384 proofs 4.14 - 4.21 against 4.18 - 4.20 ms.  Workspace bounds are taken with riders = true (the larger layout).
+constexpr uint32_t kRiderLatencyProofs = 16384;
+terms_cfg verify_terms_cfg(const zkp_ctx* c, const fused_plan& pl, bool riders = true) {
   const uint32_t N = pl.N, nc = pl.s.nc, T1 = pl.T1;
   terms_cfg tk = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2);
   tk.stmt.toff = pl.d_tarr; tk.stmt.tpt = pl.d_tarr + nc + 1 + T1; tk.stmt.N = N; tk.stmt.T = T1; tk.stmt.nc = nc; tk.stmt.ns = pl.s.ns; tk.stmt.np = pl.s.np;
   tk.stmt.on = c->stmt_classify;
   if (c->joint_ladder && pl.d_pair && stmt_classify_applies(tk, N * T1)) {
-    const terms_cfg paired = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2, pl.pair.data(), c->rider_tables);
+    riders = riders && c->rider_tables;
+    const terms_cfg paired = cfg_from_terms(pl.tpt.data(), T1, pl.s.ns, pl.s.np, N, 2, pl.pair.data(), riders);
     tk.max_tables = paired.max_tables; tk.max_ladder = paired.max_ladder; tk.teeth = paired.teeth;
     tk.stmt.pair = pl.d_pair;
-    tk.rider_tables = c->rider_tables;           // (the classifier hands them out only if the job's tables have 16 teeth: 129 entries hold 128 multiples)
+    tk.rider_tables = riders;                    // (the classifier hands them out only if the job's tables have 16 teeth: 129 entries hold 128 multiples)
   }
   return tk;
 }
@@ -1201,7 +1206,7 @@ int verify_core(zkp_ctx* c, const fused_plan& pl, const verify_inter& o, uint8_t
   HIP_TRY(hipMemsetAsync(w.base + o.failed, 0, (size_t)N * 4, c->stream));
   prof_begin(c);
   const size_t lanes = std::max<size_t>((size_t)N * T1, (size_t)N * nc) + 1;
-  terms_cfg tk = verify_terms_cfg(c, pl);
+  terms_cfg tk = verify_terms_cfg(c, pl, throughput || N >= kRiderLatencyProofs);
   tk.throughput = throughput;
   if (pl.d_order) { tk.map.N = N; tk.map.nc = nc; tk.map.order = pl.d_order; }
   tk.stmt.off = w.u32(o.off); tk.stmt.pidx = w.u32(o.pidx);

@@ -151,6 +151,7 @@ const char* zkp_version(void);
  *     constraint (Straus interleaving: eight multiples + 64 additions, no doublings, no comb table) -- CMZ: P joins C_i's chain in ten constraints and needs no
  *     table, Q joins V's: 11 chains instead of 12 and no 16-teeth table per proof.  A per-proof point ALL of whose terms ride (P) gets a table of its multiples
  *     1 .. 128 where its comb table was: its riders add one signed 8-bit digit per byte (32 additions instead of 64) and build no multiples of their own;
+ *     (a table is a chain of 127 additions: built on the throughput schedule and in calls of >= 16,384 proofs, not in a lone synchronous call of fewer);
  *     2 = pairs without these tables.  0 = every term on its own (rounds 2 - 5).  Same bytes.
  *   This enum is the whole option surface of the shipped library; measurement hooks live in test-hook builds only (end of file). */
 enum { ZKP_OPT_BATCH_ENCODE_MIN = 1, ZKP_OPT_COMB_TEETH = 2, ZKP_OPT_CT_SINGLE_USE_TABLES = 3, ZKP_OPT_TRANSCRIPT_LANES = 4, ZKP_OPT_DEV_OVERLAP = 5, ZKP_OPT_GROUPED_COMB = 6, ZKP_OPT_TABLES_LANE = 7,

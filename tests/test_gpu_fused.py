@@ -434,7 +434,7 @@ def test_random_statements_fused_equals_host_route_and_oracle(eng, seed):
         ts4 = _fresh(label, n)
         each = T.verify_batchable_each(eng, st, ts4, inst, common, coms, resp, np.ascontiguousarray(w.transpose(1, 0, 2)))
         bad = resp.copy()
-        bad[n // 2, 0, 0] ^= 1
+        bad[n // 2, cons[0][1][0][0], 0] ^= 1                             # (a response some constraint uses: an unused one changes no commitment)
         ts5 = _fresh(label, n)
         res_bad = T.verify_compact_batch(eng, st, ts5, inst, common, chal, bad)
         out[route] = (chal, resp, coms, ts[:, :203], res, ts2[:, :203], coeffs, ts3[:, :203], each, res_bad)
